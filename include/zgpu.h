@@ -1,0 +1,159 @@
+/*
+ * zgpu.h — C ABI of the MI355X-native zstd block-decode engine (libzgpu.so).
+ *
+ * This is the drop-in boundary for the reference's block-decode path. The reference (KillingSpark/zstd-rs,
+ * crate ruzstd 0.9.1) has no FFI of its own; the seam this library replaces is
+ *     BlockDecoder::decode_block_content          ruzstd/src/decoding/block_decoder.rs:39-95
+ * as called from FrameDecoder::decode_blocks        ruzstd/src/decoding/frame_decoder.rs:338-340
+ * and FrameDecoder::decode_from_to                  ruzstd/src/decoding/frame_decoder.rs:495-501,
+ * together with the state it mutates (DecoderScratch, ruzstd/src/decoding/scratch.rs:15-27).
+ * Because one launch per block would be ~7.6 K launches for enwik9, the ABI is batched: the host walks the
+ * 3-byte block headers and hands over whole runs of blocks (INTEGRATION.md shows the Rust-side binding).
+ *
+ * All functions return 0 on success or a positive zgpu status (values below); nothing throws or unwinds across
+ * the boundary; pointers are plain host pointers unless a name says "device". There is no CPU fallback: without
+ * a usable gfx950 device zgpu_ctx_create fails with ZGPU_E_HIP.
+ */
+#ifndef ZGPU_H
+#define ZGPU_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Status codes: leaves of the reference's error enums (ruzstd/src/decoding/errors.rs). */
+enum zgpu_status {
+  ZGPU_OK = 0,
+  ZGPU_E_SKIP_FRAME = 1,              /* ReadFrameHeaderError::SkipFrame                errors.rs (frame.rs:15-23) */
+  ZGPU_E_BAD_MAGIC = 2,               /* ReadFrameHeaderError::BadMagicNumber */
+  ZGPU_E_HEADER_READ = 3,             /* ReadFrameHeaderError::*ReadError */
+  ZGPU_E_WINDOW_TOO_BIG_SPEC = 4,     /* FrameHeaderError::WindowTooBig */
+  ZGPU_E_WINDOW_TOO_SMALL = 5,        /* FrameHeaderError::WindowTooSmall */
+  ZGPU_E_WINDOW_SIZE_TOO_BIG = 6,     /* FrameDecoderError::WindowSizeTooBig */
+  ZGPU_E_DICT_NOT_PROVIDED = 7,       /* FrameDecoderError::DictNotProvided */
+  ZGPU_E_NOT_INITIALIZED = 8,         /* FrameDecoderError::NotYetInitialized */
+  ZGPU_E_FAILED_READ_BLOCK_HEADER = 9,
+  ZGPU_E_FAILED_READ_BLOCK_BODY = 10,
+  ZGPU_E_FAILED_READ_CHECKSUM = 11,
+  ZGPU_E_TARGET_TOO_SMALL = 12,
+  ZGPU_E_FAILED_SKIP_FRAME = 13,
+  ZGPU_E_RESERVED_BLOCK = 20,         /* BlockHeaderReadError::FoundReservedBlock */
+  ZGPU_E_BLOCK_SIZE_TOO_LARGE = 21,   /* BlockSizeError::BlockSizeTooLarge */
+  ZGPU_E_MALFORMED_SECTION_HEADER = 22, /* DecompressBlockError::MalformedSectionHeader */
+  ZGPU_E_LITERALS_HEADER = 23,        /* LiteralsSectionParseError */
+  ZGPU_E_SEQUENCES_HEADER = 24,       /* SequencesHeaderParseError */
+  ZGPU_E_LIT_UNINIT_HUF = 30,         /* DecompressLiteralsError::UninitializedHuffmanTable */
+  ZGPU_E_LIT_MISSING_JUMP = 31,
+  ZGPU_E_LIT_MISSING_BYTES = 32,
+  ZGPU_E_LIT_EXTRA_PADDING = 33,
+  ZGPU_E_LIT_BITSTREAM_MISMATCH = 34,
+  ZGPU_E_LIT_COUNT_MISMATCH = 35,
+  ZGPU_E_HUF_TABLE = 36,              /* HuffmanTableError::* */
+  ZGPU_E_FSE_TABLE = 40,              /* FSETableError::* */
+  ZGPU_E_FSE_UNINIT = 41,             /* FSEDecoderError::TableIsUninitialized */
+  ZGPU_E_SEQ_MISSING_MODE = 42,
+  ZGPU_E_SEQ_RLE_BYTE = 43,
+  ZGPU_E_SEQ_EXTRA_PADDING = 44,
+  ZGPU_E_SEQ_UNSUPPORTED_OFFSET = 45,
+  ZGPU_E_SEQ_NOT_ENOUGH_BYTES = 46,
+  ZGPU_E_SEQ_EXTRA_BITS = 47,
+  ZGPU_E_EXE_NOT_ENOUGH_LITERALS = 50, /* ExecuteSequencesError::NotEnoughBytesForSequence */
+  ZGPU_E_EXE_ZERO_OFFSET = 51,
+  ZGPU_E_EXE_OFFSET_TOO_BIG = 52,     /* DecodeBufferError::OffsetTooBig */
+  ZGPU_E_EXE_DICT_TOO_SMALL = 53,
+  ZGPU_E_DICT_DECODE = 60,
+  ZGPU_E_UNSUPPORTED = 80,            /* input the reference tolerates but this engine rejects */
+  ZGPU_E_INTERNAL = 90,               /* where the reference would panic */
+  ZGPU_E_NOMEM = 91,
+  ZGPU_E_HIP = 92,                    /* HIP runtime error / no device */
+  ZGPU_E_BAD_ARG = 93
+};
+
+typedef struct zgpu_ctx zgpu_ctx;         /* one per (GPU, HIP stream); not thread-safe, may move between threads */
+typedef struct zgpu_batch zgpu_batch;     /* one submit: a run of whole frames, parsed and resident on the device */
+typedef struct zgpu_decoder zgpu_decoder; /* mirror of ruzstd's FrameDecoder for one frame at a time */
+
+/* ---- context ------------------------------------------------------------------------------------------- */
+int zgpu_ctx_create(int device_id, zgpu_ctx** out);                 /* ~ FrameDecoder::new  frame_decoder.rs:158 */
+void zgpu_ctx_destroy(zgpu_ctx*);
+void zgpu_set_max_window_size(zgpu_ctx*, uint64_t max_window_size); /* frame_decoder.rs:175 (clamped to the format maximum) */
+uint64_t zgpu_max_window_size(const zgpu_ctx*);                     /* frame_decoder.rs:180 */
+const char* zgpu_last_error(const zgpu_ctx*);
+const char* zgpu_status_name(int status);
+
+/* ---- FrameDecoder::decode_all (frame_decoder.rs:541-577) -------------------------------------------------
+ * src holds concatenated frames (skippable frames are skipped); the plaintext of all frames is written back to
+ * back into dst. ZGPU_E_TARGET_TOO_SMALL if it does not fit. H2D + kernels + D2H. */
+int zgpu_decode_all(zgpu_ctx*, const uint8_t* src, size_t len, uint8_t* dst, size_t cap, size_t* written);
+
+/* ---- staged form of the same path, for device-resident runs (bench / roofline) ---------------------------- */
+typedef struct {
+  uint64_t src_begin, src_end;   /* byte range of the frame in the input */
+  uint64_t window_size;          /* FrameHeader::window_size  frame.rs:116-139 */
+  uint64_t frame_content_size;   /* FrameHeader::frame_content_size (0 if absent) */
+  uint64_t out_base, out_size;   /* where the frame's plaintext sits in the batch output (after sync) */
+  uint32_t nblocks;
+  uint32_t status;               /* first error of the frame, 0 if none */
+  uint32_t bad_block;            /* frame-relative index of the failing block */
+  uint32_t has_checksum;         /* Content_Checksum flag + value read from the data (frame_decoder.rs:347-359) */
+  uint32_t checksum;
+  uint32_t pad;
+} zgpu_frame_info;
+
+/* parse the frame/block/section headers on the host and upload: after this the compressed bytes and the block
+ * table are resident in HBM. Returns the frame-layer status of the walk (0, or the error decode_all would return);
+ * *out is valid unless the status is ZGPU_E_NOMEM / ZGPU_E_HIP. */
+int zgpu_batch_prepare(zgpu_ctx*, const uint8_t* src, size_t len, zgpu_batch** out);
+int zgpu_batch_run(zgpu_batch*);                                     /* enqueue the kernels (async on the ctx stream) */
+int zgpu_batch_sync(zgpu_batch*, uint64_t* total_out, uint32_t* first_bad_frame /* UINT32_MAX if none */, uint32_t* its_status);
+uint32_t zgpu_batch_num_frames(const zgpu_batch*);
+uint32_t zgpu_batch_num_blocks(const zgpu_batch*);
+uint64_t zgpu_batch_compressed_size(const zgpu_batch*);
+int zgpu_batch_frame_info(const zgpu_batch*, uint32_t frame, zgpu_frame_info* out);
+int zgpu_batch_read(zgpu_batch*, uint64_t offset, uint8_t* dst, uint64_t n);   /* D2H of plaintext bytes */
+const void* zgpu_batch_output_device(const zgpu_batch*);            /* device pointer of the plaintext (no copy) */
+/* kernel times of the last run in ms, measured with HIP events on the ctx stream:
+ * [0] tables [1] huffman [2] sequences [3] scan [4] literals [5] lz [6] whole pipeline. Returns how many were written. */
+int zgpu_batch_timings(const zgpu_batch*, float* ms, int n);
+void zgpu_batch_destroy(zgpu_batch*);
+
+/* intermediates of a batch, for parity tests against the oracle (blocks are numbered across the whole batch) */
+typedef struct {
+  uint32_t btype, lit_type, nstreams, seq_modes;
+  uint32_t regen_size, nseq, frame, status;
+  int32_t huf_slot, ll_slot, of_slot, ml_slot;
+  uint32_t sum_ll, sum_ml;
+  uint32_t hist_init[3];
+  uint32_t active;
+  uint64_t out_base;
+} zgpu_block_info;
+typedef struct { uint32_t of, ml, mdst, lit_start; } zgpu_seq;   /* of: resolved offset or symbolic (see zg_dev.h) */
+int zgpu_batch_block_info(zgpu_batch*, uint32_t block, zgpu_block_info* out);
+int zgpu_batch_block_literals(zgpu_batch*, uint32_t block, uint8_t* dst, size_t cap, size_t* n);
+int zgpu_batch_block_sequences(zgpu_batch*, uint32_t block, zgpu_seq* dst, size_t cap, size_t* n);
+int zgpu_batch_fse_slot(zgpu_batch*, uint32_t slot, uint32_t* entries /* 1280 */, uint8_t logs[4]);
+int zgpu_batch_huf_slot(zgpu_batch*, uint32_t slot, uint16_t* entries /* 2048 */, int* max_bits);
+
+/* ---- FrameDecoder mirror (frame_decoder.rs:80-627): one frame at a time ---------------------------------- */
+enum { ZGPU_STRAT_ALL = 0, ZGPU_STRAT_UPTO_BLOCKS = 1, ZGPU_STRAT_UPTO_BYTES = 2 };  /* BlockDecodingStrategy :96-100 */
+int zgpu_decoder_create(zgpu_ctx*, zgpu_decoder** out);
+void zgpu_decoder_destroy(zgpu_decoder*);
+/* init/reset (:190-221): parses a frame header from src; *consumed = header bytes. ZGPU_E_SKIP_FRAME fills skip_*. */
+int zgpu_decoder_init(zgpu_decoder*, const uint8_t* src, size_t len, size_t* consumed, uint32_t* skip_magic, uint32_t* skip_len);
+/* decode_blocks (:309-377): src continues where the previous call stopped; *consumed = bytes taken. */
+int zgpu_decoder_decode_blocks(zgpu_decoder*, const uint8_t* src, size_t len, size_t* consumed, int strat, size_t n, int* frame_finished);
+size_t zgpu_decoder_can_collect(const zgpu_decoder*);                /* :410-424 */
+size_t zgpu_decoder_collect(zgpu_decoder*, uint8_t* dst, size_t cap);/* :381-389 */
+size_t zgpu_decoder_read(zgpu_decoder*, uint8_t* dst, size_t cap);   /* impl Read :615-627 */
+int zgpu_decoder_is_finished(const zgpu_decoder*);                   /* :284-294 */
+uint64_t zgpu_decoder_blocks_decoded(const zgpu_decoder*);           /* :297 */
+uint64_t zgpu_decoder_bytes_read_from_source(const zgpu_decoder*);   /* :273 */
+uint64_t zgpu_decoder_content_size(const zgpu_decoder*);             /* :246 */
+int zgpu_decoder_checksum_from_data(const zgpu_decoder*, uint32_t* out); /* :254 — returns 1 if present */
+uint32_t zgpu_decoder_calculated_checksum(const zgpu_decoder*);      /* :263-270 XXH64 seed 0, low 32 bits */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

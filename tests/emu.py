@@ -1,0 +1,101 @@
+"""ctypes binding of the TEST-ONLY host harness (tests/emu/libzg_emu.so): the engine's lane routines and host parser
+run on the CPU. Used by the not-gpu tests to check the decode logic against the oracle and the golden fixtures."""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class Seq(C.Structure):
+    _fields_ = [("of", C.c_uint32), ("ml", C.c_uint32), ("mdst", C.c_uint32), ("lit_start", C.c_uint32)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        d = os.path.join(HERE, "emu")
+        subprocess.check_call(["make", "-C", d, "-s"])
+        L = C.CDLL(os.path.join(d, "libzg_emu.so"))
+        L.zgemu_decode.restype = C.c_void_p
+        L.zgemu_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64]
+        L.zgemu_free.argtypes = [C.c_void_p]
+        L.zgemu_parse_status.argtypes = [C.c_void_p]
+        L.zgemu_num_frames.argtypes = [C.c_void_p]
+        L.zgemu_num_blocks.argtypes = [C.c_void_p]
+        L.zgemu_frame.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.zgemu_output.restype = C.POINTER(C.c_uint8)
+        L.zgemu_output.argtypes = [C.c_void_p]
+        L.zgemu_block_status.argtypes = [C.c_void_p, C.c_uint32]
+        L.zgemu_block_status.restype = C.c_uint32
+        L.zgemu_block.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32 * 12)]
+        L.zgemu_block_literals.restype = C.POINTER(C.c_uint8)
+        L.zgemu_block_literals.argtypes = [C.c_void_p, C.c_uint32]
+        L.zgemu_block_sequences.restype = C.POINTER(Seq)
+        L.zgemu_block_sequences.argtypes = [C.c_void_p, C.c_uint32]
+        L.zgemu_block_hist.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32 * 3)]
+        L.zgemu_fse_slot.restype = C.POINTER(C.c_uint32)
+        L.zgemu_fse_slot.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint8 * 4)]
+        L.zgemu_huf_slot.restype = C.POINTER(C.c_uint16)
+        L.zgemu_huf_slot.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int)]
+        _LIB = L
+    return _LIB
+
+
+class EmuBatch:
+    def __init__(self, src, max_window=128 << 20):
+        self.L = lib()
+        self.h = self.L.zgemu_decode(src, len(src), max_window)
+        self.parse_status = self.L.zgemu_parse_status(self.h)
+        self.nframes = self.L.zgemu_num_frames(self.h)
+        self.nblocks = self.L.zgemu_num_blocks(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.zgemu_free(self.h)
+            self.h = None
+
+    def frame(self, f):
+        b, s, st, bb = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint32()
+        assert self.L.zgemu_frame(self.h, f, C.byref(b), C.byref(s), C.byref(st), C.byref(bb)) == 0
+        return b.value, s.value, st.value, bb.value
+
+    def frame_bytes(self, f):
+        b, s, st, _ = self.frame(f)
+        p = self.L.zgemu_output(self.h)
+        return C.string_at(C.addressof(p.contents) + b, s), st
+
+    def block(self, b):
+        a = (C.c_uint32 * 12)()
+        self.L.zgemu_block(self.h, b, C.byref(a))
+        keys = ["btype", "lit_type", "nstreams", "seq_modes", "regen_size", "nseq", "frame", "huf_slot", "ll_slot", "of_slot", "ml_slot", "active"]
+        d = dict(zip(keys, list(a)))
+        for k in ("huf_slot", "ll_slot", "of_slot", "ml_slot"):
+            if d[k] >= 1 << 31:
+                d[k] -= 1 << 32
+        d["status"] = self.L.zgemu_block_status(self.h, b)
+        return d
+
+    def block_literals(self, b, n):
+        p = self.L.zgemu_block_literals(self.h, b)
+        return C.string_at(p, n)
+
+    def block_sequences(self, b, n):
+        p = self.L.zgemu_block_sequences(self.h, b)
+        return [(p[i].of, p[i].ml, p[i].mdst, p[i].lit_start) for i in range(n)]
+
+    def block_hist(self, b):
+        a = (C.c_uint32 * 3)()
+        self.L.zgemu_block_hist(self.h, b, C.byref(a))
+        return list(a)
+
+    def fse_slot(self, slot):
+        lg = (C.c_uint8 * 4)()
+        p = self.L.zgemu_fse_slot(self.h, slot, C.byref(lg))
+        return p, list(lg)
+
+    def huf_slot(self, slot):
+        mb = C.c_int()
+        p = self.L.zgemu_huf_slot(self.h, slot, C.byref(mb))
+        return p, mb.value

@@ -1,0 +1,317 @@
+// zg_engine.cpp — see zg_engine.h. Compiled by hipcc as host code.
+#include "zg_engine.h"
+#include <string.h>
+
+namespace zg {
+
+#define ZG_HIP(call)                                  \
+  do {                                                \
+    hipError_t e_ = (call);                           \
+    if (e_ != hipSuccess) return eng->fail(e_, #call); \
+  } while (0)
+
+int DevBuf::reserve(size_t n, bool keep, hipStream_t s) {
+  if (n <= cap && p) return 0;
+  size_t ncap = n < 256 ? 256 : n;
+  void* np = nullptr;
+  if (hipMalloc(&np, ncap) != hipSuccess) return ZG_NOMEM;
+  if (p) {
+    if (keep && cap) {
+      if (hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, s) != hipSuccess) return ZG_HIP_ERROR;
+      if (hipStreamSynchronize(s) != hipSuccess) return ZG_HIP_ERROR;
+    }
+    (void)hipFree(p);
+  }
+  p = np;
+  cap = ncap;
+  return 0;
+}
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  cap = 0;
+}
+
+int Engine::fail(hipError_t e, const char* what) {
+  last_error = std::string(what) + ": " + hipGetErrorString(e);
+  return ZG_HIP_ERROR;
+}
+
+int Engine::create(int device, Engine** out) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device >= n) return ZG_HIP_ERROR;  // no GPU: fail loudly, no CPU path
+  if (hipSetDevice(device) != hipSuccess) return ZG_HIP_ERROR;
+  Engine* e = new Engine();
+  e->device_ = device;
+  if (hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking) != hipSuccess) { delete e; return ZG_HIP_ERROR; }
+  *out = e;
+  return ZG_OK;
+}
+Engine::~Engine() {
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+int parse_frames(const uint8_t* src, size_t len, uint64_t max_window, BatchBuilder* bb, std::vector<FrameInfo>* info) {
+  // FrameDecoder::decode_all (frame_decoder.rs:541-577): concatenated frames, skippable frames skipped;
+  // the first error ends the walk (the reference returns it).
+  size_t p = 0;
+  static const uint32_t kHist[3] = {1, 4, 8};  // scratch.rs:44
+  while (p < len) {
+    FrameHeader h;
+    size_t c;
+    uint32_t sm = 0, sl = 0;
+    int st = read_frame_header(src + p, len - p, &h, &c, &sm, &sl);
+    if (st == ZG_SKIP_FRAME) {
+      p += c;
+      if ((size_t)sl > len - p) return ZG_FAILED_SKIP_FRAME;  // :550-556
+      p += sl;
+      continue;
+    }
+    if (st) return st;
+    uint64_t w;
+    if ((st = frame_window_size(h, &w))) return st;
+    if (w > max_window) return ZG_WINDOW_SIZE_TOO_BIG;          // frame_decoder.rs:137-145
+    if (h.has_dict_id) return ZG_DICT_NOT_PROVIDED;             // :212-217 (dictionaries: see DESIGN.md "next")
+    FrameInfo fi;
+    fi.header = h;
+    fi.window_size = w;
+    fi.src_begin = p;
+    p += c;
+    bb->begin_frame(w, kHist, false, false);
+    for (;;) {
+      if (len - p < 3) { st = ZG_FAILED_READ_BLOCK_HEADER; break; }
+      BlockHeader bh;
+      if ((st = read_block_header(src + p, &bh))) break;
+      p += 3;
+      if (len - p < bh.content_size) { st = ZG_FAILED_READ_BLOCK_BODY; break; }
+      st = bb->add_block(bh, src + p, p);
+      p += bh.content_size;
+      fi.nblocks++;
+      if (st) break;
+      if (bh.last) {
+        if (h.content_checksum()) {
+          if (len - p < 4) { st = ZG_FAILED_READ_CHECKSUM; break; }
+          memcpy(&fi.checksum, src + p, 4);
+          fi.has_checksum = true;
+          p += 4;
+        }
+        break;
+      }
+    }
+    fi.src_end = p;
+    fi.host_status = st;
+    info->push_back(fi);
+    if (st) return st;
+  }
+  return ZG_OK;
+}
+
+Batch::~Batch() {
+  DevBuf* all[] = {&d_src, &d_blocks, &d_frames, &d_aux, &d_slot_log, &d_fse, &d_huf, &d_hufmax, &d_status, &d_lit, &d_seq,
+                   &d_seqout, &d_pos, &d_frameout, &d_dst, &d_seqblocks, &d_hufitems, &d_hufgroups, &d_totals};
+  for (DevBuf* b : all) b->release();
+  for (auto& e : ev)
+    if (e) (void)hipEventDestroy(e);
+}
+
+int parse_block_run(const uint8_t* src, size_t len, uint64_t window, bool has_checksum, BatchBuilder* bb, std::vector<FrameInfo>* info,
+                    size_t* consumed) {
+  // the block loop of FrameDecoder::decode_blocks (frame_decoder.rs:319-375) on a run that starts at a block header
+  static const uint32_t kHist[3] = {1, 4, 8};
+  FrameInfo fi;
+  fi.window_size = window;
+  bb->begin_frame(window, kHist, false, false);
+  size_t p = 0;
+  int st = ZG_OK;
+  for (;;) {
+    if (len - p < 3) { st = ZG_FAILED_READ_BLOCK_HEADER; break; }
+    BlockHeader bh;
+    if ((st = read_block_header(src + p, &bh))) break;
+    p += 3;
+    if (len - p < bh.content_size) { st = ZG_FAILED_READ_BLOCK_BODY; break; }
+    st = bb->add_block(bh, src + p, p);
+    p += bh.content_size;
+    fi.nblocks++;
+    if (st) break;
+    if (bh.last) {
+      if (has_checksum) {
+        if (len - p < 4) { st = ZG_FAILED_READ_CHECKSUM; break; }
+        memcpy(&fi.checksum, src + p, 4);
+        fi.has_checksum = true;
+        p += 4;
+      }
+      break;
+    }
+  }
+  fi.src_end = p;
+  fi.host_status = st;
+  info->push_back(fi);
+  *consumed = p;
+  return st;
+}
+
+int Engine::prepare(const uint8_t* src, size_t len, Batch** out) {
+  Batch* b = new Batch();
+  b->eng = this;
+  b->src_len = len;
+  b->parse_status = parse_frames(src, len, max_window, &b->bb, &b->info);
+  return upload(b, src, len, out);
+}
+
+int Engine::prepare_run(const uint8_t* src, size_t len, uint64_t window, bool has_checksum, Batch** out, size_t* consumed) {
+  Batch* b = new Batch();
+  b->eng = this;
+  b->parse_status = parse_block_run(src, len, window, has_checksum, &b->bb, &b->info, consumed);
+  b->src_len = *consumed;
+  return upload(b, src, *consumed, out);
+}
+
+int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
+  Engine* eng = this;
+  ZG_HIP(hipSetDevice(device_));
+  // a frame-layer error after some good frames: the good frames are still uploaded (callers such as the
+  // FrameDecoder mirror may want them); decode_all reports parse_status.
+  b->bb.finish();
+  BatchBuilder& bb = b->bb;
+  const uint32_t nb = (uint32_t)bb.blocks.size(), nf = (uint32_t)bb.frames.size();
+  auto up = [&](DevBuf& d, const void* h, size_t bytes) -> int {
+    int st = d.reserve(bytes ? bytes : 16);
+    if (st) return st;
+    if (bytes && hipMemcpyAsync(d.p, h, bytes, hipMemcpyHostToDevice, stream_) != hipSuccess) return ZG_HIP_ERROR;
+    return 0;
+  };
+  int st = 0;
+  // compressed bytes, padded so that 8-byte bit-window loads near the end stay inside the allocation
+  if ((st = b->d_src.reserve(len + 64))) { delete b; return st; }
+  if (len && hipMemcpyAsync(b->d_src.p, src, len, hipMemcpyHostToDevice, stream_) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
+  (void)hipMemsetAsync((uint8_t*)b->d_src.p + len, 0, 64, stream_);
+  if ((st = up(b->d_blocks, bb.blocks.data(), nb * sizeof(ZgBlock))) || (st = up(b->d_frames, bb.frames.data(), nf * sizeof(ZgFrame))) ||
+      (st = up(b->d_seqblocks, bb.seq_blocks.data(), bb.seq_blocks.size() * 4)) ||
+      (st = up(b->d_hufitems, bb.huf_items.data(), bb.huf_items.size() * 4)) ||
+      (st = up(b->d_hufgroups, bb.huf_groups.data(), bb.huf_groups.size() * sizeof(ZgHufGroup)))) {
+    delete b;
+    return st;
+  }
+  const uint32_t nslots = bb.nslots();
+  if ((st = b->d_aux.reserve((size_t)nb * sizeof(ZgBlockAux) + 16)) || (st = b->d_slot_log.reserve((size_t)nslots * 4)) ||
+      (st = b->d_fse.reserve((size_t)nslots * ZG_FSE_SLOT_U32 * 4)) || (st = b->d_huf.reserve((size_t)(bb.nhuf_slots + 1) * ZG_HUF_SLOT_U16 * 2)) ||
+      (st = b->d_hufmax.reserve(bb.nhuf_slots + 16)) || (st = b->d_status.reserve((size_t)nb * 4 + 16)) ||
+      (st = b->d_lit.reserve(bb.lit_bytes + 64)) || (st = b->d_seq.reserve((bb.seq_count + 1) * sizeof(ZgSeq))) ||
+      (st = b->d_seqout.reserve((size_t)nb * sizeof(ZgBlockSeqOut) + 16)) || (st = b->d_pos.reserve((size_t)nb * sizeof(ZgBlockPos) + 16)) ||
+      (st = b->d_frameout.reserve((size_t)nf * sizeof(ZgFrameOut) + 16)) || (st = b->d_dst.reserve(bb.out_bound + 64)) ||
+      (st = b->d_totals.reserve(64))) {
+    delete b;
+    return st;
+  }
+  ZgBatchDev& d = b->dev;
+  d.src = b->d_src.as<uint8_t>(); d.src_len = len;
+  d.blocks = b->d_blocks.as<ZgBlock>(); d.nblocks = nb;
+  d.frames = b->d_frames.as<ZgFrame>(); d.nframes = nf;
+  d.nslots = nslots; d.nhuf_slots = bb.nhuf_slots;
+  d.aux = b->d_aux.as<ZgBlockAux>(); d.slot_log = b->d_slot_log.as<uint8_t>();
+  d.fse_arena = b->d_fse.as<uint32_t>(); d.huf_arena = b->d_huf.as<uint16_t>(); d.huf_maxbits = b->d_hufmax.as<uint8_t>();
+  d.status = b->d_status.as<uint32_t>(); d.lit_arena = b->d_lit.as<uint8_t>(); d.seq_arena = b->d_seq.as<ZgSeq>();
+  d.seq_out = b->d_seqout.as<ZgBlockSeqOut>(); d.pos = b->d_pos.as<ZgBlockPos>(); d.frame_out = b->d_frameout.as<ZgFrameOut>();
+  d.dst = b->d_dst.as<uint8_t>(); d.dst_cap = bb.out_bound; d.dict = nullptr;
+  d.seq_blocks = b->d_seqblocks.as<uint32_t>(); d.nseq_blocks = (uint32_t)bb.seq_blocks.size();
+  d.huf_items = b->d_hufitems.as<uint32_t>(); d.huf_groups = b->d_hufgroups.as<ZgHufGroup>(); d.nhuf_groups = (uint32_t)bb.huf_groups.size();
+  d.totals = b->d_totals.as<uint32_t>();
+  for (auto& e : b->ev)
+    if (hipEventCreate(&e) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
+  if (hipStreamSynchronize(stream_) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
+  *out = b;
+  return ZG_OK;
+}
+
+int Batch::run() {
+  ZG_HIP(hipSetDevice(eng->device_));
+  hipStream_t s = eng->stream_;
+  const ZgBatchDev& d = dev;
+  if (d.nframes == 0) { ran = true; total_out = 0; return ZG_OK; }
+  ZG_HIP(hipEventRecord(ev[0], s));
+  ZG_HIP(hipMemsetAsync(d.status, 0, (size_t)d.nblocks * 4 + 16, s));
+  ZG_HIP(hipMemsetAsync(d.huf_maxbits, 0, d.nhuf_slots + 16, s));
+  ZG_HIP(hipMemsetAsync(d.slot_log, 0, (size_t)d.nslots * 4, s));
+  ZG_HIP(hipMemsetAsync(d.totals, 0, 64, s));
+  zg_launch_tables(d, s);
+  ZG_HIP(hipEventRecord(ev[1], s));
+  zg_launch_huf(d, s);
+  ZG_HIP(hipEventRecord(ev[2], s));
+  zg_launch_seq(d, s);
+  ZG_HIP(hipEventRecord(ev[3], s));
+  zg_launch_scan(d, s);
+  ZG_HIP(hipEventRecord(ev[4], s));
+  zg_launch_lit(d, s);
+  ZG_HIP(hipEventRecord(ev[5], s));
+  zg_launch_lz(d, s);
+  ZG_HIP(hipEventRecord(ev[6], s));
+  ZG_HIP(hipGetLastError());
+  ran = true;
+  return ZG_OK;
+}
+
+int Batch::sync() {
+  ZG_HIP(hipSetDevice(eng->device_));
+  ZG_HIP(hipStreamSynchronize(eng->stream_));
+  if (dev.nframes == 0) return ZG_OK;
+  frame_out.resize(dev.nframes);
+  uint32_t totals[4] = {0, 0, 0, 0};
+  ZG_HIP(hipMemcpy(frame_out.data(), dev.frame_out, (size_t)dev.nframes * sizeof(ZgFrameOut), hipMemcpyDeviceToHost));
+  ZG_HIP(hipMemcpy(totals, dev.totals, 16, hipMemcpyDeviceToHost));
+  total_out = (uint64_t)totals[0] | ((uint64_t)totals[1] << 32);
+  overflow = totals[2] != 0;
+  for (int i = 0; i < ZG_T_TOTAL; i++) {
+    float m = 0;
+    if (hipEventElapsedTime(&m, ev[i], ev[i + 1]) == hipSuccess) ms[i] = m;
+  }
+  float m = 0;
+  if (hipEventElapsedTime(&m, ev[0], ev[ZG_T_TOTAL]) == hipSuccess) ms[ZG_T_TOTAL] = m;
+  return ZG_OK;
+}
+
+int Batch::read_output(uint64_t off, uint8_t* dst, uint64_t n) {
+  if (off + n > dev.dst_cap) return ZG_BAD_ARG;
+  if (n) ZG_HIP(hipMemcpy(dst, dev.dst + off, n, hipMemcpyDeviceToHost));
+  return ZG_OK;
+}
+int Batch::read_block_status(std::vector<uint32_t>* out) {
+  out->resize(dev.nblocks);
+  if (dev.nblocks) ZG_HIP(hipMemcpy(out->data(), dev.status, (size_t)dev.nblocks * 4, hipMemcpyDeviceToHost));
+  return ZG_OK;
+}
+int Batch::read_literals(uint32_t block, std::vector<uint8_t>* out) {
+  if (block >= dev.nblocks) return ZG_BAD_ARG;
+  const ZgBlock& b = bb.blocks[block];
+  out->clear();
+  if (b.btype != ZG_BT_COMPRESSED || b.lit_type < ZG_LT_COMPRESSED) return ZG_OK;
+  out->resize(b.regen_size);
+  if (b.regen_size) ZG_HIP(hipMemcpy(out->data(), dev.lit_arena + b.lit_base, b.regen_size, hipMemcpyDeviceToHost));
+  return ZG_OK;
+}
+int Batch::read_sequences(uint32_t block, std::vector<ZgSeq>* seqs, ZgBlockSeqOut* so, ZgBlockPos* pos) {
+  if (block >= dev.nblocks) return ZG_BAD_ARG;
+  const ZgBlock& b = bb.blocks[block];
+  seqs->resize(b.btype == ZG_BT_COMPRESSED ? b.nseq : 0);
+  if (!seqs->empty()) ZG_HIP(hipMemcpy(seqs->data(), dev.seq_arena + b.seq_base, seqs->size() * sizeof(ZgSeq), hipMemcpyDeviceToHost));
+  if (so) ZG_HIP(hipMemcpy(so, dev.seq_out + block, sizeof *so, hipMemcpyDeviceToHost));
+  if (pos) ZG_HIP(hipMemcpy(pos, dev.pos + block, sizeof *pos, hipMemcpyDeviceToHost));
+  return ZG_OK;
+}
+int Batch::read_fse_slot(uint32_t slot, std::vector<uint32_t>* entries, uint8_t logs[4]) {
+  if (slot >= dev.nslots) return ZG_BAD_ARG;
+  entries->resize(ZG_FSE_SLOT_U32);
+  ZG_HIP(hipMemcpy(entries->data(), dev.fse_arena + (size_t)slot * ZG_FSE_SLOT_U32, ZG_FSE_SLOT_U32 * 4, hipMemcpyDeviceToHost));
+  ZG_HIP(hipMemcpy(logs, dev.slot_log + (size_t)slot * 4, 4, hipMemcpyDeviceToHost));
+  return ZG_OK;
+}
+int Batch::read_huf_slot(uint32_t slot, std::vector<uint16_t>* entries, int* max_bits) {
+  if (slot >= dev.nhuf_slots) return ZG_BAD_ARG;
+  entries->resize(ZG_HUF_SLOT_U16);
+  uint8_t mb = 0;
+  ZG_HIP(hipMemcpy(entries->data(), dev.huf_arena + (size_t)slot * ZG_HUF_SLOT_U16, ZG_HUF_SLOT_U16 * 2, hipMemcpyDeviceToHost));
+  ZG_HIP(hipMemcpy(&mb, dev.huf_maxbits + slot, 1, hipMemcpyDeviceToHost));
+  *max_bits = mb;
+  return ZG_OK;
+}
+
+}  // namespace zg

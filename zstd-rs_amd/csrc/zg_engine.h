@@ -1,0 +1,100 @@
+// zg_engine.h — one engine per (GPU, HIP stream): device memory, upload of a parsed submit, the kernel
+// pipeline, and result download. Host buffers never enter the kernels; torch is not involved.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "zg_host_parse.h"
+#include "zg_kernels.h"
+
+namespace zg {
+
+// growable device buffer
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t n, bool keep = false, hipStream_t s = nullptr);
+  void release();
+  template <typename T> T* as() const { return (T*)p; }
+};
+
+// What the host knows about each frame of a submit (header fields + where it sits in the input).
+struct FrameInfo {
+  FrameHeader header;
+  uint64_t window_size = 0;
+  uint64_t src_begin = 0, src_end = 0;   // byte range of the frame in the input (header .. checksum)
+  bool has_checksum = false;
+  uint32_t checksum = 0;                 // Content_Checksum read from the data
+  uint32_t nblocks = 0;
+  int host_status = 0;                   // error found while walking the frame (truncated input, bad header, ...)
+};
+
+enum { ZG_T_TABLES = 0, ZG_T_HUF, ZG_T_SEQ, ZG_T_SCAN, ZG_T_LIT, ZG_T_LZ, ZG_T_TOTAL, ZG_T_COUNT };
+
+class Engine;
+
+// One submit: parsed input + its device state. Created by Engine::prepare.
+class Batch {
+ public:
+  ~Batch();
+  BatchBuilder bb;
+  std::vector<FrameInfo> info;
+  std::vector<ZgFrameOut> frame_out;     // valid after sync()
+  uint64_t total_out = 0;                // valid after sync()
+  bool overflow = false;
+  float ms[ZG_T_COUNT] = {0};
+  int parse_status = 0;                  // frame-layer error that stops decode_all (first failing frame's status)
+  uint64_t src_len = 0;
+
+  int run();                             // enqueue the kernel pipeline on the engine's stream
+  int sync();                            // wait, download per-frame results, compute timings
+  int read_output(uint64_t off, uint8_t* dst, uint64_t n);   // D2H
+  const uint8_t* device_output() const { return (const uint8_t*)d_dst.p; }
+  // intermediates, for parity tests
+  int read_block_status(std::vector<uint32_t>* out);
+  int read_literals(uint32_t block, std::vector<uint8_t>* out);
+  int read_sequences(uint32_t block, std::vector<ZgSeq>* seqs, ZgBlockSeqOut* so, ZgBlockPos* pos);
+  int read_fse_slot(uint32_t slot, std::vector<uint32_t>* entries, uint8_t logs[4]);
+  int read_huf_slot(uint32_t slot, std::vector<uint16_t>* entries, int* max_bits);
+
+ private:
+  friend class Engine;
+  Engine* eng = nullptr;
+  ZgBatchDev dev{};
+  DevBuf d_src, d_blocks, d_frames, d_aux, d_slot_log, d_fse, d_huf, d_hufmax, d_status, d_lit, d_seq, d_seqout, d_pos, d_frameout,
+      d_dst, d_seqblocks, d_hufitems, d_hufgroups, d_totals;
+  hipEvent_t ev[ZG_T_COUNT + 1] = {};
+  bool ran = false;
+};
+
+class Engine {
+ public:
+  static int create(int device, Engine** out);
+  ~Engine();
+  uint64_t max_window = kDefaultMaxWindow;
+  // Walk `len` bytes of concatenated frames (decode_all semantics, frame_decoder.rs:541-577), upload everything.
+  // dst_cap_hint: 0 = size the output from the block walk.
+  int prepare(const uint8_t* src, size_t len, Batch** out);
+  // Same for a run of blocks of ONE frame that starts at a block header (the FrameDecoder mirror parsed the frame
+  // header itself). *consumed = bytes of the run (block headers, bodies, checksum).
+  int prepare_run(const uint8_t* src, size_t len, uint64_t window, bool has_checksum, Batch** out, size_t* consumed);
+  hipStream_t stream() const { return stream_; }
+  int device() const { return device_; }
+  std::string last_error;
+
+ private:
+  friend class Batch;
+  int device_ = 0;
+  hipStream_t stream_ = nullptr;
+  int fail(hipError_t e, const char* what);
+  int upload(Batch* b, const uint8_t* src, size_t len, Batch** out);
+};
+
+// Host-only walk of concatenated frames into a BatchBuilder (no GPU involved; unit-tested on CPU).
+int parse_frames(const uint8_t* src, size_t len, uint64_t max_window, BatchBuilder* bb, std::vector<FrameInfo>* info);
+int parse_block_run(const uint8_t* src, size_t len, uint64_t window, bool has_checksum, BatchBuilder* bb, std::vector<FrameInfo>* info,
+                    size_t* consumed);
+
+}  // namespace zg

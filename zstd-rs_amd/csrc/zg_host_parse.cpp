@@ -1,0 +1,248 @@
+// zg_host_parse.cpp — see zg_host_parse.h.
+#include "zg_host_parse.h"
+#include <string.h>
+
+namespace zg {
+
+static uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+
+int read_frame_header(const uint8_t* src, size_t len, FrameHeader* h, size_t* consumed, uint32_t* skip_magic, uint32_t* skip_len) {
+  // ruzstd decoding/frame.rs:6-85
+  *consumed = 0;
+  if (len < 4) return ZG_HEADER_READ;
+  uint32_t magic = rd32(src);
+  size_t p = 4;
+  if (magic >= 0x184D2A50u && magic <= 0x184D2A5Fu) {  // skippable frame, reported like the reference does (:15-23)
+    if (len < 8) return ZG_HEADER_READ;
+    if (skip_magic) *skip_magic = magic;
+    if (skip_len) *skip_len = rd32(src + 4);
+    *consumed = 8;
+    return ZG_SKIP_FRAME;
+  }
+  if (magic != kMagic) return ZG_BAD_MAGIC;
+  if (len < p + 1) return ZG_HEADER_READ;
+  *h = FrameHeader();
+  h->descriptor = src[p++];
+  if (!h->single_segment()) {
+    if (len < p + 1) return ZG_HEADER_READ;
+    h->window_descriptor = src[p++];
+  }
+  static const unsigned kDidLen[4] = {0, 1, 2, 4};  // frame.rs:231-239
+  unsigned dl = kDidLen[h->descriptor & 3];
+  if (dl) {
+    if (len < p + dl) return ZG_HEADER_READ;
+    uint32_t id = 0;
+    for (unsigned i = 0; i < dl; i++) id += (uint32_t)src[p + i] << (8 * i);
+    p += dl;
+    if (id != 0) { h->has_dict_id = true; h->dict_id = id; }  // dict id 0 means "none" (:60-62)
+  }
+  unsigned fl;  // frame.rs:212-226
+  switch (h->descriptor >> 6) {
+    case 0: fl = h->single_segment() ? 1 : 0; break;
+    case 1: fl = 2; break;
+    case 2: fl = 4; break;
+    default: fl = 8; break;
+  }
+  if (fl) {
+    if (len < p + fl) return ZG_HEADER_READ;
+    uint64_t fcs = 0;
+    for (unsigned i = 0; i < fl; i++) fcs += (uint64_t)src[p + i] << (8 * i);
+    if (fl == 2) fcs += 256;  // :78-80
+    h->frame_content_size = fcs;
+    p += fl;
+  }
+  h->header_size = (uint32_t)p;
+  *consumed = p;
+  return ZG_OK;
+}
+
+int frame_window_size(const FrameHeader& h, uint64_t* out) {
+  // frame.rs:116-139: single-segment frames use the content size, with no minimum
+  if (h.single_segment()) { *out = h.frame_content_size; return ZG_OK; }
+  unsigned exp = h.window_descriptor >> 3, mant = h.window_descriptor & 7;
+  uint64_t base = 1ull << (10 + exp), w = base + (base / 8) * mant;
+  if (w < kMinWindow) return ZG_WINDOW_TOO_SMALL;
+  if (w >= kMaxWindow) return ZG_WINDOW_TOO_BIG_SPEC;
+  *out = w;
+  return ZG_OK;
+}
+
+int read_block_header(const uint8_t* p, BlockHeader* h) {
+  // block_decoder.rs:201-247, :249-283
+  h->last = p[0] & 1;
+  h->type = (p[0] >> 1) & 3;
+  if (h->type == 3) return ZG_RESERVED_BLOCK;
+  uint32_t size = (uint32_t)(p[0] >> 3) | ((uint32_t)p[1] << 5) | ((uint32_t)p[2] << 13);
+  if (size > kMaxBlockSize) return ZG_BLOCK_SIZE_TOO_LARGE;
+  h->decompressed_size = (h->type == ZG_BT_COMPRESSED) ? 0 : size;
+  h->content_size = (h->type == ZG_BT_RLE) ? 1 : size;
+  return ZG_OK;
+}
+
+uint32_t BatchBuilder::begin_frame(uint64_t window_size, const uint32_t hist[3], bool has_carry_tables, bool has_carry_huf) {
+  ZgFrame f;
+  memset(&f, 0, sizeof f);
+  f.first_block = (uint32_t)blocks.size();
+  f.nblocks = 0;
+  f.window_size = window_size;
+  f.hist_init[0] = hist[0]; f.hist_init[1] = hist[1]; f.hist_init[2] = hist[2];
+  f.carry_huf_slot = ZG_REF_UNINIT;
+  frames.push_back(f);
+  cur_ = Lineage();
+  if (has_carry_tables) cur_.ll = cur_.of = cur_.ml = kCarry;
+  if (has_carry_huf) cur_.huf = kCarryHuf;
+  frame_failed_ = false;
+  return (uint32_t)frames.size() - 1;
+}
+
+void BatchBuilder::fail_frame(int status) {
+  // a zero-size raw block carrying the error stops the frame at this point
+  ZgBlock b;
+  memset(&b, 0, sizeof b);
+  b.btype = ZG_BT_RAW;
+  b.frame = (uint32_t)frames.size() - 1;
+  b.huf_slot = b.ll_slot = b.of_slot = b.ml_slot = ZG_REF_UNINIT;
+  b.host_status = (uint32_t)status;
+  blocks.push_back(b);
+  frames.back().nblocks++;
+  frame_failed_ = true;
+}
+
+int BatchBuilder::add_block(const BlockHeader& bh, const uint8_t* body, uint64_t src_off) {
+  ZgBlock b;
+  memset(&b, 0, sizeof b);
+  b.src_off = src_off;
+  b.src_len = bh.content_size;
+  b.btype = bh.type;
+  b.frame = (uint32_t)frames.size() - 1;
+  b.huf_slot = b.ll_slot = b.of_slot = b.ml_slot = ZG_REF_UNINIT;
+  const uint32_t bidx = (uint32_t)blocks.size();
+  int st = ZG_OK;
+  if (bh.type != ZG_BT_COMPRESSED) {
+    b.regen_size = bh.decompressed_size;
+    out_bound += b.regen_size;
+  } else {
+    // decompress_block (block_decoder.rs:97-197): header of the literals section
+    const uint32_t n = bh.content_size;
+    out_bound += kMaxBlockSize;
+    do {
+      if (n == 0) { st = ZG_LITERALS_HEADER; break; }               // literals_section.rs:119 (no bits to read)
+      b.lit_type = body[0] & 3;
+      const unsigned sf = (body[0] >> 2) & 3;
+      unsigned need;
+      if (b.lit_type == ZG_LT_RAW || b.lit_type == ZG_LT_RLE) need = (sf == 0 || sf == 2) ? 1 : (sf == 1 ? 2 : 3);
+      else need = sf <= 1 ? 3 : (sf == 2 ? 4 : 5);
+      if (n < need) { st = ZG_LITERALS_HEADER; break; }             // NotEnoughBytes :124-129
+      uint32_t upper;
+      if (b.lit_type == ZG_LT_RAW || b.lit_type == ZG_LT_RLE) {     // :132-159
+        if (sf == 0 || sf == 2) b.regen_size = body[0] >> 3;
+        else if (sf == 1) b.regen_size = (body[0] >> 4) + ((uint32_t)body[1] << 4);
+        else b.regen_size = (body[0] >> 4) + ((uint32_t)body[1] << 4) + ((uint32_t)body[2] << 12);
+        upper = b.lit_type == ZG_LT_RLE ? 1 : b.regen_size;          // block_decoder.rs:120-127
+      } else {                                                      // :161-221
+        b.nstreams = sf == 0 ? 1 : 4;
+        if (sf <= 1) {
+          b.regen_size = (body[0] >> 4) + (((uint32_t)body[1] & 0x3f) << 4);
+          b.lit_comp_size = (body[1] >> 6) + ((uint32_t)body[2] << 2);
+        } else if (sf == 2) {
+          b.regen_size = (body[0] >> 4) + ((uint32_t)body[1] << 4) + (((uint32_t)body[2] & 0x3) << 12);
+          b.lit_comp_size = (body[2] >> 2) + ((uint32_t)body[3] << 6);
+        } else {
+          b.regen_size = (body[0] >> 4) + ((uint32_t)body[1] << 4) + (((uint32_t)body[2] & 0x3F) << 12);
+          b.lit_comp_size = (body[2] >> 6) + ((uint32_t)body[3] << 2) + ((uint32_t)body[4] << 10);
+        }
+        upper = b.lit_comp_size;
+      }
+      b.lit_off = need;
+      if (n - need < upper) { st = ZG_MALFORMED_SECTION_HEADER; break; }  // block_decoder.rs:129-134
+      if (b.lit_type == ZG_LT_COMPRESSED) {
+        cur_.huf = (int32_t)nhuf_slots++;                            // this block defines the Huffman table from now on
+      } else if (b.lit_type == ZG_LT_TREELESS && cur_.huf == ZG_REF_UNINIT) {
+        st = ZG_LIT_UNINIT_HUF; break;                               // literals_section_decoder.rs:60-63
+      }
+      if (b.lit_type >= ZG_LT_COMPRESSED) b.huf_slot = cur_.huf;
+      // sequences section header (sequence_section.rs:108-167)
+      const uint8_t* s = body + need + upper;
+      const uint32_t rem = n - need - upper;
+      if (rem == 0) { st = ZG_SEQUENCES_HEADER; break; }
+      unsigned shl;
+      bool has_modes = false;
+      if (s[0] == 0) { b.nseq = 0; shl = 1; }
+      else if (s[0] < 128) {
+        if (rem < 2) { st = ZG_SEQUENCES_HEADER; break; }
+        b.nseq = s[0]; b.seq_modes = s[1]; has_modes = true; shl = 2;
+      } else if (s[0] < 255) {
+        if (rem < 2) { st = ZG_SEQUENCES_HEADER; break; }
+        b.nseq = (((uint32_t)s[0] - 128) << 8) + s[1]; shl = 2;
+        if (b.nseq != 0) {
+          if (rem < 3) { st = ZG_SEQUENCES_HEADER; break; }
+          b.seq_modes = s[2]; has_modes = true; shl = 3;
+        }
+      } else {
+        if (rem < 4) { st = ZG_SEQUENCES_HEADER; break; }
+        b.nseq = (uint32_t)s[1] + ((uint32_t)s[2] << 8) + 0x7F00; b.seq_modes = s[3]; has_modes = true; shl = 4;
+      }
+      b.seq_off = need + upper + shl;
+      if (b.nseq == 0) {
+        if (rem != shl) { st = ZG_SEQ_EXTRA_BITS; break; }           // block_decoder.rs:184-190
+      } else {
+        if (!has_modes) { st = ZG_SEQ_MISSING_MODE; break; }
+        // maybe_update_fse_tables lineage (sequence_section_decoder.rs:294-410): LL, OF, ML
+        int32_t* cur[3] = {&cur_.ll, &cur_.of, &cur_.ml};
+        const int modes[3] = {b.seq_modes >> 6, (b.seq_modes >> 4) & 3, (b.seq_modes >> 2) & 3};
+        for (int k = 0; k < 3; k++) {
+          if (modes[k] == ZG_MODE_PREDEFINED) *cur[k] = kPredef;
+          else if (modes[k] == ZG_MODE_RLE || modes[k] == ZG_MODE_FSE) *cur[k] = (int32_t)bidx;
+        }
+        b.ll_slot = cur_.ll; b.of_slot = cur_.of; b.ml_slot = cur_.ml;
+        // a Repeat mode with nothing to repeat fails in FSEDecoder::init_state (fse_decoder.rs:33-35); the device
+        // reports it (ZG_FSE_UNINIT) after the table descriptions of the other streams were checked, like the reference
+      }
+    } while (0);
+  }
+  if (frame_failed_ && !st) st = ZG_INTERNAL;
+  b.host_status = (uint32_t)st;
+  if (!st && bh.type == ZG_BT_COMPRESSED) {
+    if (b.lit_type >= ZG_LT_COMPRESSED) { b.lit_base = lit_bytes; lit_bytes += b.regen_size; }
+    if (b.nseq) { b.seq_base = seq_count; seq_count += b.nseq; }
+  }
+  blocks.push_back(b);
+  frames.back().nblocks++;
+  if (st) frame_failed_ = true;
+  return st;
+}
+
+void BatchBuilder::finish() {
+  const uint32_t nb = (uint32_t)blocks.size();
+  const uint32_t block_huf_slots = nhuf_slots;
+  nhuf_slots += (uint32_t)frames.size();
+  for (uint32_t f = 0; f < frames.size(); f++) {
+    frames[f].carry_slot = nb + 1 + f;
+    frames[f].carry_huf_slot = (int32_t)(block_huf_slots + f);
+  }
+  seq_blocks.clear(); huf_items.clear(); huf_groups.clear();
+  for (uint32_t i = 0; i < nb; i++) {
+    ZgBlock& b = blocks[i];
+    if (b.btype != ZG_BT_COMPRESSED || b.host_status) continue;
+    int32_t* sl[3] = {&b.ll_slot, &b.of_slot, &b.ml_slot};
+    for (int k = 0; k < 3; k++) {
+      if (*sl[k] == kPredef) *sl[k] = (int32_t)nb;
+      else if (*sl[k] == kCarry) *sl[k] = (int32_t)frames[b.frame].carry_slot;
+    }
+    if (b.huf_slot == kCarryHuf) b.huf_slot = frames[b.frame].carry_huf_slot;
+    if (b.nseq) seq_blocks.push_back(i);
+    if (b.lit_type >= ZG_LT_COMPRESSED) {
+      for (uint32_t k = 0; k < b.nstreams; k++) {
+        if (huf_groups.empty() || huf_groups.back().slot != b.huf_slot || huf_groups.back().nitems >= 256) {
+          ZgHufGroup g;
+          g.slot = b.huf_slot; g.first_item = (uint32_t)huf_items.size(); g.nitems = 0; g.pad = 0;
+          huf_groups.push_back(g);
+        }
+        huf_items.push_back((i << 2) | k);
+        huf_groups.back().nitems++;
+      }
+    }
+  }
+}
+
+}  // namespace zg

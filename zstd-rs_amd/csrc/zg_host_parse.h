@@ -1,0 +1,87 @@
+// zg_host_parse.h — host side of the boundary: frame header, block headers, the two section headers of a
+// compressed block, and table lineage. This is the work the north star leaves on the host
+// (ruzstd: decoding/frame.rs, block_decoder.rs:201-247, blocks/literals_section.rs:117-223,
+// blocks/sequence_section.rs:108-167); everything per-byte runs in the HIP kernels.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <vector>
+#include "zg_types.h"
+
+namespace zg {
+
+constexpr uint32_t kMagic = 0xFD2FB528u;                       // common/mod.rs:6
+constexpr uint64_t kMinWindow = 1024;                          // common/mod.rs:10
+constexpr uint64_t kMaxWindow = (1ull << 41) + 7ull * (1ull << 38);  // common/mod.rs:14
+constexpr uint32_t kMaxBlockSize = 128 * 1024;                 // common/mod.rs:21
+constexpr uint64_t kDefaultMaxWindow = 1024ull * 1024 * 128;   // frame_decoder.rs:25
+
+struct FrameHeader {          // decoding/frame.rs:88-114
+  uint8_t descriptor = 0;
+  uint8_t window_descriptor = 0;
+  bool has_dict_id = false;
+  uint32_t dict_id = 0;
+  uint64_t frame_content_size = 0;
+  uint32_t header_size = 0;
+  bool single_segment() const { return (descriptor >> 5) & 1; }
+  bool content_checksum() const { return (descriptor >> 2) & 1; }
+  bool has_fcs() const { return (descriptor >> 6) != 0 || single_segment(); }
+};
+
+// read_frame_header (frame.rs:6-85). On ZG_SKIP_FRAME *skip_magic/*skip_len are filled and *consumed = 8.
+int read_frame_header(const uint8_t* src, size_t len, FrameHeader* h, size_t* consumed, uint32_t* skip_magic, uint32_t* skip_len);
+// FrameHeader::window_size (frame.rs:116-139)
+int frame_window_size(const FrameHeader& h, uint64_t* out);
+
+struct BlockHeader {          // blocks/block.rs:31-44
+  bool last = false;
+  uint8_t type = 0;           // ZG_BT_*; 3 = reserved
+  uint32_t decompressed_size = 0;
+  uint32_t content_size = 0;
+};
+// read_block_header (block_decoder.rs:201-247) on 3 bytes. Returns ZG_RESERVED_BLOCK / ZG_BLOCK_SIZE_TOO_LARGE / 0.
+int read_block_header(const uint8_t* p, BlockHeader* h);
+
+// Table lineage of one frame: which arena slot holds the table each entropy stream decodes with right now
+// (the state DecoderScratch carries from block to block, scratch.rs:15-27).
+struct Lineage {
+  int32_t huf = ZG_REF_UNINIT;
+  int32_t ll = ZG_REF_UNINIT, of = ZG_REF_UNINIT, ml = ZG_REF_UNINIT;
+};
+
+// Builds the submit: appends blocks (with parsed section headers and lineage) and frames.
+class BatchBuilder {
+ public:
+  std::vector<ZgBlock> blocks;
+  std::vector<ZgFrame> frames;
+  std::vector<uint32_t> seq_blocks;
+  std::vector<uint32_t> huf_items;
+  std::vector<ZgHufGroup> huf_groups;
+  uint64_t lit_bytes = 0;      // literals arena size
+  uint64_t seq_count = 0;      // sequence arena size
+  uint32_t nhuf_slots = 0;
+  uint64_t out_bound = 0;      // upper bound of the output when every compressed block regenerates <= 128 KiB
+
+  // Start a frame. carry: lineage handed in by a dictionary or an earlier submit (slots are resolved in finish()).
+  uint32_t begin_frame(uint64_t window_size, const uint32_t hist[3], bool has_carry_tables, bool has_carry_huf);
+  // Add one block of the current frame. body points at Block_Content (content_size bytes available).
+  // src_off is the body's offset in the buffer that will be uploaded. Returns the block's host status.
+  int add_block(const BlockHeader& bh, const uint8_t* body, uint64_t src_off);
+  // Mark the current frame as failed at its next block (host-side errors: truncated input, reserved block...).
+  void fail_frame(int status);
+  // Resolve slot numbers and build the work lists. Call once after the last block.
+  void finish();
+
+  uint32_t predefined_slot() const { return (uint32_t)blocks.size(); }
+  uint32_t carry_slot(uint32_t frame) const { return (uint32_t)blocks.size() + 1 + frame; }
+  uint32_t nslots() const { return (uint32_t)blocks.size() + 1 + (uint32_t)frames.size(); }
+
+ private:
+  Lineage cur_;
+  bool frame_failed_ = false;
+  static constexpr int32_t kPredef = -2;   // resolved in finish()
+  static constexpr int32_t kCarry = -3;
+  static constexpr int32_t kCarryHuf = -3;
+};
+
+}  // namespace zg

@@ -1,0 +1,45 @@
+// zg_kernels.h — launch interface of the gfx950 kernels (implemented in zg_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "zg_types.h"
+
+// Device-side view of one submit (all pointers are device pointers).
+struct ZgBatchDev {
+  const uint8_t* src;          // compressed bytes of the whole submit (padded by >= 16 bytes at the end)
+  uint64_t src_len;
+  const ZgBlock* blocks;
+  uint32_t nblocks;
+  const ZgFrame* frames;
+  uint32_t nframes;
+  uint32_t nslots;             // FSE arena slots = nblocks + 1 (predefined) + nframes (carry)
+  uint32_t nhuf_slots;         // Huffman arena slots
+  ZgBlockAux* aux;             // [nblocks]
+  uint8_t* slot_log;           // [nslots][4]: accuracy logs LL, OF, ML of the tables held by each FSE slot
+  uint32_t* fse_arena;         // [nslots][ZG_FSE_SLOT_U32]
+  uint16_t* huf_arena;         // [nhuf_slots][ZG_HUF_SLOT_U16]
+  uint8_t* huf_maxbits;        // [nhuf_slots]
+  uint32_t* status;            // [nblocks] first error per block (ZgStatus), 0 = ok
+  uint8_t* lit_arena;          // regenerated Huffman literals
+  ZgSeq* seq_arena;            // decoded sequences
+  ZgBlockSeqOut* seq_out;      // [nblocks]
+  ZgBlockPos* pos;             // [nblocks]
+  ZgFrameOut* frame_out;       // [nframes]
+  uint8_t* dst;                // decompressed output of the submit (frames back to back)
+  uint64_t dst_cap;
+  const uint8_t* dict;         // dictionary contents (may be null)
+  // work lists
+  const uint32_t* seq_blocks;  // compressed blocks with nseq > 0
+  uint32_t nseq_blocks;
+  const uint32_t* huf_items;   // (block << 2) | stream
+  const ZgHufGroup* huf_groups;
+  uint32_t nhuf_groups;
+  uint32_t* totals;            // [4]: [0..1] total output bytes (u64), [2] overflow flag
+};
+
+void zg_launch_tables(const ZgBatchDev& d, hipStream_t s);
+void zg_launch_huf(const ZgBatchDev& d, hipStream_t s);
+void zg_launch_seq(const ZgBatchDev& d, hipStream_t s);
+void zg_launch_scan(const ZgBatchDev& d, hipStream_t s);
+void zg_launch_lit(const ZgBatchDev& d, hipStream_t s);
+void zg_launch_lz(const ZgBatchDev& d, hipStream_t s);

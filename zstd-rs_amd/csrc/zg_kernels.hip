@@ -1,0 +1,476 @@
+// zg_kernels.hip — gfx950 (MI355X, CDNA4, wave64) kernels of the zstd block-decode engine.
+//
+// Pipeline of one submit (all on one HIP stream, no host round trip in between):
+//   zg_k_tables   one lane per block      FSE table descriptions + Huffman tree descriptions -> table arenas
+//   zg_k_huf      one lane per stream     Huffman literal streams -> literals arena (table staged in LDS)
+//   zg_k_seq      one lane per block      FSE sequence bitstream -> ZgSeq[] (three tables per lane staged in LDS)
+//   zg_k_scan     one workgroup per frame block output positions + offset-history resolution (function-composition scan)
+//   zg_k_scanf    one workgroup           frame output positions
+//   zg_k_lit      one workgroup per block literal runs, raw and RLE blocks -> output
+//   zg_k_lz       one workgroup per frame LZ77 match copies, in order, multi-round resolution inside a batch of sequences
+//
+// The reference functions each kernel reproduces are cited at the lane routines in zg_dev.h.
+#include "zg_kernels.h"
+#include "zg_dev.h"
+
+#define ZG_SEQ_G 8        // blocks (lanes) per workgroup in zg_k_seq: 8 x 5 KiB of tables in LDS -> 4 workgroups per CU
+#define ZG_LZ_T 256       // threads per frame in zg_k_lz
+
+__device__ __forceinline__ void zg_set_status(uint32_t* status, uint32_t b, int st) {
+  if (st) atomicCAS(&status[b], 0u, (uint32_t)st);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// zg_k_tables: table descriptions. One lane per block (+ one lane that builds the predefined tables).
+// Reproduces maybe_update_fse_tables (sequence_section_decoder.rs:294-410) and
+// HuffmanTable::build_decoder (huff0_decoder.rs:117-124) for the blocks that define tables.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) zg_k_tables(ZgBatchDev d) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  int16_t probs[256];
+  uint16_t counter[256];
+  if (b == d.nblocks) {  // predefined tables (acc logs 6/5/6)
+    uint32_t* slot = d.fse_arena + (uint64_t)d.nblocks * ZG_FSE_SLOT_U32;
+    for (int i = 0; i < 36; i++) probs[i] = ZG_LL_DEFAULT[i];
+    zg_fse_build(probs, 36, 6, ZG_KIND_LL, slot + ZG_FSE_LL_OFF, counter);
+    for (int i = 0; i < 29; i++) probs[i] = ZG_OF_DEFAULT[i];
+    zg_fse_build(probs, 29, 5, ZG_KIND_OF, slot + ZG_FSE_OF_OFF, counter);
+    for (int i = 0; i < 53; i++) probs[i] = ZG_ML_DEFAULT[i];
+    zg_fse_build(probs, 53, 6, ZG_KIND_ML, slot + ZG_FSE_ML_OFF, counter);
+    uint8_t* lg = d.slot_log + (uint64_t)d.nblocks * 4;
+    lg[0] = 6; lg[1] = 5; lg[2] = 6; lg[3] = 0;
+    return;
+  }
+  if (b >= d.nblocks) return;
+  const ZgBlock blk = d.blocks[b];
+  if (blk.host_status || blk.btype != ZG_BT_COMPRESSED) return;
+  const uint8_t* body = d.src + blk.src_off;
+  ZgBlockAux aux;
+  aux.seq_bits_off = blk.seq_off; aux.huf_desc_bytes = 0; aux.log[0] = aux.log[1] = aux.log[2] = 0; aux.pad = 0;
+  int st = ZG_OK;
+  if (blk.lit_type == ZG_LT_COMPRESSED) {
+    uint8_t weights[264];
+    uint32_t fsew[64];
+    int nw = 0, mb = 0;
+    uint32_t used = 0;
+    st = zg_huf_read_weights(body + blk.lit_off, blk.lit_comp_size, weights, &nw, &used, fsew, probs, counter);
+    if (!st) st = zg_huf_build(weights, nw, d.huf_arena + (uint64_t)blk.huf_slot * ZG_HUF_SLOT_U16, &mb);
+    if (!st) { d.huf_maxbits[blk.huf_slot] = (uint8_t)mb; aux.huf_desc_bytes = used; }
+  }
+  if (!st && blk.nseq > 0) {
+    const uint8_t* p = body + blk.seq_off;
+    uint32_t rem = blk.src_len - blk.seq_off;
+    uint32_t* slot = d.fse_arena + (uint64_t)b * ZG_FSE_SLOT_U32;
+    // order LL, OF, ML (sequence_section_decoder.rs:305,341,376)
+    const int kinds[3] = {ZG_KIND_LL, ZG_KIND_OF, ZG_KIND_ML};
+    const int modes[3] = {blk.seq_modes >> 6, (blk.seq_modes >> 4) & 3, (blk.seq_modes >> 2) & 3};
+    const int max_log[3] = {9, 8, 9}, max_sym[3] = {35, 31, 52};
+    const uint32_t offs[3] = {ZG_FSE_LL_OFF, ZG_FSE_OF_OFF, ZG_FSE_ML_OFF};
+    for (int k = 0; k < 3 && !st; k++) {
+      if (modes[k] == ZG_MODE_FSE) {
+        int np, al;
+        uint32_t used;
+        st = zg_fse_read_probs(p, rem, max_log[k], max_sym[k], probs, &np, &al, &used);
+        if (!st) st = zg_fse_build(probs, np, al, kinds[k], slot + offs[k], counter);
+        if (!st) { aux.log[k] = (uint8_t)al; p += used; rem -= used; }
+      } else if (modes[k] == ZG_MODE_RLE) {
+        if (rem == 0) st = ZG_SEQ_RLE_BYTE;
+        else if (p[0] > max_sym[k]) st = ZG_SEQ_RLE_BYTE;
+        else { slot[offs[k]] = zg_fse_pack(kinds[k], 0, 0, p[0]); aux.log[k] = 0; p += 1; rem -= 1; }
+      }
+    }
+    aux.seq_bits_off = (uint32_t)(p - body);
+    uint8_t* lg = d.slot_log + (uint64_t)b * 4;
+    lg[0] = aux.log[0]; lg[1] = aux.log[1]; lg[2] = aux.log[2]; lg[3] = 0;
+  }
+  d.aux[b] = aux;
+  zg_set_status(d.status, b, st);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// zg_k_huf: Huffman literal streams (literals_section_decoder.rs:40-158). One workgroup per group of streams
+// that share a table; the table (<= 2^11 x 2 B) is staged in LDS; one lane decodes one stream.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) zg_k_huf(ZgBatchDev d) {
+  __shared__ uint16_t s_tab[ZG_HUF_SLOT_U16];
+  const ZgHufGroup grp = d.huf_groups[blockIdx.x];
+  unsigned max_bits = grp.slot >= 0 ? d.huf_maxbits[grp.slot] : 0;
+  if (max_bits > 11) max_bits = 0;
+  if (max_bits) {
+    const uint16_t* g = d.huf_arena + (uint64_t)grp.slot * ZG_HUF_SLOT_U16;
+    for (uint32_t i = threadIdx.x; i < (1u << max_bits); i += blockDim.x) s_tab[i] = g[i];
+  }
+  __syncthreads();
+  if (threadIdx.x >= grp.nitems) return;
+  uint32_t item = d.huf_items[grp.first_item + threadIdx.x];
+  uint32_t b = item >> 2, k = item & 3;
+  const ZgBlock blk = d.blocks[b];
+  if (max_bits == 0) { zg_set_status(d.status, b, ZG_LIT_UNINIT_HUF); return; }  // literals_section_decoder.rs:60-63
+  if (d.status[b]) return;                                                        // its own tree description failed
+  uint32_t desc = blk.lit_type == ZG_LT_COMPRESSED ? d.aux[b].huf_desc_bytes : 0;
+  if (desc > blk.lit_comp_size) { zg_set_status(d.status, b, ZG_INTERNAL); return; }
+  const uint8_t* pay = d.src + blk.src_off + blk.lit_off + desc;
+  uint32_t total = blk.lit_comp_size - desc;
+  uint32_t regen = blk.regen_size;
+  uint8_t* lit = d.lit_arena + blk.lit_base;
+  const uint8_t* sp;
+  uint32_t slen, doff, cap;
+  if (blk.nstreams == 4) {
+    if (total < 6) { zg_set_status(d.status, b, ZG_LIT_MISSING_JUMP); return; }
+    uint32_t j1 = zg_ld16(pay), j2 = j1 + zg_ld16(pay + 2), j3 = j2 + zg_ld16(pay + 4);
+    uint32_t rest = total - 6;
+    if (rest < j3) { zg_set_status(d.status, b, ZG_LIT_MISSING_BYTES); return; }
+    uint32_t start = k == 0 ? 0 : k == 1 ? j1 : k == 2 ? j2 : j3;
+    uint32_t end = k == 0 ? j1 : k == 1 ? j2 : k == 2 ? j3 : rest;
+    sp = pay + 6 + start; slen = end - start;
+    uint32_t seg = (regen + 3) / 4;
+    doff = k * seg; if (doff > regen) doff = regen;
+    cap = k < 3 ? seg : regen - doff;
+    if (cap > regen - doff) cap = regen - doff;
+  } else {
+    sp = pay; slen = total; doff = 0; cap = regen;
+  }
+  uint32_t count = 0;
+  int32_t endbits = 0;
+  int st = zg_huf_decode_stream((const uint8_t*)sp, slen, (const uint16_t*)s_tab, max_bits, lit + doff, cap, &count, &endbits);
+  if (!st && blk.nstreams == 4 && endbits != -(int32_t)max_bits) st = ZG_LIT_BITSTREAM_MISMATCH;  // :116-121
+  if (!st && count != cap) st = ZG_LIT_COUNT_MISMATCH;                                              // :150-155 (per stream, spec split)
+  zg_set_status(d.status, b, st);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// zg_k_seq: sequence sections (decode_sequences, sequence_section_decoder.rs:14-221). The bitstream of a block is
+// one serial chain, so one lane owns one block; ZG_SEQ_G lanes of a wave work on ZG_SEQ_G blocks with their
+// three tables staged in LDS by all 64 lanes.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
+  __shared__ uint32_t s_tab[ZG_SEQ_G][ZG_FSE_SLOT_U32];
+  __shared__ uint8_t s_log[ZG_SEQ_G][4];
+  __shared__ int s_ok[ZG_SEQ_G];
+  const uint32_t base = blockIdx.x * ZG_SEQ_G;
+  for (uint32_t g = 0; g < ZG_SEQ_G; g++) {
+    uint32_t idx = base + g;
+    if (idx >= d.nseq_blocks) break;
+    uint32_t b = d.seq_blocks[idx];
+    const ZgBlock* blk = &d.blocks[b];
+    int32_t sl[3] = {blk->ll_slot, blk->of_slot, blk->ml_slot};
+    const uint32_t offs[3] = {ZG_FSE_LL_OFF, ZG_FSE_OF_OFF, ZG_FSE_ML_OFF};
+    bool ok = d.status[b] == 0;
+    for (int k = 0; k < 3; k++) {
+      if (sl[k] < 0) { ok = false; continue; }
+      if ((uint32_t)sl[k] < d.nblocks && d.status[sl[k]] != 0) { ok = false; continue; }  // defining block failed
+      unsigned lg = d.slot_log[(uint64_t)sl[k] * 4 + k];
+      if (lg > 9) { ok = false; continue; }
+      const uint32_t* g_t = d.fse_arena + (uint64_t)sl[k] * ZG_FSE_SLOT_U32 + offs[k];
+      for (uint32_t i = threadIdx.x; i < (1u << lg); i += 64) s_tab[g][offs[k] + i] = g_t[i];
+      if (threadIdx.x == 0) s_log[g][k] = (uint8_t)lg;
+    }
+    if (threadIdx.x == 0) s_ok[g] = ok ? 1 : 0;
+  }
+  __syncthreads();
+  uint32_t g = threadIdx.x;
+  if (g >= ZG_SEQ_G || base + g >= d.nseq_blocks) return;
+  uint32_t b = d.seq_blocks[base + g];
+  const ZgBlock blk = d.blocks[b];
+  if (!s_ok[g]) {
+    // FSEDecoder::init_state on a table that was never set (fse_decoder.rs:33-35), or an upstream failure
+    zg_set_status(d.status, b, ZG_FSE_UNINIT);
+    return;
+  }
+  uint32_t bits_off = d.aux[b].seq_bits_off;
+  if (bits_off > blk.src_len) { zg_set_status(d.status, b, ZG_INTERNAL); return; }
+  const uint8_t* bs = d.src + blk.src_off + bits_off;
+  ZgBlockSeqOut so;
+  int st = zg_seq_decode_block((const uint8_t*)bs, blk.src_len - bits_off, blk.nseq, (const uint32_t*)&s_tab[g][ZG_FSE_LL_OFF], s_log[g][0],
+                               (const uint32_t*)&s_tab[g][ZG_FSE_OF_OFF], s_log[g][1], (const uint32_t*)&s_tab[g][ZG_FSE_ML_OFF], s_log[g][2],
+                               blk.regen_size, d.seq_arena + blk.seq_base, &so);
+  d.seq_out[b] = so;
+  zg_set_status(d.status, b, st);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// zg_k_scan: per frame — output position of every block and the offset history at every block start.
+// The history recurrence (sequence_execution.rs:59-118; never reset between blocks, scratch.rs:22) is a
+// composition of per-block maps on three symbolic slots, so it is scanned like a prefix sum.
+// ------------------------------------------------------------------------------------------------------------
+struct ZgHistMap { uint32_t s[3]; };
+__device__ __forceinline__ ZgHistMap zg_map_identity() { return {{1u << 30, 2u << 30, 3u << 30}}; }
+// apply A first, then B
+__device__ __forceinline__ ZgHistMap zg_map_compose(const ZgHistMap& A, const ZgHistMap& B) {
+  ZgHistMap r;
+  for (int i = 0; i < 3; i++) {
+    uint32_t v = B.s[i], t = ZG_SYM_TAG(v);
+    if (!t) { r.s[i] = v; continue; }
+    uint32_t a = A.s[t - 1], k = ZG_SYM_K(v);
+    if (ZG_SYM_TAG(a)) {
+      uint32_t kk = ZG_SYM_K(a) + k;
+      if (kk > 0x3FFFFFFFu) kk = 0x3FFFFFFFu;
+      r.s[i] = (a & 0xC0000000u) | kk;
+    } else r.s[i] = a > k ? a - k : 0;
+  }
+  return r;
+}
+
+__global__ void __launch_bounds__(256) zg_k_scan(ZgBatchDev d) {
+  __shared__ uint64_t s_size[256];
+  __shared__ ZgHistMap s_map[256];
+  __shared__ uint32_t s_bad;       // chunk-local index of the first failing block
+  __shared__ uint32_t s_badst;
+  const uint32_t f = blockIdx.x, t = threadIdx.x;
+  const ZgFrame fr = d.frames[f];
+  uint64_t carry_size = 0;
+  ZgHistMap carry_map = zg_map_identity();
+  uint32_t good = fr.nblocks, bad_status = 0;
+  for (uint32_t c0 = 0; c0 < fr.nblocks; c0 += 256) {
+    uint32_t i = c0 + t;
+    bool have = i < fr.nblocks;
+    uint32_t b = fr.first_block + i;
+    uint64_t size = 0;
+    ZgHistMap m = zg_map_identity();
+    uint32_t st = 0;
+    if (t == 0) { s_bad = 0xFFFFFFFFu; s_badst = 0; }
+    __syncthreads();
+    if (have) {
+      const ZgBlock* blk = &d.blocks[b];
+      st = blk->host_status ? blk->host_status : d.status[b];
+      if (blk->btype != ZG_BT_COMPRESSED) size = blk->regen_size;
+      else if (blk->nseq == 0) size = blk->regen_size;
+      else {
+        const ZgBlockSeqOut so = d.seq_out[b];
+        size = (uint64_t)blk->regen_size + so.sum_ml;
+        m.s[0] = so.hist_end[0]; m.s[1] = so.hist_end[1]; m.s[2] = so.hist_end[2];
+      }
+      if (st) atomicMin(&s_bad, t);
+    }
+    __syncthreads();
+    const uint32_t bad = s_bad;
+    if (t >= bad) { size = 0; m = zg_map_identity(); }  // the failing block and everything after it produce nothing
+    s_size[t] = size;
+    s_map[t] = m;
+    __syncthreads();
+    // inclusive Hillis-Steele scans over the chunk
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+      uint64_t vs = 0;
+      ZgHistMap vm = zg_map_identity();
+      bool take = t >= off;
+      if (take) { vs = s_size[t - off]; vm = s_map[t - off]; }
+      __syncthreads();
+      if (take) { s_size[t] += vs; s_map[t] = zg_map_compose(vm, s_map[t]); }
+      __syncthreads();
+    }
+    if (have) {
+      uint64_t excl = carry_size + (t ? s_size[t - 1] : 0);
+      ZgHistMap pre = t ? zg_map_compose(carry_map, s_map[t - 1]) : carry_map;
+      ZgBlockPos p;
+      p.out_base = excl;
+      p.hist_init[0] = zg_sym_resolve(pre.s[0], fr.hist_init);
+      p.hist_init[1] = zg_sym_resolve(pre.s[1], fr.hist_init);
+      p.hist_init[2] = zg_sym_resolve(pre.s[2], fr.hist_init);
+      p.active = t < bad ? 1u : 0u;
+      d.pos[b] = p;
+      if (t == bad) s_badst = st;
+    }
+    __syncthreads();
+    if (bad != 0xFFFFFFFFu) {  // sizes / maps of blocks from the failing one on are zero / identity
+      good = c0 + bad;
+      bad_status = s_badst;
+      carry_size += s_size[255];
+      carry_map = zg_map_compose(carry_map, s_map[255]);
+      // blocks after this chunk are inactive
+      for (uint32_t j = c0 + 256 + t; j < fr.nblocks; j += 256) d.pos[fr.first_block + j].active = 0;
+      break;
+    }
+    carry_size += s_size[255];
+    carry_map = zg_map_compose(carry_map, s_map[255]);
+    __syncthreads();
+  }
+  if (t == 0) {
+    ZgFrameOut fo;
+    fo.out_base = 0; fo.out_size = carry_size; fo.status = bad_status; fo.bad_block = good;
+    fo.hist_end[0] = zg_sym_resolve(carry_map.s[0], fr.hist_init);
+    fo.hist_end[1] = zg_sym_resolve(carry_map.s[1], fr.hist_init);
+    fo.hist_end[2] = zg_sym_resolve(carry_map.s[2], fr.hist_init);
+    fo.good_blocks = good;
+    d.frame_out[f] = fo;
+  }
+}
+
+// frames are laid out back to back in the output, like FrameDecoder::decode_all (frame_decoder.rs:541-577)
+__global__ void __launch_bounds__(1024) zg_k_scanf(ZgBatchDev d) {
+  __shared__ uint64_t s_v[1024];
+  const uint32_t t = threadIdx.x;
+  uint64_t carry = 0;
+  for (uint32_t c0 = 0; c0 < d.nframes; c0 += 1024) {
+    uint32_t f = c0 + t;
+    s_v[t] = (f < d.nframes && !d.frames[f].fixed_base) ? d.frame_out[f].out_size : 0;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+      uint64_t v = t >= off ? s_v[t - off] : 0;
+      __syncthreads();
+      s_v[t] += v;
+      __syncthreads();
+    }
+    if (f < d.nframes) d.frame_out[f].out_base = d.frames[f].fixed_base ? d.frames[f].out_base_fixed : carry + (t ? s_v[t - 1] : 0);
+    carry += s_v[1023];
+    __syncthreads();
+  }
+  if (t == 0) {
+    d.totals[0] = (uint32_t)carry; d.totals[1] = (uint32_t)(carry >> 32);
+    uint32_t over = carry > d.dst_cap ? 1u : 0u;
+    for (uint32_t f = 0; f < d.nframes; f++)
+      if (d.frames[f].fixed_base && d.frames[f].out_base_fixed + d.frame_out[f].out_size > d.dst_cap) over = 1u;
+    d.totals[2] = over;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// zg_k_lit: everything that does not depend on earlier output — literal runs of compressed blocks
+// (DecodeBuffer::push, decode_buffer.rs:74-77), raw blocks and RLE blocks (block_decoder.rs:55-82).
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void zg_wg_copy(uint8_t* dst, const uint8_t* src, uint64_t n, uint32_t t, uint32_t T) {
+  uint64_t n8 = n >> 3;
+  for (uint64_t i = t; i < n8; i += T) ((zg_u64u*)(dst + i * 8))->v = zg_ld64(src + i * 8);
+  for (uint64_t i = (n8 << 3) + t; i < n; i += T) dst[i] = src[i];
+}
+__device__ __forceinline__ void zg_wg_fill(uint8_t* dst, uint8_t byte, uint64_t n, uint32_t t, uint32_t T) {
+  uint64_t v = 0x0101010101010101ull * byte, n8 = n >> 3;
+  for (uint64_t i = t; i < n8; i += T) ((zg_u64u*)(dst + i * 8))->v = v;
+  for (uint64_t i = (n8 << 3) + t; i < n; i += T) dst[i] = byte;
+}
+
+__global__ void __launch_bounds__(256) zg_k_lit(ZgBatchDev d) {
+  if (d.totals[2]) return;
+  const uint32_t b = blockIdx.x, t = threadIdx.x;
+  const ZgBlockPos p = d.pos[b];
+  if (!p.active) return;
+  const ZgBlock blk = d.blocks[b];
+  uint8_t* out = d.dst + d.frame_out[blk.frame].out_base + p.out_base;
+  const uint8_t* body = d.src + blk.src_off;
+  if (blk.btype == ZG_BT_RAW) { zg_wg_copy(out, body, blk.regen_size, t, 256); return; }
+  if (blk.btype == ZG_BT_RLE) { zg_wg_fill(out, body[0], blk.regen_size, t, 256); return; }
+  const bool rle = blk.lit_type == ZG_LT_RLE;
+  const uint8_t* lit = blk.lit_type == ZG_LT_RAW ? body + blk.lit_off : blk.lit_type == ZG_LT_RLE ? body + blk.lit_off : d.lit_arena + blk.lit_base;
+  uint32_t sum_ll = 0, sum_ml = 0;
+  if (blk.nseq) {
+    const ZgBlockSeqOut so = d.seq_out[b];
+    sum_ll = so.sum_ll; sum_ml = so.sum_ml;
+    const ZgSeq* sq = d.seq_arena + blk.seq_base;
+    for (uint32_t i = t; i < blk.nseq; i += 256) {
+      const ZgSeq q = sq[i];
+      uint32_t next = i + 1 < blk.nseq ? sq[i + 1].lit_start : sum_ll;
+      uint32_t ll = next - q.lit_start;
+      uint8_t* o = out + (q.mdst - ll);
+      if (rle) { uint8_t v = lit[0]; for (uint32_t k = 0; k < ll; k++) o[k] = v; }
+      else { const uint8_t* s = lit + q.lit_start; for (uint32_t k = 0; k < ll; k++) o[k] = s[k]; }
+    }
+  }
+  // trailing literals (sequence_execution.rs:40-44) or the whole section when there are no sequences (block_decoder.rs:192)
+  uint32_t rest = blk.regen_size - sum_ll;
+  uint8_t* o = out + ((uint64_t)sum_ll + sum_ml);
+  if (rle) zg_wg_fill(o, lit[0], rest, t, 256);
+  else zg_wg_copy(o, lit + sum_ll, rest, t, 256);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// zg_k_lz: match copies (DecodeBuffer::repeat / repeat_in_chunks, decode_buffer.rs:79-141). One workgroup walks
+// its frame in order. A batch of ZG_LZ_T consecutive sequences is resolved in rounds: every lane owns one match;
+// a match is copied once all of its source bytes lie below the high-water mark (the destination of the first
+// match of the batch that is still pending); the first pending match always qualifies, so each round progresses.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void zg_lane_match_copy(uint8_t* dst, uint32_t off, uint32_t ml) {
+  const uint8_t* src = dst - off;
+  uint32_t k = 0;
+  if (off >= 8) {
+    for (; k + 8 <= ml; k += 8) ((zg_u64u*)(dst + k))->v = zg_ld64(src + k);
+  }
+  for (; k < ml; k++) dst[k] = src[k];  // also the overlapping case (offset < match length): periodic extension
+}
+
+__global__ void __launch_bounds__(ZG_LZ_T) zg_k_lz(ZgBatchDev d) {
+  __shared__ uint32_t s_min[ZG_LZ_T / 64];
+  __shared__ uint32_t s_err;
+  __shared__ uint32_t s_errblk;
+  if (d.totals[2]) return;
+  const uint32_t f = blockIdx.x, t = threadIdx.x;
+  const ZgFrame fr = d.frames[f];
+  const ZgFrameOut fo = d.frame_out[f];
+  uint8_t* frame_out = d.dst + fo.out_base;
+  if (t == 0) { s_err = 0; s_errblk = 0; }
+  __syncthreads();
+  for (uint32_t bi = 0; bi < fo.good_blocks; bi++) {
+    const uint32_t b = fr.first_block + bi;
+    const ZgBlock* blk = &d.blocks[b];
+    if (blk->btype != ZG_BT_COMPRESSED || blk->nseq == 0) continue;
+    const uint32_t nseq = blk->nseq;
+    const ZgBlockPos p = d.pos[b];
+    const ZgSeq* sq = d.seq_arena + blk->seq_base;
+    for (uint32_t s0 = 0; s0 < nseq; s0 += ZG_LZ_T) {
+      const uint32_t i = s0 + t;
+      bool pending = false;
+      uint32_t off = 0, ml = 0, mdst = 0xFFFFFFFFu;
+      uint64_t dpos = 0;  // frame-relative position of the match destination
+      if (i < nseq) {
+        const ZgSeq q = sq[i];
+        off = zg_sym_resolve(q.of, p.hist_init);
+        ml = q.ml; mdst = q.mdst;
+        dpos = p.out_base + mdst;
+        if (off == 0) { atomicCAS(&s_err, 0u, (uint32_t)ZG_EXE_ZERO_OFFSET); }
+        else if ((uint64_t)off > dpos + fr.prior_out + fr.dict_len) { atomicCAS(&s_err, 0u, (uint32_t)ZG_EXE_OFFSET_TOO_BIG); }
+        else pending = ml > 0;
+      }
+      __syncthreads();
+      if (s_err) break;
+      for (;;) {
+        // high-water mark = smallest destination among pending matches of this batch
+        uint32_t m = pending ? mdst : 0xFFFFFFFFu;
+        for (int sh = 32; sh >= 1; sh >>= 1) { uint32_t o = __shfl_xor(m, sh, 64); m = o < m ? o : m; }
+        if ((t & 63) == 0) s_min[t >> 6] = m;
+        __syncthreads();
+        uint32_t hwm = s_min[0];
+        for (int w = 1; w < ZG_LZ_T / 64; w++) hwm = s_min[w] < hwm ? s_min[w] : hwm;
+        if (hwm == 0xFFFFFFFFu) break;
+        if (pending) {
+          // source bytes that must already exist: [dpos - off, min(dpos - off + ml, dpos))
+          uint64_t need_end = ml < off ? dpos - off + ml : dpos;
+          if (need_end <= p.out_base + hwm) {
+            zg_lane_match_copy(frame_out + dpos, off, ml);
+            pending = false;
+          }
+        }
+        __syncthreads();  // makes the copies visible to the other waves of this workgroup (same CU, shared L1)
+      }
+      __syncthreads();
+    }
+    if (s_err) { if (t == 0) s_errblk = bi; break; }
+  }
+  __syncthreads();
+  if (t == 0 && s_err) {
+    d.frame_out[f].status = s_err;
+    d.frame_out[f].bad_block = s_errblk;
+    d.frame_out[f].good_blocks = s_errblk;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------------------
+void zg_launch_tables(const ZgBatchDev& d, hipStream_t s) {
+  uint32_t n = d.nblocks + 1;
+  hipLaunchKernelGGL(zg_k_tables, dim3((n + 63) / 64), dim3(64), 0, s, d);
+}
+void zg_launch_huf(const ZgBatchDev& d, hipStream_t s) {
+  if (d.nhuf_groups) hipLaunchKernelGGL(zg_k_huf, dim3(d.nhuf_groups), dim3(256), 0, s, d);
+}
+void zg_launch_seq(const ZgBatchDev& d, hipStream_t s) {
+  if (d.nseq_blocks) hipLaunchKernelGGL(zg_k_seq, dim3((d.nseq_blocks + ZG_SEQ_G - 1) / ZG_SEQ_G), dim3(64), 0, s, d);
+}
+void zg_launch_scan(const ZgBatchDev& d, hipStream_t s) {
+  hipLaunchKernelGGL(zg_k_scan, dim3(d.nframes), dim3(256), 0, s, d);
+  hipLaunchKernelGGL(zg_k_scanf, dim3(1), dim3(1024), 0, s, d);
+}
+void zg_launch_lit(const ZgBatchDev& d, hipStream_t s) {
+  if (d.nblocks) hipLaunchKernelGGL(zg_k_lit, dim3(d.nblocks), dim3(256), 0, s, d);
+}
+void zg_launch_lz(const ZgBatchDev& d, hipStream_t s) {
+  hipLaunchKernelGGL(zg_k_lz, dim3(d.nframes), dim3(ZG_LZ_T), 0, s, d);
+}

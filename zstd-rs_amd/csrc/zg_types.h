@@ -1,0 +1,166 @@
+// zg_types.h — plain structs shared by the host parser, the engine and the HIP kernels.
+//
+// Vocabulary follows the reference (ruzstd): frames, blocks, literals section, sequences section,
+// FSE tables (LL/OF/ML), Huffman table, offset history, decode window.
+#pragma once
+#include <stdint.h>
+
+// Status codes. Each maps onto a leaf of the reference's error enums (ruzstd/src/decoding/errors.rs);
+// the C ABI (include/zgpu.h) re-exports them as ZGPU_E_*.
+enum ZgStatus : int32_t {
+  ZG_OK = 0,
+  // frame layer — FrameDecoderError / ReadFrameHeaderError / FrameHeaderError
+  ZG_SKIP_FRAME = 1,
+  ZG_BAD_MAGIC = 2,
+  ZG_HEADER_READ = 3,
+  ZG_WINDOW_TOO_BIG_SPEC = 4,
+  ZG_WINDOW_TOO_SMALL = 5,
+  ZG_WINDOW_SIZE_TOO_BIG = 6,
+  ZG_DICT_NOT_PROVIDED = 7,
+  ZG_NOT_INITIALIZED = 8,
+  ZG_FAILED_READ_BLOCK_HEADER = 9,
+  ZG_FAILED_READ_BLOCK_BODY = 10,
+  ZG_FAILED_READ_CHECKSUM = 11,
+  ZG_TARGET_TOO_SMALL = 12,
+  ZG_FAILED_SKIP_FRAME = 13,
+  // block layer — BlockHeaderReadError / DecompressBlockError
+  ZG_RESERVED_BLOCK = 20,
+  ZG_BLOCK_SIZE_TOO_LARGE = 21,
+  ZG_MALFORMED_SECTION_HEADER = 22,
+  ZG_LITERALS_HEADER = 23,
+  ZG_SEQUENCES_HEADER = 24,
+  // literals — DecompressLiteralsError / HuffmanTableError
+  ZG_LIT_UNINIT_HUF = 30,
+  ZG_LIT_MISSING_JUMP = 31,
+  ZG_LIT_MISSING_BYTES = 32,
+  ZG_LIT_EXTRA_PADDING = 33,
+  ZG_LIT_BITSTREAM_MISMATCH = 34,
+  ZG_LIT_COUNT_MISMATCH = 35,
+  ZG_HUF_TABLE = 36,
+  // sequences — DecodeSequenceError / FSETableError / FSEDecoderError
+  ZG_FSE_TABLE = 40,
+  ZG_FSE_UNINIT = 41,
+  ZG_SEQ_MISSING_MODE = 42,
+  ZG_SEQ_RLE_BYTE = 43,
+  ZG_SEQ_EXTRA_PADDING = 44,
+  ZG_SEQ_UNSUPPORTED_OFFSET = 45,
+  ZG_SEQ_NOT_ENOUGH_BYTES = 46,
+  ZG_SEQ_EXTRA_BITS = 47,
+  // execution — ExecuteSequencesError / DecodeBufferError
+  ZG_EXE_NOT_ENOUGH_LITERALS = 50,
+  ZG_EXE_ZERO_OFFSET = 51,
+  ZG_EXE_OFFSET_TOO_BIG = 52,
+  ZG_EXE_DICT_TOO_SMALL = 53,
+  ZG_DICT_DECODE = 60,
+  // engine limits (inputs the reference would accept or panic on; documented in DESIGN.md)
+  ZG_UNSUPPORTED = 80,         // e.g. uneven 4-stream Huffman split, block regenerating > 2^31 bytes
+  ZG_INTERNAL = 90,            // where the reference would panic/assert
+  ZG_NOMEM = 91,
+  ZG_HIP_ERROR = 92,
+  ZG_BAD_ARG = 93
+};
+
+enum { ZG_BT_RAW = 0, ZG_BT_RLE = 1, ZG_BT_COMPRESSED = 2 };
+enum { ZG_LT_RAW = 0, ZG_LT_RLE = 1, ZG_LT_COMPRESSED = 2, ZG_LT_TREELESS = 3 };
+enum { ZG_MODE_PREDEFINED = 0, ZG_MODE_RLE = 1, ZG_MODE_FSE = 2, ZG_MODE_REPEAT = 3 };
+
+// FSE table arena: one slot per block of the batch + 1 predefined slot + 1 carry slot per frame.
+// Slot layout in u32 entries: [LL 512][ML 512][OF 256].
+#define ZG_FSE_SLOT_U32 1280
+#define ZG_FSE_LL_OFF 0
+#define ZG_FSE_ML_OFF 512
+#define ZG_FSE_OF_OFF 1024
+// Huffman table arena: one slot of 2048 u16 per table.
+#define ZG_HUF_SLOT_U16 2048
+#define ZG_REF_UNINIT (-1)
+
+// Packed FSE decode entry (u32): [0,16) next-state base_line, [16,20) num_bits, [20,26) symbol (code),
+// [26,31) number of extra bits that code reads from the stream.
+#define ZG_FSE_PACK(bl, nb, sym, xb) ((uint32_t)(bl) | ((uint32_t)(nb) << 16) | ((uint32_t)(sym) << 20) | ((uint32_t)(xb) << 26))
+#define ZG_FSE_BL(e) ((e) & 0xFFFFu)
+#define ZG_FSE_NB(e) (((e) >> 16) & 15u)
+#define ZG_FSE_SYM(e) (((e) >> 20) & 63u)
+#define ZG_FSE_XB(e) (((e) >> 26) & 31u)
+// Huffman-weight FSE tables hold 8-bit symbols: [0,16) base_line, [16,20) num_bits, [20,28) symbol.
+#define ZG_FSEW_PACK(bl, nb, sym) ((uint32_t)(bl) | ((uint32_t)(nb) << 16) | ((uint32_t)(sym) << 20))
+#define ZG_FSEW_SYM(e) (((e) >> 20) & 255u)
+// Packed Huffman entry (u16): low byte symbol, high byte num_bits.
+#define ZG_HUF_PACK(sym, nb) ((uint16_t)((sym) | ((nb) << 8)))
+
+// One block as described by the host parser (block header + both section headers + table lineage).
+struct ZgBlock {
+  uint64_t src_off;        // offset of the block body in the compressed buffer
+  uint32_t src_len;        // body length (Block_Content: 1 for RLE blocks)
+  uint32_t regen_size;     // raw/RLE block: decompressed size; compressed block: literals regenerated size
+  uint32_t lit_comp_size;  // compressed/treeless literals: compressed size (tree description included)
+  uint32_t lit_off;        // offset in the body of the literals payload (after the 1-5 byte header)
+  uint32_t seq_off;        // offset in the body of the first byte after the sequences header
+  uint32_t nseq;           // number of sequences
+  uint8_t btype;           // ZG_BT_*
+  uint8_t lit_type;        // ZG_LT_*
+  uint8_t nstreams;        // 1 or 4 (Huffman literals)
+  uint8_t seq_modes;       // modes byte (LL bits 7-6, OF 5-4, ML 3-2)
+  uint32_t frame;          // index of the owning frame in the batch
+  int32_t huf_slot;        // Huffman table slot this block decodes with (ZG_REF_UNINIT if none)
+  int32_t ll_slot, of_slot, ml_slot;  // FSE arena slots holding the tables this block decodes with
+  uint32_t host_status;    // error found by the host parser for this block (it and later blocks are not decoded)
+  uint64_t lit_base;       // offset of this block's regenerated literals in the literals arena
+  uint64_t seq_base;       // index of this block's first sequence in the sequence arena
+};
+
+// One frame of the batch.
+struct ZgFrame {
+  uint32_t first_block, nblocks;   // range in the batch's block array
+  uint32_t carry_slot;             // FSE arena slot holding the tables carried into this frame (dictionary / previous submit)
+  int32_t carry_huf_slot;
+  uint32_t hist_init[3];           // offset history at the first block (1,4,8 or dictionary / carried)
+  uint32_t fixed_base;             // 1: the frame's new bytes start at out_base_fixed; 0: frames are packed back to back
+  uint64_t out_base_fixed;
+  uint64_t window_size;
+  uint64_t prior_out;              // bytes of this frame already decoded by earlier submits (streaming)
+  uint64_t dict_len;               // dictionary content length reachable before the frame start
+  uint64_t dict_off;               // offset of that content in the dictionary buffer
+};
+
+// What the table kernel records per block.
+struct ZgBlockAux {
+  uint32_t seq_bits_off;   // offset in the body where the sequence bitstream starts (after table descriptions)
+  uint32_t huf_desc_bytes; // bytes used by the Huffman tree description
+  uint8_t log[3];          // accuracy logs of the tables DEFINED by this block (LL, OF, ML); 0 for RLE
+  uint8_t pad;
+};
+
+// What the sequence kernel records per block.
+struct ZgBlockSeqOut {
+  uint32_t sum_ll;         // Σ literal lengths
+  uint32_t sum_ml;         // Σ match lengths (block output size = regen_size + sum_ml)
+  uint32_t hist_end[3];    // offset history after the block, symbolic encoding (see zg_dev.h)
+  uint32_t pad;
+};
+
+// One decoded sequence, ready for execution.
+struct ZgSeq {
+  uint32_t of;             // resolved offset, or symbolic reference into the block's initial offset history
+  uint32_t ml;             // match length
+  uint32_t mdst;           // block-relative output position where the match starts (= Σ earlier ll+ml, + this ll)
+  uint32_t lit_start;      // index of this sequence's first literal in the block's literals
+};
+
+// Per block, after the scan.
+struct ZgBlockPos {
+  uint64_t out_base;       // absolute position of the block's first output byte in the batch output
+  uint32_t hist_init[3];   // resolved offset history at block start
+  uint32_t active;         // 1 if the block is to be executed (no earlier error in its frame)
+};
+
+struct ZgFrameOut {
+  uint64_t out_base;       // where the frame's new bytes start in the batch output
+  uint64_t out_size;       // bytes produced by this submit
+  uint32_t status;         // first error (ZgStatus) or 0
+  uint32_t bad_block;      // frame-relative index of the failing block
+  uint32_t hist_end[3];    // offset history after the last good block
+  uint32_t good_blocks;
+};
+
+// Huffman work: one group = streams that decode with the same table.
+struct ZgHufGroup { int32_t slot; uint32_t first_item; uint32_t nitems; uint32_t pad; };
