@@ -69,6 +69,21 @@ def main():
         for fn in sorted(os.listdir(os.path.join(art, sub))):
             entries.append((sub + "/" + fn, rd(os.path.join(art, sub, fn))))
     write_pack(os.path.join(HERE, "fuzz_artifacts.pack"), entries)
+    # synthetic inputs compressed by the image's libzstd (SURVEY.md Appendix C generators, tools/zgdata.py):
+    # real-encoder streams (all-FSE modes, 4-stream Huffman, Treeless/Repeat lineage) small enough to commit
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "tools"))
+    import zgdata
+    syn, sman = [], {}
+    cases = [("text_1m_l3.zst", zgdata.text_like(1 << 20), 3), ("text_1m_l1.zst", zgdata.text_like(1 << 20, seed=0xEA), 1),
+             ("text_768k_l19.zst", zgdata.text_like(768 << 10, seed=0xEB), 19), ("iso_512k_l3.zst", zgdata.iso_like(512 << 10), 3),
+             ("mixed_640k_l3.zst", zgdata.text_like(256 << 10, seed=7) + zgdata.iso_like(128 << 10, seed=9) + bytes(64 << 10) + zgdata.text_like(192 << 10, seed=7), 3)]
+    for nm, plain, lvl in cases:
+        z = zgdata.zstd_compress(plain, level=lvl)
+        syn.append((nm, z))
+        sman[nm] = {"zst_size": len(z), "size": len(plain), "sha256": sha(plain), "level": lvl, "zstd": zgdata.zstd_version()}
+    write_pack(os.path.join(HERE, "synthetic.pack"), syn)
+    with open(os.path.join(HERE, "synthetic.json"), "w") as f:
+        json.dump(sman, f, indent=0, sort_keys=True)
     print("packed", n1, "corpus pairs,", n2, "dict pairs, 4 fixtures,", len(entries), "fuzz artefacts")
 
 

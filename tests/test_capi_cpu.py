@@ -1,0 +1,49 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every symbol include/zgpu.h declares, it
+refuses to run without a GPU (no CPU fallback), and nothing under oracle/ is linked into it."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "zstd-rs_amd", "libzgpu.so")
+HDR = os.path.join(ROOT, "include", "zgpu.h")
+
+
+def _built():
+    if not os.path.exists(LIB):
+        import __graft_entry__
+        __graft_entry__.build()
+    return LIB
+
+
+def test_header_symbols_exported():
+    _built()
+    hdr = open(HDR).read()
+    declared = set(re.findall(r"\b(zgpu_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"zgpu_status"}
+    import zgpu
+    L = zgpu.load_library()
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    assert set(zgpu.EXPORTS) <= declared
+
+
+def test_no_oracle_in_product():
+    _built()
+    syms = subprocess.check_output(["nm", "-D", LIB]).decode()
+    assert "zor_" not in syms
+    for f in os.listdir(os.path.join(ROOT, "zstd-rs_amd", "csrc")):
+        src = open(os.path.join(ROOT, "zstd-rs_amd", "csrc", f), errors="ignore").read()
+        assert "zstd_oracle" not in src and "zor_" not in src, f
+
+
+def test_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import zgpu
+    with pytest.raises(zgpu.ZgpuError) as e:
+        zgpu.Context()
+    assert e.value.status == zgpu.E_HIP

@@ -1,0 +1,325 @@
+"""ctypes binding of libzgpu.so (include/zgpu.h) + thin Python mirrors of the reference's decoder surface.
+
+Names follow ruzstd (FrameDecoder, StreamingDecoder, decode_all, decode_blocks, collect ...). There is no CPU path:
+if libzgpu.so is missing or no gfx950 device is usable, construction raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libzgpu.so")
+_LIB = None
+
+STRAT_ALL, STRAT_UPTO_BLOCKS, STRAT_UPTO_BYTES = 0, 1, 2
+E_SKIP_FRAME = 1
+E_WINDOW_SIZE_TOO_BIG = 6
+E_DICT_NOT_PROVIDED = 7
+E_FAILED_READ_BLOCK_HEADER, E_FAILED_READ_BLOCK_BODY, E_FAILED_READ_CHECKSUM = 9, 10, 11
+E_TARGET_TOO_SMALL = 12
+E_FAILED_SKIP_FRAME = 13
+E_UNSUPPORTED = 80
+E_HIP = 92
+
+
+class FrameInfo(C.Structure):
+    _fields_ = [("src_begin", C.c_uint64), ("src_end", C.c_uint64), ("window_size", C.c_uint64), ("frame_content_size", C.c_uint64),
+                ("out_base", C.c_uint64), ("out_size", C.c_uint64), ("nblocks", C.c_uint32), ("status", C.c_uint32),
+                ("bad_block", C.c_uint32), ("has_checksum", C.c_uint32), ("checksum", C.c_uint32), ("pad", C.c_uint32)]
+
+
+class BlockInfo(C.Structure):
+    _fields_ = [("btype", C.c_uint32), ("lit_type", C.c_uint32), ("nstreams", C.c_uint32), ("seq_modes", C.c_uint32),
+                ("regen_size", C.c_uint32), ("nseq", C.c_uint32), ("frame", C.c_uint32), ("status", C.c_uint32),
+                ("huf_slot", C.c_int32), ("ll_slot", C.c_int32), ("of_slot", C.c_int32), ("ml_slot", C.c_int32),
+                ("sum_ll", C.c_uint32), ("sum_ml", C.c_uint32), ("hist_init", C.c_uint32 * 3), ("active", C.c_uint32),
+                ("out_base", C.c_uint64)]
+
+
+class Seq(C.Structure):
+    _fields_ = [("of", C.c_uint32), ("ml", C.c_uint32), ("mdst", C.c_uint32), ("lit_start", C.c_uint32)]
+
+
+EXPORTS = [
+    "zgpu_ctx_create", "zgpu_ctx_destroy", "zgpu_set_max_window_size", "zgpu_max_window_size", "zgpu_last_error", "zgpu_status_name",
+    "zgpu_decode_all", "zgpu_batch_prepare", "zgpu_batch_run", "zgpu_batch_sync", "zgpu_batch_num_frames", "zgpu_batch_num_blocks",
+    "zgpu_batch_compressed_size", "zgpu_batch_frame_info", "zgpu_batch_read", "zgpu_batch_output_device", "zgpu_batch_timings",
+    "zgpu_batch_destroy", "zgpu_batch_block_info", "zgpu_batch_block_literals", "zgpu_batch_block_sequences", "zgpu_batch_fse_slot",
+    "zgpu_batch_huf_slot", "zgpu_decoder_create", "zgpu_decoder_destroy", "zgpu_decoder_init", "zgpu_decoder_decode_blocks",
+    "zgpu_decoder_can_collect", "zgpu_decoder_collect", "zgpu_decoder_read", "zgpu_decoder_is_finished", "zgpu_decoder_blocks_decoded",
+    "zgpu_decoder_bytes_read_from_source", "zgpu_decoder_content_size", "zgpu_decoder_checksum_from_data",
+    "zgpu_decoder_calculated_checksum",
+]
+
+
+def load_library():
+    """Load libzgpu.so and declare the prototypes. Does not touch the GPU."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libzgpu.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, u8p = C.c_void_p, C.c_size_t, C.c_char_p
+    P = C.POINTER
+    L.zgpu_ctx_create.argtypes = [C.c_int, P(vp)]
+    L.zgpu_ctx_destroy.argtypes = [vp]
+    L.zgpu_set_max_window_size.argtypes = [vp, C.c_uint64]
+    L.zgpu_max_window_size.argtypes = [vp]
+    L.zgpu_max_window_size.restype = C.c_uint64
+    L.zgpu_last_error.argtypes = [vp]
+    L.zgpu_last_error.restype = C.c_char_p
+    L.zgpu_status_name.argtypes = [C.c_int]
+    L.zgpu_status_name.restype = C.c_char_p
+    L.zgpu_decode_all.argtypes = [vp, u8p, sz, vp, sz, P(sz)]
+    L.zgpu_batch_prepare.argtypes = [vp, u8p, sz, P(vp)]
+    L.zgpu_batch_run.argtypes = [vp]
+    L.zgpu_batch_sync.argtypes = [vp, P(C.c_uint64), P(C.c_uint32), P(C.c_uint32)]
+    L.zgpu_batch_num_frames.argtypes = [vp]
+    L.zgpu_batch_num_frames.restype = C.c_uint32
+    L.zgpu_batch_num_blocks.argtypes = [vp]
+    L.zgpu_batch_num_blocks.restype = C.c_uint32
+    L.zgpu_batch_compressed_size.argtypes = [vp]
+    L.zgpu_batch_compressed_size.restype = C.c_uint64
+    L.zgpu_batch_frame_info.argtypes = [vp, C.c_uint32, P(FrameInfo)]
+    L.zgpu_batch_read.argtypes = [vp, C.c_uint64, vp, C.c_uint64]
+    L.zgpu_batch_output_device.argtypes = [vp]
+    L.zgpu_batch_output_device.restype = vp
+    L.zgpu_batch_timings.argtypes = [vp, P(C.c_float), C.c_int]
+    L.zgpu_batch_destroy.argtypes = [vp]
+    L.zgpu_batch_block_info.argtypes = [vp, C.c_uint32, P(BlockInfo)]
+    L.zgpu_batch_block_literals.argtypes = [vp, C.c_uint32, vp, sz, P(sz)]
+    L.zgpu_batch_block_sequences.argtypes = [vp, C.c_uint32, P(Seq), sz, P(sz)]
+    L.zgpu_batch_fse_slot.argtypes = [vp, C.c_uint32, P(C.c_uint32), P(C.c_uint8)]
+    L.zgpu_batch_huf_slot.argtypes = [vp, C.c_uint32, P(C.c_uint16), P(C.c_int)]
+    L.zgpu_decoder_create.argtypes = [vp, P(vp)]
+    L.zgpu_decoder_destroy.argtypes = [vp]
+    L.zgpu_decoder_init.argtypes = [vp, u8p, sz, P(sz), P(C.c_uint32), P(C.c_uint32)]
+    L.zgpu_decoder_decode_blocks.argtypes = [vp, u8p, sz, P(sz), C.c_int, sz, P(C.c_int)]
+    L.zgpu_decoder_can_collect.argtypes = [vp]
+    L.zgpu_decoder_can_collect.restype = sz
+    L.zgpu_decoder_collect.argtypes = [vp, vp, sz]
+    L.zgpu_decoder_collect.restype = sz
+    L.zgpu_decoder_read.argtypes = [vp, vp, sz]
+    L.zgpu_decoder_read.restype = sz
+    L.zgpu_decoder_is_finished.argtypes = [vp]
+    for nm in ("zgpu_decoder_blocks_decoded", "zgpu_decoder_bytes_read_from_source", "zgpu_decoder_content_size"):
+        getattr(L, nm).argtypes = [vp]
+        getattr(L, nm).restype = C.c_uint64
+    L.zgpu_decoder_checksum_from_data.argtypes = [vp, P(C.c_uint32)]
+    L.zgpu_decoder_calculated_checksum.argtypes = [vp]
+    L.zgpu_decoder_calculated_checksum.restype = C.c_uint32
+    _LIB = L
+    return L
+
+
+class ZgpuError(Exception):
+    def __init__(self, status, what=""):
+        self.status = status
+        name = load_library().zgpu_status_name(status).decode()
+        super().__init__("%s (status %d) %s" % (name, status, what))
+
+
+class Context:
+    """One engine per GPU (zgpu_ctx)."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        st = self.L.zgpu_ctx_create(device, C.byref(h))
+        if st:
+            raise ZgpuError(st, "zgpu_ctx_create: no usable MI355X/HIP device — the engine has no CPU path")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.zgpu_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_max_window_size(self, n):
+        self.L.zgpu_set_max_window_size(self.h, n)
+
+    def max_window_size(self):
+        return self.L.zgpu_max_window_size(self.h)
+
+    def decode_all(self, src, cap):
+        """FrameDecoder::decode_all (frame_decoder.rs:541-577). Returns the plaintext or raises ZgpuError."""
+        buf = C.create_string_buffer(max(cap, 1))
+        w = C.c_size_t()
+        st = self.L.zgpu_decode_all(self.h, src, len(src), buf, cap, C.byref(w))
+        if st:
+            raise ZgpuError(st)
+        return buf.raw[:w.value]
+
+    def prepare(self, src):
+        return Batch(self, src)
+
+
+class Batch:
+    """A run of whole frames resident on the device (zgpu_batch)."""
+
+    def __init__(self, ctx, src):
+        self.ctx, self.L = ctx, ctx.L
+        h = C.c_void_p()
+        self.parse_status = self.L.zgpu_batch_prepare(ctx.h, src, len(src), C.byref(h))
+        if not h:
+            raise ZgpuError(self.parse_status)
+        self.h = h
+        self.nframes = self.L.zgpu_batch_num_frames(h)
+        self.nblocks = self.L.zgpu_batch_num_blocks(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.zgpu_batch_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def run(self):
+        st = self.L.zgpu_batch_run(self.h)
+        if st:
+            raise ZgpuError(st, self.L.zgpu_last_error(self.ctx.h).decode())
+
+    def sync(self):
+        tot, bf, bs = C.c_uint64(), C.c_uint32(), C.c_uint32()
+        st = self.L.zgpu_batch_sync(self.h, C.byref(tot), C.byref(bf), C.byref(bs))
+        if st and st != E_UNSUPPORTED:
+            raise ZgpuError(st, self.L.zgpu_last_error(self.ctx.h).decode())
+        self.total_out, self.bad_frame, self.bad_status = tot.value, bf.value, bs.value or st
+        return self.total_out
+
+    def timings(self):
+        a = (C.c_float * 7)()
+        self.L.zgpu_batch_timings(self.h, a, 7)
+        return dict(zip(["tables", "huf", "seq", "scan", "lit", "lz", "total"], list(a)))
+
+    def frame_info(self, f):
+        fi = FrameInfo()
+        assert self.L.zgpu_batch_frame_info(self.h, f, C.byref(fi)) == 0
+        return fi
+
+    def read(self, off, n):
+        buf = C.create_string_buffer(max(n, 1))
+        st = self.L.zgpu_batch_read(self.h, off, buf, n)
+        if st:
+            raise ZgpuError(st)
+        return buf.raw[:n]
+
+    def frame_bytes(self, f):
+        fi = self.frame_info(f)
+        return self.read(fi.out_base, fi.out_size)
+
+    def output_device_ptr(self):
+        return self.L.zgpu_batch_output_device(self.h)
+
+    def block_info(self, b):
+        bi = BlockInfo()
+        st = self.L.zgpu_batch_block_info(self.h, b, C.byref(bi))
+        if st:
+            raise ZgpuError(st)
+        return bi
+
+    def block_literals(self, b, n):
+        buf = C.create_string_buffer(max(n, 1))
+        got = C.c_size_t()
+        st = self.L.zgpu_batch_block_literals(self.h, b, buf, n, C.byref(got))
+        if st:
+            raise ZgpuError(st)
+        return buf.raw[:got.value]
+
+    def block_sequences(self, b, n):
+        arr = (Seq * max(n, 1))()
+        got = C.c_size_t()
+        st = self.L.zgpu_batch_block_sequences(self.h, b, arr, n, C.byref(got))
+        if st:
+            raise ZgpuError(st)
+        return [(arr[i].of, arr[i].ml, arr[i].mdst, arr[i].lit_start) for i in range(got.value)]
+
+    def fse_slot(self, slot):
+        ent = (C.c_uint32 * 1280)()
+        lg = (C.c_uint8 * 4)()
+        st = self.L.zgpu_batch_fse_slot(self.h, slot, ent, lg)
+        if st:
+            raise ZgpuError(st)
+        return ent, list(lg)
+
+    def huf_slot(self, slot):
+        ent = (C.c_uint16 * 2048)()
+        mb = C.c_int()
+        st = self.L.zgpu_batch_huf_slot(self.h, slot, ent, C.byref(mb))
+        if st:
+            raise ZgpuError(st)
+        return ent, mb.value
+
+
+class FrameDecoder:
+    """Mirror of ruzstd::decoding::FrameDecoder (frame_decoder.rs:80-627) on the GPU engine."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or Context()
+        self.L = self.ctx.L
+        h = C.c_void_p()
+        st = self.L.zgpu_decoder_create(self.ctx.h, C.byref(h))
+        if st:
+            raise ZgpuError(st)
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.zgpu_decoder_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_max_window_size(self, n):
+        self.ctx.set_max_window_size(n)
+
+    def init(self, src):
+        """reset(): returns (status, consumed, skip_magic, skip_len); SkipFrame is a status, as in the reference"""
+        c, sm, sl = C.c_size_t(), C.c_uint32(), C.c_uint32()
+        st = self.L.zgpu_decoder_init(self.h, src, len(src), C.byref(c), C.byref(sm), C.byref(sl))
+        return st, c.value, sm.value, sl.value
+
+    reset = init
+
+    def decode_blocks(self, src, strat=STRAT_ALL, n=0):
+        c, fin = C.c_size_t(), C.c_int()
+        st = self.L.zgpu_decoder_decode_blocks(self.h, src, len(src), C.byref(c), strat, n, C.byref(fin))
+        return st, c.value, bool(fin.value)
+
+    def can_collect(self):
+        return self.L.zgpu_decoder_can_collect(self.h)
+
+    def collect(self):
+        n = self.can_collect()
+        buf = C.create_string_buffer(max(n, 1))
+        got = self.L.zgpu_decoder_collect(self.h, buf, n)
+        return buf.raw[:got]
+
+    def read(self, cap):
+        buf = C.create_string_buffer(max(cap, 1))
+        got = self.L.zgpu_decoder_read(self.h, buf, cap)
+        return buf.raw[:got]
+
+    def is_finished(self):
+        return bool(self.L.zgpu_decoder_is_finished(self.h))
+
+    def blocks_decoded(self):
+        return self.L.zgpu_decoder_blocks_decoded(self.h)
+
+    def bytes_read_from_source(self):
+        return self.L.zgpu_decoder_bytes_read_from_source(self.h)
+
+    def content_size(self):
+        return self.L.zgpu_decoder_content_size(self.h)
+
+    def get_checksum_from_data(self):
+        v = C.c_uint32()
+        return v.value if self.L.zgpu_decoder_checksum_from_data(self.h, C.byref(v)) else None
+
+    def get_calculated_checksum(self):
+        return self.L.zgpu_decoder_calculated_checksum(self.h)
+
+    def decode_all(self, src, cap):
+        return self.ctx.decode_all(src, cap)
