@@ -228,3 +228,13 @@ def test_generated_large_text_and_iso(ctx):
         assert out == plain, (lvl, wl)
         oout, _ = oracle.decode_frame_all(z)                     # and the oracle agrees on the same input
         assert oout == plain
+
+
+def test_inorder_fallback_path(ctx, monkeypatch):
+    """the in-order kernel (zg_k_lz) that serves frames with a block regenerating more than 128 KiB: forced on here"""
+    monkeypatch.setenv("ZGPU_FORCE_INORDER", "1")
+    pack, man = read_pack("decodecorpus.pack"), read_manifest("decodecorpus.json")
+    for name in sorted(man)[::9]:
+        assert _sha(ctx.decode_all(pack[name], man[name]["size"])) == man[name]["sha256"], name
+    spack, sman = read_pack("synthetic.pack"), read_manifest("synthetic.json")
+    assert _sha(ctx.decode_all(spack["text_1m_l3.zst"], sman["text_1m_l3.zst"]["size"])) == sman["text_1m_l3.zst"]["sha256"]

@@ -1,5 +1,6 @@
 // zg_engine.cpp — see zg_engine.h. Compiled by hipcc as host code.
 #include "zg_engine.h"
+#include <stdlib.h>
 #include <string.h>
 
 namespace zg {
@@ -108,7 +109,7 @@ int parse_frames(const uint8_t* src, size_t len, uint64_t max_window, BatchBuild
 
 Batch::~Batch() {
   DevBuf* all[] = {&d_src, &d_blocks, &d_frames, &d_aux, &d_slot_log, &d_fse, &d_huf, &d_hufmax, &d_status, &d_lit, &d_seq,
-                   &d_seqout, &d_pos, &d_frameout, &d_dst, &d_seqblocks, &d_hufitems, &d_hufgroups, &d_totals};
+                   &d_seqout, &d_pos, &d_frameout, &d_dst, &d_seqblocks, &d_hufitems, &d_hufgroups, &d_totals, &d_og};
   for (DevBuf* b : all) b->release();
   for (auto& e : ev)
     if (e) (void)hipEventDestroy(e);
@@ -199,7 +200,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
       (st = b->d_lit.reserve(bb.lit_bytes + 64)) || (st = b->d_seq.reserve((bb.seq_count + 1) * sizeof(ZgSeq))) ||
       (st = b->d_seqout.reserve((size_t)nb * sizeof(ZgBlockSeqOut) + 16)) || (st = b->d_pos.reserve((size_t)nb * sizeof(ZgBlockPos) + 16)) ||
       (st = b->d_frameout.reserve((size_t)nf * sizeof(ZgFrameOut) + 16)) || (st = b->d_dst.reserve(bb.out_bound + 64)) ||
-      (st = b->d_totals.reserve(64))) {
+      (st = b->d_totals.reserve(64)) || (st = b->d_og.reserve((size_t)bb.seq_blocks.size() * 131072 * 4 + 64))) {
     delete b;
     return st;
   }
@@ -216,6 +217,8 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   d.seq_blocks = b->d_seqblocks.as<uint32_t>(); d.nseq_blocks = (uint32_t)bb.seq_blocks.size();
   d.huf_items = b->d_hufitems.as<uint32_t>(); d.huf_groups = b->d_hufgroups.as<ZgHufGroup>(); d.nhuf_groups = (uint32_t)bb.huf_groups.size();
   d.totals = b->d_totals.as<uint32_t>();
+  d.og = b->d_og.as<uint32_t>();
+  { const char* e = getenv("ZGPU_FORCE_INORDER"); d.flags = (e && e[0] == '1') ? 1u : 0u; }
   for (auto& e : b->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
   if (hipStreamSynchronize(stream_) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
@@ -243,8 +246,12 @@ int Batch::run() {
   ZG_HIP(hipEventRecord(ev[4], s));
   zg_launch_lit(d, s);
   ZG_HIP(hipEventRecord(ev[5], s));
-  zg_launch_lz(d, s);
+  zg_launch_flat(d, s);
   ZG_HIP(hipEventRecord(ev[6], s));
+  zg_launch_sweep(d, s);
+  ZG_HIP(hipEventRecord(ev[7], s));
+  zg_launch_lz(d, s);   // only frames that left the flatten path (a block regenerating > 128 KiB)
+  ZG_HIP(hipEventRecord(ev[8], s));
   ZG_HIP(hipGetLastError());
   ran = true;
   return ZG_OK;

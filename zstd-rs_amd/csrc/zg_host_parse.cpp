@@ -230,7 +230,7 @@ void BatchBuilder::finish() {
       else if (*sl[k] == kCarry) *sl[k] = (int32_t)frames[b.frame].carry_slot;
     }
     if (b.huf_slot == kCarryHuf) b.huf_slot = frames[b.frame].carry_huf_slot;
-    if (b.nseq) seq_blocks.push_back(i);
+    if (b.nseq) { b.seq_idx = (uint32_t)seq_blocks.size(); seq_blocks.push_back(i); }
     if (b.lit_type >= ZG_LT_COMPRESSED) {
       for (uint32_t k = 0; k < b.nstreams; k++) {
         if (huf_groups.empty() || huf_groups.back().slot != b.huf_slot || huf_groups.back().nitems >= 256) {

@@ -35,6 +35,8 @@ struct ZgBatchDev {
   const ZgHufGroup* huf_groups;
   uint32_t nhuf_groups;
   uint32_t* totals;            // [4]: [0..1] total output bytes (u64), [2] overflow flag
+  uint32_t flags;              // bit 0: force the in-order fallback for every frame (tests)
+  uint32_t* og;                // flatten scratch: per block with sequences, 128 Ki u32 "effective offsets" (0 = byte already final)
 };
 
 void zg_launch_tables(const ZgBatchDev& d, hipStream_t s);
@@ -42,4 +44,6 @@ void zg_launch_huf(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_seq(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_scan(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_lit(const ZgBatchDev& d, hipStream_t s);
+void zg_launch_flat(const ZgBatchDev& d, hipStream_t s);
+void zg_launch_sweep(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_lz(const ZgBatchDev& d, hipStream_t s);

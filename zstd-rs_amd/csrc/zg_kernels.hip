@@ -15,6 +15,13 @@
 
 #define ZG_SEQ_G 8        // blocks (lanes) per workgroup in zg_k_seq: 8 x 5 KiB of tables in LDS -> 4 workgroups per CU
 #define ZG_LZ_T 256       // threads per frame in zg_k_lz
+#define ZG_FLAT_MAX 131072u  // largest block output the flatten path handles (Block_Maximum_Size)
+#define ZG_FL_T 512       // threads per block in zg_k_flat
+#define ZG_FL_TS 16384    // tile: bytes of block output resolved at a time in LDS
+#define ZG_FL_PER (ZG_FL_TS / ZG_FL_T)
+#define ZG_PAR_LIT 0xFFFFu   // tile byte is a literal: value in s_val
+#define ZG_PAR_EXIT 0xFFFEu  // tile byte is a match byte whose source lies before the tile
+#define ZG_SW_T 1024      // threads per frame in zg_k_sweep
 
 __device__ __forceinline__ void zg_set_status(uint32_t* status, uint32_t b, int st) {
   if (st) atomicCAS(&status[b], 0u, (uint32_t)st);
@@ -216,11 +223,13 @@ __global__ void __launch_bounds__(256) zg_k_scan(ZgBatchDev d) {
   __shared__ ZgHistMap s_map[256];
   __shared__ uint32_t s_bad;       // chunk-local index of the first failing block
   __shared__ uint32_t s_badst;
+  __shared__ uint32_t s_slow;      // some block regenerates more than 128 KiB (non-conforming): in-order fallback
   const uint32_t f = blockIdx.x, t = threadIdx.x;
   const ZgFrame fr = d.frames[f];
   uint64_t carry_size = 0;
   ZgHistMap carry_map = zg_map_identity();
   uint32_t good = fr.nblocks, bad_status = 0;
+  if (t == 0) s_slow = 0;
   for (uint32_t c0 = 0; c0 < fr.nblocks; c0 += 256) {
     uint32_t i = c0 + t;
     bool have = i < fr.nblocks;
@@ -238,6 +247,7 @@ __global__ void __launch_bounds__(256) zg_k_scan(ZgBatchDev d) {
       else {
         const ZgBlockSeqOut so = d.seq_out[b];
         size = (uint64_t)blk->regen_size + so.sum_ml;
+        if (size > ZG_FLAT_MAX) s_slow = 1;
         m.s[0] = so.hist_end[0]; m.s[1] = so.hist_end[1]; m.s[2] = so.hist_end[2];
       }
       if (st) atomicMin(&s_bad, t);
@@ -291,6 +301,8 @@ __global__ void __launch_bounds__(256) zg_k_scan(ZgBatchDev d) {
     fo.hist_end[1] = zg_sym_resolve(carry_map.s[1], fr.hist_init);
     fo.hist_end[2] = zg_sym_resolve(carry_map.s[2], fr.hist_init);
     fo.good_blocks = good;
+    fo.fast = (s_slow || (d.flags & 1u)) ? 0u : 1u;
+    fo.err_packed = 0xFFFFFFFFu;
     d.frame_out[f] = fo;
   }
 }
@@ -348,6 +360,7 @@ __global__ void __launch_bounds__(256) zg_k_lit(ZgBatchDev d) {
   const uint8_t* body = d.src + blk.src_off;
   if (blk.btype == ZG_BT_RAW) { zg_wg_copy(out, body, blk.regen_size, t, 256); return; }
   if (blk.btype == ZG_BT_RLE) { zg_wg_fill(out, body[0], blk.regen_size, t, 256); return; }
+  if (blk.nseq && d.frame_out[blk.frame].fast) return;  // literals of these blocks are placed by zg_k_flat
   const bool rle = blk.lit_type == ZG_LT_RLE;
   const uint8_t* lit = blk.lit_type == ZG_LT_RAW ? body + blk.lit_off : blk.lit_type == ZG_LT_RLE ? body + blk.lit_off : d.lit_arena + blk.lit_base;
   uint32_t sum_ll = 0, sum_ml = 0;
@@ -369,6 +382,194 @@ __global__ void __launch_bounds__(256) zg_k_lit(ZgBatchDev d) {
   uint8_t* o = out + ((uint64_t)sum_ll + sum_ml);
   if (rle) zg_wg_fill(o, lit[0], rest, t, 256);
   else zg_wg_copy(o, lit + sum_ll, rest, t, 256);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// zg_k_flat + zg_k_sweep: LZ77 execution (execute_sequences, sequence_execution.rs:5-54; DecodeBuffer::repeat,
+// decode_buffer.rs:79-141) without walking the frame's sequences one after the other.
+//
+// Chains of matches (a match copying the output of an earlier match ...) are what makes in-order execution slow on
+// a GPU: every hop is a memory round trip. Instead every output byte is resolved to where its value finally comes from:
+//   zg_k_flat  (all blocks at once, one workgroup per block) walks the block in 16 KiB tiles held in LDS. A tile byte
+//              points to its parent byte (position - offset). Pointer jumping inside the tile (u16 pointers) shortens
+//              every chain to its tile root in O(log depth) rounds; roots are literal bytes (value known) or bytes whose
+//              parent lies before the tile. Parents in earlier tiles of the same block are already final. Result per
+//              byte: the value, or an "effective offset" o such that byte = frame[pos - o] with pos - o BEFORE the block.
+//   zg_k_sweep (one workgroup per frame, blocks in order) fills the unresolved bytes of block b from the finished
+//              output of blocks < b — a pure gather, all bytes of the block in parallel, no chains left.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_val[ZG_FL_TS];
+  __shared__ uint16_t s_par[ZG_FL_TS];
+  __shared__ uint32_t s_next;
+  __shared__ uint32_t s_err;
+  if (d.totals[2]) return;
+  const uint32_t idx = blockIdx.x, t = threadIdx.x;
+  const uint32_t b = d.seq_blocks[idx];
+  const ZgBlockPos p = d.pos[b];
+  if (!p.active) return;
+  const ZgBlock blk = d.blocks[b];
+  const ZgFrameOut fo = d.frame_out[blk.frame];
+  if (!fo.fast) return;
+  const ZgFrame fr = d.frames[blk.frame];
+  const ZgBlockSeqOut so = d.seq_out[b];
+  const uint32_t S = blk.regen_size + so.sum_ml;  // <= ZG_FLAT_MAX on this path
+  const uint32_t nseq = blk.nseq;
+  uint8_t* out = d.dst + fo.out_base + p.out_base;            // first output byte of the block
+  uint32_t* og = d.og + (uint64_t)idx * ZG_FLAT_MAX;
+  const ZgSeq* sq = d.seq_arena + blk.seq_base;
+  const uint8_t* body = d.src + blk.src_off;
+  const bool lit_rle = blk.lit_type == ZG_LT_RLE;
+  const uint8_t* lit = blk.lit_type <= ZG_LT_RLE ? body + blk.lit_off : d.lit_arena + blk.lit_base;
+  const uint8_t lit_fill = lit_rle ? lit[0] : 0;
+  // bytes of the frame (and dictionary) that exist before this block: the farthest a match may reach
+  const uint64_t reach = p.out_base + fr.prior_out + fr.dict_len;
+  if (t == 0) s_err = 0;
+  uint32_t i_start = 0;
+  for (uint32_t t0 = 0; t0 < S; t0 += ZG_FL_TS) {
+    const uint32_t t1 = t0 + ZG_FL_TS < S ? t0 + ZG_FL_TS : S;
+    if (t == 0) s_next = 0xFFFFFFFFu;
+    __syncthreads();
+    // ---- S1: parents. Sequence i covers [mdst-ll, mdst+ml); index nseq stands for the trailing literals.
+    for (uint32_t i = i_start + t; i <= nseq; i += ZG_FL_T) {
+      uint32_t a, m0, m1, lstart, off = 0;
+      if (i < nseq) {
+        const ZgSeq q = sq[i];
+        const uint32_t next = i + 1 < nseq ? sq[i + 1].lit_start : so.sum_ll;
+        lstart = q.lit_start; m0 = q.mdst; m1 = q.mdst + q.ml; a = m0 - (next - lstart);
+        off = zg_sym_resolve(q.of, p.hist_init);
+        if (off == 0) atomicCAS(&s_err, 0u, (uint32_t)ZG_EXE_ZERO_OFFSET);                     // sequence_execution.rs:28-30
+        else if ((uint64_t)off > reach + m0) atomicCAS(&s_err, 0u, (uint32_t)ZG_EXE_OFFSET_TOO_BIG);  // decode_buffer.rs:173-177
+      } else {
+        lstart = so.sum_ll; a = so.sum_ll + so.sum_ml; m0 = m1 = S;
+      }
+      if (m1 > t1 || a >= t1) atomicMin(&s_next, i);  // first sequence that reaches beyond this tile starts the next one
+      if (a >= t1) break;
+      // literal run
+      uint32_t x0 = a > t0 ? a : t0, x1 = m0 < t1 ? m0 : t1;
+      for (uint32_t x = x0; x < x1; x++) {
+        s_val[x - t0] = lit_rle ? lit_fill : lit[lstart + (x - a)];
+        s_par[x - t0] = ZG_PAR_LIT;
+      }
+      // match
+      x0 = m0 > t0 ? m0 : t0; x1 = m1 < t1 ? m1 : t1;
+      if (x0 < x1 && off) {
+        if (off <= x0 - t0) {            // every parent of the clipped range lies inside the tile
+          for (uint32_t x = x0; x < x1; x++) s_par[x - t0] = (uint16_t)(x - t0 - off);
+        } else {
+          for (uint32_t x = x0; x < x1; x++) {
+            if (x - t0 >= off) s_par[x - t0] = (uint16_t)(x - t0 - off);
+            else { s_par[x - t0] = ZG_PAR_EXIT; og[x] = off; }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    i_start = s_next == 0xFFFFFFFFu ? nseq + 1 : s_next;
+    if (s_err) break;
+    // ---- S2: pointer jumping inside the tile. Updates are applied in place; reading a newer pointer only helps.
+    uint16_t pr[ZG_FL_PER];
+    uint32_t unresolved = 0;
+#pragma unroll
+    for (int k = 0; k < ZG_FL_PER; k++) {
+      const uint32_t x = t + k * ZG_FL_T;
+      pr[k] = ZG_PAR_LIT;
+      if (t0 + x < t1) { pr[k] = s_par[x]; if (pr[k] < ZG_PAR_EXIT) unresolved |= 1u << k; }
+    }
+    for (int round = 0; round < 40; round++) {
+      if (!__syncthreads_or(unresolved != 0)) break;
+#pragma unroll
+      for (int k = 0; k < ZG_FL_PER; k++) {
+        if (unresolved & (1u << k)) {
+          const uint16_t q = s_par[pr[k]];
+          if (q >= ZG_PAR_EXIT) unresolved &= ~(1u << k);   // pr[k] is the root
+          else { pr[k] = q; s_par[t + k * ZG_FL_T] = q; }
+        }
+      }
+    }
+    if (__syncthreads_or(unresolved != 0)) { if (t == 0) s_err = ZG_INTERNAL; __syncthreads(); break; }  // cannot happen: depth < 2^14
+    // ---- S3: value or effective offset of every byte of the tile
+    uint32_t oo[ZG_FL_PER];
+    uint8_t vv[ZG_FL_PER];
+#pragma unroll
+    for (int k = 0; k < ZG_FL_PER; k++) {
+      const uint32_t xr = t + k * ZG_FL_T, x = t0 + xr;
+      oo[k] = 0; vv[k] = 0;
+      if (x >= t1) continue;
+      const uint16_t own = s_par[xr];
+      uint32_t r;  // tile-relative root
+      bool is_lit;
+      if (own >= ZG_PAR_EXIT) { r = xr; is_lit = own == ZG_PAR_LIT; }
+      else { r = pr[k]; is_lit = s_par[r] == ZG_PAR_LIT; }
+      if (is_lit) { vv[k] = s_val[r]; continue; }
+      const uint32_t off_r = og[t0 + r];                 // offset of the match the root byte belongs to
+      const int32_t pb = (int32_t)(t0 + r) - (int32_t)off_r;   // block position of the root's parent (< t0)
+      if (pb >= 0) {                                     // an earlier tile of this block: already final
+        const uint32_t o2 = og[pb];
+        if (o2 == 0) vv[k] = out[pb];
+        else oo[k] = (x - (uint32_t)pb) + o2;
+      } else oo[k] = x + (uint32_t)(-pb);                // reaches before the block: x - pb
+    }
+    __syncthreads();
+    // ---- S4: publish the tile
+#pragma unroll
+    for (int k = 0; k < ZG_FL_PER; k++) {
+      const uint32_t xr = t + k * ZG_FL_T;
+      if (t0 + xr < t1) { s_val[xr] = vv[k]; og[t0 + xr] = oo[k]; }
+    }
+    __syncthreads();
+    {
+      const uint32_t n = t1 - t0;
+      uint8_t* o = out + t0;
+      const uint32_t n8 = n >> 3;
+      for (uint32_t i = t; i < n8; i += ZG_FL_T) ((zg_u64u*)(o + i * 8))->v = *(const uint64_t*)(s_val + i * 8);
+      for (uint32_t i = (n8 << 3) + t; i < n; i += ZG_FL_T) o[i] = s_val[i];
+    }
+    __syncthreads();  // the next tile reads og[] / out[] of this one
+  }
+  if (t == 0 && s_err) atomicMin(&d.frame_out[blk.frame].err_packed, ((b - fr.first_block) << 8) | s_err);
+}
+
+// One workgroup per frame; blocks in order. All unresolved bytes of a block copy from strictly earlier blocks.
+__global__ void __launch_bounds__(ZG_SW_T) zg_k_sweep(ZgBatchDev d) {
+  if (d.totals[2]) return;
+  const uint32_t f = blockIdx.x, t = threadIdx.x;
+  const ZgFrameOut fo = d.frame_out[f];
+  if (!fo.fast) return;
+  const ZgFrame fr = d.frames[f];
+  uint32_t good = fo.good_blocks;
+  const uint32_t ep = fo.err_packed;
+  if (ep != 0xFFFFFFFFu && (ep >> 8) < good) good = ep >> 8;
+  uint8_t* frame_out = d.dst + fo.out_base;
+  for (uint32_t bi = 0; bi < good; bi++) {
+    const uint32_t b = fr.first_block + bi;
+    const ZgBlock* blk = &d.blocks[b];
+    if (blk->btype != ZG_BT_COMPRESSED || blk->nseq == 0) continue;
+    const uint32_t S = blk->regen_size + d.seq_out[b].sum_ml;
+    uint8_t* out = frame_out + d.pos[b].out_base;
+    const uint32_t* og = d.og + (uint64_t)blk->seq_idx * ZG_FLAT_MAX;
+    const uint32_t n4 = S >> 2;
+    for (uint32_t i = t; i < n4; i += ZG_SW_T) {
+      const uint4 o = *(const uint4*)(og + 4 * i);
+      if ((o.x | o.y | o.z | o.w) == 0) continue;
+      uint8_t* w = out + 4 * i;
+      if (o.x == o.y && o.x == o.z && o.x == o.w) { ((zg_u32u*)w)->v = zg_ld32(w - o.x); continue; }  // one run
+      if (o.x) w[0] = w[0 - (int64_t)o.x];
+      if (o.y) w[1] = w[1 - (int64_t)o.y];
+      if (o.z) w[2] = w[2 - (int64_t)o.z];
+      if (o.w) w[3] = w[3 - (int64_t)o.w];
+    }
+    for (uint32_t x = (n4 << 2) + t; x < S; x += ZG_SW_T) {
+      const uint32_t o = og[x];
+      if (o) out[x] = out[(int64_t)x - o];
+    }
+    __syncthreads();  // block b is final before block b+1 reads it (same CU, shared L1)
+  }
+  if (t == 0 && ep != 0xFFFFFFFFu) {
+    d.frame_out[f].status = ep & 0xFF;
+    d.frame_out[f].bad_block = ep >> 8;
+    d.frame_out[f].good_blocks = ep >> 8;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -394,6 +595,7 @@ __global__ void __launch_bounds__(ZG_LZ_T) zg_k_lz(ZgBatchDev d) {
   const uint32_t f = blockIdx.x, t = threadIdx.x;
   const ZgFrame fr = d.frames[f];
   const ZgFrameOut fo = d.frame_out[f];
+  if (fo.fast) return;
   uint8_t* frame_out = d.dst + fo.out_base;
   if (t == 0) { s_err = 0; s_errblk = 0; }
   __syncthreads();
@@ -470,6 +672,12 @@ void zg_launch_scan(const ZgBatchDev& d, hipStream_t s) {
 }
 void zg_launch_lit(const ZgBatchDev& d, hipStream_t s) {
   if (d.nblocks) hipLaunchKernelGGL(zg_k_lit, dim3(d.nblocks), dim3(256), 0, s, d);
+}
+void zg_launch_flat(const ZgBatchDev& d, hipStream_t s) {
+  if (d.nseq_blocks) hipLaunchKernelGGL(zg_k_flat, dim3(d.nseq_blocks), dim3(ZG_FL_T), 0, s, d);
+}
+void zg_launch_sweep(const ZgBatchDev& d, hipStream_t s) {
+  hipLaunchKernelGGL(zg_k_sweep, dim3(d.nframes), dim3(ZG_SW_T), 0, s, d);
 }
 void zg_launch_lz(const ZgBatchDev& d, hipStream_t s) {
   hipLaunchKernelGGL(zg_k_lz, dim3(d.nframes), dim3(ZG_LZ_T), 0, s, d);

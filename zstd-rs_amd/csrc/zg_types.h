@@ -106,6 +106,8 @@ struct ZgBlock {
   uint32_t host_status;    // error found by the host parser for this block (it and later blocks are not decoded)
   uint64_t lit_base;       // offset of this block's regenerated literals in the literals arena
   uint64_t seq_base;       // index of this block's first sequence in the sequence arena
+  uint32_t seq_idx;        // position of this block in the list of blocks that have sequences (flatten scratch slot)
+  uint32_t pad1;
 };
 
 // One frame of the batch.
@@ -160,6 +162,8 @@ struct ZgFrameOut {
   uint32_t bad_block;      // frame-relative index of the failing block
   uint32_t hist_end[3];    // offset history after the last good block
   uint32_t good_blocks;
+  uint32_t fast;           // 1: every block regenerates <= 128 KiB -> flatten + sweep path; 0: in-order fallback (zg_k_lz)
+  uint32_t err_packed;     // (frame-relative block << 8) | status of the first execution error, 0xFFFFFFFF if none
 };
 
 // Huffman work: one group = streams that decode with the same table.

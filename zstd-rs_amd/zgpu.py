@@ -190,9 +190,9 @@ class Batch:
         return self.total_out
 
     def timings(self):
-        a = (C.c_float * 7)()
-        self.L.zgpu_batch_timings(self.h, a, 7)
-        return dict(zip(["tables", "huf", "seq", "scan", "lit", "lz", "total"], list(a)))
+        a = (C.c_float * 9)()
+        self.L.zgpu_batch_timings(self.h, a, 9)
+        return dict(zip(["tables", "huf", "seq", "scan", "lit", "flat", "sweep", "lz", "total"], list(a)))
 
     def frame_info(self, f):
         fi = FrameInfo()
