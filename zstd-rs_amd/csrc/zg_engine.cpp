@@ -109,7 +109,7 @@ int parse_frames(const uint8_t* src, size_t len, uint64_t max_window, BatchBuild
 
 Batch::~Batch() {
   DevBuf* all[] = {&d_src, &d_blocks, &d_frames, &d_aux, &d_slot_log, &d_fse, &d_huf, &d_hufmax, &d_status, &d_lit, &d_seq,
-                   &d_seqout, &d_pos, &d_frameout, &d_dst, &d_seqblocks, &d_hufitems, &d_hufgroups, &d_totals, &d_og};
+                   &d_seqout, &d_pos, &d_frameout, &d_dst, &d_seqblocks, &d_hufitems, &d_hufgroups, &d_totals, &d_og, &d_units, &d_unitinfo, &d_sweepwgs, &d_bar};
   for (DevBuf* b : all) b->release();
   for (auto& e : ev)
     if (e) (void)hipEventDestroy(e);
@@ -172,6 +172,8 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   ZG_HIP(hipSetDevice(device_));
   // a frame-layer error after some good frames: the good frames are still uploaded (callers such as the
   // FrameDecoder mirror may want them); decode_all reports parse_status.
+  { const char* e = getenv("ZGPU_UNIT_BLOCKS"); if (e && atoi(e) > 0) b->bb.unit_blocks = (uint32_t)atoi(e); }
+  { const char* e = getenv("ZGPU_SWEEP_WGS"); if (e && atoi(e) > 0) b->bb.sweep_budget = (uint32_t)atoi(e); }
   b->bb.finish();
   BatchBuilder& bb = b->bb;
   const uint32_t nb = (uint32_t)bb.blocks.size(), nf = (uint32_t)bb.frames.size();
@@ -200,7 +202,10 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
       (st = b->d_lit.reserve(bb.lit_bytes + 64)) || (st = b->d_seq.reserve((bb.seq_count + 1) * sizeof(ZgSeq))) ||
       (st = b->d_seqout.reserve((size_t)nb * sizeof(ZgBlockSeqOut) + 16)) || (st = b->d_pos.reserve((size_t)nb * sizeof(ZgBlockPos) + 16)) ||
       (st = b->d_frameout.reserve((size_t)nf * sizeof(ZgFrameOut) + 16)) || (st = b->d_dst.reserve(bb.out_bound + 64)) ||
-      (st = b->d_totals.reserve(64)) || (st = b->d_og.reserve((size_t)bb.seq_blocks.size() * 131072 * 4 + 64))) {
+      (st = b->d_totals.reserve(64)) || (st = b->d_og.reserve((size_t)bb.og_count * 4 + 64)) ||
+      (st = up(b->d_units, bb.units.data(), bb.units.size() * sizeof(ZgUnit))) ||
+      (st = up(b->d_sweepwgs, bb.sweep_wgs.data(), bb.sweep_wgs.size() * sizeof(ZgSweepWg))) ||
+      (st = b->d_unitinfo.reserve(bb.units.size() * sizeof(ZgUnitInfo) + 16)) || (st = b->d_bar.reserve((size_t)nf * 4 + 16))) {
     delete b;
     return st;
   }
@@ -218,6 +223,8 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   d.huf_items = b->d_hufitems.as<uint32_t>(); d.huf_groups = b->d_hufgroups.as<ZgHufGroup>(); d.nhuf_groups = (uint32_t)bb.huf_groups.size();
   d.totals = b->d_totals.as<uint32_t>();
   d.og = b->d_og.as<uint32_t>();
+  d.units = b->d_units.as<ZgUnit>(); d.nunits = (uint32_t)bb.units.size(); d.unit_info = b->d_unitinfo.as<ZgUnitInfo>();
+  d.sweep_wgs = b->d_sweepwgs.as<ZgSweepWg>(); d.nsweep_wgs = (uint32_t)bb.sweep_wgs.size(); d.bar = b->d_bar.as<uint32_t>();
   { const char* e = getenv("ZGPU_FORCE_INORDER"); d.flags = (e && e[0] == '1') ? 1u : 0u; }
   for (auto& e : b->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
@@ -236,6 +243,7 @@ int Batch::run() {
   ZG_HIP(hipMemsetAsync(d.huf_maxbits, 0, d.nhuf_slots + 16, s));
   ZG_HIP(hipMemsetAsync(d.slot_log, 0, (size_t)d.nslots * 4, s));
   ZG_HIP(hipMemsetAsync(d.totals, 0, 64, s));
+  ZG_HIP(hipMemsetAsync(d.bar, 0, (size_t)d.nframes * 4 + 16, s));
   zg_launch_tables(d, s);
   ZG_HIP(hipEventRecord(ev[1], s));
   zg_launch_huf(d, s);

@@ -64,7 +64,7 @@ class Batch {
   Engine* eng = nullptr;
   ZgBatchDev dev{};
   DevBuf d_src, d_blocks, d_frames, d_aux, d_slot_log, d_fse, d_huf, d_hufmax, d_status, d_lit, d_seq, d_seqout, d_pos, d_frameout,
-      d_dst, d_seqblocks, d_hufitems, d_hufgroups, d_totals, d_og;
+      d_dst, d_seqblocks, d_hufitems, d_hufgroups, d_totals, d_og, d_units, d_unitinfo, d_sweepwgs, d_bar;
   hipEvent_t ev[ZG_T_COUNT + 1] = {};
   bool ran = false;
 };

@@ -220,7 +220,33 @@ void BatchBuilder::finish() {
     frames[f].carry_slot = nb + 1 + f;
     frames[f].carry_huf_slot = (int32_t)(block_huf_slots + f);
   }
-  seq_blocks.clear(); huf_items.clear(); huf_groups.clear();
+  seq_blocks.clear(); huf_items.clear(); huf_groups.clear(); units.clear(); sweep_wgs.clear();
+  og_count = 0;
+  for (uint32_t f = 0; f < frames.size(); f++) {
+    ZgFrame& fr = frames[f];
+    fr.first_unit = (uint32_t)units.size();
+    for (uint32_t i = 0; i < fr.nblocks; i += unit_blocks) {
+      ZgUnit u;
+      u.frame = f; u.first_block = fr.first_block + i;
+      u.nblocks = fr.nblocks - i < unit_blocks ? fr.nblocks - i : unit_blocks; u.pad = 0;
+      u.og_base = og_count;
+      og_count += (uint64_t)u.nblocks * kMaxBlockSize;
+      units.push_back(u);
+    }
+    fr.nunits = (uint32_t)units.size() - fr.first_unit;
+  }
+  // workgroups of the sweep: proportional to the frame's share of the blocks, at least one, all resident at once
+  {
+    const uint64_t nbt = nb ? nb : 1;
+    for (uint32_t f = 0; f < frames.size(); f++) {
+      uint64_t w = ((uint64_t)sweep_budget * frames[f].nblocks + nbt - 1) / nbt;
+      uint32_t cap = (frames[f].nblocks + 1) / 2;   // at least ~256 KiB of output per workgroup
+      if (w > cap) w = cap;
+      if (w < 1) w = 1;
+      if (w > 256) w = 256;
+      for (uint32_t r = 0; r < w; r++) { ZgSweepWg g; g.frame = f; g.rank = r; g.wpf = (uint32_t)w; g.pad = 0; sweep_wgs.push_back(g); }
+    }
+  }
   for (uint32_t i = 0; i < nb; i++) {
     ZgBlock& b = blocks[i];
     if (b.btype != ZG_BT_COMPRESSED || b.host_status) continue;

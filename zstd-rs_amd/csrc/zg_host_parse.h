@@ -57,6 +57,11 @@ class BatchBuilder {
   std::vector<uint32_t> seq_blocks;
   std::vector<uint32_t> huf_items;
   std::vector<ZgHufGroup> huf_groups;
+  std::vector<ZgUnit> units;
+  std::vector<ZgSweepWg> sweep_wgs;
+  uint64_t og_count = 0;       // flatten scratch size in u32
+  uint32_t unit_blocks = 16;   // blocks per unit (tunable)
+  uint32_t sweep_budget = 256; // workgroups of zg_k_sweep over the whole submit
   uint64_t lit_bytes = 0;      // literals arena size
   uint64_t seq_count = 0;      // sequence arena size
   uint32_t nhuf_slots = 0;

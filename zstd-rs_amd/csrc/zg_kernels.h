@@ -36,7 +36,13 @@ struct ZgBatchDev {
   uint32_t nhuf_groups;
   uint32_t* totals;            // [4]: [0..1] total output bytes (u64), [2] overflow flag
   uint32_t flags;              // bit 0: force the in-order fallback for every frame (tests)
-  uint32_t* og;                // flatten scratch: per block with sequences, 128 Ki u32 "effective offsets" (0 = byte already final)
+  uint32_t* og;                // flatten scratch: one u32 "effective offset" per output byte of a unit (0 = byte already final)
+  const ZgUnit* units;
+  uint32_t nunits;
+  ZgUnitInfo* unit_info;       // [nunits]
+  const ZgSweepWg* sweep_wgs;
+  uint32_t nsweep_wgs;
+  uint32_t* bar;               // [nframes] arrival counters of the sweep's per-frame barrier (zeroed every run)
 };
 
 void zg_launch_tables(const ZgBatchDev& d, hipStream_t s);

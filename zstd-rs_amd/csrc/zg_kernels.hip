@@ -21,7 +21,7 @@
 #define ZG_FL_PER (ZG_FL_TS / ZG_FL_T)
 #define ZG_PAR_LIT 0xFFFFu   // tile byte is a literal: value in s_val
 #define ZG_PAR_EXIT 0xFFFEu  // tile byte is a match byte whose source lies before the tile
-#define ZG_SW_T 1024      // threads per frame in zg_k_sweep
+#define ZG_SW_T 256       // threads per workgroup in zg_k_sweep
 
 __device__ __forceinline__ void zg_set_status(uint32_t* status, uint32_t b, int st) {
   if (st) atomicCAS(&status[b], 0u, (uint32_t)st);
@@ -390,185 +390,265 @@ __global__ void __launch_bounds__(256) zg_k_lit(ZgBatchDev d) {
 //
 // Chains of matches (a match copying the output of an earlier match ...) are what makes in-order execution slow on
 // a GPU: every hop is a memory round trip. Instead every output byte is resolved to where its value finally comes from:
-//   zg_k_flat  (all blocks at once, one workgroup per block) walks the block in 16 KiB tiles held in LDS. A tile byte
-//              points to its parent byte (position - offset). Pointer jumping inside the tile (u16 pointers) shortens
-//              every chain to its tile root in O(log depth) rounds; roots are literal bytes (value known) or bytes whose
-//              parent lies before the tile. Parents in earlier tiles of the same block are already final. Result per
-//              byte: the value, or an "effective offset" o such that byte = frame[pos - o] with pos - o BEFORE the block.
-//   zg_k_sweep (one workgroup per frame, blocks in order) fills the unresolved bytes of block b from the finished
-//              output of blocks < b — a pure gather, all bytes of the block in parallel, no chains left.
+//   zg_k_flat  (all units at once; a unit = a run of consecutive blocks of a frame; one workgroup per unit) walks the
+//              unit in 16 KiB tiles held in LDS. A tile byte points to its parent byte (position - offset). Pointer
+//              jumping inside the tile (u16 pointers) shortens every chain to its tile root in O(log depth) rounds; roots
+//              are literal bytes (value known) or bytes whose parent lies before the tile. Parents in earlier tiles of
+//              the unit are already final. Result per byte: the value, or an "effective offset" o such that
+//              byte = frame[pos - o] with pos - o BEFORE the unit.
+//   zg_k_sweep (several workgroups per frame, units in order, one grid barrier per unit) fills the unresolved bytes of
+//              unit u from the finished output of units < u — a pure gather, all bytes of the unit in parallel.
 // ------------------------------------------------------------------------------------------------------------
+#define ZG_FL_SOFF 5632   // most matches that can start in / overlap one tile (match length >= 3) + slack
+
 __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
   __shared__ __attribute__((aligned(16))) uint8_t s_val[ZG_FL_TS];
   __shared__ uint16_t s_par[ZG_FL_TS];
-  __shared__ uint32_t s_next;
-  __shared__ uint32_t s_err;
+  __shared__ uint32_t s_soff[ZG_FL_SOFF];   // offset of the tile's j-th sequence (for bytes whose parent is before the tile)
+  __shared__ uint32_t s_next, s_err, s_unres;
+  const uint32_t t = threadIdx.x;
+  const ZgUnit un = d.units[blockIdx.x];
+  if (t == 0) { ZgUnitInfo ui; ui.size = 0; ui.unresolved = 0; d.unit_info[blockIdx.x] = ui; }
   if (d.totals[2]) return;
-  const uint32_t idx = blockIdx.x, t = threadIdx.x;
-  const uint32_t b = d.seq_blocks[idx];
-  const ZgBlockPos p = d.pos[b];
-  if (!p.active) return;
-  const ZgBlock blk = d.blocks[b];
-  const ZgFrameOut fo = d.frame_out[blk.frame];
+  const ZgFrameOut fo = d.frame_out[un.frame];
   if (!fo.fast) return;
-  const ZgFrame fr = d.frames[blk.frame];
-  const ZgBlockSeqOut so = d.seq_out[b];
-  const uint32_t S = blk.regen_size + so.sum_ml;  // <= ZG_FLAT_MAX on this path
-  const uint32_t nseq = blk.nseq;
-  uint8_t* out = d.dst + fo.out_base + p.out_base;            // first output byte of the block
-  uint32_t* og = d.og + (uint64_t)idx * ZG_FLAT_MAX;
-  const ZgSeq* sq = d.seq_arena + blk.seq_base;
-  const uint8_t* body = d.src + blk.src_off;
-  const bool lit_rle = blk.lit_type == ZG_LT_RLE;
-  const uint8_t* lit = blk.lit_type <= ZG_LT_RLE ? body + blk.lit_off : d.lit_arena + blk.lit_base;
-  const uint8_t lit_fill = lit_rle ? lit[0] : 0;
-  // bytes of the frame (and dictionary) that exist before this block: the farthest a match may reach
-  const uint64_t reach = p.out_base + fr.prior_out + fr.dict_len;
-  if (t == 0) s_err = 0;
-  uint32_t i_start = 0;
-  for (uint32_t t0 = 0; t0 < S; t0 += ZG_FL_TS) {
-    const uint32_t t1 = t0 + ZG_FL_TS < S ? t0 + ZG_FL_TS : S;
-    if (t == 0) s_next = 0xFFFFFFFFu;
-    __syncthreads();
-    // ---- S1: parents. Sequence i covers [mdst-ll, mdst+ml); index nseq stands for the trailing literals.
-    for (uint32_t i = i_start + t; i <= nseq; i += ZG_FL_T) {
-      uint32_t a, m0, m1, lstart, off = 0;
-      if (i < nseq) {
-        const ZgSeq q = sq[i];
-        const uint32_t next = i + 1 < nseq ? sq[i + 1].lit_start : so.sum_ll;
-        lstart = q.lit_start; m0 = q.mdst; m1 = q.mdst + q.ml; a = m0 - (next - lstart);
-        off = zg_sym_resolve(q.of, p.hist_init);
-        if (off == 0) atomicCAS(&s_err, 0u, (uint32_t)ZG_EXE_ZERO_OFFSET);                     // sequence_execution.rs:28-30
-        else if ((uint64_t)off > reach + m0) atomicCAS(&s_err, 0u, (uint32_t)ZG_EXE_OFFSET_TOO_BIG);  // decode_buffer.rs:173-177
-      } else {
-        lstart = so.sum_ll; a = so.sum_ll + so.sum_ml; m0 = m1 = S;
-      }
-      if (m1 > t1 || a >= t1) atomicMin(&s_next, i);  // first sequence that reaches beyond this tile starts the next one
-      if (a >= t1) break;
-      // literal run
-      uint32_t x0 = a > t0 ? a : t0, x1 = m0 < t1 ? m0 : t1;
-      for (uint32_t x = x0; x < x1; x++) {
-        s_val[x - t0] = lit_rle ? lit_fill : lit[lstart + (x - a)];
-        s_par[x - t0] = ZG_PAR_LIT;
-      }
-      // match
-      x0 = m0 > t0 ? m0 : t0; x1 = m1 < t1 ? m1 : t1;
-      if (x0 < x1 && off) {
-        if (off <= x0 - t0) {            // every parent of the clipped range lies inside the tile
-          for (uint32_t x = x0; x < x1; x++) s_par[x - t0] = (uint16_t)(x - t0 - off);
+  const ZgFrame fr = d.frames[un.frame];
+  const uint64_t unit_abs0 = d.pos[un.first_block].out_base;     // frame-relative position of the unit's first byte
+  uint8_t* out_u = d.dst + fo.out_base + unit_abs0;
+  uint32_t* og = d.og + un.og_base;
+  if (t == 0) { s_err = 0; s_unres = 0; }
+  uint32_t unit_size = 0;
+  __syncthreads();
+  for (uint32_t bi = 0; bi < un.nblocks; bi++) {
+    const uint32_t b = un.first_block + bi;
+    const ZgBlockPos p = d.pos[b];
+    if (!p.active) break;
+    const ZgBlock blk = d.blocks[b];
+    const uint32_t bu0 = (uint32_t)(p.out_base - unit_abs0);      // unit-relative position of the block
+    if (blk.btype != ZG_BT_COMPRESSED || blk.nseq == 0) {        // already final (zg_k_lit): nothing to resolve
+      const uint32_t n = blk.regen_size;
+      for (uint32_t i = t; i < n; i += ZG_FL_T) og[bu0 + i] = 0;
+      unit_size = bu0 + n;
+      continue;
+    }
+    const ZgBlockSeqOut so = d.seq_out[b];
+    const uint32_t S = blk.regen_size + so.sum_ml;               // <= ZG_FLAT_MAX on this path
+    unit_size = bu0 + S;
+    const uint32_t nseq = blk.nseq;
+    const ZgSeq* sq = d.seq_arena + blk.seq_base;
+    const uint8_t* body = d.src + blk.src_off;
+    const bool lit_rle = blk.lit_type == ZG_LT_RLE;
+    const uint8_t* lit = blk.lit_type <= ZG_LT_RLE ? body + blk.lit_off : d.lit_arena + blk.lit_base;
+    const uint8_t lit_fill = lit_rle ? lit[0] : 0;
+    // bytes of the frame (and dictionary) that exist before this block: the farthest a match may reach
+    const uint64_t reach = p.out_base + fr.prior_out + fr.dict_len;
+    uint32_t i_start = 0;
+    for (uint32_t t0 = 0; t0 < S; t0 += ZG_FL_TS) {
+      const uint32_t t1 = t0 + ZG_FL_TS < S ? t0 + ZG_FL_TS : S;
+      const uint32_t tu0 = bu0 + t0;                             // unit-relative position of the tile
+      if (t == 0) s_next = 0xFFFFFFFFu;
+      __syncthreads();
+      // ---- S1: parents. Sequence i covers [mdst-ll, mdst+ml); index nseq stands for the trailing literals.
+      for (uint32_t i = i_start + t; i <= nseq; i += ZG_FL_T) {
+        uint32_t a, m0, m1, lstart, off = 0;
+        if (i < nseq) {
+          const ZgSeq q = sq[i];
+          const uint32_t next = i + 1 < nseq ? sq[i + 1].lit_start : so.sum_ll;
+          lstart = q.lit_start; m0 = q.mdst; m1 = q.mdst + q.ml; a = m0 - (next - lstart);
+          off = zg_sym_resolve(q.of, p.hist_init);
+          if (off == 0) atomicCAS(&s_err, 0u, (uint32_t)ZG_EXE_ZERO_OFFSET);                     // sequence_execution.rs:28-30
+          else if ((uint64_t)off > reach + m0) atomicCAS(&s_err, 0u, (uint32_t)ZG_EXE_OFFSET_TOO_BIG);  // decode_buffer.rs:173-177
         } else {
-          for (uint32_t x = x0; x < x1; x++) {
-            if (x - t0 >= off) s_par[x - t0] = (uint16_t)(x - t0 - off);
-            else { s_par[x - t0] = ZG_PAR_EXIT; og[x] = off; }
+          lstart = so.sum_ll; a = so.sum_ll + so.sum_ml; m0 = m1 = S;
+        }
+        if (m1 > t1 || a >= t1) atomicMin(&s_next, i);  // first sequence that reaches beyond this tile starts the next one
+        if (a >= t1) break;
+        uint32_t x0 = a > t0 ? a : t0, x1 = m0 < t1 ? m0 : t1;  // literal run
+        for (uint32_t x = x0; x < x1; x++) {
+          s_val[x - t0] = lit_rle ? lit_fill : lit[lstart + (x - a)];
+          s_par[x - t0] = ZG_PAR_LIT;
+        }
+        x0 = m0 > t0 ? m0 : t0; x1 = m1 < t1 ? m1 : t1;         // match
+        if (x0 < x1 && off) {
+          const uint32_t j = i - i_start;                       // tile-local sequence index (< ZG_FL_SOFF: matches are >= 3 bytes)
+          if (off > x0 - t0) {
+            if (j < ZG_FL_SOFF) s_soff[j] = off; else atomicCAS(&s_err, 0u, (uint32_t)ZG_INTERNAL);
+          }
+          for (uint32_t x = x0; x < x1; x++)
+            s_par[x - t0] = (x - t0 >= off) ? (uint16_t)(x - t0 - off) : (uint16_t)(0x8000u | j);
+        }
+      }
+      __syncthreads();
+      i_start = s_next == 0xFFFFFFFFu ? nseq + 1 : s_next;
+      if (s_err) break;
+      // ---- S2: pointer jumping inside the tile. Pointers are < 0x8000; 0x8000|j = parent before the tile; 0xFFFF = literal.
+      uint16_t pr[ZG_FL_PER];
+      uint32_t unresolved = 0;
+#pragma unroll
+      for (int k = 0; k < ZG_FL_PER; k++) {
+        const uint32_t x = t + k * ZG_FL_T;
+        pr[k] = ZG_PAR_LIT;
+        if (t0 + x < t1) { pr[k] = s_par[x]; if (pr[k] < 0x8000u) unresolved |= 1u << k; }
+      }
+      for (int round = 0; round < 40; round++) {
+        if (!__syncthreads_or(unresolved != 0)) break;
+        uint16_t q[ZG_FL_PER];
+#pragma unroll
+        for (int k = 0; k < ZG_FL_PER; k++) q[k] = (unresolved & (1u << k)) ? s_par[pr[k]] : (uint16_t)0xFFFF;
+#pragma unroll
+        for (int k = 0; k < ZG_FL_PER; k++) {
+          if (unresolved & (1u << k)) {
+            if (q[k] >= 0x8000u) unresolved &= ~(1u << k);   // pr[k] is the root
+            else { pr[k] = q[k]; s_par[t + k * ZG_FL_T] = q[k]; }
           }
         }
       }
-    }
-    __syncthreads();
-    i_start = s_next == 0xFFFFFFFFu ? nseq + 1 : s_next;
-    if (s_err) break;
-    // ---- S2: pointer jumping inside the tile. Updates are applied in place; reading a newer pointer only helps.
-    uint16_t pr[ZG_FL_PER];
-    uint32_t unresolved = 0;
-#pragma unroll
-    for (int k = 0; k < ZG_FL_PER; k++) {
-      const uint32_t x = t + k * ZG_FL_T;
-      pr[k] = ZG_PAR_LIT;
-      if (t0 + x < t1) { pr[k] = s_par[x]; if (pr[k] < ZG_PAR_EXIT) unresolved |= 1u << k; }
-    }
-    for (int round = 0; round < 40; round++) {
-      if (!__syncthreads_or(unresolved != 0)) break;
+      if (__syncthreads_or(unresolved != 0)) { if (t == 0) s_err = ZG_INTERNAL; __syncthreads(); break; }  // cannot happen: depth < 2^14
+      // ---- S3: value or effective offset of every byte of the tile
+      uint32_t oo[ZG_FL_PER];
+      int32_t pu[ZG_FL_PER];      // unit position of the root's parent when it must be looked up, else -1
+      uint8_t vv[ZG_FL_PER];
 #pragma unroll
       for (int k = 0; k < ZG_FL_PER; k++) {
-        if (unresolved & (1u << k)) {
-          const uint16_t q = s_par[pr[k]];
-          if (q >= ZG_PAR_EXIT) unresolved &= ~(1u << k);   // pr[k] is the root
-          else { pr[k] = q; s_par[t + k * ZG_FL_T] = q; }
+        const uint32_t xr = t + k * ZG_FL_T;
+        oo[k] = 0; vv[k] = 0; pu[k] = -1;
+        if (t0 + xr >= t1) continue;
+        const uint16_t own = s_par[xr];
+        const uint32_t r = own >= 0x8000u ? xr : pr[k];   // tile-relative root
+        const uint16_t rp = own >= 0x8000u ? own : s_par[r];
+        if (rp == ZG_PAR_LIT) { vv[k] = s_val[r]; continue; }
+        const uint32_t off_r = s_soff[rp & 0x7FFFu];
+        const int32_t par_u = (int32_t)(tu0 + r) - (int32_t)off_r;   // unit position of the root's parent (< tu0)
+        if (par_u >= 0) pu[k] = par_u;                               // an earlier tile of this unit: already final
+        else oo[k] = (tu0 + xr) + (uint32_t)(-par_u);                // reaches before the unit
+      }
+      uint32_t o2[ZG_FL_PER];
+#pragma unroll
+      for (int k = 0; k < ZG_FL_PER; k++) o2[k] = pu[k] >= 0 ? og[pu[k]] : 1u;
+#pragma unroll
+      for (int k = 0; k < ZG_FL_PER; k++) {
+        if (pu[k] >= 0) {
+          if (o2[k] == 0) vv[k] = out_u[pu[k]];
+          else oo[k] = ((tu0 + t + k * ZG_FL_T) - (uint32_t)pu[k]) + o2[k];
         }
       }
-    }
-    if (__syncthreads_or(unresolved != 0)) { if (t == 0) s_err = ZG_INTERNAL; __syncthreads(); break; }  // cannot happen: depth < 2^14
-    // ---- S3: value or effective offset of every byte of the tile
-    uint32_t oo[ZG_FL_PER];
-    uint8_t vv[ZG_FL_PER];
+      __syncthreads();
+      // ---- S4: publish the tile
+      uint32_t nun = 0;
 #pragma unroll
-    for (int k = 0; k < ZG_FL_PER; k++) {
-      const uint32_t xr = t + k * ZG_FL_T, x = t0 + xr;
-      oo[k] = 0; vv[k] = 0;
-      if (x >= t1) continue;
-      const uint16_t own = s_par[xr];
-      uint32_t r;  // tile-relative root
-      bool is_lit;
-      if (own >= ZG_PAR_EXIT) { r = xr; is_lit = own == ZG_PAR_LIT; }
-      else { r = pr[k]; is_lit = s_par[r] == ZG_PAR_LIT; }
-      if (is_lit) { vv[k] = s_val[r]; continue; }
-      const uint32_t off_r = og[t0 + r];                 // offset of the match the root byte belongs to
-      const int32_t pb = (int32_t)(t0 + r) - (int32_t)off_r;   // block position of the root's parent (< t0)
-      if (pb >= 0) {                                     // an earlier tile of this block: already final
-        const uint32_t o2 = og[pb];
-        if (o2 == 0) vv[k] = out[pb];
-        else oo[k] = (x - (uint32_t)pb) + o2;
-      } else oo[k] = x + (uint32_t)(-pb);                // reaches before the block: x - pb
+      for (int k = 0; k < ZG_FL_PER; k++) {
+        const uint32_t xr = t + k * ZG_FL_T;
+        if (t0 + xr < t1) { s_val[xr] = vv[k]; og[tu0 + xr] = oo[k]; nun += oo[k] != 0; }
+      }
+      if (nun) atomicAdd(&s_unres, nun);
+      __syncthreads();
+      {
+        const uint32_t n = t1 - t0;
+        uint8_t* o = out_u + tu0;
+        const uint32_t n8 = n >> 3;
+        for (uint32_t i = t; i < n8; i += ZG_FL_T) ((zg_u64u*)(o + i * 8))->v = *(const uint64_t*)(s_val + i * 8);
+        for (uint32_t i = (n8 << 3) + t; i < n; i += ZG_FL_T) o[i] = s_val[i];
+      }
+      __syncthreads();  // the next tile reads og[] / out[] of this one
     }
-    __syncthreads();
-    // ---- S4: publish the tile
-#pragma unroll
-    for (int k = 0; k < ZG_FL_PER; k++) {
-      const uint32_t xr = t + k * ZG_FL_T;
-      if (t0 + xr < t1) { s_val[xr] = vv[k]; og[t0 + xr] = oo[k]; }
+    if (s_err) {
+      if (t == 0) atomicMin(&d.frame_out[un.frame].err_packed, ((b - fr.first_block) << 8) | s_err);
+      break;
     }
-    __syncthreads();
-    {
-      const uint32_t n = t1 - t0;
-      uint8_t* o = out + t0;
-      const uint32_t n8 = n >> 3;
-      for (uint32_t i = t; i < n8; i += ZG_FL_T) ((zg_u64u*)(o + i * 8))->v = *(const uint64_t*)(s_val + i * 8);
-      for (uint32_t i = (n8 << 3) + t; i < n; i += ZG_FL_T) o[i] = s_val[i];
-    }
-    __syncthreads();  // the next tile reads og[] / out[] of this one
   }
-  if (t == 0 && s_err) atomicMin(&d.frame_out[blk.frame].err_packed, ((b - fr.first_block) << 8) | s_err);
+  __syncthreads();
+  if (t == 0) { ZgUnitInfo ui; ui.size = unit_size; ui.unresolved = s_unres; d.unit_info[blockIdx.x] = ui; }
 }
 
-// One workgroup per frame; blocks in order. All unresolved bytes of a block copy from strictly earlier blocks.
+// per-frame barrier of the sweep: monotonic arrival counter, agent-scope release before arriving, relaxed polling,
+// one agent-scope acquire after (the per-XCD L2s and per-CU L1s are not coherent with each other).
+__device__ __forceinline__ bool zg_frame_barrier(uint32_t* counter, uint32_t target, uint32_t t) {
+  __shared__ uint32_t s_ok;
+  __syncthreads();
+  if (t == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t ok = 0;
+    for (uint32_t spin = 0; spin < (1u << 24); spin++) {
+      if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    s_ok = ok;
+  }
+  __syncthreads();
+  return s_ok != 0;
+}
+
+#define ZG_SW_B 8   // groups of 4 output bytes a thread has in flight
+
 __global__ void __launch_bounds__(ZG_SW_T) zg_k_sweep(ZgBatchDev d) {
   if (d.totals[2]) return;
-  const uint32_t f = blockIdx.x, t = threadIdx.x;
+  const ZgSweepWg wg = d.sweep_wgs[blockIdx.x];
+  const uint32_t f = wg.frame, t = threadIdx.x;
   const ZgFrameOut fo = d.frame_out[f];
   if (!fo.fast) return;
   const ZgFrame fr = d.frames[f];
-  uint32_t good = fo.good_blocks;
-  const uint32_t ep = fo.err_packed;
-  if (ep != 0xFFFFFFFFu && (ep >> 8) < good) good = ep >> 8;
   uint8_t* frame_out = d.dst + fo.out_base;
-  for (uint32_t bi = 0; bi < good; bi++) {
-    const uint32_t b = fr.first_block + bi;
-    const ZgBlock* blk = &d.blocks[b];
-    if (blk->btype != ZG_BT_COMPRESSED || blk->nseq == 0) continue;
-    const uint32_t S = blk->regen_size + d.seq_out[b].sum_ml;
-    uint8_t* out = frame_out + d.pos[b].out_base;
-    const uint32_t* og = d.og + (uint64_t)blk->seq_idx * ZG_FLAT_MAX;
-    const uint32_t n4 = S >> 2;
-    for (uint32_t i = t; i < n4; i += ZG_SW_T) {
-      const uint4 o = *(const uint4*)(og + 4 * i);
-      if ((o.x | o.y | o.z | o.w) == 0) continue;
-      uint8_t* w = out + 4 * i;
-      if (o.x == o.y && o.x == o.z && o.x == o.w) { ((zg_u32u*)w)->v = zg_ld32(w - o.x); continue; }  // one run
-      if (o.x) w[0] = w[0 - (int64_t)o.x];
-      if (o.y) w[1] = w[1 - (int64_t)o.y];
-      if (o.z) w[2] = w[2 - (int64_t)o.z];
-      if (o.w) w[3] = w[3 - (int64_t)o.w];
+  uint32_t steps = 0;
+  bool alive = true;
+  for (uint32_t ui = 0; ui < fr.nunits && alive; ui++) {
+    const uint32_t u = fr.first_unit + ui;
+    const ZgUnitInfo info = d.unit_info[u];
+    if (info.size == 0) break;            // first unit that was not (fully) flattened: error or inactive blocks
+    if (info.unresolved == 0) continue;   // nothing points before this unit
+    const ZgUnit un = d.units[u];
+    uint8_t* out = frame_out + d.pos[un.first_block].out_base;
+    const uint32_t* og = d.og + un.og_base;
+    const uint32_t n4 = info.size >> 2;
+    const uint32_t per = (n4 + wg.wpf - 1) / wg.wpf;
+    const uint32_t g0 = wg.rank * per, g1 = g0 + per < n4 ? g0 + per : n4;
+    for (uint32_t base = g0 + t; base < g1; base += ZG_SW_T * ZG_SW_B) {
+      uint4 o[ZG_SW_B];
+#pragma unroll
+      for (int k = 0; k < ZG_SW_B; k++) {
+        const uint32_t g = base + k * ZG_SW_T;
+        o[k] = g < g1 ? *(const uint4*)(og + 4 * (uint64_t)g) : make_uint4(0, 0, 0, 0);
+      }
+      uint32_t w4[ZG_SW_B];
+      bool run[ZG_SW_B];
+#pragma unroll
+      for (int k = 0; k < ZG_SW_B; k++) {
+        run[k] = o[k].x != 0 && o[k].x == o[k].y && o[k].x == o[k].z && o[k].x == o[k].w;
+        const uint8_t* w = out + 4 * (uint64_t)(base + k * ZG_SW_T);
+        w4[k] = run[k] ? zg_ld32(w - o[k].x) : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < ZG_SW_B; k++) {
+        const uint32_t g = base + k * ZG_SW_T;
+        if (g >= g1) continue;
+        uint8_t* w = out + 4 * (uint64_t)g;
+        if (run[k]) { ((zg_u32u*)w)->v = w4[k]; continue; }
+        if (o[k].x) w[0] = w[0 - (int64_t)o[k].x];
+        if (o[k].y) w[1] = w[1 - (int64_t)o[k].y];
+        if (o[k].z) w[2] = w[2 - (int64_t)o[k].z];
+        if (o[k].w) w[3] = w[3 - (int64_t)o[k].w];
+      }
     }
-    for (uint32_t x = (n4 << 2) + t; x < S; x += ZG_SW_T) {
-      const uint32_t o = og[x];
-      if (o) out[x] = out[(int64_t)x - o];
+    if (wg.rank == wg.wpf - 1) {          // tail bytes of the unit
+      for (uint32_t x = (n4 << 2) + t; x < info.size; x += ZG_SW_T) {
+        const uint32_t o = og[x];
+        if (o) out[x] = out[(int64_t)x - o];
+      }
     }
-    __syncthreads();  // block b is final before block b+1 reads it (same CU, shared L1)
+    steps++;
+    if (wg.wpf > 1) alive = zg_frame_barrier(d.bar + f, steps * wg.wpf, t);
+    else __syncthreads();               // same CU: later loads see these stores
   }
-  if (t == 0 && ep != 0xFFFFFFFFu) {
-    d.frame_out[f].status = ep & 0xFF;
-    d.frame_out[f].bad_block = ep >> 8;
-    d.frame_out[f].good_blocks = ep >> 8;
+  const uint32_t ep = d.frame_out[f].err_packed;
+  if (t == 0 && wg.rank == 0) {
+    if (!alive) { d.frame_out[f].status = ZG_INTERNAL; d.frame_out[f].bad_block = 0; d.frame_out[f].good_blocks = 0; }
+    else if (ep != 0xFFFFFFFFu) {
+      d.frame_out[f].status = ep & 0xFF;
+      d.frame_out[f].bad_block = ep >> 8;
+      d.frame_out[f].good_blocks = ep >> 8;
+    }
   }
 }
 
@@ -674,10 +754,10 @@ void zg_launch_lit(const ZgBatchDev& d, hipStream_t s) {
   if (d.nblocks) hipLaunchKernelGGL(zg_k_lit, dim3(d.nblocks), dim3(256), 0, s, d);
 }
 void zg_launch_flat(const ZgBatchDev& d, hipStream_t s) {
-  if (d.nseq_blocks) hipLaunchKernelGGL(zg_k_flat, dim3(d.nseq_blocks), dim3(ZG_FL_T), 0, s, d);
+  if (d.nunits) hipLaunchKernelGGL(zg_k_flat, dim3(d.nunits), dim3(ZG_FL_T), 0, s, d);
 }
 void zg_launch_sweep(const ZgBatchDev& d, hipStream_t s) {
-  hipLaunchKernelGGL(zg_k_sweep, dim3(d.nframes), dim3(ZG_SW_T), 0, s, d);
+  if (d.nsweep_wgs) hipLaunchKernelGGL(zg_k_sweep, dim3(d.nsweep_wgs), dim3(ZG_SW_T), 0, s, d);
 }
 void zg_launch_lz(const ZgBatchDev& d, hipStream_t s) {
   hipLaunchKernelGGL(zg_k_lz, dim3(d.nframes), dim3(ZG_LZ_T), 0, s, d);

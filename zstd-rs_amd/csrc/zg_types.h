@@ -113,6 +113,7 @@ struct ZgBlock {
 // One frame of the batch.
 struct ZgFrame {
   uint32_t first_block, nblocks;   // range in the batch's block array
+  uint32_t first_unit, nunits;     // range in the batch's unit array
   uint32_t carry_slot;             // FSE arena slot holding the tables carried into this frame (dictionary / previous submit)
   int32_t carry_huf_slot;
   uint32_t hist_init[3];           // offset history at the first block (1,4,8 or dictionary / carried)
@@ -165,6 +166,12 @@ struct ZgFrameOut {
   uint32_t fast;           // 1: every block regenerates <= 128 KiB -> flatten + sweep path; 0: in-order fallback (zg_k_lz)
   uint32_t err_packed;     // (frame-relative block << 8) | status of the first execution error, 0xFFFFFFFF if none
 };
+
+// LZ77 execution works on units: runs of consecutive blocks of one frame that zg_k_flat resolves together.
+struct ZgUnit { uint32_t frame, first_block, nblocks, pad; uint64_t og_base; };   // og_base: offset (in u32) into the flatten scratch
+struct ZgUnitInfo { uint32_t size; uint32_t unresolved; };   // written by zg_k_flat: bytes of the unit, bytes left for the sweep
+// One workgroup of zg_k_sweep: frame it serves, its rank among the frame's workgroups, and how many there are.
+struct ZgSweepWg { uint32_t frame, rank, wpf, pad; };
 
 // Huffman work: one group = streams that decode with the same table.
 struct ZgHufGroup { int32_t slot; uint32_t first_item; uint32_t nitems; uint32_t pad; };
