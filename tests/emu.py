@@ -20,6 +20,8 @@ def lib():
         L = C.CDLL(os.path.join(d, "libzg_emu.so"))
         L.zgemu_decode.restype = C.c_void_p
         L.zgemu_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64]
+        L.zgemu_decode2.restype = C.c_void_p
+        L.zgemu_decode2.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64, C.c_int]
         L.zgemu_free.argtypes = [C.c_void_p]
         L.zgemu_parse_status.argtypes = [C.c_void_p]
         L.zgemu_num_frames.argtypes = [C.c_void_p]
@@ -44,9 +46,9 @@ def lib():
 
 
 class EmuBatch:
-    def __init__(self, src, max_window=128 << 20):
+    def __init__(self, src, max_window=128 << 20, fast_seq=True):
         self.L = lib()
-        self.h = self.L.zgemu_decode(src, len(src), max_window)
+        self.h = self.L.zgemu_decode2(src, len(src), max_window, 1 if fast_seq else 0)
         self.parse_status = self.L.zgemu_parse_status(self.h)
         self.nframes = self.L.zgemu_num_frames(self.h)
         self.nblocks = self.L.zgemu_num_blocks(self.h)

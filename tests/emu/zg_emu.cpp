@@ -17,7 +17,9 @@ int parse_frames(const uint8_t* src, size_t len, uint64_t max_window, BatchBuild
 
 struct EmuBatch {
   BatchBuilder bb;
-  std::vector<uint8_t> src;
+  std::vector<uint8_t> src_store;   // 64 bytes of padding in front and behind, as the engine allocates it
+  uint8_t* src = nullptr;
+  int use_fast = 1;
   std::vector<ZgBlockAux> aux;
   std::vector<uint8_t> slot_log;
   std::vector<uint32_t> fse;
@@ -81,7 +83,7 @@ static void k_tables(EmuBatch& e) {
   for (uint32_t b = 0; b < nb; b++) {
     const ZgBlock blk = e.bb.blocks[b];
     if (blk.host_status || blk.btype != ZG_BT_COMPRESSED) continue;
-    const uint8_t* body = e.src.data() + blk.src_off;
+    const uint8_t* body = e.src + blk.src_off;
     ZgBlockAux aux; memset(&aux, 0, sizeof aux); aux.seq_bits_off = blk.seq_off;
     int st = ZG_OK;
     if (blk.lit_type == ZG_LT_COMPRESSED) {
@@ -129,7 +131,7 @@ static void k_huf(EmuBatch& e) {
       if (e.status[b]) continue;
       uint32_t desc = blk.lit_type == ZG_LT_COMPRESSED ? e.aux[b].huf_desc_bytes : 0;
       if (desc > blk.lit_comp_size) { set_status(e, b, ZG_INTERNAL); continue; }
-      const uint8_t* pay = e.src.data() + blk.src_off + blk.lit_off + desc;
+      const uint8_t* pay = e.src + blk.src_off + blk.lit_off + desc;
       uint32_t total = blk.lit_comp_size - desc, regen = blk.regen_size;
       uint8_t* lit = e.lit.data() + blk.lit_base;
       const uint8_t* sp; uint32_t slen, doff, cap;
@@ -171,9 +173,11 @@ static void k_seq(EmuBatch& e) {
     if (!ok) { set_status(e, b, ZG_FSE_UNINIT); continue; }
     uint32_t bits_off = e.aux[b].seq_bits_off;
     if (bits_off > blk.src_len) { set_status(e, b, ZG_INTERNAL); continue; }
-    const uint8_t* bs = e.src.data() + blk.src_off + bits_off;
+    const uint8_t* bs = e.src + blk.src_off + bits_off;
     ZgBlockSeqOut so;
-    int st = zg_seq_decode_block(bs, blk.src_len - bits_off, blk.nseq, tp[0], lg[0], tp[1], lg[1], tp[2], lg[2], blk.regen_size,
+    int st = e.use_fast ? zg_seq_decode_block_fast(bs, blk.src_len - bits_off, blk.nseq, tp[0], lg[0], tp[1], lg[1], tp[2], lg[2], blk.regen_size,
+                                 e.seq.data() + blk.seq_base, &so)
+                        : zg_seq_decode_block(bs, blk.src_len - bits_off, blk.nseq, tp[0], lg[0], tp[1], lg[1], tp[2], lg[2], blk.regen_size,
                                  e.seq.data() + blk.seq_base, &so);
     e.seqout[b] = so;
     set_status(e, b, st);
@@ -219,7 +223,7 @@ static void k_exec(EmuBatch& e) {  // zg_k_lit + zg_k_lz, serial
       const ZgBlock& blk = e.bb.blocks[b];
       const ZgBlockPos& p = e.pos[b];
       uint8_t* out = fbase + p.out_base;
-      const uint8_t* body = e.src.data() + blk.src_off;
+      const uint8_t* body = e.src + blk.src_off;
       if (blk.btype == ZG_BT_RAW) { memcpy(out, body, blk.regen_size); continue; }
       if (blk.btype == ZG_BT_RLE) { memset(out, body[0], blk.regen_size); continue; }
       const bool rle = blk.lit_type == ZG_LT_RLE;
@@ -252,11 +256,13 @@ static void k_exec(EmuBatch& e) {  // zg_k_lit + zg_k_lz, serial
 
 extern "C" {
 
-void* zgemu_decode(const uint8_t* src, size_t len, uint64_t max_window) {
+void* zgemu_decode2(const uint8_t* src, size_t len, uint64_t max_window, int use_fast) {
   EmuBatch* e = new EmuBatch();
-  e->src.assign(src, src + len);
-  e->src.resize(len + 64, 0);
-  e->parse_status = walk(e->src.data(), len, max_window, &e->bb);
+  e->use_fast = use_fast;
+  e->src_store.assign(len + 128, 0);
+  memcpy(e->src_store.data() + 64, src, len);
+  e->src = e->src_store.data() + 64;
+  e->parse_status = walk(e->src, len, max_window, &e->bb);
   e->bb.finish();
   const uint32_t nb = (uint32_t)e->bb.blocks.size(), nf = (uint32_t)e->bb.frames.size();
   e->aux.resize(nb + 1); e->slot_log.assign((size_t)e->bb.nslots() * 4, 0);
@@ -270,6 +276,7 @@ void* zgemu_decode(const uint8_t* src, size_t len, uint64_t max_window) {
   k_tables(*e); k_huf(*e); k_seq(*e); k_scan(*e); k_exec(*e);
   return e;
 }
+void* zgemu_decode(const uint8_t* src, size_t len, uint64_t max_window) { return zgemu_decode2(src, len, max_window, 1); }
 void zgemu_free(void* h) { delete (EmuBatch*)h; }
 int zgemu_parse_status(void* h) { return ((EmuBatch*)h)->parse_status; }
 uint32_t zgemu_num_frames(void* h) { return (uint32_t)((EmuBatch*)h)->bb.frames.size(); }

@@ -21,6 +21,14 @@ def test_corpus_bit_exact():
         assert hashlib.sha256(out).hexdigest() == man[name]["sha256"], name
 
 
+def test_corpus_bit_exact_reference_sequence_routine():
+    """the plain (one read per field) sequence routine, kept as the readable statement of the windowed one"""
+    pack, man = read_pack("decodecorpus.pack"), read_manifest("decodecorpus.json")
+    for name in sorted(man)[::5]:
+        out, st = emu.EmuBatch(pack[name], fast_seq=False).frame_bytes(0)
+        assert st == 0 and hashlib.sha256(out).hexdigest() == man[name]["sha256"], name
+
+
 def test_window_fixtures():
     pack, man = read_pack("test_fixtures.pack"), read_manifest("test_fixtures.json")
     for name in ("window_8mib.zst", "window_128mib.zst"):

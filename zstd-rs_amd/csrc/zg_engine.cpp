@@ -185,9 +185,11 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   };
   int st = 0;
   // compressed bytes, padded so that 8-byte bit-window loads near the end stay inside the allocation
-  if ((st = b->d_src.reserve(len + 64))) { delete b; return st; }
-  if (len && hipMemcpyAsync(b->d_src.p, src, len, hipMemcpyHostToDevice, stream_) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
-  (void)hipMemsetAsync((uint8_t*)b->d_src.p + len, 0, 64, stream_);
+  // ... and 64 bytes in front for the 16-byte windows of the sequence decoder
+  if ((st = b->d_src.reserve(len + 128))) { delete b; return st; }
+  (void)hipMemsetAsync(b->d_src.p, 0, 64, stream_);
+  if (len && hipMemcpyAsync((uint8_t*)b->d_src.p + 64, src, len, hipMemcpyHostToDevice, stream_) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
+  (void)hipMemsetAsync((uint8_t*)b->d_src.p + 64 + len, 0, 64, stream_);
   if ((st = up(b->d_blocks, bb.blocks.data(), nb * sizeof(ZgBlock))) || (st = up(b->d_frames, bb.frames.data(), nf * sizeof(ZgFrame))) ||
       (st = up(b->d_seqblocks, bb.seq_blocks.data(), bb.seq_blocks.size() * 4)) ||
       (st = up(b->d_hufitems, bb.huf_items.data(), bb.huf_items.size() * 4)) ||
@@ -210,7 +212,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
     return st;
   }
   ZgBatchDev& d = b->dev;
-  d.src = b->d_src.as<uint8_t>(); d.src_len = len;
+  d.src = b->d_src.as<uint8_t>() + 64; d.src_len = len;
   d.blocks = b->d_blocks.as<ZgBlock>(); d.nblocks = nb;
   d.frames = b->d_frames.as<ZgFrame>(); d.nframes = nf;
   d.nslots = nslots; d.nhuf_slots = bb.nhuf_slots;

@@ -13,7 +13,7 @@
 #include "zg_kernels.h"
 #include "zg_dev.h"
 
-#define ZG_SEQ_G 8        // blocks (lanes) per workgroup in zg_k_seq: 8 x 5 KiB of tables in LDS -> 4 workgroups per CU
+#define ZG_SEQ_G 9        // blocks (lanes) per workgroup in zg_k_seq: 9 x (5 KiB tables + ring + out) in LDS -> 3 workgroups per CU
 #define ZG_LZ_T 256       // threads per frame in zg_k_lz
 #define ZG_FLAT_MAX 131072u  // largest block output the flatten path handles (Block_Maximum_Size)
 #define ZG_FL_T 512       // threads per block in zg_k_flat
@@ -148,13 +148,48 @@ __global__ void __launch_bounds__(256) zg_k_huf(ZgBatchDev d) {
 // ------------------------------------------------------------------------------------------------------------
 // zg_k_seq: sequence sections (decode_sequences, sequence_section_decoder.rs:14-221). The bitstream of a block is
 // one serial chain, so one lane owns one block; ZG_SEQ_G lanes of a wave work on ZG_SEQ_G blocks with their
-// three tables staged in LDS by all 64 lanes.
+// three tables staged in LDS.
+//
+// gfx950 counts loads and stores in one in-order counter (vmcnt), so a store inside the decode loop would make the
+// next bitstream load wait for the store's full round trip. The loop therefore never touches global memory: the wave
+// alternates between a DECODE phase (ZG_SEQ_CH sequences per lane: tables, bitstream and output all in LDS) and a
+// MOVER phase in which all 64 lanes extend every lane's bitstream ring downwards with 16-byte loads (landing one
+// phase later, i.e. behind a whole decode phase) and flush the decoded sequences with coalesced 16-byte stores.
 // ------------------------------------------------------------------------------------------------------------
+#define ZG_SEQ_CH 8                                   // sequences per lane between two mover phases
+#define ZG_SEQ_CMAX 96                                // >= bytes ZG_SEQ_CH sequences can consume (8 x 89 bits)
+#define ZG_SEQ_MARGIN (2 * ZG_SEQ_CMAX + 32)          // bytes of bitstream kept resident below the current position
+#define ZG_SEQ_RING 512                               // per-lane ring, indexed by the low bits of the global address
+#define ZG_SEQ_PIECES 7                               // 16-byte pieces one mover phase can add per lane (>= CMAX/16 + 1)
+
+// bits [q, q+n) of the stream (n <= 31) read from the lane's ring: two adjacent dwords + one funnel shift.
+// rbits = (stream address & (ring size - 1)) * 8; the ring has a 16-byte mirror of its start behind its end.
+__device__ __forceinline__ uint32_t zg_ring_bits(const uint32_t* ring32, uint32_t rbits, int32_t q, uint32_t n) {
+  const uint32_t rb = (uint32_t)q + rbits;
+  const uint32_t di = (rb >> 5) & (ZG_SEQ_RING / 4 - 1);
+  const uint32_t d0 = ring32[di], d1 = ring32[di + 1];
+  return __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(d1, d0, rb & 31u), 0u, n);
+}
+typedef uint32_t zg_v4u __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) zg_v4u zg_gv4u;   // 16 bytes in global memory: global_load/store, not flat
+__device__ __forceinline__ uint32_t zg_sym_dec_bf(uint32_t v) {  // zg_sym_dec without branches
+  const uint32_t c = v ? v - 1 : 0u;
+  return (v >> 30) ? v + 1 : c;
+}
+
 __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
   __shared__ uint32_t s_tab[ZG_SEQ_G][ZG_FSE_SLOT_U32];
+  __shared__ __attribute__((aligned(16))) uint8_t s_ring[ZG_SEQ_G][ZG_SEQ_RING + 16];
+  __shared__ __attribute__((aligned(16))) ZgSeq s_out[ZG_SEQ_G][ZG_SEQ_CH];
+  __shared__ uint64_t s_fetch_hi[ZG_SEQ_G], s_fetch_lo[ZG_SEQ_G];   // ring extension requested by each lane: [lo, hi)
+  __shared__ uint64_t s_dst[ZG_SEQ_G];                              // where each lane's chunk goes in the sequence arena
+  __shared__ uint32_t s_cnt[ZG_SEQ_G];                              // sequences of the chunk to flush
   __shared__ uint8_t s_log[ZG_SEQ_G][4];
   __shared__ int s_ok[ZG_SEQ_G];
-  const uint32_t base = blockIdx.x * ZG_SEQ_G;
+  __shared__ uint32_t s_llbase[36], s_mlbase[53];   // value tables in LDS: a constant-memory lookup is a global load here
+  const uint32_t base = blockIdx.x * ZG_SEQ_G, t = threadIdx.x;
+  if (t < 36) s_llbase[t] = ZG_LL_BASE[t];
+  if (t < 53) s_mlbase[t] = ZG_ML_BASE[t];
   for (uint32_t g = 0; g < ZG_SEQ_G; g++) {
     uint32_t idx = base + g;
     if (idx >= d.nseq_blocks) break;
@@ -169,30 +204,189 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
       unsigned lg = d.slot_log[(uint64_t)sl[k] * 4 + k];
       if (lg > 9) { ok = false; continue; }
       const uint32_t* g_t = d.fse_arena + (uint64_t)sl[k] * ZG_FSE_SLOT_U32 + offs[k];
-      for (uint32_t i = threadIdx.x; i < (1u << lg); i += 64) s_tab[g][offs[k] + i] = g_t[i];
-      if (threadIdx.x == 0) s_log[g][k] = (uint8_t)lg;
+      {  // <= 512 entries: every lane loads its (up to 8) entries first, then stores them
+        uint32_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const uint32_t i = t + 64 * j; v[j] = i < (1u << lg) ? g_t[i] : 0u; }
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const uint32_t i = t + 64 * j; if (i < (1u << lg)) s_tab[g][offs[k] + i] = v[j]; }
+      }
+      if (t == 0) s_log[g][k] = (uint8_t)lg;
     }
-    if (threadIdx.x == 0) s_ok[g] = ok ? 1 : 0;
+    if (t == 0) s_ok[g] = ok ? 1 : 0;
   }
   __syncthreads();
-  uint32_t g = threadIdx.x;
-  if (g >= ZG_SEQ_G || base + g >= d.nseq_blocks) return;
-  uint32_t b = d.seq_blocks[base + g];
-  const ZgBlock blk = d.blocks[b];
-  if (!s_ok[g]) {
-    // FSEDecoder::init_state on a table that was never set (fse_decoder.rs:33-35), or an upstream failure
-    zg_set_status(d.status, b, ZG_FSE_UNINIT);
-    return;
+  // ---- per-lane setup (lanes >= ZG_SEQ_G only help moving data)
+  const uint32_t g = t < ZG_SEQ_G ? t : 0;
+  bool act = t < ZG_SEQ_G && base + t < d.nseq_blocks;
+  bool have = false;
+  uint32_t b = 0, nseq = 0, regen = 0, done = 0, rbits = 0;
+  uint64_t bsA = 0, floorA = 0, lo = 0;
+  const uint32_t* t_ll = &s_tab[g][ZG_FSE_LL_OFF];
+  const uint32_t* t_of = &s_tab[g][ZG_FSE_OF_OFF];
+  const uint32_t* t_ml = &s_tab[g][ZG_FSE_ML_OFF];
+  const uint32_t* ring32 = (const uint32_t*)s_ring[g];
+  int32_t P = 0;
+  uint32_t e_ll = 0, e_of = 0, e_ml = 0;
+  uint32_t h0 = 1u << 30, h1 = 2u << 30, h2 = 3u << 30, lit_pos = 0, out_pos = 0, sum_ml = 0, emitted = 0;
+  int status = ZG_OK, exe_status = ZG_OK;
+  if (act) {
+    b = d.seq_blocks[base + g];
+    const ZgBlock blk = d.blocks[b];
+    if (!s_ok[g]) {
+      // FSEDecoder::init_state on a table that was never set (fse_decoder.rs:33-35), or an upstream failure
+      zg_set_status(d.status, b, ZG_FSE_UNINIT);
+      act = false;
+    } else {
+      const uint32_t bits_off = d.aux[b].seq_bits_off;
+      if (bits_off > blk.src_len) { zg_set_status(d.status, b, ZG_INTERNAL); act = false; }
+      else {
+        const uint8_t* bs = d.src + blk.src_off + bits_off;
+        const uint32_t bs_len = blk.src_len - bits_off;
+        nseq = blk.nseq; regen = blk.regen_size;
+        const uint32_t lastb = bs_len ? bs[bs_len - 1] : 0;
+        if (bs_len == 0 || lastb == 0) { zg_set_status(d.status, b, ZG_SEQ_EXTRA_PADDING); act = false; }  // :29-40
+        else {
+          P = (int32_t)(bs_len - 1) * 8 + (int32_t)(zg_hbit(lastb) - 1);
+          bsA = (uint64_t)bs;
+          rbits = (uint32_t)(bsA & (ZG_SEQ_RING - 1)) * 8u;
+          floorA = (bsA & ~15ull) - 16;                 // the engine keeps 64 bytes of padding in front of the buffer
+          s_dst[g] = (uint64_t)(d.seq_arena + blk.seq_base);
+          have = true;
+        }
+      }
+    }
   }
-  uint32_t bits_off = d.aux[b].seq_bits_off;
-  if (bits_off > blk.src_len) { zg_set_status(d.status, b, ZG_INTERNAL); return; }
-  const uint8_t* bs = d.src + blk.src_off + bits_off;
-  ZgBlockSeqOut so;
-  int st = zg_seq_decode_block((const uint8_t*)bs, blk.src_len - bits_off, blk.nseq, (const uint32_t*)&s_tab[g][ZG_FSE_LL_OFF], s_log[g][0],
-                               (const uint32_t*)&s_tab[g][ZG_FSE_OF_OFF], s_log[g][1], (const uint32_t*)&s_tab[g][ZG_FSE_ML_OFF], s_log[g][2],
-                               blk.regen_size, d.seq_arena + blk.seq_base, &so);
-  d.seq_out[b] = so;
-  zg_set_status(d.status, b, st);
+  // ---- prologue: fill the rings from the top of each stream downwards
+  {
+    uint64_t top = 0, want = 0;
+    if (act) {
+      top = (bsA + (uint64_t)(P >> 3) + 8 + 15) & ~15ull;       // a read at bit P touches bytes up to P/8 + 7
+      const uint64_t p0 = bsA + (uint64_t)(P >> 3);
+      want = p0 > ZG_SEQ_MARGIN + 16 ? (p0 - ZG_SEQ_MARGIN - 16) & ~15ull : 0;
+      if (want < floorA) want = floorA;
+      lo = want;
+    }
+    if (t < ZG_SEQ_G) { s_fetch_hi[t] = act ? top : 0; s_fetch_lo[t] = act ? want : 0; }
+    __syncthreads();
+    for (uint32_t j = t; j < ZG_SEQ_G * 20; j += 64) {        // (MARGIN + 16 + 8 + 15 + 15) / 16 + 1 <= 20 pieces per lane
+      const uint32_t gg = j / 20, k = j % 20;
+      const uint64_t hi = s_fetch_hi[gg], addr = hi - 16ull * (k + 1);
+      if (hi && addr >= s_fetch_lo[gg] && addr < hi) {
+        const uint4 v = *(const uint4*)addr;
+        const uint32_t ro = (uint32_t)(addr & (ZG_SEQ_RING - 1));
+        *(uint4*)(s_ring[gg] + ro) = v;
+        if (ro == 0) *(uint4*)(s_ring[gg] + ZG_SEQ_RING) = v;
+      }
+    }
+    __syncthreads();
+  }
+  if (act) {  // initial states, order LL, OF, ML (:164-166); a negative position is reported after the first sequence
+    const uint32_t ll_log = s_log[g][0], of_log = s_log[g][1], ml_log = s_log[g][2];
+    P -= (int32_t)ll_log; e_ll = t_ll[P >= 0 ? zg_ring_bits(ring32, rbits, P, ll_log) : 0];
+    P -= (int32_t)of_log; e_of = t_of[P >= 0 ? zg_ring_bits(ring32, rbits, P, of_log) : 0];
+    P -= (int32_t)ml_log; e_ml = t_ml[P >= 0 ? zg_ring_bits(ring32, rbits, P, ml_log) : 0];
+  }
+  zg_v4u piece = {0, 0, 0, 0};
+  uint64_t piece_addr = 0;
+  uint32_t piece_g = 0xFFFFFFFFu;
+  // ---- main loop
+  while (__any(act)) {
+    // DECODE phase: LDS only. Same arithmetic as zg_seq_step (zg_dev.h), 32-bit and branch-free.
+    const uint32_t em0 = emitted;
+    if (act) {
+#pragma unroll 1
+      for (int c = 0; c < ZG_SEQ_CH; c++) {
+        const bool last = done + 1 == nseq;
+        const uint32_t of_code = ZG_FSE_SYM(e_of), ml_code = ZG_FSE_SYM(e_ml), ll_code = ZG_FSE_SYM(e_ll);
+        const uint32_t xb_of = ZG_FSE_XB(e_of), xb_ml = ZG_FSE_XB(e_ml), xb_ll = ZG_FSE_XB(e_ll);
+        const uint32_t nb_ll = last ? 0u : ZG_FSE_NB(e_ll), nb_ml = last ? 0u : ZG_FSE_NB(e_ml), nb_of = last ? 0u : ZG_FSE_NB(e_of);
+        // extra bits in the order OF, ML, LL (:185), then the state bits LL, ML, OF (:204-206)
+        const int32_t q_of = P - (int32_t)xb_of, q_ml = q_of - (int32_t)xb_ml, q_ll = q_ml - (int32_t)xb_ll;
+        const int32_t q_sll = q_ll - (int32_t)nb_ll, q_sml = q_sll - (int32_t)nb_ml, q_sof = q_sml - (int32_t)nb_of;
+        if (q_sof < 0) { status = ZG_SEQ_NOT_ENOUGH_BYTES; act = false; break; }   // :209-211
+        const uint32_t obits = zg_ring_bits(ring32, rbits, q_of, xb_of);
+        const uint32_t ml_add = zg_ring_bits(ring32, rbits, q_ml, xb_ml);
+        const uint32_t ll_add = zg_ring_bits(ring32, rbits, q_ll, xb_ll);
+        const uint32_t s_ll = ZG_FSE_BL(e_ll) + zg_ring_bits(ring32, rbits, q_sll, nb_ll);
+        const uint32_t s_ml = ZG_FSE_BL(e_ml) + zg_ring_bits(ring32, rbits, q_sml, nb_ml);
+        const uint32_t s_of = ZG_FSE_BL(e_of) + zg_ring_bits(ring32, rbits, q_sof, nb_of);
+        const uint32_t ml = s_mlbase[ml_code] + ml_add, ll = s_llbase[ll_code] + ll_add;
+        if (!last) { e_ll = t_ll[s_ll]; e_ml = t_ml[s_ml]; e_of = t_of[s_of]; }
+        P = q_sof;
+        const uint32_t of = obits + (1u << of_code);
+        // do_offset_history (sequence_execution.rs:59-118) on symbolic slots, select form of zg_hist_step
+        const bool rep = of <= 3u;
+        const uint32_t idx = of - 1u + (ll == 0u ? 1u : 0u);
+        const uint32_t cand = idx == 0 ? h0 : idx == 1 ? h1 : idx == 2 ? h2 : zg_sym_dec_bf(h0);
+        const uint32_t actual = rep ? cand : of - 3u;
+        const bool keep = rep && idx == 0;
+        const uint32_t n2 = (rep && idx <= 1) ? h2 : h1, n1 = keep ? h1 : h0, n0 = keep ? h0 : actual;
+        if (exe_status == ZG_OK) {
+          h0 = n0; h1 = n1; h2 = n2;
+          int bad = ZG_OK;
+          if ((uint64_t)out_pos + ll + ml >= (1ull << 31)) bad = ZG_UNSUPPORTED;
+          if (lit_pos + ll > regen) bad = ZG_EXE_NOT_ENOUGH_LITERALS;
+          if (!(actual >> 30) && actual >= (1u << 30)) bad = ZG_EXE_OFFSET_TOO_BIG;
+          if (actual == 0) bad = ZG_EXE_ZERO_OFFSET;
+          if (bad) exe_status = bad;
+          else {
+            ZgSeq q;
+            q.of = actual; q.ml = ml; q.mdst = out_pos + ll; q.lit_start = lit_pos;
+            s_out[g][emitted - em0] = q;
+            lit_pos += ll; out_pos += ll + ml; sum_ml += ml; emitted++;
+          }
+        }
+        done++;
+        if (done == nseq) { act = false; break; }
+      }
+    }
+    // MOVER phase
+    if (t < ZG_SEQ_G) {
+      s_cnt[t] = emitted - em0;
+      uint64_t hi = 0, want = 0;
+      if (act) {
+        const uint64_t p0 = bsA + (uint64_t)(P >> 3);
+        want = p0 > ZG_SEQ_MARGIN ? (p0 - ZG_SEQ_MARGIN) & ~15ull : 0;
+        if (want < floorA) want = floorA;
+        if (want < lo) { hi = lo; lo = want; } else want = 0;
+      }
+      s_fetch_hi[t] = hi; s_fetch_lo[t] = want;
+    }
+    __syncthreads();
+    // (1) land the pieces requested one phase ago
+    if (piece_g != 0xFFFFFFFFu) {
+      const uint32_t ro = (uint32_t)(piece_addr & (ZG_SEQ_RING - 1));
+      *(zg_v4u*)(s_ring[piece_g] + ro) = piece;
+      if (ro == 0) *(zg_v4u*)(s_ring[piece_g] + ZG_SEQ_RING) = piece;
+    }
+    // (2) flush the chunk: ZG_SEQ_G x ZG_SEQ_CH records of 16 bytes
+    for (uint32_t j = t; j < ZG_SEQ_G * ZG_SEQ_CH; j += 64) {
+      const uint32_t gg = j / ZG_SEQ_CH, k = j % ZG_SEQ_CH;
+      if (k < s_cnt[gg]) ((zg_gv4u*)s_dst[gg])[k] = *(const zg_v4u*)&s_out[gg][k];
+    }
+    // (3) request the next pieces
+    piece_g = 0xFFFFFFFFu;
+    if (t < ZG_SEQ_G * ZG_SEQ_PIECES) {
+      const uint32_t gg = t / ZG_SEQ_PIECES, k = t % ZG_SEQ_PIECES;
+      const uint64_t hi = s_fetch_hi[gg];
+      const uint64_t addr = hi - 16ull * (k + 1);
+      if (hi && addr >= s_fetch_lo[gg] && addr < hi) {
+        piece = *(const zg_gv4u*)addr; piece_addr = addr; piece_g = gg;
+      }
+    }
+    __syncthreads();
+    if (t < ZG_SEQ_G) s_dst[t] += (uint64_t)s_cnt[t] * sizeof(ZgSeq);
+    __syncthreads();
+  }
+  if (have) {
+    if (status == ZG_OK && P > 0) status = ZG_SEQ_EXTRA_BITS;  // :214-220
+    if (status == ZG_OK) status = exe_status;
+    ZgBlockSeqOut so;
+    so.sum_ll = lit_pos; so.sum_ml = sum_ml; so.hist_end[0] = h0; so.hist_end[1] = h1; so.hist_end[2] = h2; so.pad = 0;
+    d.seq_out[b] = so;
+    zg_set_status(d.status, b, status);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
