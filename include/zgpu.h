@@ -133,6 +133,8 @@ typedef struct { uint32_t of, ml, mdst, lit_start; } zgpu_seq;   /* of: resolved
 int zgpu_batch_block_info(zgpu_batch*, uint32_t block, zgpu_block_info* out);
 int zgpu_batch_block_literals(zgpu_batch*, uint32_t block, uint8_t* dst, size_t cap, size_t* n);
 int zgpu_batch_block_sequences(zgpu_batch*, uint32_t block, zgpu_seq* dst, size_t cap, size_t* n);
+/* diagnostics: cycle counters accumulated by the kernels when ZGPU_DEBUG_TIMERS is set (all zero otherwise) */
+int zgpu_batch_debug_timers(zgpu_batch*, uint64_t out[8]);
 int zgpu_batch_fse_slot(zgpu_batch*, uint32_t slot, uint32_t* entries /* 1280 */, uint8_t logs[4]);
 int zgpu_batch_huf_slot(zgpu_batch*, uint32_t slot, uint16_t* entries /* 2048 */, int* max_bits);
 

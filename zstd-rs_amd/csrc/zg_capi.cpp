@@ -199,6 +199,7 @@ int zgpu_batch_block_sequences(zgpu_batch* zb, uint32_t i, zgpu_seq* dst, size_t
   if (!v.empty()) memcpy(dst, v.data(), v.size() * sizeof(ZgSeq));
   return ZGPU_OK;
 }
+int zgpu_batch_debug_timers(zgpu_batch* zb, uint64_t out[8]) { return zb->b->read_debug(out); }
 int zgpu_batch_fse_slot(zgpu_batch* zb, uint32_t slot, uint32_t* entries, uint8_t logs[4]) {
   std::vector<uint32_t> v;
   int r = zb->b->read_fse_slot(slot, &v, logs);

@@ -109,7 +109,7 @@ int parse_frames(const uint8_t* src, size_t len, uint64_t max_window, BatchBuild
 
 Batch::~Batch() {
   DevBuf* all[] = {&d_src, &d_blocks, &d_frames, &d_aux, &d_slot_log, &d_fse, &d_huf, &d_hufmax, &d_status, &d_lit, &d_seq,
-                   &d_seqout, &d_pos, &d_frameout, &d_dst, &d_seqblocks, &d_hufitems, &d_hufgroups, &d_totals, &d_og, &d_units, &d_unitinfo, &d_sweepwgs, &d_bar};
+                   &d_seqout, &d_pos, &d_frameout, &d_dst, &d_seqblocks, &d_hufitems, &d_hufgroups, &d_totals, &d_og, &d_units, &d_unitinfo, &d_sweepwgs, &d_bar, &d_dbg};
   for (DevBuf* b : all) b->release();
   for (auto& e : ev)
     if (e) (void)hipEventDestroy(e);
@@ -207,7 +207,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
       (st = b->d_totals.reserve(64)) || (st = b->d_og.reserve((size_t)bb.og_count * 4 + 64)) ||
       (st = up(b->d_units, bb.units.data(), bb.units.size() * sizeof(ZgUnit))) ||
       (st = up(b->d_sweepwgs, bb.sweep_wgs.data(), bb.sweep_wgs.size() * sizeof(ZgSweepWg))) ||
-      (st = b->d_unitinfo.reserve(bb.units.size() * sizeof(ZgUnitInfo) + 16)) || (st = b->d_bar.reserve((size_t)nf * 4 + 16))) {
+      (st = b->d_unitinfo.reserve(bb.units.size() * sizeof(ZgUnitInfo) + 16)) || (st = b->d_bar.reserve((size_t)nf * 4 + 16)) || (st = b->d_dbg.reserve(64))) {
     delete b;
     return st;
   }
@@ -227,7 +227,9 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   d.og = b->d_og.as<uint32_t>();
   d.units = b->d_units.as<ZgUnit>(); d.nunits = (uint32_t)bb.units.size(); d.unit_info = b->d_unitinfo.as<ZgUnitInfo>();
   d.sweep_wgs = b->d_sweepwgs.as<ZgSweepWg>(); d.nsweep_wgs = (uint32_t)bb.sweep_wgs.size(); d.bar = b->d_bar.as<uint32_t>();
+  d.dbg = getenv("ZGPU_DEBUG_TIMERS") ? b->d_dbg.as<unsigned long long>() : nullptr;
   { const char* e = getenv("ZGPU_FORCE_INORDER"); d.flags = (e && e[0] == '1') ? 1u : 0u; }
+  { const char* e = getenv("ZGPU_SWEEP_T1024"); if (!e || e[0] != '0') d.flags |= 2u; }
   for (auto& e : b->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
   if (hipStreamSynchronize(stream_) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
@@ -246,6 +248,7 @@ int Batch::run() {
   ZG_HIP(hipMemsetAsync(d.slot_log, 0, (size_t)d.nslots * 4, s));
   ZG_HIP(hipMemsetAsync(d.totals, 0, 64, s));
   ZG_HIP(hipMemsetAsync(d.bar, 0, (size_t)d.nframes * 4 + 16, s));
+  if (d.dbg) ZG_HIP(hipMemsetAsync(d.dbg, 0, 64, s));
   zg_launch_tables(d, s);
   ZG_HIP(hipEventRecord(ev[1], s));
   zg_launch_huf(d, s);
@@ -319,6 +322,11 @@ int Batch::read_fse_slot(uint32_t slot, std::vector<uint32_t>* entries, uint8_t 
   entries->resize(ZG_FSE_SLOT_U32);
   ZG_HIP(hipMemcpy(entries->data(), dev.fse_arena + (size_t)slot * ZG_FSE_SLOT_U32, ZG_FSE_SLOT_U32 * 4, hipMemcpyDeviceToHost));
   ZG_HIP(hipMemcpy(logs, dev.slot_log + (size_t)slot * 4, 4, hipMemcpyDeviceToHost));
+  return ZG_OK;
+}
+int Batch::read_debug(uint64_t out[8]) {
+  for (int i = 0; i < 8; i++) out[i] = 0;
+  if (dev.dbg) ZG_HIP(hipMemcpy(out, dev.dbg, 64, hipMemcpyDeviceToHost));
   return ZG_OK;
 }
 int Batch::read_huf_slot(uint32_t slot, std::vector<uint16_t>* entries, int* max_bits) {

@@ -58,13 +58,14 @@ class Batch {
   int read_sequences(uint32_t block, std::vector<ZgSeq>* seqs, ZgBlockSeqOut* so, ZgBlockPos* pos);
   int read_fse_slot(uint32_t slot, std::vector<uint32_t>* entries, uint8_t logs[4]);
   int read_huf_slot(uint32_t slot, std::vector<uint16_t>* entries, int* max_bits);
+  int read_debug(uint64_t out[8]);
 
  private:
   friend class Engine;
   Engine* eng = nullptr;
   ZgBatchDev dev{};
   DevBuf d_src, d_blocks, d_frames, d_aux, d_slot_log, d_fse, d_huf, d_hufmax, d_status, d_lit, d_seq, d_seqout, d_pos, d_frameout,
-      d_dst, d_seqblocks, d_hufitems, d_hufgroups, d_totals, d_og, d_units, d_unitinfo, d_sweepwgs, d_bar;
+      d_dst, d_seqblocks, d_hufitems, d_hufgroups, d_totals, d_og, d_units, d_unitinfo, d_sweepwgs, d_bar, d_dbg;
   hipEvent_t ev[ZG_T_COUNT + 1] = {};
   bool ran = false;
 };

@@ -222,13 +222,21 @@ void BatchBuilder::finish() {
   }
   seq_blocks.clear(); huf_items.clear(); huf_groups.clear(); units.clear(); sweep_wgs.clear();
   og_count = 0;
+  // blocks per unit: zg_k_flat runs about one workgroup per CU, so aim at ~flat_slots units over the whole submit
+  // (more blocks per unit = fewer sweep steps, but less parallelism in the flatten pass)
+  uint32_t ub = unit_blocks;
+  if (ub == 0) {
+    ub = (nb + flat_slots - 1) / flat_slots;
+    if (ub < 8) ub = 8;
+    if (ub > 64) ub = 64;
+  }
   for (uint32_t f = 0; f < frames.size(); f++) {
     ZgFrame& fr = frames[f];
     fr.first_unit = (uint32_t)units.size();
-    for (uint32_t i = 0; i < fr.nblocks; i += unit_blocks) {
+    for (uint32_t i = 0; i < fr.nblocks; i += ub) {
       ZgUnit u;
       u.frame = f; u.first_block = fr.first_block + i;
-      u.nblocks = fr.nblocks - i < unit_blocks ? fr.nblocks - i : unit_blocks; u.pad = 0;
+      u.nblocks = fr.nblocks - i < ub ? fr.nblocks - i : ub; u.pad = 0;
       u.og_base = og_count;
       og_count += (uint64_t)u.nblocks * kMaxBlockSize;
       units.push_back(u);

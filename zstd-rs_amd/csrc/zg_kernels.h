@@ -42,6 +42,7 @@ struct ZgBatchDev {
   ZgUnitInfo* unit_info;       // [nunits]
   const ZgSweepWg* sweep_wgs;
   uint32_t nsweep_wgs;
+  unsigned long long* dbg;     // [8]: phase cycle counters of zg_k_flat (summed over workgroups), diagnostics only
   uint32_t* bar;               // [nframes] arrival counters of the sweep's per-frame barrier (zeroed every run)
 };
 

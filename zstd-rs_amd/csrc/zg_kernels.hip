@@ -16,12 +16,11 @@
 #define ZG_SEQ_G 9        // blocks (lanes) per workgroup in zg_k_seq: 9 x (5 KiB tables + ring + out) in LDS -> 3 workgroups per CU
 #define ZG_LZ_T 256       // threads per frame in zg_k_lz
 #define ZG_FLAT_MAX 131072u  // largest block output the flatten path handles (Block_Maximum_Size)
-#define ZG_FL_T 512       // threads per block in zg_k_flat
+#define ZG_FL_T 1024      // threads per unit in zg_k_flat
 #define ZG_FL_TS 16384    // tile: bytes of block output resolved at a time in LDS
 #define ZG_FL_PER (ZG_FL_TS / ZG_FL_T)
 #define ZG_PAR_LIT 0xFFFFu   // tile byte is a literal: value in s_val
 #define ZG_PAR_EXIT 0xFFFEu  // tile byte is a match byte whose source lies before the tile
-#define ZG_SW_T 256       // threads per workgroup in zg_k_sweep
 
 __device__ __forceinline__ void zg_set_status(uint32_t* status, uint32_t b, int st) {
   if (st) atomicCAS(&status[b], 0u, (uint32_t)st);
@@ -612,6 +611,12 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
   uint32_t* og = d.og + un.og_base;
   if (t == 0) { s_err = 0; s_unres = 0; }
   uint32_t unit_size = 0;
+#ifdef ZG_PROFILE_FLAT   // per-phase cycle counters (tools/dev/flat_phases.py); costs registers, off in the product build
+  unsigned long long tc[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
+#define ZG_TICK(i) { const unsigned long long n_ = clock64(); tc[i] += n_ - tlast; tlast = n_; }
+#else
+#define ZG_TICK(i)
+#endif
   __syncthreads();
   for (uint32_t bi = 0; bi < un.nblocks; bi++) {
     const uint32_t b = un.first_block + bi;
@@ -642,6 +647,7 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
       const uint32_t tu0 = bu0 + t0;                             // unit-relative position of the tile
       if (t == 0) s_next = 0xFFFFFFFFu;
       __syncthreads();
+      ZG_TICK(0)
       // ---- S1: parents. Sequence i covers [mdst-ll, mdst+ml); index nseq stands for the trailing literals.
       for (uint32_t i = i_start + t; i <= nseq; i += ZG_FL_T) {
         uint32_t a, m0, m1, lstart, off = 0;
@@ -657,10 +663,15 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
         }
         if (m1 > t1 || a >= t1) atomicMin(&s_next, i);  // first sequence that reaches beyond this tile starts the next one
         if (a >= t1) break;
-        uint32_t x0 = a > t0 ? a : t0, x1 = m0 < t1 ? m0 : t1;  // literal run
-        for (uint32_t x = x0; x < x1; x++) {
-          s_val[x - t0] = lit_rle ? lit_fill : lit[lstart + (x - a)];
-          s_par[x - t0] = ZG_PAR_LIT;
+        uint32_t x0 = a > t0 ? a : t0, x1 = m0 < t1 ? m0 : t1;  // literal run (usually 0-3 bytes: fetched 4 at a time)
+        if (lit_rle) {
+          for (uint32_t x = x0; x < x1; x++) { s_val[x - t0] = lit_fill; s_par[x - t0] = ZG_PAR_LIT; }
+        } else {
+          for (uint32_t x = x0; x < x1; x += 4) {
+            const uint32_t w4 = zg_ld32(lit + lstart + (x - a));   // literal buffers are padded: reading 3 bytes past the run is safe
+            const uint32_t n = x1 - x < 4 ? x1 - x : 4;
+            for (uint32_t k = 0; k < n; k++) { s_val[x + k - t0] = (uint8_t)(w4 >> (8 * k)); s_par[x + k - t0] = ZG_PAR_LIT; }
+          }
         }
         x0 = m0 > t0 ? m0 : t0; x1 = m1 < t1 ? m1 : t1;         // match
         if (x0 < x1 && off) {
@@ -673,6 +684,7 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
         }
       }
       __syncthreads();
+      ZG_TICK(1)
       i_start = s_next == 0xFFFFFFFFu ? nseq + 1 : s_next;
       if (s_err) break;
       // ---- S2: pointer jumping inside the tile. Pointers are < 0x8000; 0x8000|j = parent before the tile; 0xFFFF = literal.
@@ -686,56 +698,68 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
       }
       for (int round = 0; round < 40; round++) {
         if (!__syncthreads_or(unresolved != 0)) break;
-        uint16_t q[ZG_FL_PER];
+        if (unresolved) {   // waves whose bytes are all resolved skip the LDS traffic
+          uint16_t q[ZG_FL_PER];
 #pragma unroll
-        for (int k = 0; k < ZG_FL_PER; k++) q[k] = (unresolved & (1u << k)) ? s_par[pr[k]] : (uint16_t)0xFFFF;
+          for (int k = 0; k < ZG_FL_PER; k++) q[k] = (unresolved & (1u << k)) ? s_par[pr[k]] : (uint16_t)0xFFFF;
 #pragma unroll
-        for (int k = 0; k < ZG_FL_PER; k++) {
-          if (unresolved & (1u << k)) {
-            if (q[k] >= 0x8000u) unresolved &= ~(1u << k);   // pr[k] is the root
-            else { pr[k] = q[k]; s_par[t + k * ZG_FL_T] = q[k]; }
+          for (int k = 0; k < ZG_FL_PER; k++) {
+            if (unresolved & (1u << k)) {
+              if (q[k] >= 0x8000u) unresolved &= ~(1u << k);   // pr[k] is the root
+              else { pr[k] = q[k]; s_par[t + k * ZG_FL_T] = q[k]; }
+            }
           }
         }
       }
       if (__syncthreads_or(unresolved != 0)) { if (t == 0) s_err = ZG_INTERNAL; __syncthreads(); break; }  // cannot happen: depth < 2^14
-      // ---- S3: value or effective offset of every byte of the tile
-      uint32_t oo[ZG_FL_PER];
-      int32_t pu[ZG_FL_PER];      // unit position of the root's parent when it must be looked up, else -1
-      uint8_t vv[ZG_FL_PER];
-#pragma unroll
-      for (int k = 0; k < ZG_FL_PER; k++) {
-        const uint32_t xr = t + k * ZG_FL_T;
-        oo[k] = 0; vv[k] = 0; pu[k] = -1;
-        if (t0 + xr >= t1) continue;
-        const uint16_t own = s_par[xr];
-        const uint32_t r = own >= 0x8000u ? xr : pr[k];   // tile-relative root
-        const uint16_t rp = own >= 0x8000u ? own : s_par[r];
-        if (rp == ZG_PAR_LIT) { vv[k] = s_val[r]; continue; }
-        const uint32_t off_r = s_soff[rp & 0x7FFFu];
-        const int32_t par_u = (int32_t)(tu0 + r) - (int32_t)off_r;   // unit position of the root's parent (< tu0)
-        if (par_u >= 0) pu[k] = par_u;                               // an earlier tile of this unit: already final
-        else oo[k] = (tu0 + xr) + (uint32_t)(-par_u);                // reaches before the unit
-      }
-      uint32_t o2[ZG_FL_PER];
-#pragma unroll
-      for (int k = 0; k < ZG_FL_PER; k++) o2[k] = pu[k] >= 0 ? og[pu[k]] : 1u;
-#pragma unroll
-      for (int k = 0; k < ZG_FL_PER; k++) {
-        if (pu[k] >= 0) {
-          if (o2[k] == 0) vv[k] = out_u[pu[k]];
-          else oo[k] = ((tu0 + t + k * ZG_FL_T) - (uint32_t)pu[k]) + o2[k];
-        }
-      }
-      __syncthreads();
-      // ---- S4: publish the tile
+      ZG_TICK(2)
+      // ---- S3: value or effective offset of every byte of the tile, written straight to their places (nobody reads
+      // s_val at match positions or og[] of the current tile during this phase). Two batches of 8 keep registers low.
       uint32_t nun = 0;
 #pragma unroll
-      for (int k = 0; k < ZG_FL_PER; k++) {
-        const uint32_t xr = t + k * ZG_FL_T;
-        if (t0 + xr < t1) { s_val[xr] = vv[k]; og[tu0 + xr] = oo[k]; nun += oo[k] != 0; }
+      for (int hb = 0; hb < ZG_FL_PER; hb += 8) {
+        uint32_t oo[8];
+        int32_t pu[8];      // unit position of the root's parent when it must be looked up, else -1
+        bool lit[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int k = hb + j;
+          const uint32_t xr = t + k * ZG_FL_T;
+          oo[j] = 0; pu[j] = -1; lit[j] = true;
+          if (t0 + xr >= t1) continue;
+          const uint16_t own = s_par[xr];
+          if (own == ZG_PAR_LIT) continue;
+          const uint32_t r = own >= 0x8000u ? xr : pr[k];   // tile-relative root
+          const uint16_t rp = own >= 0x8000u ? own : s_par[r];
+          if (rp == ZG_PAR_LIT) { s_val[xr] = s_val[r]; continue; }
+          lit[j] = false;
+          const uint32_t off_r = s_soff[rp & 0x7FFFu];
+          const int32_t par_u = (int32_t)(tu0 + r) - (int32_t)off_r;   // unit position of the root's parent (< tu0)
+          if (par_u >= 0) pu[j] = par_u;                               // an earlier tile of this unit: already final
+          else oo[j] = (tu0 + xr) + (uint32_t)(-par_u);                // reaches before the unit
+        }
+        uint32_t o2[8];
+        uint8_t v2[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) o2[j] = og[pu[j] >= 0 ? pu[j] : 0];      // clamped addresses: all loads issued back to back
+#pragma unroll
+        for (int j = 0; j < 8; j++) v2[j] = out_u[pu[j] >= 0 ? pu[j] : 0];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const uint32_t xr = t + (hb + j) * ZG_FL_T;
+          if (t0 + xr >= t1) continue;
+          if (pu[j] >= 0) {
+            if (o2[j] == 0) s_val[xr] = v2[j];
+            else oo[j] = ((tu0 + xr) - (uint32_t)pu[j]) + o2[j];
+          }
+          og[tu0 + xr] = oo[j];
+          nun += oo[j] != 0;
+        }
       }
       if (nun) atomicAdd(&s_unres, nun);
       __syncthreads();
+      ZG_TICK(3)
+      // ---- S4: publish the tile
       {
         const uint32_t n = t1 - t0;
         uint8_t* o = out_u + tu0;
@@ -744,6 +768,7 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
         for (uint32_t i = (n8 << 3) + t; i < n; i += ZG_FL_T) o[i] = s_val[i];
       }
       __syncthreads();  // the next tile reads og[] / out[] of this one
+      ZG_TICK(4)
     }
     if (s_err) {
       if (t == 0) atomicMin(&d.frame_out[un.frame].err_packed, ((b - fr.first_block) << 8) | s_err);
@@ -752,6 +777,10 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
   }
   __syncthreads();
   if (t == 0) { ZgUnitInfo ui; ui.size = unit_size; ui.unresolved = s_unres; d.unit_info[blockIdx.x] = ui; }
+#ifdef ZG_PROFILE_FLAT
+  if (t == 0 && d.dbg) for (int i = 0; i < 6; i++) atomicAdd(&d.dbg[i], tc[i]);
+#endif
+#undef ZG_TICK
 }
 
 // per-frame barrier of the sweep: monotonic arrival counter, agent-scope release before arriving, relaxed polling,
@@ -775,9 +804,14 @@ __device__ __forceinline__ bool zg_frame_barrier(uint32_t* counter, uint32_t tar
   return s_ok != 0;
 }
 
-#define ZG_SW_B 8   // groups of 4 output bytes a thread has in flight
+#define ZG_SW_B 8       // groups of 4 output bytes a thread has in flight
+#define ZG_SW_UMAX 512  // units whose metadata is staged in LDS at a time
 
-__global__ void __launch_bounds__(ZG_SW_T) zg_k_sweep(ZgBatchDev d) {
+struct ZgSweepUnit { uint32_t size, unresolved; uint64_t out_off, og_base; };
+
+template <int T>
+__global__ void __launch_bounds__(T) zg_k_sweep(ZgBatchDev d) {
+  __shared__ ZgSweepUnit s_u[ZG_SW_UMAX];
   if (d.totals[2]) return;
   const ZgSweepWg wg = d.sweep_wgs[blockIdx.x];
   const uint32_t f = wg.frame, t = threadIdx.x;
@@ -786,54 +820,108 @@ __global__ void __launch_bounds__(ZG_SW_T) zg_k_sweep(ZgBatchDev d) {
   const ZgFrame fr = d.frames[f];
   uint8_t* frame_out = d.dst + fo.out_base;
   uint32_t steps = 0;
-  bool alive = true;
-  for (uint32_t ui = 0; ui < fr.nunits && alive; ui++) {
-    const uint32_t u = fr.first_unit + ui;
-    const ZgUnitInfo info = d.unit_info[u];
-    if (info.size == 0) break;            // first unit that was not (fully) flattened: error or inactive blocks
-    if (info.unresolved == 0) continue;   // nothing points before this unit
-    const ZgUnit un = d.units[u];
-    uint8_t* out = frame_out + d.pos[un.first_block].out_base;
-    const uint32_t* og = d.og + un.og_base;
-    const uint32_t n4 = info.size >> 2;
-    const uint32_t per = (n4 + wg.wpf - 1) / wg.wpf;
-    const uint32_t g0 = wg.rank * per, g1 = g0 + per < n4 ? g0 + per : n4;
-    for (uint32_t base = g0 + t; base < g1; base += ZG_SW_T * ZG_SW_B) {
-      uint4 o[ZG_SW_B];
-#pragma unroll
-      for (int k = 0; k < ZG_SW_B; k++) {
-        const uint32_t g = base + k * ZG_SW_T;
-        o[k] = g < g1 ? *(const uint4*)(og + 4 * (uint64_t)g) : make_uint4(0, 0, 0, 0);
-      }
-      uint32_t w4[ZG_SW_B];
-      bool run[ZG_SW_B];
-#pragma unroll
-      for (int k = 0; k < ZG_SW_B; k++) {
-        run[k] = o[k].x != 0 && o[k].x == o[k].y && o[k].x == o[k].z && o[k].x == o[k].w;
-        const uint8_t* w = out + 4 * (uint64_t)(base + k * ZG_SW_T);
-        w4[k] = run[k] ? zg_ld32(w - o[k].x) : 0;
-      }
-#pragma unroll
-      for (int k = 0; k < ZG_SW_B; k++) {
-        const uint32_t g = base + k * ZG_SW_T;
-        if (g >= g1) continue;
-        uint8_t* w = out + 4 * (uint64_t)g;
-        if (run[k]) { ((zg_u32u*)w)->v = w4[k]; continue; }
-        if (o[k].x) w[0] = w[0 - (int64_t)o[k].x];
-        if (o[k].y) w[1] = w[1 - (int64_t)o[k].y];
-        if (o[k].z) w[2] = w[2 - (int64_t)o[k].z];
-        if (o[k].w) w[3] = w[3 - (int64_t)o[k].w];
-      }
+  bool alive = true, stop = false;
+  for (uint32_t c0 = 0; c0 < fr.nunits && alive && !stop; c0 += ZG_SW_UMAX) {
+    const uint32_t cn = fr.nunits - c0 < ZG_SW_UMAX ? fr.nunits - c0 : ZG_SW_UMAX;
+    __syncthreads();
+    for (uint32_t i = t; i < cn; i += T) {   // unit metadata: three dependent loads each, done once and in parallel
+      const uint32_t u = fr.first_unit + c0 + i;
+      const ZgUnitInfo info = d.unit_info[u];
+      const ZgUnit un = d.units[u];
+      ZgSweepUnit su;
+      su.size = info.size; su.unresolved = info.unresolved; su.og_base = un.og_base;
+      su.out_off = d.pos[un.first_block].out_base;
+      s_u[i] = su;
     }
-    if (wg.rank == wg.wpf - 1) {          // tail bytes of the unit
-      for (uint32_t x = (n4 << 2) + t; x < info.size; x += ZG_SW_T) {
-        const uint32_t o = og[x];
-        if (o) out[x] = out[(int64_t)x - o];
+    __syncthreads();
+    // next unit of this chunk (from index i on) that has bytes to fill; cn if none; stop at the first unflattened unit
+    auto next_unit = [&](uint32_t i) -> uint32_t {
+      for (; i < cn; i++) {
+        if (s_u[i].size == 0) { stop = true; return cn; }
+        if (s_u[i].unresolved) return i;
       }
+      return cn;
+    };
+    uint4 onext[ZG_SW_B];
+    auto prefetch = [&](uint32_t i) {
+      const ZgSweepUnit su = s_u[i];
+      const uint32_t* og = d.og + su.og_base;
+      const uint32_t n4 = su.size >> 2, per = (n4 + wg.wpf - 1) / wg.wpf;
+      const uint32_t g0 = wg.rank * per, g1 = g0 + per < n4 ? g0 + per : n4;
+#pragma unroll
+      for (int k = 0; k < ZG_SW_B; k++) {
+        const uint32_t g = g0 + t + k * T;
+        onext[k] = g < g1 ? *(const uint4*)(og + 4 * (uint64_t)g) : make_uint4(0, 0, 0, 0);
+      }
+    };
+    uint32_t ui = next_unit(0);
+    if (ui < cn) prefetch(ui);
+    while (ui < cn) {
+      const ZgSweepUnit su = s_u[ui];
+      uint8_t* out = frame_out + su.out_off;
+      const uint32_t* og = d.og + su.og_base;
+      const uint32_t n4 = su.size >> 2, per = (n4 + wg.wpf - 1) / wg.wpf;
+      const uint32_t g0 = wg.rank * per, g1 = g0 + per < n4 ? g0 + per : n4;
+      bool first = true;
+      for (uint32_t base = g0 + t; base < g1 + t; base += T * ZG_SW_B) {   // every thread runs the same number of batches
+        uint4 o[ZG_SW_B];
+        if (first) {
+#pragma unroll
+          for (int k = 0; k < ZG_SW_B; k++) o[k] = onext[k];
+          first = false;
+        } else {
+#pragma unroll
+          for (int k = 0; k < ZG_SW_B; k++) {
+            const uint32_t g = base + k * T;
+            o[k] = g < g1 ? *(const uint4*)(og + 4 * (uint64_t)g) : make_uint4(0, 0, 0, 0);
+          }
+        }
+        // all loads of the batch first (sources lie before the unit: no hazards with this step's stores), then the stores
+        uint32_t w4[ZG_SW_B], cur[ZG_SW_B];
+        uint8_t b0[ZG_SW_B], b1[ZG_SW_B], b2[ZG_SW_B], b3[ZG_SW_B];
+        bool run[ZG_SW_B];
+#pragma unroll
+        for (int k = 0; k < ZG_SW_B; k++) {
+          run[k] = o[k].x != 0 && o[k].x == o[k].y && o[k].x == o[k].z && o[k].x == o[k].w;
+          const uint8_t* w = out + 4 * (uint64_t)(base + k * T);
+          const bool any = (o[k].x | o[k].y | o[k].z | o[k].w) != 0;
+          w4[k] = run[k] ? zg_ld32(w - o[k].x) : 0;
+          const bool mix = any && !run[k];
+          cur[k] = mix ? zg_ld32(w) : 0;
+          b0[k] = mix && o[k].x ? w[0 - (int64_t)o[k].x] : 0;
+          b1[k] = mix && o[k].y ? w[1 - (int64_t)o[k].y] : 0;
+          b2[k] = mix && o[k].z ? w[2 - (int64_t)o[k].z] : 0;
+          b3[k] = mix && o[k].w ? w[3 - (int64_t)o[k].w] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < ZG_SW_B; k++) {
+          const uint32_t g = base + k * T;
+          if (g >= g1 || (o[k].x | o[k].y | o[k].z | o[k].w) == 0) continue;
+          uint8_t* w = out + 4 * (uint64_t)g;
+          uint32_t v = w4[k];
+          if (!run[k]) {
+            v = cur[k];
+            if (o[k].x) v = (v & 0xFFFFFF00u) | b0[k];
+            if (o[k].y) v = (v & 0xFFFF00FFu) | ((uint32_t)b1[k] << 8);
+            if (o[k].z) v = (v & 0xFF00FFFFu) | ((uint32_t)b2[k] << 16);
+            if (o[k].w) v = (v & 0x00FFFFFFu) | ((uint32_t)b3[k] << 24);
+          }
+          ((zg_u32u*)w)->v = v;
+        }
+      }
+      if (wg.rank == wg.wpf - 1) {          // tail bytes of the unit
+        for (uint32_t x = (n4 << 2) + t; x < su.size; x += T) {
+          const uint32_t o = og[x];
+          if (o) out[x] = out[(int64_t)x - o];
+        }
+      }
+      const uint32_t nx = next_unit(ui + 1);
+      if (nx < cn) prefetch(nx);            // the scratch of the next unit does not depend on this step: load it across the barrier
+      steps++;
+      if (wg.wpf > 1) { alive = zg_frame_barrier(d.bar + f, steps * wg.wpf, t); if (!alive) break; }
+      else __syncthreads();                 // same CU: later loads see these stores
+      ui = nx;
     }
-    steps++;
-    if (wg.wpf > 1) alive = zg_frame_barrier(d.bar + f, steps * wg.wpf, t);
-    else __syncthreads();               // same CU: later loads see these stores
   }
   const uint32_t ep = d.frame_out[f].err_packed;
   if (t == 0 && wg.rank == 0) {
@@ -951,7 +1039,9 @@ void zg_launch_flat(const ZgBatchDev& d, hipStream_t s) {
   if (d.nunits) hipLaunchKernelGGL(zg_k_flat, dim3(d.nunits), dim3(ZG_FL_T), 0, s, d);
 }
 void zg_launch_sweep(const ZgBatchDev& d, hipStream_t s) {
-  if (d.nsweep_wgs) hipLaunchKernelGGL(zg_k_sweep, dim3(d.nsweep_wgs), dim3(ZG_SW_T), 0, s, d);
+  if (!d.nsweep_wgs) return;
+  if (d.flags & 2u) hipLaunchKernelGGL(zg_k_sweep<1024>, dim3(d.nsweep_wgs), dim3(1024), 0, s, d);
+  else hipLaunchKernelGGL(zg_k_sweep<256>, dim3(d.nsweep_wgs), dim3(256), 0, s, d);
 }
 void zg_launch_lz(const ZgBatchDev& d, hipStream_t s) {
   hipLaunchKernelGGL(zg_k_lz, dim3(d.nframes), dim3(ZG_LZ_T), 0, s, d);
