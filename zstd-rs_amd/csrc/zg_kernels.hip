@@ -13,7 +13,7 @@
 #include "zg_kernels.h"
 #include "zg_dev.h"
 
-#define ZG_SEQ_G 9        // blocks (lanes) per workgroup in zg_k_seq: 9 x (5 KiB tables + ring + out) in LDS -> 3 workgroups per CU
+#define ZG_SEQ_G 16       // blocks (lanes) per workgroup in zg_k_seq: 16 x (2.5 KiB tables + ring + out) in LDS -> 3 workgroups per CU
 #define ZG_LZ_T 256       // threads per frame in zg_k_lz
 #define ZG_FLAT_MAX 131072u  // largest block output the flatten path handles (Block_Maximum_Size)
 #define ZG_FL_T 1024      // threads per unit in zg_k_flat
@@ -177,7 +177,8 @@ __device__ __forceinline__ uint32_t zg_sym_dec_bf(uint32_t v) {  // zg_sym_dec w
 }
 
 __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
-  __shared__ uint32_t s_tab[ZG_SEQ_G][ZG_FSE_SLOT_U32];
+  // tables are re-packed to 16 bits while they are staged: [15:10] symbol, [9:0] x = (1 << (log - num_bits)) | (base_line >> num_bits)
+  __shared__ uint16_t s_tab[ZG_SEQ_G][ZG_FSE_SLOT_U32];
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[ZG_SEQ_G][ZG_SEQ_RING + 16];
   __shared__ __attribute__((aligned(16))) ZgSeq s_out[ZG_SEQ_G][ZG_SEQ_CH];
   __shared__ uint64_t s_fetch_hi[ZG_SEQ_G], s_fetch_lo[ZG_SEQ_G];   // ring extension requested by each lane: [lo, hi)
@@ -185,10 +186,10 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
   __shared__ uint32_t s_cnt[ZG_SEQ_G];                              // sequences of the chunk to flush
   __shared__ uint8_t s_log[ZG_SEQ_G][4];
   __shared__ int s_ok[ZG_SEQ_G];
-  __shared__ uint32_t s_llbase[36], s_mlbase[53];   // value tables in LDS: a constant-memory lookup is a global load here
+  __shared__ uint32_t s_llbase[36], s_mlbase[53];   // base | extra_bits << 24: in LDS, a constant-memory lookup is a global load here
   const uint32_t base = blockIdx.x * ZG_SEQ_G, t = threadIdx.x;
-  if (t < 36) s_llbase[t] = ZG_LL_BASE[t];
-  if (t < 53) s_mlbase[t] = ZG_ML_BASE[t];
+  if (t < 36) s_llbase[t] = ZG_LL_BASE[t] | ((uint32_t)ZG_LL_BITS[t] << 24);
+  if (t < 53) s_mlbase[t] = ZG_ML_BASE[t] | ((uint32_t)ZG_ML_BITS[t] << 24);
   for (uint32_t g = 0; g < ZG_SEQ_G; g++) {
     uint32_t idx = base + g;
     if (idx >= d.nseq_blocks) break;
@@ -208,7 +209,13 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
 #pragma unroll
         for (int j = 0; j < 8; j++) { const uint32_t i = t + 64 * j; v[j] = i < (1u << lg) ? g_t[i] : 0u; }
 #pragma unroll
-        for (int j = 0; j < 8; j++) { const uint32_t i = t + 64 * j; if (i < (1u << lg)) s_tab[g][offs[k] + i] = v[j]; }
+        for (int j = 0; j < 8; j++) {
+          const uint32_t i = t + 64 * j;
+          if (i < (1u << lg)) {
+            const uint32_t nb = ZG_FSE_NB(v[j]);
+            s_tab[g][offs[k] + i] = (uint16_t)((ZG_FSE_SYM(v[j]) << 10) | (1u << (lg - nb)) | (ZG_FSE_BL(v[j]) >> nb));
+          }
+        }
       }
       if (t == 0) s_log[g][k] = (uint8_t)lg;
     }
@@ -221,9 +228,10 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
   bool have = false;
   uint32_t b = 0, nseq = 0, regen = 0, done = 0, rbits = 0;
   uint64_t bsA = 0, floorA = 0, lo = 0;
-  const uint32_t* t_ll = &s_tab[g][ZG_FSE_LL_OFF];
-  const uint32_t* t_of = &s_tab[g][ZG_FSE_OF_OFF];
-  const uint32_t* t_ml = &s_tab[g][ZG_FSE_ML_OFF];
+  const uint16_t* t_ll = &s_tab[g][ZG_FSE_LL_OFF];
+  const uint16_t* t_of = &s_tab[g][ZG_FSE_OF_OFF];
+  const uint16_t* t_ml = &s_tab[g][ZG_FSE_ML_OFF];
+  uint32_t ll_log = 0, of_log = 0, ml_log = 0;
   const uint32_t* ring32 = (const uint32_t*)s_ring[g];
   int32_t P = 0;
   uint32_t e_ll = 0, e_of = 0, e_ml = 0;
@@ -268,7 +276,7 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
     }
     if (t < ZG_SEQ_G) { s_fetch_hi[t] = act ? top : 0; s_fetch_lo[t] = act ? want : 0; }
     __syncthreads();
-    for (uint32_t j = t; j < ZG_SEQ_G * 20; j += 64) {        // (MARGIN + 16 + 8 + 15 + 15) / 16 + 1 <= 20 pieces per lane
+    for (uint32_t j = t; j < ZG_SEQ_G * 20; j += 64) {        // (MARGIN + 16 + 8 + 15 + 15) / 16 + 1 <= 20 pieces per block
       const uint32_t gg = j / 20, k = j % 20;
       const uint64_t hi = s_fetch_hi[gg], addr = hi - 16ull * (k + 1);
       if (hi && addr >= s_fetch_lo[gg] && addr < hi) {
@@ -281,14 +289,14 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
     __syncthreads();
   }
   if (act) {  // initial states, order LL, OF, ML (:164-166); a negative position is reported after the first sequence
-    const uint32_t ll_log = s_log[g][0], of_log = s_log[g][1], ml_log = s_log[g][2];
+    ll_log = s_log[g][0]; of_log = s_log[g][1]; ml_log = s_log[g][2];
     P -= (int32_t)ll_log; e_ll = t_ll[P >= 0 ? zg_ring_bits(ring32, rbits, P, ll_log) : 0];
     P -= (int32_t)of_log; e_of = t_of[P >= 0 ? zg_ring_bits(ring32, rbits, P, of_log) : 0];
     P -= (int32_t)ml_log; e_ml = t_ml[P >= 0 ? zg_ring_bits(ring32, rbits, P, ml_log) : 0];
   }
-  zg_v4u piece = {0, 0, 0, 0};
-  uint64_t piece_addr = 0;
-  uint32_t piece_g = 0xFFFFFFFFu;
+  zg_v4u piece[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};     // ZG_SEQ_G * ZG_SEQ_PIECES = 112 requests per phase: two per lane
+  uint64_t piece_addr[2] = {0, 0};
+  uint32_t piece_g[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
   // ---- main loop
   while (__any(act)) {
     // DECODE phase: LDS only. Same arithmetic as zg_seq_step (zg_dev.h), 32-bit and branch-free.
@@ -297,9 +305,12 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
 #pragma unroll 1
       for (int c = 0; c < ZG_SEQ_CH; c++) {
         const bool last = done + 1 == nseq;
-        const uint32_t of_code = ZG_FSE_SYM(e_of), ml_code = ZG_FSE_SYM(e_ml), ll_code = ZG_FSE_SYM(e_ll);
-        const uint32_t xb_of = ZG_FSE_XB(e_of), xb_ml = ZG_FSE_XB(e_ml), xb_ll = ZG_FSE_XB(e_ll);
-        const uint32_t nb_ll = last ? 0u : ZG_FSE_NB(e_ll), nb_ml = last ? 0u : ZG_FSE_NB(e_ml), nb_of = last ? 0u : ZG_FSE_NB(e_of);
+        const uint32_t of_code = e_of >> 10, ml_code = e_ml >> 10, ll_code = e_ll >> 10;
+        const uint32_t vll = s_llbase[ll_code], vml = s_mlbase[ml_code];
+        const uint32_t x_ll = e_ll & 1023u, x_ml = e_ml & 1023u, x_of = e_of & 1023u;
+        const uint32_t k_ll = 31u - (uint32_t)__builtin_clz(x_ll), k_ml = 31u - (uint32_t)__builtin_clz(x_ml), k_of = 31u - (uint32_t)__builtin_clz(x_of);
+        const uint32_t xb_of = of_code, xb_ml = vml >> 24, xb_ll = vll >> 24;
+        const uint32_t nb_ll = last ? 0u : ll_log - k_ll, nb_ml = last ? 0u : ml_log - k_ml, nb_of = last ? 0u : of_log - k_of;
         // extra bits in the order OF, ML, LL (:185), then the state bits LL, ML, OF (:204-206)
         const int32_t q_of = P - (int32_t)xb_of, q_ml = q_of - (int32_t)xb_ml, q_ll = q_ml - (int32_t)xb_ll;
         const int32_t q_sll = q_ll - (int32_t)nb_ll, q_sml = q_sll - (int32_t)nb_ml, q_sof = q_sml - (int32_t)nb_of;
@@ -307,10 +318,10 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
         const uint32_t obits = zg_ring_bits(ring32, rbits, q_of, xb_of);
         const uint32_t ml_add = zg_ring_bits(ring32, rbits, q_ml, xb_ml);
         const uint32_t ll_add = zg_ring_bits(ring32, rbits, q_ll, xb_ll);
-        const uint32_t s_ll = ZG_FSE_BL(e_ll) + zg_ring_bits(ring32, rbits, q_sll, nb_ll);
-        const uint32_t s_ml = ZG_FSE_BL(e_ml) + zg_ring_bits(ring32, rbits, q_sml, nb_ml);
-        const uint32_t s_of = ZG_FSE_BL(e_of) + zg_ring_bits(ring32, rbits, q_sof, nb_of);
-        const uint32_t ml = s_mlbase[ml_code] + ml_add, ll = s_llbase[ll_code] + ll_add;
+        const uint32_t s_ll = ((x_ll ^ (1u << k_ll)) << nb_ll) + zg_ring_bits(ring32, rbits, q_sll, nb_ll);
+        const uint32_t s_ml = ((x_ml ^ (1u << k_ml)) << nb_ml) + zg_ring_bits(ring32, rbits, q_sml, nb_ml);
+        const uint32_t s_of = ((x_of ^ (1u << k_of)) << nb_of) + zg_ring_bits(ring32, rbits, q_sof, nb_of);
+        const uint32_t ml = (vml & 0xFFFFFFu) + ml_add, ll = (vll & 0xFFFFFFu) + ll_add;
         if (!last) { e_ll = t_ll[s_ll]; e_ml = t_ml[s_ml]; e_of = t_of[s_of]; }
         P = q_sof;
         const uint32_t of = obits + (1u << of_code);
@@ -354,10 +365,13 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
     }
     __syncthreads();
     // (1) land the pieces requested one phase ago
-    if (piece_g != 0xFFFFFFFFu) {
-      const uint32_t ro = (uint32_t)(piece_addr & (ZG_SEQ_RING - 1));
-      *(zg_v4u*)(s_ring[piece_g] + ro) = piece;
-      if (ro == 0) *(zg_v4u*)(s_ring[piece_g] + ZG_SEQ_RING) = piece;
+#pragma unroll
+    for (int pi = 0; pi < 2; pi++) {
+      if (piece_g[pi] != 0xFFFFFFFFu) {
+        const uint32_t ro = (uint32_t)(piece_addr[pi] & (ZG_SEQ_RING - 1));
+        *(zg_v4u*)(s_ring[piece_g[pi]] + ro) = piece[pi];
+        if (ro == 0) *(zg_v4u*)(s_ring[piece_g[pi]] + ZG_SEQ_RING) = piece[pi];
+      }
     }
     // (2) flush the chunk: ZG_SEQ_G x ZG_SEQ_CH records of 16 bytes
     for (uint32_t j = t; j < ZG_SEQ_G * ZG_SEQ_CH; j += 64) {
@@ -365,13 +379,17 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
       if (k < s_cnt[gg]) ((zg_gv4u*)s_dst[gg])[k] = *(const zg_v4u*)&s_out[gg][k];
     }
     // (3) request the next pieces
-    piece_g = 0xFFFFFFFFu;
-    if (t < ZG_SEQ_G * ZG_SEQ_PIECES) {
-      const uint32_t gg = t / ZG_SEQ_PIECES, k = t % ZG_SEQ_PIECES;
-      const uint64_t hi = s_fetch_hi[gg];
-      const uint64_t addr = hi - 16ull * (k + 1);
-      if (hi && addr >= s_fetch_lo[gg] && addr < hi) {
-        piece = *(const zg_gv4u*)addr; piece_addr = addr; piece_g = gg;
+#pragma unroll
+    for (int pi = 0; pi < 2; pi++) {
+      piece_g[pi] = 0xFFFFFFFFu;
+      const uint32_t j = t + 64 * pi;
+      if (j < ZG_SEQ_G * ZG_SEQ_PIECES) {
+        const uint32_t gg = j / ZG_SEQ_PIECES, k = j % ZG_SEQ_PIECES;
+        const uint64_t hi = s_fetch_hi[gg];
+        const uint64_t addr = hi - 16ull * (k + 1);
+        if (hi && addr >= s_fetch_lo[gg] && addr < hi) {
+          piece[pi] = *(const zg_gv4u*)addr; piece_addr[pi] = addr; piece_g[pi] = gg;
+        }
       }
     }
     __syncthreads();
