@@ -62,7 +62,7 @@ class BatchBuilder {
   uint64_t og_count = 0;       // flatten scratch size in u32
   uint32_t unit_blocks = 0;    // blocks per unit; 0 = choose from the submit size
   uint32_t flat_slots = 256;   // workgroups of zg_k_flat the chip runs at once (1 per CU)
-  uint32_t sweep_budget = 128; // workgroups of zg_k_sweep over the whole submit
+  uint32_t sweep_budget = 256; // workgroups of zg_k_sweep over the whole submit
   uint64_t lit_bytes = 0;      // literals arena size
   uint64_t seq_count = 0;      // sequence arena size
   uint32_t nhuf_slots = 0;

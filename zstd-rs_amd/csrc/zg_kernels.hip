@@ -807,7 +807,8 @@ __device__ __forceinline__ bool zg_frame_barrier(uint32_t* counter, uint32_t tar
   __shared__ uint32_t s_ok;
   __syncthreads();
   if (t == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // the sweep's payload stores are write-through (sc1) and were drained by the __syncthreads above (vmcnt(0) in every
+    // wave), so no L2 write-back fence is needed before the arrival is published
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t ok = 0;
@@ -924,13 +925,13 @@ __global__ void __launch_bounds__(T) zg_k_sweep(ZgBatchDev d) {
             if (o[k].z) v = (v & 0xFF00FFFFu) | ((uint32_t)b2[k] << 16);
             if (o[k].w) v = (v & 0x00FFFFFFu) | ((uint32_t)b3[k] << 24);
           }
-          ((zg_u32u*)w)->v = v;
+          __hip_atomic_store((uint32_t*)w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through store (sc1)
         }
       }
       if (wg.rank == wg.wpf - 1) {          // tail bytes of the unit
         for (uint32_t x = (n4 << 2) + t; x < su.size; x += T) {
           const uint32_t o = og[x];
-          if (o) out[x] = out[(int64_t)x - o];
+          if (o) __hip_atomic_store(&out[x], out[(int64_t)x - o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       const uint32_t nx = next_unit(ui + 1);
