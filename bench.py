@@ -124,6 +124,18 @@ def main():
     dom = max(("tables", "huf", "seq", "scan", "lit", "flat", "sweep", "lz"), key=lambda k: kern[k])
     # algorithmic bytes of one pass: every compressed byte read once + every plaintext byte written once
     achieved = (Cb + D) / (kern[dom] / 1e3) / 1e9 if kern[dom] > 0 else 0.0
+    # HBM bytes of the dominant kernel from the committed rocprofv3 PMC passes of this same command (profiles/r01/):
+    # FETCH_SIZE and WRITE_SIZE need separate profiler passes, so they cannot be read live here
+    traffic, traffic_src = None, None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "bench_1e9_pmc.json")))
+        if args.kind == "text" and D == 1000000000:
+            for kname, rec in pm["kernels"].items():
+                if kname.split("<")[0] == "zg_k_" + dom:
+                    traffic = rec["hbm_bytes_per_launch_corrected"]
+                    traffic_src = "profiles/r01/bench_1e9_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, x2 fetch correction calibrated on zg_k_calib_copy)"
+    except Exception:
+        pass
     out = {
         "metric": "decompressed_GB_per_s", "value": round(value, 4), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
@@ -134,7 +146,7 @@ def main():
                    "timed_region": "kernels only, inputs + block table resident in HBM, output left in HBM",
                    "host_prepare_s": round(prep_s, 4)},
         "roofline": {"bound": "hbm", "kernel": "zg_k_" + dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes": Cb + D, "kernel_ms": round(kern[dom], 4),
                      "pipeline_achieved": round((Cb + D) / (kern["total"] / 1e3) / 1e9, 3) if kern["total"] > 0 else 0.0},
         "kernel_ms": {k: round(v, 4) for k, v in kern.items()},

@@ -135,6 +135,9 @@ int zgpu_batch_block_literals(zgpu_batch*, uint32_t block, uint8_t* dst, size_t 
 int zgpu_batch_block_sequences(zgpu_batch*, uint32_t block, zgpu_seq* dst, size_t cap, size_t* n);
 /* diagnostics: cycle counters accumulated by the kernels when ZGPU_DEBUG_TIMERS is set (all zero otherwise) */
 int zgpu_batch_debug_timers(zgpu_batch*, uint64_t out[8]);
+/* diagnostics: runs a copy kernel (zg_k_calib_copy) of exactly `bytes` read + `bytes` written, twice, to calibrate
+ * the profiler's HBM byte counters on a known amount of traffic */
+int zgpu_debug_calibrate(zgpu_ctx*, uint64_t bytes);
 int zgpu_batch_fse_slot(zgpu_batch*, uint32_t slot, uint32_t* entries /* 1280 */, uint8_t logs[4]);
 int zgpu_batch_huf_slot(zgpu_batch*, uint32_t slot, uint16_t* entries /* 2048 */, int* max_bits);
 

@@ -44,7 +44,8 @@ def libzstd():
     if _ZSTD is None:
         for cand in ("/opt/conda/lib/libzstd.so.1", "libzstd.so.1", "libzstd.so"):
             try:
-                L = C.CDLL(cand)
+                # DEEPBIND: under rocprofv3 another libzstd is already loaded; this copy must bind its internals to itself
+                L = C.CDLL(cand, mode=os.RTLD_NOW | getattr(os, "RTLD_DEEPBIND", 0))
                 break
             except OSError:
                 L = None

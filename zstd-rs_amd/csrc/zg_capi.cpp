@@ -200,6 +200,18 @@ int zgpu_batch_block_sequences(zgpu_batch* zb, uint32_t i, zgpu_seq* dst, size_t
   return ZGPU_OK;
 }
 int zgpu_batch_debug_timers(zgpu_batch* zb, uint64_t out[8]) { return zb->b->read_debug(out); }
+int zgpu_debug_calibrate(zgpu_ctx* c, uint64_t bytes) {
+  // profiler calibration: one device-to-device copy kernel of exactly `bytes` read + `bytes` written
+  void *a = nullptr, *b = nullptr;
+  if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) return ZGPU_E_NOMEM;
+  (void)hipMemset(a, 1, bytes);
+  (void)hipMemset(b, 2, bytes);
+  zg_launch_calib(a, b, bytes, c->eng->stream());
+  zg_launch_calib(a, b, bytes, c->eng->stream());
+  hipError_t e = hipStreamSynchronize(c->eng->stream());
+  (void)hipFree(a); (void)hipFree(b);
+  return e == hipSuccess ? ZGPU_OK : ZGPU_E_HIP;
+}
 int zgpu_batch_fse_slot(zgpu_batch* zb, uint32_t slot, uint32_t* entries, uint8_t logs[4]) {
   std::vector<uint32_t> v;
   int r = zb->b->read_fse_slot(slot, &v, logs);

@@ -54,3 +54,4 @@ void zg_launch_lit(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_flat(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_sweep(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_lz(const ZgBatchDev& d, hipStream_t s);
+void zg_launch_calib(const void* src, void* dst, uint64_t bytes, hipStream_t s);

@@ -1034,6 +1034,14 @@ __global__ void __launch_bounds__(ZG_LZ_T) zg_k_lz(ZgBatchDev d) {
   }
 }
 
+// known-traffic kernel used to calibrate the profiler's HBM byte counters (tools/dev/profile.sh): copies n16 x 16 bytes
+__global__ void __launch_bounds__(256) zg_k_calib_copy(const uint4* src, uint4* dst, uint64_t n16) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256) dst[i] = src[i];
+}
+void zg_launch_calib(const void* src, void* dst, uint64_t bytes, hipStream_t s) {
+  hipLaunchKernelGGL(zg_k_calib_copy, dim3(2048), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, bytes / 16);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------------------

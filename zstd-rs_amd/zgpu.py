@@ -44,7 +44,7 @@ EXPORTS = [
     "zgpu_decode_all", "zgpu_batch_prepare", "zgpu_batch_run", "zgpu_batch_sync", "zgpu_batch_num_frames", "zgpu_batch_num_blocks",
     "zgpu_batch_compressed_size", "zgpu_batch_frame_info", "zgpu_batch_read", "zgpu_batch_output_device", "zgpu_batch_timings",
     "zgpu_batch_destroy", "zgpu_batch_block_info", "zgpu_batch_block_literals", "zgpu_batch_block_sequences", "zgpu_batch_fse_slot",
-    "zgpu_batch_huf_slot", "zgpu_batch_debug_timers", "zgpu_decoder_create", "zgpu_decoder_destroy", "zgpu_decoder_init", "zgpu_decoder_decode_blocks",
+    "zgpu_batch_huf_slot", "zgpu_batch_debug_timers", "zgpu_debug_calibrate", "zgpu_decoder_create", "zgpu_decoder_destroy", "zgpu_decoder_init", "zgpu_decoder_decode_blocks",
     "zgpu_decoder_can_collect", "zgpu_decoder_collect", "zgpu_decoder_read", "zgpu_decoder_is_finished", "zgpu_decoder_blocks_decoded",
     "zgpu_decoder_bytes_read_from_source", "zgpu_decoder_content_size", "zgpu_decoder_checksum_from_data",
     "zgpu_decoder_calculated_checksum",
@@ -92,6 +92,7 @@ def load_library():
     L.zgpu_batch_fse_slot.argtypes = [vp, C.c_uint32, P(C.c_uint32), P(C.c_uint8)]
     L.zgpu_batch_huf_slot.argtypes = [vp, C.c_uint32, P(C.c_uint16), P(C.c_int)]
     L.zgpu_batch_debug_timers.argtypes = [vp, P(C.c_uint64)]
+    L.zgpu_debug_calibrate.argtypes = [vp, C.c_uint64]
     L.zgpu_decoder_create.argtypes = [vp, P(vp)]
     L.zgpu_decoder_destroy.argtypes = [vp]
     L.zgpu_decoder_init.argtypes = [vp, u8p, sz, P(sz), P(C.c_uint32), P(C.c_uint32)]
