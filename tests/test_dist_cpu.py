@@ -1,0 +1,72 @@
+"""The N>1 path on CPU: world_size-2 gloo. Frames shard with no data-path collective; the ranks only
+exchange digests. The decode itself is stood in by the CPU harness of the engine's lane routines (tests/emu)."""
+import hashlib
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _worker(rank, world, port, names, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(ROOT, "zstd-rs_amd"))
+    import emu
+    import zgpu_dist
+    from golden_io import read_pack
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pack = read_pack("decodecorpus.pack")
+    frames = [pack[n] for n in names]
+
+    def decode(z):
+        out, st = emu.EmuBatch(z).frame_bytes(0)
+        assert st == 0
+        return out
+
+    local = zgpu_dist.decode_sharded(frames, decode, rank, world)
+    dist.barrier()
+    res = zgpu_dist.gather_digests(local, len(frames), dist)
+    t = torch.tensor([float(len(local))])
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)           # same reduction bench.py uses for the step time
+    if rank == 0:
+        q.put((res, sorted(local), float(t.item())))
+    dist.destroy_process_group()
+
+
+def test_lpt_sharding_properties():
+    sys.path.insert(0, os.path.join(ROOT, "zstd-rs_amd"))
+    import zgpu_dist
+    sizes = [51220480, 41458703, 33553445, 21606400, 10192446, 10085684, 9970564, 8474240, 7251944, 6627202, 6152192, 5345280]  # Silesia
+    for w in (1, 2, 4, 8):
+        sh = zgpu_dist.shard_frames(sizes, w)
+        assert sorted(i for s in sh for i in s) == list(range(12))
+        loads = [sum(sizes[i] for i in s) for s in sh]
+        assert max(loads) <= max(sum(sizes) / w * 1.34, max(sizes))      # LPT bound 4/3 - 1/(3w), or one huge frame
+    assert zgpu_dist.shard_frames([], 2) == [[], []]
+
+
+def test_two_ranks_gloo():
+    from golden_io import read_manifest
+    man = read_manifest("decodecorpus.json")
+    names = sorted(man)[:12]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, names, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res, mine0, tmax = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(res) == list(range(len(names)))        # every frame decoded exactly once across the two ranks
+    for i, n in enumerate(names):
+        assert res[i][0] == man[n]["size"]
+        assert res[i][1] == int.from_bytes(bytes.fromhex(man[n]["sha256"])[:7], "little")
+    assert 0 < len(mine0) < len(names) and tmax >= len(mine0)
