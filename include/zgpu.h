@@ -143,12 +143,19 @@ int zgpu_batch_huf_slot(zgpu_batch*, uint32_t slot, uint16_t* entries /* 2048 */
 
 /* ---- FrameDecoder mirror (frame_decoder.rs:80-627): one frame at a time ---------------------------------- */
 enum { ZGPU_STRAT_ALL = 0, ZGPU_STRAT_UPTO_BLOCKS = 1, ZGPU_STRAT_UPTO_BYTES = 2 };  /* BlockDecodingStrategy :96-100 */
+/* add_dict (frame_decoder.rs:224-227) with Dictionary::decode_dict (dictionary.rs:45-126): raw = a zstd dictionary file */
+int zgpu_add_dict(zgpu_ctx*, const uint8_t* raw, size_t len, uint32_t* id_out);
 int zgpu_decoder_create(zgpu_ctx*, zgpu_decoder** out);
 void zgpu_decoder_destroy(zgpu_decoder*);
 /* init/reset (:190-221): parses a frame header from src; *consumed = header bytes. ZGPU_E_SKIP_FRAME fills skip_*. */
 int zgpu_decoder_init(zgpu_decoder*, const uint8_t* src, size_t len, size_t* consumed, uint32_t* skip_magic, uint32_t* skip_len);
 /* decode_blocks (:309-377): src continues where the previous call stopped; *consumed = bytes taken. */
 int zgpu_decoder_decode_blocks(zgpu_decoder*, const uint8_t* src, size_t len, size_t* consumed, int strat, size_t n, int* frame_finished);
+/* force_dict (:229-243): use a registered dictionary although the frame header names none (before the first block) */
+int zgpu_decoder_force_dict(zgpu_decoder*, uint32_t dict_id);
+/* decode_from_to (:439-529): consumes only whole blocks of src, then drains into dst; *read_out / *written_out as the
+ * reference's (usize, usize). May be called without init: it then parses the frame header from src itself. */
+int zgpu_decoder_decode_from_to(zgpu_decoder*, const uint8_t* src, size_t len, uint8_t* dst, size_t cap, size_t* read_out, size_t* written_out);
 size_t zgpu_decoder_can_collect(const zgpu_decoder*);                /* :410-424 */
 size_t zgpu_decoder_collect(zgpu_decoder*, uint8_t* dst, size_t cap);/* :381-389 */
 size_t zgpu_decoder_read(zgpu_decoder*, uint8_t* dst, size_t cap);   /* impl Read :615-627 */

@@ -51,7 +51,7 @@ static int walk(const uint8_t* src, size_t len, uint64_t max_window, BatchBuilde
     if (w > max_window) return ZG_WINDOW_SIZE_TOO_BIG;
     if (h.has_dict_id) return ZG_DICT_NOT_PROVIDED;
     p += c;
-    bb->begin_frame(w, kHist, false, false);
+    bb->begin_frame(w, kHist, 0);
     for (;;) {
       if (len - p < 3) return ZG_FAILED_READ_BLOCK_HEADER;
       BlockHeader bh;

@@ -238,3 +238,118 @@ def test_inorder_fallback_path(ctx, monkeypatch):
         assert _sha(ctx.decode_all(pack[name], man[name]["size"])) == man[name]["sha256"], name
     spack, sman = read_pack("synthetic.pack"), read_manifest("synthetic.json")
     assert _sha(ctx.decode_all(spack["text_1m_l3.zst"], sman["text_1m_l3.zst"]["size"])) == sman["text_1m_l3.zst"]["sha256"]
+
+
+# ---- streaming / partial decode surface, dictionaries ------------------------------------------
+
+def test_dict_corpus(ctx):
+    """dict_test.rs:77-262: 207 frames that need the dictionary (tables, offset history and content all come from it)"""
+    import zgpu
+    pack, man = read_pack("dict_tests.pack"), read_manifest("dict_tests.json")
+    raw = pack["dictionary"]
+    d = zgpu.FrameDecoder(ctx)
+    name0 = sorted(man)[0]
+    st, _, _, _ = d.reset(pack[name0])
+    assert st == zgpu.E_DICT_NOT_PROVIDED                       # before add_dict (frame_decoder.rs:212-217)
+    assert d.add_dict(raw) == 618557512
+    bad = []
+    for name in sorted(man):
+        z = pack[name]
+        st, c, _, _ = d.reset(z)
+        assert st == 0, name
+        st, used, fin = d.decode_blocks(z[c:], zgpu.STRAT_ALL)
+        out = d.collect()
+        ok = (not st) and fin and _sha(out) == man[name]["sha256"] and d.bytes_read_from_source() == len(z)
+        if not ok or d.get_checksum_from_data() != d.get_calculated_checksum():
+            bad.append((name, st))
+    assert not bad, bad[:5]
+    # and through decode_all (several dictionary frames back to back)
+    names = sorted(man)[:5]
+    out = ctx.decode_all(b"".join(pack[n] for n in names), sum(man[n]["size"] for n in names))
+    pos = 0
+    for n in names:
+        assert _sha(out[pos:pos + man[n]["size"]]) == man[n]["sha256"]
+        pos += man[n]["size"]
+    d.close()
+
+
+@pytest.mark.parametrize("name", ["z000088.zst", "z000033.zst", "z000059.zst"])
+def test_block_strategies_match_oracle(ctx, name):
+    """decode_blocks with UptoBlocks / UptoBytes (frame_decoder.rs:361-373): after every call the counters and the bytes
+    that may be collected (window-retention rule, decode_buffer.rs:182-188) equal the oracle's"""
+    import zgpu
+    z = read_pack("decodecorpus.pack")[name]
+    for strat, n in ((zgpu.STRAT_UPTO_BLOCKS, 1), (zgpu.STRAT_UPTO_BLOCKS, 3), (zgpu.STRAT_UPTO_BYTES, 1), (zgpu.STRAT_UPTO_BYTES, 300000)):
+        d, o = zgpu.FrameDecoder(ctx), oracle.FrameDecoder()
+        st, c, _, _ = d.reset(z)
+        ost, oc, _, _ = o.init(z)
+        assert (st, c) == (ost, oc) == (0, c)
+        pos, out, oout = c, b"", b""
+        for _ in range(10000):
+            st, used, fin = d.decode_blocks(z[pos:], strat, n)
+            ost, oused, ofin = o.decode_blocks(z[pos:], strat, n)
+            assert (st, used, fin) == (ost, oused, ofin), (name, strat, n)
+            pos += used
+            assert d.blocks_decoded() == o.blocks_decoded() and d.bytes_read_from_source() == o.bytes_read_from_source()
+            assert d.can_collect() == o.can_collect()
+            out += d.collect()
+            oout += o.collect()
+            if fin:
+                break
+        assert out == oout and d.is_finished()
+        assert d.get_calculated_checksum() == o.calculated_checksum()
+        d.close()
+
+
+def test_decode_from_to(ctx):
+    """tests/mod.rs:129-230: source split at 50 KiB, checksum delivered separately, byte counter exact"""
+    import zgpu
+    pack, man = read_pack("decodecorpus.pack"), read_manifest("decodecorpus.json")
+    content = pack["z000088.zst"]
+    d = zgpu.FrameDecoder(ctx)
+    st, read1, out1 = d.decode_from_to(content[:50 * 1024], 1 << 20)
+    assert st == 0
+    st, read2, out2 = d.decode_from_to(content[read1:len(content) - 4], 1 << 20)
+    assert st == 0 and read1 + read2 == len(content) - 4
+    st, read3, out3 = d.decode_from_to(content[read1 + read2:], 1 << 20)
+    assert (st, read3, out3) == (0, 4, b"")
+    assert read1 + read2 + read3 == len(content)
+    assert _sha(out1 + out2) == man["z000088.zst"]["sha256"]
+    assert d.get_checksum_from_data() == d.get_calculated_checksum()
+    d.close()
+
+
+def test_incremental_read(ctx):
+    """tests/mod.rs:382-404: a 3-byte target, then the rest"""
+    import zgpu
+    z = read_pack("test_fixtures.pack")["abc.txt.zst"]
+    d = zgpu.FrameDecoder(ctx)
+    st, c, _, _ = d.reset(z)
+    assert st == 0
+    st, _, out = d.decode_from_to(z[c:], 3)
+    assert st == 0 and out == b"abc" and d.is_finished()
+    assert d.read(3) == b"def"
+    d.close()
+
+
+def test_streaming_decoder(ctx):
+    """tests/mod.rs:294-380: read_to_end through the io::Read mirror, then reuse of the decoder for another frame"""
+    import io
+    import zgpu
+    pack, man = read_pack("decodecorpus.pack"), read_manifest("decodecorpus.json")
+    s = zgpu.StreamingDecoder(io.BytesIO(pack["z000088.zst"]), ctx=ctx)
+    res = s.read()
+    assert _sha(res) == man["z000088.zst"]["sha256"]
+    s2 = zgpu.StreamingDecoder(io.BytesIO(pack["z000068.zst"]), decoder=s.into_frame_decoder())
+    chunks = []
+    while True:                                                     # small reads exercise the window-retention rule
+        c = s2.read(4096)
+        if not c:
+            break
+        chunks.append(c)
+    assert _sha(b"".join(chunks)) == man["z000068.zst"]["sha256"]
+    # tests/mod.rs:700-725: the window limit applies to the streaming wrapper too
+    big = read_pack("test_fixtures.pack")["window_256mib.zst"]
+    with pytest.raises(zgpu.ZgpuError) as e:
+        zgpu.StreamingDecoder(io.BytesIO(big), ctx=ctx)
+    assert e.value.status == zgpu.E_WINDOW_SIZE_TOO_BIG

@@ -4,13 +4,25 @@
 #include <new>
 #include <vector>
 #include "../../include/zgpu.h"
+#include <map>
+#include "zg_dev.h"
 #include "zg_engine.h"
 #include "zg_xxh64.h"
 
 using namespace zg;
 
+struct ZgDict {   // Dictionary (decoding/dictionary.rs:12-37), tables in the engine's packed formats
+  uint32_t id = 0;
+  std::vector<uint32_t> fse;   // one FSE arena slot
+  uint8_t logs[4] = {0, 0, 0, 0};
+  std::vector<uint16_t> huf;
+  uint8_t huf_maxbits = 0;
+  uint32_t hist[3] = {1, 4, 8};
+  std::vector<uint8_t> content;
+};
 struct zgpu_ctx {
   Engine* eng = nullptr;
+  std::map<uint32_t, ZgDict> dicts;   // FrameDecoder::dicts (frame_decoder.rs:82)
   std::string err;
 };
 struct zgpu_batch {
@@ -228,11 +240,17 @@ int zgpu_batch_huf_slot(zgpu_batch* zb, uint32_t slot, uint16_t* entries, int* m
 }
 
 // ---- decode_all --------------------------------------------------------------------------------------------
+static int decode_all_per_frame(zgpu_ctx* c, const uint8_t* src, size_t len, uint8_t* dst, size_t cap, size_t* written);
 int zgpu_decode_all(zgpu_ctx* c, const uint8_t* src, size_t len, uint8_t* dst, size_t cap, size_t* written) {
   if (!c || !written || (!src && len) || (!dst && cap)) return ZGPU_E_BAD_ARG;
   *written = 0;
   zgpu_batch* zb = nullptr;
   int st = zgpu_batch_prepare(c, src, len, &zb);
+  if (st == ZGPU_E_DICT_NOT_PROVIDED && !c->dicts.empty()) {
+    // frames that need a dictionary go through the FrameDecoder mirror one by one, like the reference's own loop (:541-577)
+    zgpu_batch_destroy(zb);
+    return decode_all_per_frame(c, src, len, dst, cap, written);
+  }
   if (st) { zgpu_batch_destroy(zb); return st; }   // the reference returns the first error of the walk
   uint64_t total = 0;
   uint32_t bf = 0, bs = 0;
@@ -248,9 +266,61 @@ int zgpu_decode_all(zgpu_ctx* c, const uint8_t* src, size_t len, uint8_t* dst, s
 
 }  // extern "C"
 
-// ---- FrameDecoder mirror ------------------------------------------------------------------------------------
-// Round-1 scope: init/reset + decode_blocks(All) + collect/read with the reference's window-retention rule and
-// counters. The UptoBlocks/UptoBytes strategies need a persistent device window across submits.
+// ---- dictionaries (decoding/dictionary.rs:45-126) -------------------------------------------------------------------------
+// Parsed on the host with the same lane routines the kernels use (zg_dev.h is host-callable); the tables travel to the
+// device as the frame's carried tables (scratch.rs:70-78 init_from_dict).
+static int parse_dict(const uint8_t* raw, size_t len, ZgDict* d) {
+  static const uint8_t kMagic[4] = {0x37, 0xA4, 0x30, 0xEC};   // dictionary.rs:39
+  if (len < 8) return ZG_DICT_DECODE;
+  if (memcmp(raw, kMagic, 4)) return ZG_DICT_DECODE;
+  memcpy(&d->id, raw + 4, 4);
+  d->fse.assign(ZG_FSE_SLOT_U32, 0);
+  d->huf.assign(ZG_HUF_SLOT_U16, 0);
+  const uint8_t* t = raw + 8;
+  size_t tl = len - 8;
+  int16_t probs[256];
+  uint16_t counter[256];
+  uint8_t weights[264];
+  uint32_t fsew[64], used = 0;
+  int nw = 0, mb = 0;
+  // the routines may look 8 bytes past a position: work on a padded copy
+  std::vector<uint8_t> pad(t, t + tl);
+  pad.resize(tl + 64, 0);
+  t = pad.data();
+  if (zg_huf_read_weights(t, (uint32_t)tl, weights, &nw, &used, fsew, probs, counter)) return ZG_DICT_DECODE;
+  if (zg_huf_build(weights, nw, d->huf.data(), &mb)) return ZG_DICT_DECODE;
+  d->huf_maxbits = (uint8_t)mb;
+  if (tl < used) return ZG_DICT_DECODE;
+  t += used; tl -= used;
+  // order OF, ML, LL (dictionary.rs:74-97); logs are kept in the order LL, OF, ML like the arena
+  const int kinds[3] = {ZG_KIND_OF, ZG_KIND_ML, ZG_KIND_LL}, maxlog[3] = {8, 9, 9}, maxsym[3] = {31, 52, 35}, logidx[3] = {1, 2, 0};
+  const uint32_t offs[3] = {ZG_FSE_OF_OFF, ZG_FSE_ML_OFF, ZG_FSE_LL_OFF};
+  for (int k = 0; k < 3; k++) {
+    int np = 0, al = 0;
+    if (zg_fse_read_probs(t, (uint32_t)tl, maxlog[k], maxsym[k], probs, &np, &al, &used)) return ZG_DICT_DECODE;
+    if (zg_fse_build(probs, np, al, kinds[k], d->fse.data() + offs[k], counter)) return ZG_DICT_DECODE;
+    d->logs[logidx[k]] = (uint8_t)al;
+    if (tl < used) return ZG_DICT_DECODE;
+    t += used; tl -= used;
+  }
+  d->logs[3] = 0;
+  if (tl < 12) return ZG_DICT_DECODE;
+  memcpy(d->hist, t, 12);
+  d->content.assign(t + 12, t + tl);
+  return ZG_OK;
+}
+
+extern "C" int zgpu_add_dict(zgpu_ctx* c, const uint8_t* raw, size_t len, uint32_t* id_out) {
+  if (!c || (!raw && len)) return ZGPU_E_BAD_ARG;
+  ZgDict d;
+  int st = parse_dict(raw, len, &d);
+  if (st) return st;
+  if (id_out) *id_out = d.id;
+  c->dicts[d.id] = std::move(d);   // BTreeMap::insert: a dictionary with the same id is replaced (frame_decoder.rs:224-227)
+  return ZGPU_OK;
+}
+
+// ---- FrameDecoder mirror (frame_decoder.rs:80-627) ---------------------------------------------------------------------------
 struct zgpu_decoder {
   zgpu_ctx* ctx = nullptr;
   bool has_state = false;
@@ -260,7 +330,9 @@ struct zgpu_decoder {
   uint64_t block_counter = 0, bytes_read = 0;
   bool has_checksum = false;
   uint32_t checksum = 0;
-  std::vector<uint8_t> buf;   // decoded, not yet drained bytes (DecodeBuffer, decode_buffer.rs:9-17)
+  uint32_t using_dict = 0;
+  FrameState fs;                 // device side of DecoderScratch
+  std::vector<uint8_t> buf;      // decoded, not yet drained bytes (DecodeBuffer, decode_buffer.rs:9-17)
   size_t head = 0;
   Xxh64 hash;
   size_t held() const { return buf.size() - head; }
@@ -272,7 +344,66 @@ static size_t dec_drain(zgpu_decoder* d, size_t n, uint8_t* dst) {  // DecodeBuf
   d->hash.update(d->buf.data() + d->head, n);
   d->head += n;
   if (d->head == d->buf.size()) { d->buf.clear(); d->head = 0; }
+  else if (d->head > (1u << 22) && d->head > d->held()) { d->buf.erase(d->buf.begin(), d->buf.begin() + d->head); d->head = 0; }
   return n;
+}
+
+static int apply_dict(zgpu_decoder* d, const ZgDict& dict) {   // DecoderScratch::init_from_dict scratch.rs:70-78
+  FrameState& fs = d->fs;
+  int st;
+  if ((st = fs.d_fse.reserve(ZG_FSE_SLOT_U32 * 4)) || (st = fs.d_huf.reserve(ZG_HUF_SLOT_U16 * 2)) ||
+      (st = fs.d_out.reserve(dict.content.size() + 256))) return st;
+  if (hipMemcpy(fs.d_fse.p, dict.fse.data(), ZG_FSE_SLOT_U32 * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(fs.d_huf.p, dict.huf.data(), ZG_HUF_SLOT_U16 * 2, hipMemcpyHostToDevice) != hipSuccess ||
+      (dict.content.size() && hipMemcpy(fs.d_out.p, dict.content.data(), dict.content.size(), hipMemcpyHostToDevice) != hipSuccess))
+    return ZGPU_E_HIP;
+  memcpy(fs.logs, dict.logs, 4);
+  fs.huf_maxbits = dict.huf_maxbits;
+  fs.carry_mask = 0xF;
+  memcpy(fs.hist, dict.hist, 12);
+  fs.base = dict.content.size();
+  d->using_dict = dict.id;
+  return ZGPU_OK;
+}
+
+// decode up to max_blocks blocks (0 = to the end of the frame) of the current frame from src
+static int decode_run(zgpu_decoder* d, const uint8_t* src, size_t len, uint32_t max_blocks, size_t* consumed) {
+  Engine* eng = d->ctx->eng;
+  Batch* b = nullptr;
+  size_t used = 0;
+  *consumed = 0;
+  int st = eng->prepare_run(src, len, &d->fs, d->fh.content_checksum(), max_blocks, &b, &used);
+  if (st) return st;
+  const int parse_status = b->parse_status;
+  const size_t nb = b->bb.blocks.size();
+  if (nb == 0) { delete b; return parse_status ? parse_status : ZGPU_E_INTERNAL; }
+  const uint64_t before = d->fs.base + d->fs.produced;
+  if ((st = b->run()) || (st = b->sync())) { delete b; return st; }
+  if (b->frame_out.empty()) { delete b; return ZGPU_E_INTERNAL; }
+  const ZgFrameOut fo = b->frame_out[0];
+  if (b->overflow) { delete b; return ZGPU_E_UNSUPPORTED; }
+  if ((st = b->commit(&d->fs))) { delete b; return st; }
+  // bring the new bytes to the host buffer the collect/read calls drain
+  const size_t old = d->buf.size();
+  d->buf.resize(old + fo.out_size);
+  if (fo.out_size && hipMemcpy(d->buf.data() + old, (const uint8_t*)d->fs.d_out.p + before, fo.out_size, hipMemcpyDeviceToHost) != hipSuccess) {
+    delete b;
+    return ZGPU_E_HIP;
+  }
+  // counters (frame_decoder.rs:328,341,343): blocks that decoded count; a failing block does not
+  const uint32_t good = fo.status ? fo.good_blocks : (uint32_t)nb - (b->bb.blocks.back().host_status ? 1u : 0u);
+  size_t bytes = 0;
+  for (uint32_t i = 0; i < good && i < nb; i++) bytes += 3 + b->bb.blocks[i].src_len;
+  d->block_counter += good;
+  int result = fo.status ? (int)fo.status : parse_status;
+  if (!result && b->saw_last_block) {
+    d->frame_finished = true;
+    if (!b->info.empty() && b->info[0].has_checksum) { d->has_checksum = true; d->checksum = b->info[0].checksum; bytes += 4; }
+  }
+  d->bytes_read += bytes;
+  *consumed = bytes;
+  delete b;
+  return result;
 }
 
 extern "C" {
@@ -285,7 +416,11 @@ int zgpu_decoder_create(zgpu_ctx* c, zgpu_decoder** out) {
   *out = d;
   return ZGPU_OK;
 }
-void zgpu_decoder_destroy(zgpu_decoder* d) { delete d; }
+void zgpu_decoder_destroy(zgpu_decoder* d) {
+  if (!d) return;
+  d->fs.release();
+  delete d;
+}
 
 int zgpu_decoder_init(zgpu_decoder* d, const uint8_t* src, size_t len, size_t* consumed, uint32_t* skip_magic, uint32_t* skip_len) {
   // FrameDecoder::reset (frame_decoder.rs:200-221), FrameDecoderState::new/reset (:103-134)
@@ -298,46 +433,55 @@ int zgpu_decoder_init(zgpu_decoder* d, const uint8_t* src, size_t len, size_t* c
   if ((st = frame_window_size(h, &w))) return st;
   if (w > d->ctx->eng->max_window) return ZGPU_E_WINDOW_SIZE_TOO_BIG;
   d->has_state = true; d->fh = h; d->window_size = w; d->frame_finished = false; d->block_counter = 0;
-  d->bytes_read = c; d->has_checksum = false; d->checksum = 0;
+  d->bytes_read = c; d->has_checksum = false; d->checksum = 0; d->using_dict = 0;
   d->buf.clear(); d->head = 0; d->hash.reset(0);
+  d->fs.reset();
+  d->fs.window_size = w;
   if (consumed) *consumed = c;
-  if (h.has_dict_id) return ZGPU_E_DICT_NOT_PROVIDED;
+  if (h.has_dict_id) {   // :212-219
+    auto it = d->ctx->dicts.find(h.dict_id);
+    if (it == d->ctx->dicts.end()) return ZGPU_E_DICT_NOT_PROVIDED;
+    return apply_dict(d, it->second);
+  }
   return ZGPU_OK;
 }
 
-int zgpu_decoder_decode_blocks(zgpu_decoder* d, const uint8_t* src, size_t len, size_t* consumed, int strat, size_t n, int* frame_finished) {
-  (void)n;
-  if (consumed) *consumed = 0;
+int zgpu_decoder_force_dict(zgpu_decoder* d, uint32_t dict_id) {   // frame_decoder.rs:229-243
   if (!d->has_state) return ZGPU_E_NOT_INITIALIZED;
-  if (strat != ZGPU_STRAT_ALL) return ZGPU_E_UNSUPPORTED;
-  // the block loop (frame_decoder.rs:319-375): the engine walks the remaining block headers of the frame and
-  // decodes the whole run on the device
-  Engine* eng = d->ctx->eng;
-  Batch* b = nullptr;
+  auto it = d->ctx->dicts.find(dict_id);
+  if (it == d->ctx->dicts.end()) return ZGPU_E_DICT_NOT_PROVIDED;
+  if (d->fs.produced) return ZGPU_E_UNSUPPORTED;   // only before the first block (the reference allows it any time)
+  return apply_dict(d, it->second);
+}
+
+int zgpu_decoder_decode_blocks(zgpu_decoder* d, const uint8_t* src, size_t len, size_t* consumed, int strat, size_t n, int* frame_finished) {
+  // FrameDecoder::decode_blocks (frame_decoder.rs:309-377)
+  if (consumed) *consumed = 0;
+  if (frame_finished) *frame_finished = 0;
+  if (!d->has_state) return ZGPU_E_NOT_INITIALIZED;
   size_t p = 0;
-  int st = eng->prepare_run(src, len, d->window_size, d->fh.content_checksum(), &b, &p);
-  if (st) return st;
-  const uint64_t nblocks = b->info.empty() ? 0 : b->info[0].nblocks;
-  const bool has_ck = !b->info.empty() && b->info[0].has_checksum;
-  const uint32_t ck = has_ck ? b->info[0].checksum : 0;
-  if (b->parse_status) { st = b->parse_status; delete b; return st; }
-  if ((st = b->run()) || (st = b->sync())) { delete b; return st; }
-  if (b->frame_out.empty()) { delete b; return ZGPU_E_INTERNAL; }
-  if (b->frame_out[0].status) { st = (int)b->frame_out[0].status; delete b; return st; }
-  if (b->overflow) { delete b; return ZGPU_E_UNSUPPORTED; }
-  uint64_t total = b->total_out;
-  size_t old = d->buf.size();
-  d->buf.resize(old + total);
-  st = b->read_output(0, d->buf.data() + old, total);
-  delete b;
-  if (st) return st;
-  d->block_counter += nblocks;
-  d->bytes_read += p;
-  d->frame_finished = true;
-  if (has_ck) { d->has_checksum = true; d->checksum = ck; }
+  int st = ZGPU_OK;
+  if (strat == ZGPU_STRAT_ALL || strat == ZGPU_STRAT_UPTO_BLOCKS) {
+    size_t used = 0;
+    st = decode_run(d, src, len, strat == ZGPU_STRAT_ALL ? 0u : (uint32_t)(n ? n : 1), &used);   // UptoBlocks(0) still decodes one block
+    p += used;
+  } else {
+    // UptoBytes(n): stop after the first block that brings the growth to n. A block regenerates at most 128 KiB, so
+    // ceil(missing / 128 KiB) blocks can never overshoot that block; repeat until the growth is reached.
+    const size_t before = d->buf.size();
+    do {
+      const size_t growth = d->buf.size() - before;
+      const size_t missing = n > growth ? n - growth : 0;
+      uint32_t m = (uint32_t)((missing + kMaxBlockSize - 1) / kMaxBlockSize);
+      if (m == 0) m = 1;
+      size_t used = 0;
+      st = decode_run(d, src + p, len - p, m, &used);
+      p += used;
+    } while (!st && !d->frame_finished && d->buf.size() - before < n);
+  }
   if (consumed) *consumed = p;
-  if (frame_finished) *frame_finished = 1;
-  return ZGPU_OK;
+  if (frame_finished) *frame_finished = d->frame_finished ? 1 : 0;
+  return st;
 }
 
 int zgpu_decoder_is_finished(const zgpu_decoder* d) {
@@ -361,6 +505,62 @@ size_t zgpu_decoder_read(zgpu_decoder* d, uint8_t* dst, size_t cap) {
   if (n > cap) n = cap;
   return dec_drain(d, n, dst);
 }
+
+int zgpu_decoder_decode_from_to(zgpu_decoder* d, const uint8_t* src, size_t len, uint8_t* dst, size_t cap, size_t* read_out, size_t* written_out) {
+  // FrameDecoder::decode_from_to (frame_decoder.rs:439-529): only whole blocks are consumed; the checksum may arrive later
+  if (read_out) *read_out = 0;
+  if (written_out) *written_out = 0;
+  const uint64_t at_start = d->has_state ? d->bytes_read : 0;
+  if (!zgpu_decoder_is_finished(d) || !d->has_state) {
+    size_t p = 0;
+    if (!d->has_state) {
+      size_t c = 0;
+      int st = zgpu_decoder_init(d, src, len, &c, nullptr, nullptr);
+      if (st) return st;
+      p = c;
+    }
+    if (d->fh.content_checksum() && d->frame_finished && !d->has_checksum) {
+      // the checksum was the only thing missing after the previous call (:465-477)
+      if (len - p >= 4) { memcpy(&d->checksum, src + p, 4); d->has_checksum = true; d->bytes_read += 4; }
+      if (read_out) *read_out = 4;
+      return ZGPU_OK;
+    }
+    // count the complete blocks the source holds (:479-492)
+    size_t q = p;
+    uint32_t nblocks = 0;
+    bool last = false;
+    while (!last && len - q >= 3) {
+      BlockHeader bh;
+      int st = read_block_header(src + q, &bh);
+      if (st) { if (nblocks == 0) return st; break; }
+      if (len - q - 3 < bh.content_size) break;
+      q += 3 + bh.content_size;
+      nblocks++;
+      last = bh.last;
+    }
+    if (nblocks) {
+      // the run must not swallow a checksum that is only partly there: hand over exactly the blocks (+ checksum if whole)
+      size_t avail = q - p;
+      if (last && d->fh.content_checksum() && len - q >= 4) avail += 4;
+      const bool cs_missing = last && d->fh.content_checksum() && len - q < 4;
+      size_t used = 0;
+      int st;
+      if (cs_missing) {
+        // decode the blocks now; the checksum is read by a later call: temporarily treat the frame as checksum-less
+        const uint8_t saved = d->fh.descriptor;
+        d->fh.descriptor &= (uint8_t)~0x04u;
+        st = decode_run(d, src + p, avail, nblocks, &used);
+        d->fh.descriptor = saved;
+      } else st = decode_run(d, src + p, avail, nblocks, &used);
+      if (st) return st;
+    }
+  }
+  const size_t w = zgpu_decoder_read(d, dst, cap);
+  if (read_out) *read_out = (size_t)(d->bytes_read - at_start);
+  if (written_out) *written_out = w;
+  return ZGPU_OK;
+}
+
 uint64_t zgpu_decoder_blocks_decoded(const zgpu_decoder* d) { return d->has_state ? d->block_counter : 0; }
 uint64_t zgpu_decoder_bytes_read_from_source(const zgpu_decoder* d) { return d->has_state ? d->bytes_read : 0; }
 uint64_t zgpu_decoder_content_size(const zgpu_decoder* d) { return d->has_state ? d->fh.frame_content_size : 0; }
@@ -372,3 +572,34 @@ int zgpu_decoder_checksum_from_data(const zgpu_decoder* d, uint32_t* out) {
 uint32_t zgpu_decoder_calculated_checksum(const zgpu_decoder* d) { return (uint32_t)d->hash.digest(); }
 
 }  // extern "C"
+
+static int decode_all_per_frame(zgpu_ctx* c, const uint8_t* src, size_t len, uint8_t* dst, size_t cap, size_t* written) {
+  // FrameDecoder::decode_all (frame_decoder.rs:541-577) frame by frame
+  zgpu_decoder* d = nullptr;
+  int st = zgpu_decoder_create(c, &d);
+  if (st) return st;
+  size_t p = 0, total = 0;
+  while (p < len) {
+    size_t used = 0;
+    uint32_t sm = 0, sl = 0;
+    st = zgpu_decoder_init(d, src + p, len - p, &used, &sm, &sl);
+    if (st == ZGPU_E_SKIP_FRAME) {
+      p += used;
+      if ((size_t)sl > len - p) { st = ZGPU_E_FAILED_SKIP_FRAME; break; }
+      p += sl;
+      st = ZGPU_OK;
+      continue;
+    }
+    if (st) break;
+    p += used;
+    int fin = 0;
+    st = zgpu_decoder_decode_blocks(d, src + p, len - p, &used, ZGPU_STRAT_ALL, 0, &fin);
+    p += used;
+    if (st) break;
+    total += zgpu_decoder_read(d, dst + total, cap - total);
+    if (zgpu_decoder_can_collect(d) != 0) { st = ZGPU_E_TARGET_TOO_SMALL; break; }
+  }
+  zgpu_decoder_destroy(d);
+  if (!st) *written = total;
+  return st;
+}

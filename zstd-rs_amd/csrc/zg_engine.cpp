@@ -78,7 +78,7 @@ int parse_frames(const uint8_t* src, size_t len, uint64_t max_window, BatchBuild
     fi.window_size = w;
     fi.src_begin = p;
     p += c;
-    bb->begin_frame(w, kHist, false, false);
+    bb->begin_frame(w, kHist, 0);
     for (;;) {
       if (len - p < 3) { st = ZG_FAILED_READ_BLOCK_HEADER; break; }
       BlockHeader bh;
@@ -115,26 +115,34 @@ Batch::~Batch() {
     if (e) (void)hipEventDestroy(e);
 }
 
-int parse_block_run(const uint8_t* src, size_t len, uint64_t window, bool has_checksum, BatchBuilder* bb, std::vector<FrameInfo>* info,
-                    size_t* consumed) {
-  // the block loop of FrameDecoder::decode_blocks (frame_decoder.rs:319-375) on a run that starts at a block header
-  static const uint32_t kHist[3] = {1, 4, 8};
+void FrameState::reset() {
+  base = 0; produced = 0; hist[0] = 1; hist[1] = 4; hist[2] = 8;
+  logs[0] = logs[1] = logs[2] = logs[3] = 0; huf_maxbits = 0; carry_mask = 0; window_size = 0;
+}
+void FrameState::release() { d_out.release(); d_fse.release(); d_huf.release(); }
+
+int parse_block_run(const uint8_t* src, size_t len, uint64_t window, bool has_checksum, const uint32_t hist[3], uint32_t carry_mask,
+                    uint32_t max_blocks, BatchBuilder* bb, std::vector<FrameInfo>* info, size_t* consumed, bool* saw_last) {
+  // the block loop of FrameDecoder::decode_blocks (frame_decoder.rs:319-375) on a run that starts at a block header.
+  // Blocks in front of a truncated one stay in the run (the reference decodes them before it fails).
   FrameInfo fi;
   fi.window_size = window;
-  bb->begin_frame(window, kHist, false, false);
+  bb->begin_frame(window, hist, carry_mask);
   size_t p = 0;
   int st = ZG_OK;
+  *saw_last = false;
   for (;;) {
     if (len - p < 3) { st = ZG_FAILED_READ_BLOCK_HEADER; break; }
     BlockHeader bh;
     if ((st = read_block_header(src + p, &bh))) break;
+    if (len - p - 3 < bh.content_size) { st = ZG_FAILED_READ_BLOCK_BODY; break; }
     p += 3;
-    if (len - p < bh.content_size) { st = ZG_FAILED_READ_BLOCK_BODY; break; }
     st = bb->add_block(bh, src + p, p);
     p += bh.content_size;
     fi.nblocks++;
     if (st) break;
     if (bh.last) {
+      *saw_last = true;
       if (has_checksum) {
         if (len - p < 4) { st = ZG_FAILED_READ_CHECKSUM; break; }
         memcpy(&fi.checksum, src + p, 4);
@@ -143,6 +151,7 @@ int parse_block_run(const uint8_t* src, size_t len, uint64_t window, bool has_ch
       }
       break;
     }
+    if (max_blocks && fi.nblocks >= max_blocks) break;
   }
   fi.src_end = p;
   fi.host_status = st;
@@ -159,11 +168,19 @@ int Engine::prepare(const uint8_t* src, size_t len, Batch** out) {
   return upload(b, src, len, out);
 }
 
-int Engine::prepare_run(const uint8_t* src, size_t len, uint64_t window, bool has_checksum, Batch** out, size_t* consumed) {
+int Engine::prepare_run(const uint8_t* src, size_t len, FrameState* fs, bool has_checksum, uint32_t max_blocks, Batch** out, size_t* consumed) {
   Batch* b = new Batch();
   b->eng = this;
-  b->parse_status = parse_block_run(src, len, window, has_checksum, &b->bb, &b->info, consumed);
+  b->fs = fs;
+  b->parse_status = parse_block_run(src, len, fs->window_size, has_checksum, fs->hist, fs->carry_mask, max_blocks, &b->bb, &b->info, consumed,
+                                    &b->saw_last_block);
   b->src_len = *consumed;
+  // this run continues the frame: its bytes go right behind what exists, and matches may reach back into it
+  ZgFrame& fr = b->bb.frames[0];
+  fr.fixed_base = 1;
+  fr.out_base_fixed = fs->base + fs->produced;
+  fr.prior_out = fs->produced;
+  fr.dict_len = fs->base;
   return upload(b, src, *consumed, out);
 }
 
@@ -203,7 +220,8 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
       (st = b->d_hufmax.reserve(bb.nhuf_slots + 16)) || (st = b->d_status.reserve((size_t)nb * 4 + 16)) ||
       (st = b->d_lit.reserve(bb.lit_bytes + 64)) || (st = b->d_seq.reserve((bb.seq_count + 1) * sizeof(ZgSeq))) ||
       (st = b->d_seqout.reserve((size_t)nb * sizeof(ZgBlockSeqOut) + 16)) || (st = b->d_pos.reserve((size_t)nb * sizeof(ZgBlockPos) + 16)) ||
-      (st = b->d_frameout.reserve((size_t)nf * sizeof(ZgFrameOut) + 16)) || (st = b->d_dst.reserve(bb.out_bound + 64)) ||
+      (st = b->d_frameout.reserve((size_t)nf * sizeof(ZgFrameOut) + 16)) ||
+      (st = b->fs ? b->fs->d_out.reserve(b->fs->base + b->fs->produced + bb.out_bound + 64, true, stream_) : b->d_dst.reserve(bb.out_bound + 64)) ||
       (st = b->d_totals.reserve(64)) || (st = b->d_og.reserve((size_t)bb.og_count * 4 + 64)) ||
       (st = up(b->d_units, bb.units.data(), bb.units.size() * sizeof(ZgUnit))) ||
       (st = up(b->d_sweepwgs, bb.sweep_wgs.data(), bb.sweep_wgs.size() * sizeof(ZgSweepWg))) ||
@@ -220,7 +238,13 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   d.fse_arena = b->d_fse.as<uint32_t>(); d.huf_arena = b->d_huf.as<uint16_t>(); d.huf_maxbits = b->d_hufmax.as<uint8_t>();
   d.status = b->d_status.as<uint32_t>(); d.lit_arena = b->d_lit.as<uint8_t>(); d.seq_arena = b->d_seq.as<ZgSeq>();
   d.seq_out = b->d_seqout.as<ZgBlockSeqOut>(); d.pos = b->d_pos.as<ZgBlockPos>(); d.frame_out = b->d_frameout.as<ZgFrameOut>();
-  d.dst = b->d_dst.as<uint8_t>(); d.dst_cap = bb.out_bound; d.dict = nullptr;
+  if (b->fs) {
+    if ((st = b->fs->d_fse.reserve(ZG_FSE_SLOT_U32 * 4)) || (st = b->fs->d_huf.reserve(ZG_HUF_SLOT_U16 * 2))) { delete b; return st; }
+    d.dst = b->fs->d_out.as<uint8_t>(); d.dst_cap = b->fs->base + b->fs->produced + bb.out_bound;
+  } else {
+    d.dst = b->d_dst.as<uint8_t>(); d.dst_cap = bb.out_bound;
+  }
+  d.dict = nullptr;
   d.seq_blocks = b->d_seqblocks.as<uint32_t>(); d.nseq_blocks = (uint32_t)bb.seq_blocks.size();
   d.huf_items = b->d_hufitems.as<uint32_t>(); d.huf_groups = b->d_hufgroups.as<ZgHufGroup>(); d.nhuf_groups = (uint32_t)bb.huf_groups.size();
   d.totals = b->d_totals.as<uint32_t>();
@@ -249,6 +273,13 @@ int Batch::run() {
   ZG_HIP(hipMemsetAsync(d.totals, 0, 64, s));
   ZG_HIP(hipMemsetAsync(d.bar, 0, (size_t)d.nframes * 4 + 16, s));
   if (d.dbg) ZG_HIP(hipMemsetAsync(d.dbg, 0, 64, s));
+  if (fs && fs->carry_mask) {   // tables carried into this run: the frame's carry slots of the two arenas
+    const ZgFrame& fr = bb.frames[0];
+    ZG_HIP(hipMemcpyAsync(d.fse_arena + (size_t)fr.carry_slot * ZG_FSE_SLOT_U32, fs->d_fse.p, ZG_FSE_SLOT_U32 * 4, hipMemcpyDeviceToDevice, s));
+    ZG_HIP(hipMemcpyAsync(d.slot_log + (size_t)fr.carry_slot * 4, fs->logs, 4, hipMemcpyHostToDevice, s));
+    ZG_HIP(hipMemcpyAsync(d.huf_arena + (size_t)fr.carry_huf_slot * ZG_HUF_SLOT_U16, fs->d_huf.p, ZG_HUF_SLOT_U16 * 2, hipMemcpyDeviceToDevice, s));
+    ZG_HIP(hipMemcpyAsync(d.huf_maxbits + fr.carry_huf_slot, &fs->huf_maxbits, 1, hipMemcpyHostToDevice, s));
+  }
   zg_launch_tables(d, s);
   ZG_HIP(hipEventRecord(ev[1], s));
   zg_launch_huf(d, s);
@@ -289,8 +320,36 @@ int Batch::sync() {
   return ZG_OK;
 }
 
+int Batch::commit(FrameState* st) {
+  // fold a finished streaming run into the frame state: DecoderScratch after decode_block_content
+  if (dev.nframes != 1 || frame_out.size() != 1) return ZG_BAD_ARG;
+  const ZgFrameOut& fo = frame_out[0];
+  st->produced += fo.out_size;
+  st->hist[0] = fo.hist_end[0]; st->hist[1] = fo.hist_end[1]; st->hist[2] = fo.hist_end[2];
+  if (fo.status) return ZG_OK;   // the frame failed: the caller reports it; tables are not needed any more
+  const Lineage fl = bb.final_lineage();
+  hipStream_t s = eng->stream_;
+  const int32_t sl[3] = {fl.ll, fl.of, fl.ml};
+  const uint32_t offs[3] = {ZG_FSE_LL_OFF, ZG_FSE_OF_OFF, ZG_FSE_ML_OFF}, nent[3] = {512, 256, 512};
+  const int32_t carry = (int32_t)bb.frames[0].carry_slot;
+  for (int k = 0; k < 3; k++) {
+    if (sl[k] < 0 || sl[k] == carry) continue;   // never set, or still the carried table
+    ZG_HIP(hipMemcpyAsync(st->d_fse.as<uint32_t>() + offs[k], dev.fse_arena + (size_t)sl[k] * ZG_FSE_SLOT_U32 + offs[k], nent[k] * 4,
+                          hipMemcpyDeviceToDevice, s));
+    ZG_HIP(hipMemcpyAsync(&st->logs[k], dev.slot_log + (size_t)sl[k] * 4 + k, 1, hipMemcpyDeviceToHost, s));
+    st->carry_mask |= 2u << k;
+  }
+  if (fl.huf >= 0 && fl.huf != bb.frames[0].carry_huf_slot) {
+    ZG_HIP(hipMemcpyAsync(st->d_huf.p, dev.huf_arena + (size_t)fl.huf * ZG_HUF_SLOT_U16, ZG_HUF_SLOT_U16 * 2, hipMemcpyDeviceToDevice, s));
+    ZG_HIP(hipMemcpyAsync(&st->huf_maxbits, dev.huf_maxbits + fl.huf, 1, hipMemcpyDeviceToHost, s));
+    st->carry_mask |= 1u;
+  }
+  ZG_HIP(hipStreamSynchronize(s));
+  return ZG_OK;
+}
+
 int Batch::read_output(uint64_t off, uint8_t* dst, uint64_t n) {
-  if (off + n > dev.dst_cap) return ZG_BAD_ARG;
+  if (off + n > dev.dst_cap + 64) return ZG_BAD_ARG;
   if (n) ZG_HIP(hipMemcpy(dst, dev.dst + off, n, hipMemcpyDeviceToHost));
   return ZG_OK;
 }

@@ -31,6 +31,24 @@ struct FrameInfo {
   int host_status = 0;                   // error found while walking the frame (truncated input, bad header, ...)
 };
 
+// What one frame carries from one submit of its blocks to the next (the reference's DecoderScratch, scratch.rs:15-27):
+// the output so far (= the decode window; a dictionary's content sits in front of it), the offset history, and the
+// Huffman / FSE tables a later Treeless / Repeat block may decode with.
+struct FrameState {
+  DevBuf d_out;                  // [dictionary content][frame output so far]
+  uint64_t base = 0;             // dictionary content bytes in front of the frame's first byte
+  uint64_t produced = 0;         // frame bytes decoded so far
+  uint32_t hist[3] = {1, 4, 8};  // scratch.rs:44
+  DevBuf d_fse;                  // carried FSE tables, one arena slot (ZG_FSE_SLOT_U32 packed entries)
+  DevBuf d_huf;                  // carried Huffman table (ZG_HUF_SLOT_U16 entries)
+  uint8_t logs[4] = {0, 0, 0, 0};// accuracy logs LL, OF, ML of the carried FSE tables
+  uint8_t huf_maxbits = 0;
+  uint32_t carry_mask = 0;       // bit 0 Huffman, 1 LL, 2 OF, 3 ML: which tables exist
+  uint64_t window_size = 0;
+  void reset();
+  void release();
+};
+
 enum { ZG_T_TABLES = 0, ZG_T_HUF, ZG_T_SEQ, ZG_T_SCAN, ZG_T_LIT, ZG_T_FLAT, ZG_T_SWEEP, ZG_T_LZ, ZG_T_TOTAL, ZG_T_COUNT };
 
 class Engine;
@@ -49,6 +67,9 @@ class Batch {
   uint64_t src_len = 0;
 
   int run();                             // enqueue the kernel pipeline on the engine's stream
+  // streaming submits: after sync(), fold this run into the frame's carried state (tables, history, produced bytes)
+  int commit(FrameState* fs);
+  bool saw_last_block = false;           // the run ended with the frame's last block
   int sync();                            // wait, download per-frame results, compute timings
   int read_output(uint64_t off, uint8_t* dst, uint64_t n);   // D2H
   const uint8_t* device_output() const { return (const uint8_t*)d_dst.p; }
@@ -68,6 +89,7 @@ class Batch {
       d_dst, d_seqblocks, d_hufitems, d_hufgroups, d_totals, d_og, d_units, d_unitinfo, d_sweepwgs, d_bar, d_dbg;
   hipEvent_t ev[ZG_T_COUNT + 1] = {};
   bool ran = false;
+  FrameState* fs = nullptr;              // streaming submit: the frame state this run reads from / writes into
 };
 
 class Engine {
@@ -80,7 +102,8 @@ class Engine {
   int prepare(const uint8_t* src, size_t len, Batch** out);
   // Same for a run of blocks of ONE frame that starts at a block header (the FrameDecoder mirror parsed the frame
   // header itself). *consumed = bytes of the run (block headers, bodies, checksum).
-  int prepare_run(const uint8_t* src, size_t len, uint64_t window, bool has_checksum, Batch** out, size_t* consumed);
+  // max_blocks: 0 = up to the last block of the frame. fs carries the frame's state across calls.
+  int prepare_run(const uint8_t* src, size_t len, FrameState* fs, bool has_checksum, uint32_t max_blocks, Batch** out, size_t* consumed);
   hipStream_t stream() const { return stream_; }
   int device() const { return device_; }
   std::string last_error;
@@ -95,7 +118,7 @@ class Engine {
 
 // Host-only walk of concatenated frames into a BatchBuilder (no GPU involved; unit-tested on CPU).
 int parse_frames(const uint8_t* src, size_t len, uint64_t max_window, BatchBuilder* bb, std::vector<FrameInfo>* info);
-int parse_block_run(const uint8_t* src, size_t len, uint64_t window, bool has_checksum, BatchBuilder* bb, std::vector<FrameInfo>* info,
-                    size_t* consumed);
+int parse_block_run(const uint8_t* src, size_t len, uint64_t window, bool has_checksum, const uint32_t hist[3], uint32_t carry_mask,
+                    uint32_t max_blocks, BatchBuilder* bb, std::vector<FrameInfo>* info, size_t* consumed, bool* saw_last);
 
 }  // namespace zg

@@ -79,7 +79,7 @@ int read_block_header(const uint8_t* p, BlockHeader* h) {
   return ZG_OK;
 }
 
-uint32_t BatchBuilder::begin_frame(uint64_t window_size, const uint32_t hist[3], bool has_carry_tables, bool has_carry_huf) {
+uint32_t BatchBuilder::begin_frame(uint64_t window_size, const uint32_t hist[3], uint32_t carry_mask) {
   ZgFrame f;
   memset(&f, 0, sizeof f);
   f.first_block = (uint32_t)blocks.size();
@@ -89,8 +89,10 @@ uint32_t BatchBuilder::begin_frame(uint64_t window_size, const uint32_t hist[3],
   f.carry_huf_slot = ZG_REF_UNINIT;
   frames.push_back(f);
   cur_ = Lineage();
-  if (has_carry_tables) cur_.ll = cur_.of = cur_.ml = kCarry;
-  if (has_carry_huf) cur_.huf = kCarryHuf;
+  if (carry_mask & 1u) cur_.huf = kCarryHuf;
+  if (carry_mask & 2u) cur_.ll = kCarry;
+  if (carry_mask & 4u) cur_.of = kCarry;
+  if (carry_mask & 8u) cur_.ml = kCarry;
   frame_failed_ = false;
   return (uint32_t)frames.size() - 1;
 }
@@ -219,6 +221,17 @@ void BatchBuilder::finish() {
   for (uint32_t f = 0; f < frames.size(); f++) {
     frames[f].carry_slot = nb + 1 + f;
     frames[f].carry_huf_slot = (int32_t)(block_huf_slots + f);
+  }
+  // lineage of the last frame after its last block (streaming: what the next submit of this frame starts from)
+  final_ = cur_;
+  if (!frames.empty()) {
+    const uint32_t lf = (uint32_t)frames.size() - 1;
+    int32_t* fl[3] = {&final_.ll, &final_.of, &final_.ml};
+    for (int k = 0; k < 3; k++) {
+      if (*fl[k] == kPredef) *fl[k] = (int32_t)nb;
+      else if (*fl[k] == kCarry) *fl[k] = (int32_t)frames[lf].carry_slot;
+    }
+    if (final_.huf == kCarryHuf) final_.huf = frames[lf].carry_huf_slot;
   }
   seq_blocks.clear(); huf_items.clear(); huf_groups.clear(); units.clear(); sweep_wgs.clear();
   og_count = 0;

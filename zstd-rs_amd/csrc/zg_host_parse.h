@@ -69,7 +69,11 @@ class BatchBuilder {
   uint64_t out_bound = 0;      // upper bound of the output when every compressed block regenerates <= 128 KiB
 
   // Start a frame. carry: lineage handed in by a dictionary or an earlier submit (slots are resolved in finish()).
-  uint32_t begin_frame(uint64_t window_size, const uint32_t hist[3], bool has_carry_tables, bool has_carry_huf);
+  // carry_mask: bit 0 Huffman, bit 1 LL, bit 2 OF, bit 3 ML — tables that already exist when the frame (or this run of
+  // its blocks) starts: handed in by a dictionary or by an earlier submit of the same frame.
+  uint32_t begin_frame(uint64_t window_size, const uint32_t hist[3], uint32_t carry_mask);
+  // lineage after the last added block, slots resolved (valid after finish()): which arena slot holds each table now
+  Lineage final_lineage() const { return final_; }
   // Add one block of the current frame. body points at Block_Content (content_size bytes available).
   // src_off is the body's offset in the buffer that will be uploaded. Returns the block's host status.
   int add_block(const BlockHeader& bh, const uint8_t* body, uint64_t src_off);
@@ -83,7 +87,7 @@ class BatchBuilder {
   uint32_t nslots() const { return (uint32_t)blocks.size() + 1 + (uint32_t)frames.size(); }
 
  private:
-  Lineage cur_;
+  Lineage cur_, final_;
   bool frame_failed_ = false;
   static constexpr int32_t kPredef = -2;   // resolved in finish()
   static constexpr int32_t kCarry = -3;

@@ -44,7 +44,8 @@ EXPORTS = [
     "zgpu_decode_all", "zgpu_batch_prepare", "zgpu_batch_run", "zgpu_batch_sync", "zgpu_batch_num_frames", "zgpu_batch_num_blocks",
     "zgpu_batch_compressed_size", "zgpu_batch_frame_info", "zgpu_batch_read", "zgpu_batch_output_device", "zgpu_batch_timings",
     "zgpu_batch_destroy", "zgpu_batch_block_info", "zgpu_batch_block_literals", "zgpu_batch_block_sequences", "zgpu_batch_fse_slot",
-    "zgpu_batch_huf_slot", "zgpu_batch_debug_timers", "zgpu_debug_calibrate", "zgpu_decoder_create", "zgpu_decoder_destroy", "zgpu_decoder_init", "zgpu_decoder_decode_blocks",
+    "zgpu_batch_huf_slot", "zgpu_batch_debug_timers", "zgpu_debug_calibrate", "zgpu_add_dict", "zgpu_decoder_force_dict",
+    "zgpu_decoder_decode_from_to", "zgpu_decoder_create", "zgpu_decoder_destroy", "zgpu_decoder_init", "zgpu_decoder_decode_blocks",
     "zgpu_decoder_can_collect", "zgpu_decoder_collect", "zgpu_decoder_read", "zgpu_decoder_is_finished", "zgpu_decoder_blocks_decoded",
     "zgpu_decoder_bytes_read_from_source", "zgpu_decoder_content_size", "zgpu_decoder_checksum_from_data",
     "zgpu_decoder_calculated_checksum",
@@ -94,6 +95,9 @@ def load_library():
     L.zgpu_batch_debug_timers.argtypes = [vp, P(C.c_uint64)]
     L.zgpu_debug_calibrate.argtypes = [vp, C.c_uint64]
     L.zgpu_decoder_create.argtypes = [vp, P(vp)]
+    L.zgpu_add_dict.argtypes = [vp, u8p, sz, P(C.c_uint32)]
+    L.zgpu_decoder_force_dict.argtypes = [vp, C.c_uint32]
+    L.zgpu_decoder_decode_from_to.argtypes = [vp, u8p, sz, vp, sz, P(sz), P(sz)]
     L.zgpu_decoder_destroy.argtypes = [vp]
     L.zgpu_decoder_init.argtypes = [vp, u8p, sz, P(sz), P(C.c_uint32), P(C.c_uint32)]
     L.zgpu_decoder_decode_blocks.argtypes = [vp, u8p, sz, P(sz), C.c_int, sz, P(C.c_int)]
@@ -144,6 +148,14 @@ class Context:
 
     def max_window_size(self):
         return self.L.zgpu_max_window_size(self.h)
+
+    def add_dict(self, raw):
+        """FrameDecoder::add_dict (frame_decoder.rs:224-227); returns the dictionary id"""
+        did = C.c_uint32()
+        st = self.L.zgpu_add_dict(self.h, raw, len(raw), C.byref(did))
+        if st:
+            raise ZgpuError(st)
+        return did.value
 
     def decode_all(self, src, cap):
         """FrameDecoder::decode_all (frame_decoder.rs:541-577). Returns the plaintext or raises ZgpuError."""
@@ -295,6 +307,19 @@ class FrameDecoder:
         st = self.L.zgpu_decoder_decode_blocks(self.h, src, len(src), C.byref(c), strat, n, C.byref(fin))
         return st, c.value, bool(fin.value)
 
+    def add_dict(self, raw):
+        return self.ctx.add_dict(raw)
+
+    def force_dict(self, dict_id):
+        return self.L.zgpu_decoder_force_dict(self.h, dict_id)
+
+    def decode_from_to(self, src, cap):
+        """returns (status, bytes_read, output_bytes) — frame_decoder.rs:439-529"""
+        buf = C.create_string_buffer(max(cap, 1))
+        r, w = C.c_size_t(), C.c_size_t()
+        st = self.L.zgpu_decoder_decode_from_to(self.h, src, len(src), buf, cap, C.byref(r), C.byref(w))
+        return st, r.value, buf.raw[:w.value]
+
     def can_collect(self):
         return self.L.zgpu_decoder_can_collect(self.h)
 
@@ -330,3 +355,75 @@ class FrameDecoder:
 
     def decode_all(self, src, cap):
         return self.ctx.decode_all(src, cap)
+
+
+class StreamingDecoder:
+    """Mirror of ruzstd::decoding::StreamingDecoder (streaming_decoder.rs:40-156): an io-style reader over ONE frame.
+
+    source: a binary file-like object positioned at the frame header. The decoder reads exactly the bytes the
+    reference would: the frame header, then whole blocks as read() needs them."""
+
+    def __init__(self, source, decoder=None, ctx=None, max_window_size=None):
+        self.source = source
+        self.decoder = decoder or FrameDecoder(ctx)
+        if max_window_size is not None:
+            self.decoder.set_max_window_size(max_window_size)
+        # frame header: 4 magic + 1 descriptor tell how long the rest is (frame.rs:6-85)
+        head = source.read(5)
+        if len(head) == 5 and head[:4] == bytes([0x28, 0xB5, 0x2F, 0xFD]):
+            desc = head[4]
+            single = (desc >> 5) & 1
+            extra = (0 if single else 1) + (0, 1, 2, 4)[desc & 3] + ((1 if single else 0), 2, 4, 8)[desc >> 6]
+            head += source.read(extra)
+        else:
+            head += source.read(3)
+        self._cs = len(head) >= 5 and bool((head[4] >> 2) & 1)
+        st, used, _, _ = self.decoder.reset(head)
+        if st:
+            raise ZgpuError(st)
+        assert used == len(head)
+
+    def _read_blocks(self, n):
+        """n whole blocks (or up to the last block) from the source, as one byte string"""
+        out = []
+        for _ in range(n):
+            hdr = self.source.read(3)
+            out.append(hdr)
+            if len(hdr) < 3:
+                break
+            btype = (hdr[0] >> 1) & 3
+            size = (hdr[0] >> 3) | (hdr[1] << 5) | (hdr[2] << 13)
+            out.append(self.source.read(1 if btype == 1 else size))
+            if hdr[0] & 1:
+                if (self.decoder_checksum_flag):
+                    out.append(self.source.read(4))
+                break
+        return b"".join(out)
+
+    @property
+    def decoder_checksum_flag(self):
+        return self._cs
+
+    def read(self, n=-1):
+        """impl Read (streaming_decoder.rs:119-155)"""
+        d = self.decoder
+        if n is None or n < 0:
+            chunks = []
+            while True:
+                c = self.read(1 << 20)
+                if not c:
+                    return b"".join(chunks)
+                chunks.append(c)
+        if d.is_finished() and d.can_collect() == 0:
+            return b""
+        while d.can_collect() < n and not d.is_finished():
+            need = n - d.can_collect()
+            m = max(1, (need + (128 << 10) - 1) // (128 << 10))      # UptoBytes(need) never stops before ceil(need / 128 KiB) blocks
+            data = self._read_blocks(m)
+            st, used, fin = d.decode_blocks(data, STRAT_UPTO_BLOCKS, m)
+            if st:
+                raise ZgpuError(st)
+        return d.read(n)
+
+    def into_frame_decoder(self):
+        return self.decoder
