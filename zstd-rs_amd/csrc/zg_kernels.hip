@@ -22,6 +22,9 @@
 #define ZG_PAR_LIT 0xFFFFu   // tile byte is a literal: value in s_val
 #define ZG_PAR_EXIT 0xFFFEu  // tile byte is a match byte whose source lies before the tile
 
+typedef uint32_t zg_v4u __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) zg_v4u zg_gv4u;   // 16 bytes in global memory: global_load/store, not flat
+
 __device__ __forceinline__ void zg_set_status(uint32_t* status, uint32_t b, int st) {
   if (st) atomicCAS(&status[b], 0u, (uint32_t)st);
 }
@@ -94,21 +97,32 @@ __global__ void __launch_bounds__(64) zg_k_tables(ZgBatchDev d) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// zg_k_huf: Huffman literal streams (literals_section_decoder.rs:40-158). One workgroup per group of streams
-// that share a table; the table (<= 2^11 x 2 B) is staged in LDS; one lane decodes one stream.
+// zg_k_huf: Huffman literal streams (literals_section_decoder.rs:40-158; HuffmanDecoder huff0_decoder.rs:25-53).
+// One workgroup per group of streams that share a table; the table (<= 2^11 x 2 B) is staged in LDS; one lane decodes
+// one stream. A stream is a serial chain (peek max_bits bits -> table -> consume num_bits), so the loop is kept free of
+// global memory like zg_k_seq's: every lane owns a 128-byte ring of its stream in LDS (dword k of lane l at [k][l]:
+// bank-conflict free) that it extends downwards with 16-byte loads landing one phase (16 symbols) later, and it
+// writes its literals 16 bytes at a time.
 // ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) zg_k_huf(ZgBatchDev d) {
+#define ZG_HUF_T 256
+#define ZG_HUF_RDW 32                      // ring dwords per lane
+#define ZG_HUF_CH 16                       // symbols per phase: <= 16 x 11 bits = 22 bytes of input, 16 bytes of output
+#define ZG_HUF_MARGIN 64                   // bytes kept resident below the read position (two phases + a piece)
+
+__global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
   __shared__ uint16_t s_tab[ZG_HUF_SLOT_U16];
+  __shared__ uint32_t s_ring[ZG_HUF_RDW][ZG_HUF_T];
   const ZgHufGroup grp = d.huf_groups[blockIdx.x];
+  const uint32_t t = threadIdx.x;
   unsigned max_bits = grp.slot >= 0 ? d.huf_maxbits[grp.slot] : 0;
   if (max_bits > 11) max_bits = 0;
   if (max_bits) {
     const uint16_t* g = d.huf_arena + (uint64_t)grp.slot * ZG_HUF_SLOT_U16;
-    for (uint32_t i = threadIdx.x; i < (1u << max_bits); i += blockDim.x) s_tab[i] = g[i];
+    for (uint32_t i = t; i < (1u << max_bits); i += ZG_HUF_T) s_tab[i] = g[i];
   }
   __syncthreads();
-  if (threadIdx.x >= grp.nitems) return;
-  uint32_t item = d.huf_items[grp.first_item + threadIdx.x];
+  if (t >= grp.nitems) return;
+  uint32_t item = d.huf_items[grp.first_item + t];
   uint32_t b = item >> 2, k = item & 3;
   const ZgBlock blk = d.blocks[b];
   if (max_bits == 0) { zg_set_status(d.status, b, ZG_LIT_UNINIT_HUF); return; }  // literals_section_decoder.rs:60-63
@@ -136,11 +150,107 @@ __global__ void __launch_bounds__(256) zg_k_huf(ZgBatchDev d) {
   } else {
     sp = pay; slen = total; doff = 0; cap = regen;
   }
-  uint32_t count = 0;
-  int32_t endbits = 0;
-  int st = zg_huf_decode_stream((const uint8_t*)sp, slen, (const uint16_t*)s_tab, max_bits, lit + doff, cap, &count, &endbits);
-  if (!st && blk.nstreams == 4 && endbits != -(int32_t)max_bits) st = ZG_LIT_BITSTREAM_MISMATCH;  // :116-121
-  if (!st && count != cap) st = ZG_LIT_COUNT_MISMATCH;                                              // :150-155 (per stream, spec split)
+  const uint32_t lastb = slen ? sp[slen - 1] : 0;
+  if (slen == 0 || lastb == 0) { zg_set_status(d.status, b, ZG_LIT_EXTRA_PADDING); return; }  // :98-109
+  const uint32_t hb = zg_hbit(lastb) - 1;                     // payload bits of the last byte (below the marker)
+  const uint32_t T = (slen - 1) * 8 + hb;                     // bits of the stream
+  const uint64_t A = (uint64_t)sp, A_last = A + slen - 1;
+  uint8_t* dst = lit + doff;
+  // ---- ring: prologue fill from the piece holding the last byte down to MARGIN below it
+  const uint64_t floorA = A & ~15ull;
+  uint64_t lo;
+  {
+    const uint64_t top = (A_last & ~15ull) + 16;
+    uint64_t want = A_last > ZG_HUF_MARGIN + 16 ? (A_last - ZG_HUF_MARGIN - 16) & ~15ull : 0;
+    if (want < floorA) want = floorA;
+    for (uint64_t addr = top - 16; addr + 16 > want && addr >= want; addr -= 16) {
+      const zg_v4u v = *(const zg_gv4u*)addr;
+      const uint32_t di = (uint32_t)(addr >> 2);
+      s_ring[(di + 0) & (ZG_HUF_RDW - 1)][t] = v.x; s_ring[(di + 1) & (ZG_HUF_RDW - 1)][t] = v.y;
+      s_ring[(di + 2) & (ZG_HUF_RDW - 1)][t] = v.z; s_ring[(di + 3) & (ZG_HUF_RDW - 1)][t] = v.w;
+      if (addr == 0) break;
+    }
+    lo = want;
+  }
+  // ---- bit buffer: upcoming bits sit at the top of bitbuf; dwords are popped downwards from the ring
+  uint64_t wp = A_last >> 2;                                  // absolute index of the next dword to pop
+  auto pop = [&]() -> uint32_t {
+    uint32_t v = s_ring[wp & (ZG_HUF_RDW - 1)][t];
+    const uint64_t wa = wp << 2;
+    if (wa + 4 <= A) v = 0;                                   // below the stream: zeros (bit_reader_reverse.rs:76-86)
+    else if (wa < A) v &= ~0u << (8u * (uint32_t)(A - wa));   // dword straddles the stream start
+    wp--;
+    return v;
+  };
+  uint64_t bitbuf;
+  int32_t avail;
+  {
+    const uint32_t vb = (uint32_t)(A_last & 3) + 1;           // bytes of the top dword that belong to the stream
+    uint32_t v = pop();
+    v <<= 8u * (4 - vb);                                      // last stream byte at the top
+    bitbuf = (uint64_t)v << 32;
+    bitbuf <<= (8 - hb);                                      // drop the zero padding and the marker bit
+    avail = (int32_t)(8 * vb) - (int32_t)(8 - hb);
+    if (avail <= 32) { bitbuf |= (uint64_t)pop() << (32 - avail); avail += 32; }
+  }
+  uint32_t c = 0, n = 0;                                      // bits consumed, symbols emitted
+  zg_v4u piece[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  uint64_t piece_addr[2] = {0, 0};
+  bool piece_ok[2] = {false, false};
+  bool overflow = false;
+  while (c < T && !overflow) {
+    // ---- mover: land the pieces requested one phase ago, request the next ones
+#pragma unroll
+    for (int pi = 0; pi < 2; pi++) {
+      if (piece_ok[pi]) {
+        const uint32_t di = (uint32_t)(piece_addr[pi] >> 2);
+        s_ring[(di + 0) & (ZG_HUF_RDW - 1)][t] = piece[pi].x; s_ring[(di + 1) & (ZG_HUF_RDW - 1)][t] = piece[pi].y;
+        s_ring[(di + 2) & (ZG_HUF_RDW - 1)][t] = piece[pi].z; s_ring[(di + 3) & (ZG_HUF_RDW - 1)][t] = piece[pi].w;
+      }
+      piece_ok[pi] = false;
+    }
+    {
+      const uint64_t pos = wp << 2;
+      uint64_t want = pos > ZG_HUF_MARGIN ? (pos - ZG_HUF_MARGIN) & ~15ull : 0;
+      if (want < floorA) want = floorA;
+#pragma unroll
+      for (int pi = 0; pi < 2; pi++) {
+        if (lo > want) {
+          lo -= 16;
+          piece[pi] = *(const zg_gv4u*)lo; piece_addr[pi] = lo; piece_ok[pi] = true;
+        }
+      }
+    }
+    // ---- decode phase: LDS and registers only
+    uint32_t ow[4] = {0, 0, 0, 0};
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < ZG_HUF_CH; i++) {
+      if (c < T && !overflow) {
+        if (n + m >= cap) overflow = true;                    // more symbols than the section holds
+        else {
+          const uint32_t e = s_tab[(uint32_t)(bitbuf >> 32) >> (32 - max_bits)];
+          const uint32_t nb = e >> 8;
+          ow[i >> 2] |= (e & 255u) << (8 * (i & 3));
+          m++;
+          bitbuf <<= nb; avail -= (int32_t)nb; c += nb;
+          if (avail <= 32) { bitbuf |= (uint64_t)pop() << (32 - avail); avail += 32; }
+        }
+      }
+    }
+    // ---- write the phase's literals
+    if (m == ZG_HUF_CH) {
+      ((zg_u64u*)(dst + n))->v = (uint64_t)ow[0] | ((uint64_t)ow[1] << 32);
+      ((zg_u64u*)(dst + n + 8))->v = (uint64_t)ow[2] | ((uint64_t)ow[3] << 32);
+    } else {
+      for (uint32_t i = 0; i < m; i++) dst[n + i] = (uint8_t)(ow[i >> 2] >> (8 * (i & 3)));
+    }
+    n += m;
+  }
+  int st = ZG_OK;
+  if (overflow) st = ZG_LIT_COUNT_MISMATCH;
+  else if (blk.nstreams == 4 && c != T) st = ZG_LIT_BITSTREAM_MISMATCH;   // bits_remaining != -max_bits (:116-121)
+  else if (n != cap) st = ZG_LIT_COUNT_MISMATCH;                           // :150-155 (per stream, spec split)
   zg_set_status(d.status, b, st);
 }
 
@@ -169,8 +279,6 @@ __device__ __forceinline__ uint32_t zg_ring_bits(const uint32_t* ring32, uint32_
   const uint32_t d0 = ring32[di], d1 = ring32[di + 1];
   return __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(d1, d0, rb & 31u), 0u, n);
 }
-typedef uint32_t zg_v4u __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(1))) zg_v4u zg_gv4u;   // 16 bytes in global memory: global_load/store, not flat
 __device__ __forceinline__ uint32_t zg_sym_dec_bf(uint32_t v) {  // zg_sym_dec without branches
   const uint32_t c = v ? v - 1 : 0u;
   return (v >> 30) ? v + 1 : c;
@@ -611,12 +719,15 @@ __global__ void __launch_bounds__(256) zg_k_lit(ZgBatchDev d) {
 //              unit u from the finished output of units < u — a pure gather, all bytes of the unit in parallel.
 // ------------------------------------------------------------------------------------------------------------
 #define ZG_FL_SOFF 5632   // most matches that can start in / overlap one tile (match length >= 3) + slack
+#define ZG_FL_LONG 48      // literal runs / matches longer than this are filled by the whole workgroup, not by one lane
+#define ZG_FL_LONGCAP 352  // > 16384 / 48 + 2
 
 __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
   __shared__ __attribute__((aligned(16))) uint8_t s_val[ZG_FL_TS];
   __shared__ uint16_t s_par[ZG_FL_TS];
   __shared__ uint32_t s_soff[ZG_FL_SOFF];   // offset of the tile's j-th sequence (for bytes whose parent is before the tile)
-  __shared__ uint32_t s_next, s_err, s_unres;
+  __shared__ uint32_t s_next, s_err, s_unres, s_nlong;
+  __shared__ uint32_t s_long[ZG_FL_LONGCAP][4];   // runs longer than ZG_FL_LONG bytes: {x0, x1, literal source index | offset, kind<<31 | j}
   const uint32_t t = threadIdx.x;
   const ZgUnit un = d.units[blockIdx.x];
   if (t == 0) { ZgUnitInfo ui; ui.size = 0; ui.unresolved = 0; d.unit_info[blockIdx.x] = ui; }
@@ -663,7 +774,7 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
     for (uint32_t t0 = 0; t0 < S; t0 += ZG_FL_TS) {
       const uint32_t t1 = t0 + ZG_FL_TS < S ? t0 + ZG_FL_TS : S;
       const uint32_t tu0 = bu0 + t0;                             // unit-relative position of the tile
-      if (t == 0) s_next = 0xFFFFFFFFu;
+      if (t == 0) { s_next = 0xFFFFFFFFu; s_nlong = 0; }
       __syncthreads();
       ZG_TICK(0)
       // ---- S1: parents. Sequence i covers [mdst-ll, mdst+ml); index nseq stands for the trailing literals.
@@ -682,7 +793,10 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
         if (m1 > t1 || a >= t1) atomicMin(&s_next, i);  // first sequence that reaches beyond this tile starts the next one
         if (a >= t1) break;
         uint32_t x0 = a > t0 ? a : t0, x1 = m0 < t1 ? m0 : t1;  // literal run (usually 0-3 bytes: fetched 4 at a time)
-        if (lit_rle) {
+        if (x1 > x0 && x1 - x0 > ZG_FL_LONG) {
+          const uint32_t e = atomicAdd(&s_nlong, 1u);
+          if (e < ZG_FL_LONGCAP) { s_long[e][0] = x0; s_long[e][1] = x1; s_long[e][2] = lstart + (x0 - a); s_long[e][3] = 0; }
+        } else if (lit_rle) {
           for (uint32_t x = x0; x < x1; x++) { s_val[x - t0] = lit_fill; s_par[x - t0] = ZG_PAR_LIT; }
         } else {
           for (uint32_t x = x0; x < x1; x += 4) {
@@ -697,9 +811,32 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
           if (off > x0 - t0) {
             if (j < ZG_FL_SOFF) s_soff[j] = off; else atomicCAS(&s_err, 0u, (uint32_t)ZG_INTERNAL);
           }
-          for (uint32_t x = x0; x < x1; x++)
-            s_par[x - t0] = (x - t0 >= off) ? (uint16_t)(x - t0 - off) : (uint16_t)(0x8000u | j);
+          if (x1 - x0 > ZG_FL_LONG) {
+            const uint32_t e = atomicAdd(&s_nlong, 1u);
+            if (e < ZG_FL_LONGCAP) { s_long[e][0] = x0; s_long[e][1] = x1; s_long[e][2] = off; s_long[e][3] = 0x80000000u | j; }
+          } else {
+            for (uint32_t x = x0; x < x1; x++)
+              s_par[x - t0] = (x - t0 >= off) ? (uint16_t)(x - t0 - off) : (uint16_t)(0x8000u | j);
+          }
         }
+      }
+      __syncthreads();
+      {  // long runs: every thread takes a stride of each
+        const uint32_t nl = s_nlong < ZG_FL_LONGCAP ? s_nlong : ZG_FL_LONGCAP;
+        for (uint32_t e = 0; e < nl; e++) {
+          const uint32_t x0 = s_long[e][0], x1 = s_long[e][1], v = s_long[e][2], kj = s_long[e][3];
+          if (kj >> 31) {
+            const uint32_t j = kj & 0x7FFFFFFFu;
+            for (uint32_t x = x0 + t; x < x1; x += ZG_FL_T)
+              s_par[x - t0] = (x - t0 >= v) ? (uint16_t)(x - t0 - v) : (uint16_t)(0x8000u | j);
+          } else {
+            for (uint32_t x = x0 + t; x < x1; x += ZG_FL_T) {
+              s_val[x - t0] = lit_rle ? lit_fill : lit[v + (x - x0)];
+              s_par[x - t0] = ZG_PAR_LIT;
+            }
+          }
+        }
+        if (s_nlong > ZG_FL_LONGCAP && t == 0) s_err = ZG_INTERNAL;   // cannot happen: every entry covers > ZG_FL_LONG bytes of the tile
       }
       __syncthreads();
       ZG_TICK(1)
@@ -1050,7 +1187,7 @@ void zg_launch_tables(const ZgBatchDev& d, hipStream_t s) {
   hipLaunchKernelGGL(zg_k_tables, dim3((n + 63) / 64), dim3(64), 0, s, d);
 }
 void zg_launch_huf(const ZgBatchDev& d, hipStream_t s) {
-  if (d.nhuf_groups) hipLaunchKernelGGL(zg_k_huf, dim3(d.nhuf_groups), dim3(256), 0, s, d);
+  if (d.nhuf_groups) hipLaunchKernelGGL(zg_k_huf, dim3(d.nhuf_groups), dim3(ZG_HUF_T), 0, s, d);
 }
 void zg_launch_seq(const ZgBatchDev& d, hipStream_t s) {
   if (d.nseq_blocks) hipLaunchKernelGGL(zg_k_seq, dim3((d.nseq_blocks + ZG_SEQ_G - 1) / ZG_SEQ_G), dim3(64), 0, s, d);
