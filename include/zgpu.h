@@ -134,7 +134,7 @@ int zgpu_batch_block_info(zgpu_batch*, uint32_t block, zgpu_block_info* out);
 int zgpu_batch_block_literals(zgpu_batch*, uint32_t block, uint8_t* dst, size_t cap, size_t* n);
 int zgpu_batch_block_sequences(zgpu_batch*, uint32_t block, zgpu_seq* dst, size_t cap, size_t* n);
 /* diagnostics: cycle counters accumulated by the kernels when ZGPU_DEBUG_TIMERS is set (all zero otherwise) */
-int zgpu_batch_debug_timers(zgpu_batch*, uint64_t out[8]);
+int zgpu_batch_debug_timers(zgpu_batch*, uint64_t out[1024]);
 /* diagnostics: runs a copy kernel (zg_k_calib_copy) of exactly `bytes` read + `bytes` written, twice, to calibrate
  * the profiler's HBM byte counters on a known amount of traffic */
 int zgpu_debug_calibrate(zgpu_ctx*, uint64_t bytes);

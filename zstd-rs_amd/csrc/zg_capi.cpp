@@ -211,7 +211,7 @@ int zgpu_batch_block_sequences(zgpu_batch* zb, uint32_t i, zgpu_seq* dst, size_t
   if (!v.empty()) memcpy(dst, v.data(), v.size() * sizeof(ZgSeq));
   return ZGPU_OK;
 }
-int zgpu_batch_debug_timers(zgpu_batch* zb, uint64_t out[8]) { return zb->b->read_debug(out); }
+int zgpu_batch_debug_timers(zgpu_batch* zb, uint64_t out[1024]) { return zb->b->read_debug(out); }
 int zgpu_debug_calibrate(zgpu_ctx* c, uint64_t bytes) {
   // profiler calibration: one device-to-device copy kernel of exactly `bytes` read + `bytes` written
   void *a = nullptr, *b = nullptr;

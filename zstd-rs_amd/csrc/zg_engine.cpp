@@ -225,7 +225,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
       (st = b->d_totals.reserve(64)) || (st = b->d_og.reserve((size_t)bb.og_count * 4 + 64)) ||
       (st = up(b->d_units, bb.units.data(), bb.units.size() * sizeof(ZgUnit))) ||
       (st = up(b->d_sweepwgs, bb.sweep_wgs.data(), bb.sweep_wgs.size() * sizeof(ZgSweepWg))) ||
-      (st = b->d_unitinfo.reserve(bb.units.size() * sizeof(ZgUnitInfo) + 16)) || (st = b->d_bar.reserve((size_t)nf * 4 + 16)) || (st = b->d_dbg.reserve(64))) {
+      (st = b->d_unitinfo.reserve(bb.units.size() * sizeof(ZgUnitInfo) + 16)) || (st = b->d_bar.reserve((size_t)nf * 64 + 64)) || (st = b->d_dbg.reserve(8192))) {
     delete b;
     return st;
   }
@@ -271,8 +271,8 @@ int Batch::run() {
   ZG_HIP(hipMemsetAsync(d.huf_maxbits, 0, d.nhuf_slots + 16, s));
   ZG_HIP(hipMemsetAsync(d.slot_log, 0, (size_t)d.nslots * 4, s));
   ZG_HIP(hipMemsetAsync(d.totals, 0, 64, s));
-  ZG_HIP(hipMemsetAsync(d.bar, 0, (size_t)d.nframes * 4 + 16, s));
-  if (d.dbg) ZG_HIP(hipMemsetAsync(d.dbg, 0, 64, s));
+  ZG_HIP(hipMemsetAsync(d.bar, 0, (size_t)d.nframes * 64 + 64, s));
+  if (d.dbg) ZG_HIP(hipMemsetAsync(d.dbg, 0, 8192, s));
   if (fs && fs->carry_mask) {   // tables carried into this run: the frame's carry slots of the two arenas
     const ZgFrame& fr = bb.frames[0];
     ZG_HIP(hipMemcpyAsync(d.fse_arena + (size_t)fr.carry_slot * ZG_FSE_SLOT_U32, fs->d_fse.p, ZG_FSE_SLOT_U32 * 4, hipMemcpyDeviceToDevice, s));
@@ -383,9 +383,9 @@ int Batch::read_fse_slot(uint32_t slot, std::vector<uint32_t>* entries, uint8_t 
   ZG_HIP(hipMemcpy(logs, dev.slot_log + (size_t)slot * 4, 4, hipMemcpyDeviceToHost));
   return ZG_OK;
 }
-int Batch::read_debug(uint64_t out[8]) {
-  for (int i = 0; i < 8; i++) out[i] = 0;
-  if (dev.dbg) ZG_HIP(hipMemcpy(out, dev.dbg, 64, hipMemcpyDeviceToHost));
+int Batch::read_debug(uint64_t out[1024]) {
+  for (int i = 0; i < 1024; i++) out[i] = 0;
+  if (dev.dbg) ZG_HIP(hipMemcpy(out, dev.dbg, 8192, hipMemcpyDeviceToHost));
   return ZG_OK;
 }
 int Batch::read_huf_slot(uint32_t slot, std::vector<uint16_t>* entries, int* max_bits) {

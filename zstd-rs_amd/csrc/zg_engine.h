@@ -79,7 +79,7 @@ class Batch {
   int read_sequences(uint32_t block, std::vector<ZgSeq>* seqs, ZgBlockSeqOut* so, ZgBlockPos* pos);
   int read_fse_slot(uint32_t slot, std::vector<uint32_t>* entries, uint8_t logs[4]);
   int read_huf_slot(uint32_t slot, std::vector<uint16_t>* entries, int* max_bits);
-  int read_debug(uint64_t out[8]);
+  int read_debug(uint64_t out[1024]);
 
  private:
   friend class Engine;

@@ -43,7 +43,7 @@ struct ZgBatchDev {
   const ZgSweepWg* sweep_wgs;
   uint32_t nsweep_wgs;
   unsigned long long* dbg;     // [8]: phase cycle counters of zg_k_flat (summed over workgroups), diagnostics only
-  uint32_t* bar;               // [nframes] arrival counters of the sweep's per-frame barrier (zeroed every run)
+  uint32_t* bar;               // [nframes][16] arrival counters of the sweep's per-frame barrier: 8 groups + top (zeroed every run)
 };
 
 void zg_launch_tables(const ZgBatchDev& d, hipStream_t s);

@@ -940,20 +940,29 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
 
 // per-frame barrier of the sweep: monotonic arrival counter, agent-scope release before arriving, relaxed polling,
 // one agent-scope acquire after (the per-XCD L2s and per-CU L1s are not coherent with each other).
-__device__ __forceinline__ bool zg_frame_barrier(uint32_t* counter, uint32_t target, uint32_t t) {
-  __shared__ uint32_t s_ok;
+// Per-frame barrier of the sweep, in two halves so that the next unit's scratch loads are in flight while waiting.
+// arrive: every wave drains its own write-through (sc1) payload stores, then one lane publishes the arrival.
+// Two levels: 8 group counters (bar[0..7]) whose last arriver bumps the top counter (bar[8]) that everybody polls.
+__device__ __forceinline__ void zg_frame_arrive(uint32_t* bar, uint32_t step, uint32_t rank, uint32_t wpf, uint32_t t) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave: its payload has left before the arrival can be seen
   __syncthreads();
   if (t == 0) {
-    // the sweep's payload stores are write-through (sc1) and were drained by the __syncthreads above (vmcnt(0) in every
-    // wave), so no L2 write-back fence is needed before the arrival is published
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t grp = rank & 7;
+    const uint32_t gsize = (wpf - grp + 7) / 8;
+    const uint32_t old = __hip_atomic_fetch_add(bar + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1 == gsize * step) __hip_atomic_fetch_add(bar + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ __forceinline__ bool zg_frame_wait(uint32_t* bar, uint32_t step, uint32_t wpf, uint32_t t) {
+  __shared__ uint32_t s_ok;
+  if (t == 0) {
+    const uint32_t ngroups = wpf < 8 ? wpf : 8;
     uint32_t ok = 0;
     for (uint32_t spin = 0; spin < (1u << 24); spin++) {
-      if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
-      __builtin_amdgcn_s_sleep(2);
+      if (__hip_atomic_load(bar + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ngroups * step) { ok = 1; break; }
+      __builtin_amdgcn_s_sleep(1);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // one acquire per workgroup: drops this CU's stale L1 lines
     s_ok = ok;
   }
   __syncthreads();
@@ -977,6 +986,12 @@ __global__ void __launch_bounds__(T) zg_k_sweep(ZgBatchDev d) {
   uint8_t* frame_out = d.dst + fo.out_base;
   uint32_t steps = 0;
   bool alive = true, stop = false;
+#ifdef ZG_PROFILE_SWEEP
+  unsigned long long tc[4] = {0, 0, 0, 0}, tlast = clock64();
+#define ZG_STICK(i) { const unsigned long long n_ = clock64(); tc[i] += n_ - tlast; tlast = n_; }
+#else
+#define ZG_STICK(i)
+#endif
   for (uint32_t c0 = 0; c0 < fr.nunits && alive && !stop; c0 += ZG_SW_UMAX) {
     const uint32_t cn = fr.nunits - c0 < ZG_SW_UMAX ? fr.nunits - c0 : ZG_SW_UMAX;
     __syncthreads();
@@ -1071,14 +1086,23 @@ __global__ void __launch_bounds__(T) zg_k_sweep(ZgBatchDev d) {
           if (o) __hip_atomic_store(&out[x], out[(int64_t)x - o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
-      const uint32_t nx = next_unit(ui + 1);
-      if (nx < cn) prefetch(nx);            // the scratch of the next unit does not depend on this step: load it across the barrier
+      ZG_STICK(0)
       steps++;
-      if (wg.wpf > 1) { alive = zg_frame_barrier(d.bar + f, steps * wg.wpf, t); if (!alive) break; }
+      if (wg.wpf > 1) zg_frame_arrive(d.bar + (size_t)f * 16, steps, wg.rank, wg.wpf, t);
+      ZG_STICK(1)
+      const uint32_t nx = next_unit(ui + 1);
+      if (nx < cn) prefetch(nx);            // the scratch of the next unit does not depend on this step: in flight during the wait
+      if (wg.wpf > 1) { alive = zg_frame_wait(d.bar + (size_t)f * 16, steps, wg.wpf, t); if (!alive) break; }
       else __syncthreads();                 // same CU: later loads see these stores
+      ZG_STICK(2)
       ui = nx;
     }
   }
+#ifdef ZG_PROFILE_SWEEP
+  if (t == 0 && wg.rank == 0 && d.dbg) for (int i = 0; i < 3; i++) atomicAdd(&d.dbg[i], tc[i]);
+  if (t == 0 && d.dbg && wg.rank < 500) { d.dbg[8 + wg.rank] = tc[0]; d.dbg[520 + wg.rank] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20); }
+#endif
+#undef ZG_STICK
   const uint32_t ep = d.frame_out[f].err_packed;
   if (t == 0 && wg.rank == 0) {
     if (!alive) { d.frame_out[f].status = ZG_INTERNAL; d.frame_out[f].bad_block = 0; d.frame_out[f].good_blocks = 0; }

@@ -209,7 +209,7 @@ class Batch:
         return dict(zip(["tables", "huf", "seq", "scan", "lit", "flat", "sweep", "lz", "total"], list(a)))
 
     def debug_timers(self):
-        a = (C.c_uint64 * 8)()
+        a = (C.c_uint64 * 1024)()
         self.L.zgpu_batch_debug_timers(self.h, a)
         return list(a)
 
