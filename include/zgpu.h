@@ -114,8 +114,8 @@ int zgpu_batch_frame_info(const zgpu_batch*, uint32_t frame, zgpu_frame_info* ou
 int zgpu_batch_read(zgpu_batch*, uint64_t offset, uint8_t* dst, uint64_t n);   /* D2H of plaintext bytes */
 const void* zgpu_batch_output_device(const zgpu_batch*);            /* device pointer of the plaintext (no copy) */
 /* kernel times of the last run in ms, measured with HIP events on the ctx stream:
- * [0] tables [1] huffman [2] sequences [3] scan [4] literals/raw/rle [5] flatten [6] sweep [7] in-order fallback
- * [8] whole pipeline. Returns how many were written. */
+ * [0] tables [1] huffman [2] sequence chains [3] sequence post-processing [4] scan [5] literals/raw/rle [6] flatten
+ * [7] sweep [8] in-order fallback [9] whole pipeline. Returns how many were written. */
 int zgpu_batch_timings(const zgpu_batch*, float* ms, int n);
 void zgpu_batch_destroy(zgpu_batch*);
 

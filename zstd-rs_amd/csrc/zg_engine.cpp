@@ -109,7 +109,7 @@ int parse_frames(const uint8_t* src, size_t len, uint64_t max_window, BatchBuild
 
 Batch::~Batch() {
   DevBuf* all[] = {&d_src, &d_blocks, &d_frames, &d_aux, &d_slot_log, &d_fse, &d_huf, &d_hufmax, &d_status, &d_lit, &d_seq,
-                   &d_seqout, &d_pos, &d_frameout, &d_dst, &d_seqblocks, &d_hufitems, &d_hufgroups, &d_totals, &d_og, &d_units, &d_unitinfo, &d_sweepwgs, &d_bar, &d_dbg};
+                   &d_seqout, &d_pos, &d_frameout, &d_dst, &d_seqblocks, &d_hufitems, &d_hufgroups, &d_totals, &d_og, &d_units, &d_unitinfo, &d_sweepwgs, &d_bar, &d_dbg, &d_raw};
   for (DevBuf* b : all) b->release();
   for (auto& e : ev)
     if (e) (void)hipEventDestroy(e);
@@ -219,6 +219,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
       (st = b->d_fse.reserve((size_t)nslots * ZG_FSE_SLOT_U32 * 4)) || (st = b->d_huf.reserve((size_t)(bb.nhuf_slots + 1) * ZG_HUF_SLOT_U16 * 2)) ||
       (st = b->d_hufmax.reserve(bb.nhuf_slots + 16)) || (st = b->d_status.reserve((size_t)nb * 4 + 16)) ||
       (st = b->d_lit.reserve(bb.lit_bytes + 64)) || (st = b->d_seq.reserve((bb.seq_count + 1) * sizeof(ZgSeq))) ||
+      (st = b->d_raw.reserve((bb.seq_count + 1) * 8)) ||
       (st = b->d_seqout.reserve((size_t)nb * sizeof(ZgBlockSeqOut) + 16)) || (st = b->d_pos.reserve((size_t)nb * sizeof(ZgBlockPos) + 16)) ||
       (st = b->d_frameout.reserve((size_t)nf * sizeof(ZgFrameOut) + 16)) ||
       (st = b->fs ? b->fs->d_out.reserve(b->fs->base + b->fs->produced + bb.out_bound + 64, true, stream_) : b->d_dst.reserve(bb.out_bound + 64)) ||
@@ -236,7 +237,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   d.nslots = nslots; d.nhuf_slots = bb.nhuf_slots;
   d.aux = b->d_aux.as<ZgBlockAux>(); d.slot_log = b->d_slot_log.as<uint8_t>();
   d.fse_arena = b->d_fse.as<uint32_t>(); d.huf_arena = b->d_huf.as<uint16_t>(); d.huf_maxbits = b->d_hufmax.as<uint8_t>();
-  d.status = b->d_status.as<uint32_t>(); d.lit_arena = b->d_lit.as<uint8_t>(); d.seq_arena = b->d_seq.as<ZgSeq>();
+  d.status = b->d_status.as<uint32_t>(); d.lit_arena = b->d_lit.as<uint8_t>(); d.seq_arena = b->d_seq.as<ZgSeq>(); d.raw_arena = b->d_raw.as<uint2>();
   d.seq_out = b->d_seqout.as<ZgBlockSeqOut>(); d.pos = b->d_pos.as<ZgBlockPos>(); d.frame_out = b->d_frameout.as<ZgFrameOut>();
   if (b->fs) {
     if ((st = b->fs->d_fse.reserve(ZG_FSE_SLOT_U32 * 4)) || (st = b->fs->d_huf.reserve(ZG_HUF_SLOT_U16 * 2))) { delete b; return st; }
@@ -286,16 +287,18 @@ int Batch::run() {
   ZG_HIP(hipEventRecord(ev[2], s));
   zg_launch_seq(d, s);
   ZG_HIP(hipEventRecord(ev[3], s));
-  zg_launch_scan(d, s);
+  zg_launch_seqpost(d, s);
   ZG_HIP(hipEventRecord(ev[4], s));
-  zg_launch_lit(d, s);
+  zg_launch_scan(d, s);
   ZG_HIP(hipEventRecord(ev[5], s));
-  zg_launch_flat(d, s);
+  zg_launch_lit(d, s);
   ZG_HIP(hipEventRecord(ev[6], s));
-  zg_launch_sweep(d, s);
+  zg_launch_flat(d, s);
   ZG_HIP(hipEventRecord(ev[7], s));
-  zg_launch_lz(d, s);   // only frames that left the flatten path (a block regenerating > 128 KiB)
+  zg_launch_sweep(d, s);
   ZG_HIP(hipEventRecord(ev[8], s));
+  zg_launch_lz(d, s);   // only frames that left the flatten path (a block regenerating > 128 KiB)
+  ZG_HIP(hipEventRecord(ev[9], s));
   ZG_HIP(hipGetLastError());
   ran = true;
   return ZG_OK;

@@ -49,7 +49,7 @@ struct FrameState {
   void release();
 };
 
-enum { ZG_T_TABLES = 0, ZG_T_HUF, ZG_T_SEQ, ZG_T_SCAN, ZG_T_LIT, ZG_T_FLAT, ZG_T_SWEEP, ZG_T_LZ, ZG_T_TOTAL, ZG_T_COUNT };
+enum { ZG_T_TABLES = 0, ZG_T_HUF, ZG_T_SEQ, ZG_T_SEQPOST, ZG_T_SCAN, ZG_T_LIT, ZG_T_FLAT, ZG_T_SWEEP, ZG_T_LZ, ZG_T_TOTAL, ZG_T_COUNT };
 
 class Engine;
 
@@ -86,7 +86,7 @@ class Batch {
   Engine* eng = nullptr;
   ZgBatchDev dev{};
   DevBuf d_src, d_blocks, d_frames, d_aux, d_slot_log, d_fse, d_huf, d_hufmax, d_status, d_lit, d_seq, d_seqout, d_pos, d_frameout,
-      d_dst, d_seqblocks, d_hufitems, d_hufgroups, d_totals, d_og, d_units, d_unitinfo, d_sweepwgs, d_bar, d_dbg;
+      d_dst, d_seqblocks, d_hufitems, d_hufgroups, d_totals, d_og, d_units, d_unitinfo, d_sweepwgs, d_bar, d_dbg, d_raw;
   hipEvent_t ev[ZG_T_COUNT + 1] = {};
   bool ran = false;
   FrameState* fs = nullptr;              // streaming submit: the frame state this run reads from / writes into

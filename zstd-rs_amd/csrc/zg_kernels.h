@@ -22,6 +22,7 @@ struct ZgBatchDev {
   uint32_t* status;            // [nblocks] first error per block (ZgStatus), 0 = ok
   uint8_t* lit_arena;          // regenerated Huffman literals
   ZgSeq* seq_arena;            // decoded sequences
+  uint2* raw_arena;            // zg_k_seq's raw records {bit position, codes}, same indexing as seq_arena
   ZgBlockSeqOut* seq_out;      // [nblocks]
   ZgBlockPos* pos;             // [nblocks]
   ZgFrameOut* frame_out;       // [nframes]
@@ -49,6 +50,7 @@ struct ZgBatchDev {
 void zg_launch_tables(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_huf(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_seq(const ZgBatchDev& d, hipStream_t s);
+void zg_launch_seqpost(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_scan(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_lit(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_flat(const ZgBatchDev& d, hipStream_t s);

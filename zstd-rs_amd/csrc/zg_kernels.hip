@@ -24,6 +24,8 @@
 
 typedef uint32_t zg_v4u __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) zg_v4u zg_gv4u;   // 16 bytes in global memory: global_load/store, not flat
+typedef uint32_t zg_v2u __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) zg_v2u zg_gv2u;
 
 __device__ __forceinline__ void zg_set_status(uint32_t* status, uint32_t b, int st) {
   if (st) atomicCAS(&status[b], 0u, (uint32_t)st);
@@ -279,6 +281,14 @@ __device__ __forceinline__ uint32_t zg_ring_bits(const uint32_t* ring32, uint32_
   const uint32_t d0 = ring32[di], d1 = ring32[di + 1];
   return __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(d1, d0, rb & 31u), 0u, n);
 }
+// same for n <= 32
+__device__ __forceinline__ uint32_t zg_ring_bits32(const uint32_t* ring32, uint32_t rbits, int32_t q, uint32_t n) {
+  const uint32_t rb = (uint32_t)q + rbits;
+  const uint32_t di = (rb >> 5) & (ZG_SEQ_RING / 4 - 1);
+  const uint32_t d0 = ring32[di], d1 = ring32[di + 1];
+  const uint32_t v = __builtin_amdgcn_alignbit(d1, d0, rb & 31u);
+  return n >= 32 ? v : __builtin_amdgcn_ubfe(v, 0u, n);
+}
 __device__ __forceinline__ uint32_t zg_sym_dec_bf(uint32_t v) {  // zg_sym_dec without branches
   const uint32_t c = v ? v - 1 : 0u;
   return (v >> 30) ? v + 1 : c;
@@ -287,17 +297,15 @@ __device__ __forceinline__ uint32_t zg_sym_dec_bf(uint32_t v) {  // zg_sym_dec w
 __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
   // tables are re-packed to 16 bits while they are staged: [15:10] symbol, [9:0] x = (1 << (log - num_bits)) | (base_line >> num_bits)
   __shared__ uint16_t s_tab[ZG_SEQ_G][ZG_FSE_SLOT_U32];
+  __shared__ uint8_t s_xb[ZG_SEQ_G][1024];           // extra bits of the symbol, per LL / ML state: read together with the entry
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[ZG_SEQ_G][ZG_SEQ_RING + 16];
-  __shared__ __attribute__((aligned(16))) ZgSeq s_out[ZG_SEQ_G][ZG_SEQ_CH];
+  __shared__ __attribute__((aligned(16))) uint2 s_out[ZG_SEQ_G][ZG_SEQ_CH];   // raw records: {bit position before the sequence, codes}
   __shared__ uint64_t s_fetch_hi[ZG_SEQ_G], s_fetch_lo[ZG_SEQ_G];   // ring extension requested by each lane: [lo, hi)
   __shared__ uint64_t s_dst[ZG_SEQ_G];                              // where each lane's chunk goes in the sequence arena
   __shared__ uint32_t s_cnt[ZG_SEQ_G];                              // sequences of the chunk to flush
   __shared__ uint8_t s_log[ZG_SEQ_G][4];
   __shared__ int s_ok[ZG_SEQ_G];
-  __shared__ uint32_t s_llbase[36], s_mlbase[53];   // base | extra_bits << 24: in LDS, a constant-memory lookup is a global load here
   const uint32_t base = blockIdx.x * ZG_SEQ_G, t = threadIdx.x;
-  if (t < 36) s_llbase[t] = ZG_LL_BASE[t] | ((uint32_t)ZG_LL_BITS[t] << 24);
-  if (t < 53) s_mlbase[t] = ZG_ML_BASE[t] | ((uint32_t)ZG_ML_BITS[t] << 24);
   for (uint32_t g = 0; g < ZG_SEQ_G; g++) {
     uint32_t idx = base + g;
     if (idx >= d.nseq_blocks) break;
@@ -322,6 +330,7 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
           if (i < (1u << lg)) {
             const uint32_t nb = ZG_FSE_NB(v[j]);
             s_tab[g][offs[k] + i] = (uint16_t)((ZG_FSE_SYM(v[j]) << 10) | (1u << (lg - nb)) | (ZG_FSE_BL(v[j]) >> nb));
+            if (k != 1) s_xb[g][(k ? 512u : 0u) + i] = (uint8_t)(v[j] >> 26);
           }
         }
       }
@@ -334,7 +343,7 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
   const uint32_t g = t < ZG_SEQ_G ? t : 0;
   bool act = t < ZG_SEQ_G && base + t < d.nseq_blocks;
   bool have = false;
-  uint32_t b = 0, nseq = 0, regen = 0, done = 0, rbits = 0;
+  uint32_t b = 0, nseq = 0, done = 0, rbits = 0;
   uint64_t bsA = 0, floorA = 0, lo = 0;
   const uint16_t* t_ll = &s_tab[g][ZG_FSE_LL_OFF];
   const uint16_t* t_of = &s_tab[g][ZG_FSE_OF_OFF];
@@ -343,8 +352,7 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
   const uint32_t* ring32 = (const uint32_t*)s_ring[g];
   int32_t P = 0;
   uint32_t e_ll = 0, e_of = 0, e_ml = 0;
-  uint32_t h0 = 1u << 30, h1 = 2u << 30, h2 = 3u << 30, lit_pos = 0, out_pos = 0, sum_ml = 0, emitted = 0;
-  int status = ZG_OK, exe_status = ZG_OK;
+  int status = ZG_OK;
   if (act) {
     b = d.seq_blocks[base + g];
     const ZgBlock blk = d.blocks[b];
@@ -358,7 +366,7 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
       else {
         const uint8_t* bs = d.src + blk.src_off + bits_off;
         const uint32_t bs_len = blk.src_len - bits_off;
-        nseq = blk.nseq; regen = blk.regen_size;
+        nseq = blk.nseq;
         const uint32_t lastb = bs_len ? bs[bs_len - 1] : 0;
         if (bs_len == 0 || lastb == 0) { zg_set_status(d.status, b, ZG_SEQ_EXTRA_PADDING); act = false; }  // :29-40
         else {
@@ -366,7 +374,7 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
           bsA = (uint64_t)bs;
           rbits = (uint32_t)(bsA & (ZG_SEQ_RING - 1)) * 8u;
           floorA = (bsA & ~15ull) - 16;                 // the engine keeps 64 bytes of padding in front of the buffer
-          s_dst[g] = (uint64_t)(d.seq_arena + blk.seq_base);
+          s_dst[g] = (uint64_t)(d.raw_arena + blk.seq_base);
           have = true;
         }
       }
@@ -396,72 +404,71 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
     }
     __syncthreads();
   }
+  const uint8_t* x_ll = &s_xb[g][0];
+  const uint8_t* x_ml = &s_xb[g][512];
+  uint32_t xb_ll = 0, xb_ml = 0;
   if (act) {  // initial states, order LL, OF, ML (:164-166); a negative position is reported after the first sequence
     ll_log = s_log[g][0]; of_log = s_log[g][1]; ml_log = s_log[g][2];
-    P -= (int32_t)ll_log; e_ll = t_ll[P >= 0 ? zg_ring_bits(ring32, rbits, P, ll_log) : 0];
+    P -= (int32_t)ll_log; { const uint32_t i = P >= 0 ? zg_ring_bits(ring32, rbits, P, ll_log) : 0; e_ll = t_ll[i]; xb_ll = x_ll[i]; }
     P -= (int32_t)of_log; e_of = t_of[P >= 0 ? zg_ring_bits(ring32, rbits, P, of_log) : 0];
-    P -= (int32_t)ml_log; e_ml = t_ml[P >= 0 ? zg_ring_bits(ring32, rbits, P, ml_log) : 0];
+    P -= (int32_t)ml_log; { const uint32_t i = P >= 0 ? zg_ring_bits(ring32, rbits, P, ml_log) : 0; e_ml = t_ml[i]; xb_ml = x_ml[i]; }
   }
   zg_v4u piece[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};     // ZG_SEQ_G * ZG_SEQ_PIECES = 112 requests per phase: two per lane
   uint64_t piece_addr[2] = {0, 0};
   uint32_t piece_g[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
   // ---- main loop
   while (__any(act)) {
-    // DECODE phase: LDS only. Same arithmetic as zg_seq_step (zg_dev.h), 32-bit and branch-free.
-    const uint32_t em0 = emitted;
-    if (act) {
+    // DECODE phase: LDS only, and one LDS round trip per sequence: the next table entries, their extra-bit counts and
+    // the 128 bits of stream below the next position are all requested together; everything between is 32-bit ALU.
+    // Only the state chain is followed here (FSEDecoder::update_state, fse_decoder.rs:40-48, three times per sequence,
+    // order LL, ML, OF :204-206); the extra bits in between are skipped by their count and read by zg_k_seqpost.
+    uint32_t cnt = 0;
+    {
+      uint32_t wbase = 0, w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+      if (act) {
+        wbase = (((uint32_t)P + rbits) & ~31u) - 96u;
+        const uint32_t di = (wbase >> 5) & (ZG_SEQ_RING / 4 - 1);
+        w0 = ring32[di]; w1 = ring32[di + 1]; w2 = ring32[di + 2]; w3 = ring32[di + 3];
+      }
 #pragma unroll 1
       for (int c = 0; c < ZG_SEQ_CH; c++) {
-        const bool last = done + 1 == nseq;
-        const uint32_t of_code = e_of >> 10, ml_code = e_ml >> 10, ll_code = e_ll >> 10;
-        const uint32_t vll = s_llbase[ll_code], vml = s_mlbase[ml_code];
-        const uint32_t x_ll = e_ll & 1023u, x_ml = e_ml & 1023u, x_of = e_of & 1023u;
-        const uint32_t k_ll = 31u - (uint32_t)__builtin_clz(x_ll), k_ml = 31u - (uint32_t)__builtin_clz(x_ml), k_of = 31u - (uint32_t)__builtin_clz(x_of);
-        const uint32_t xb_of = of_code, xb_ml = vml >> 24, xb_ll = vll >> 24;
-        const uint32_t nb_ll = last ? 0u : ll_log - k_ll, nb_ml = last ? 0u : ml_log - k_ml, nb_of = last ? 0u : of_log - k_of;
-        // extra bits in the order OF, ML, LL (:185), then the state bits LL, ML, OF (:204-206)
-        const int32_t q_of = P - (int32_t)xb_of, q_ml = q_of - (int32_t)xb_ml, q_ll = q_ml - (int32_t)xb_ll;
-        const int32_t q_sll = q_ll - (int32_t)nb_ll, q_sml = q_sll - (int32_t)nb_ml, q_sof = q_sml - (int32_t)nb_of;
-        if (q_sof < 0) { status = ZG_SEQ_NOT_ENOUGH_BYTES; act = false; break; }   // :209-211
-        const uint32_t obits = zg_ring_bits(ring32, rbits, q_of, xb_of);
-        const uint32_t ml_add = zg_ring_bits(ring32, rbits, q_ml, xb_ml);
-        const uint32_t ll_add = zg_ring_bits(ring32, rbits, q_ll, xb_ll);
-        const uint32_t s_ll = ((x_ll ^ (1u << k_ll)) << nb_ll) + zg_ring_bits(ring32, rbits, q_sll, nb_ll);
-        const uint32_t s_ml = ((x_ml ^ (1u << k_ml)) << nb_ml) + zg_ring_bits(ring32, rbits, q_sml, nb_ml);
-        const uint32_t s_of = ((x_of ^ (1u << k_of)) << nb_of) + zg_ring_bits(ring32, rbits, q_sof, nb_of);
-        const uint32_t ml = (vml & 0xFFFFFFu) + ml_add, ll = (vll & 0xFFFFFFu) + ll_add;
-        if (!last) { e_ll = t_ll[s_ll]; e_ml = t_ml[s_ml]; e_of = t_of[s_of]; }
-        P = q_sof;
-        const uint32_t of = obits + (1u << of_code);
-        // do_offset_history (sequence_execution.rs:59-118) on symbolic slots, select form of zg_hist_step
-        const bool rep = of <= 3u;
-        const uint32_t idx = of - 1u + (ll == 0u ? 1u : 0u);
-        const uint32_t cand = idx == 0 ? h0 : idx == 1 ? h1 : idx == 2 ? h2 : zg_sym_dec_bf(h0);
-        const uint32_t actual = rep ? cand : of - 3u;
-        const bool keep = rep && idx == 0;
-        const uint32_t n2 = (rep && idx <= 1) ? h2 : h1, n1 = keep ? h1 : h0, n0 = keep ? h0 : actual;
-        if (exe_status == ZG_OK) {
-          h0 = n0; h1 = n1; h2 = n2;
-          int bad = ZG_OK;
-          if ((uint64_t)out_pos + ll + ml >= (1ull << 31)) bad = ZG_UNSUPPORTED;
-          if (lit_pos + ll > regen) bad = ZG_EXE_NOT_ENOUGH_LITERALS;
-          if (!(actual >> 30) && actual >= (1u << 30)) bad = ZG_EXE_OFFSET_TOO_BIG;
-          if (actual == 0) bad = ZG_EXE_ZERO_OFFSET;
-          if (bad) exe_status = bad;
-          else {
-            ZgSeq q;
-            q.of = actual; q.ml = ml; q.mdst = out_pos + ll; q.lit_start = lit_pos;
-            s_out[g][emitted - em0] = q;
-            lit_pos += ll; out_pos += ll + ml; sum_ml += ml; emitted++;
-          }
+        if (act) {
+          const uint32_t of_code = e_of >> 10, ml_code = e_ml >> 10, ll_code = e_ll >> 10;
+          const uint32_t v_ll = e_ll & 1023u, v_ml = e_ml & 1023u, v_of = e_of & 1023u;
+          const uint32_t k_ll = 31u - (uint32_t)__builtin_clz(v_ll), k_ml = 31u - (uint32_t)__builtin_clz(v_ml), k_of = 31u - (uint32_t)__builtin_clz(v_of);
+          const uint32_t nb_ll = ll_log - k_ll, nb_ml = ml_log - k_ml, nb_of = of_log - k_of;
+          const bool last = done + 1 == nseq;                       // no state update after the last sequence (:203)
+          const uint32_t nbs = last ? 0u : nb_ll + nb_ml + nb_of;
+          // the sequence's bits, from the top: OF, ML, LL extra bits (:185), then the LL, ML, OF state bits
+          const int32_t q_sof = P - (int32_t)(of_code + xb_ml + xb_ll) - (int32_t)nbs;
+          const bool ok = q_sof >= 0;                               // :209-211
+          s_out[g][cnt] = make_uint2((uint32_t)P, ll_code | (ml_code << 8) | (of_code << 16));
+          cnt += ok ? 1u : 0u;
+          status = ok ? status : ZG_SEQ_NOT_ENOUGH_BYTES;
+          // bits [q_sof, q_sof + nbs) out of the window (q_sof >= P - 89, so they are inside it)
+          const uint32_t rel = (uint32_t)q_sof + rbits - wbase;
+          const bool up = rel >= 64u, odd = (rel & 32u) != 0u;
+          const uint32_t a0 = up ? w2 : w0, a1 = up ? w3 : w1, a2 = up ? w3 : w2;
+          const uint32_t d0 = odd ? a1 : a0, d1 = odd ? a2 : a1;
+          const uint32_t sb = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(d1, d0, rel & 31u), 0u, nbs);
+          const uint32_t s_of = ((v_of ^ (1u << k_of)) << nb_of) + __builtin_amdgcn_ubfe(sb, 0u, nb_of);
+          const uint32_t s_ml = ((v_ml ^ (1u << k_ml)) << nb_ml) + __builtin_amdgcn_ubfe(sb, nb_of, nb_ml);
+          const uint32_t s_ll = ((v_ll ^ (1u << k_ll)) << nb_ll) + __builtin_amdgcn_ubfe(sb, nb_of + nb_ml, nb_ll);
+          e_ll = t_ll[s_ll]; xb_ll = x_ll[s_ll];
+          e_ml = t_ml[s_ml]; xb_ml = x_ml[s_ml];
+          e_of = t_of[s_of];
+          P = q_sof;
+          wbase = (((uint32_t)P + rbits) & ~31u) - 96u;
+          const uint32_t di = (wbase >> 5) & (ZG_SEQ_RING / 4 - 1);
+          w0 = ring32[di]; w1 = ring32[di + 1]; w2 = ring32[di + 2]; w3 = ring32[di + 3];
+          done++;
+          act = ok && done != nseq;
         }
-        done++;
-        if (done == nseq) { act = false; break; }
       }
     }
     // MOVER phase
     if (t < ZG_SEQ_G) {
-      s_cnt[t] = emitted - em0;
+      s_cnt[t] = cnt;
       uint64_t hi = 0, want = 0;
       if (act) {
         const uint64_t p0 = bsA + (uint64_t)(P >> 3);
@@ -484,7 +491,7 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
     // (2) flush the chunk: ZG_SEQ_G x ZG_SEQ_CH records of 16 bytes
     for (uint32_t j = t; j < ZG_SEQ_G * ZG_SEQ_CH; j += 64) {
       const uint32_t gg = j / ZG_SEQ_CH, k = j % ZG_SEQ_CH;
-      if (k < s_cnt[gg]) ((zg_gv4u*)s_dst[gg])[k] = *(const zg_v4u*)&s_out[gg][k];
+      if (k < s_cnt[gg]) ((zg_gv2u*)s_dst[gg])[k] = *(const zg_v2u*)&s_out[gg][k];
     }
     // (3) request the next pieces
 #pragma unroll
@@ -501,24 +508,24 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
       }
     }
     __syncthreads();
-    if (t < ZG_SEQ_G) s_dst[t] += (uint64_t)s_cnt[t] * sizeof(ZgSeq);
+    if (t < ZG_SEQ_G) s_dst[t] += (uint64_t)s_cnt[t] * sizeof(uint2);
     __syncthreads();
   }
   if (have) {
     if (status == ZG_OK && P > 0) status = ZG_SEQ_EXTRA_BITS;  // :214-220
-    if (status == ZG_OK) status = exe_status;
-    ZgBlockSeqOut so;
-    so.sum_ll = lit_pos; so.sum_ml = sum_ml; so.hist_end[0] = h0; so.hist_end[1] = h1; so.hist_end[2] = h2; so.pad = 0;
-    d.seq_out[b] = so;
     zg_set_status(d.status, b, status);
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// zg_k_scan: per frame — output position of every block and the offset history at every block start.
-// The history recurrence (sequence_execution.rs:59-118; never reset between blocks, scratch.rs:22) is a
-// composition of per-block maps on three symbolic slots, so it is scanned like a prefix sum.
+// zg_k_seqpost: everything about a block's sequences that is not the serial state chain, done in parallel over the raw
+// records of zg_k_seq: extra bits read from the bitstream (get_bits_triple, bit_reader_reverse.rs:151-162), values
+// (lookup_ll_code / lookup_ml_code, sequence_section_decoder.rs:227-284), the output position of every sequence
+// (prefix sums, sequence_execution.rs:6-39) and the offset history (do_offset_history :59-118) as a scan of symbolic
+// maps: the history after sequence i is the composition of the maps of sequences 0..i, and the actual offset of
+// sequence i is slot 0 of it. One workgroup per block, 256 sequences per pass.
 // ------------------------------------------------------------------------------------------------------------
+#define ZG_SP_T 256
 struct ZgHistMap { uint32_t s[3]; };
 __device__ __forceinline__ ZgHistMap zg_map_identity() { return {{1u << 30, 2u << 30, 3u << 30}}; }
 // apply A first, then B
@@ -537,6 +544,99 @@ __device__ __forceinline__ ZgHistMap zg_map_compose(const ZgHistMap& A, const Zg
   return r;
 }
 
+
+__global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
+  __shared__ ZgHistMap s_wm[ZG_SP_T / 64];
+  __shared__ uint32_t s_wl[ZG_SP_T / 64], s_wo[ZG_SP_T / 64];
+  __shared__ uint32_t s_err;
+  const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const uint32_t b = d.seq_blocks[blockIdx.x];
+  if (d.status[b]) return;                       // the bitstream (or a table) failed: nothing to post-process
+  const ZgBlock blk = d.blocks[b];
+  const uint32_t nseq = blk.nseq, regen = blk.regen_size;
+  const uint8_t* bs = d.src + blk.src_off + d.aux[b].seq_bits_off;
+  const uint2* raw = d.raw_arena + blk.seq_base;
+  ZgSeq* out = d.seq_arena + blk.seq_base;
+  if (t == 0) s_err = 0xFFFFFFFFu;
+  ZgHistMap carry = zg_map_identity();
+  uint32_t lit_carry = 0, out_carry = 0, ml_carry = 0;
+  __syncthreads();
+  for (uint32_t i0 = 0; i0 < nseq; i0 += ZG_SP_T) {
+    const uint32_t i = i0 + t;
+    const bool have = i < nseq;
+    uint32_t ll = 0, ml = 0, of = 4;
+    if (have) {
+      const uint2 r = raw[i];
+      const uint32_t ll_code = r.y & 63u, ml_code = (r.y >> 8) & 63u, of_code = (r.y >> 16) & 31u;
+      const uint32_t xb_ll = ZG_LL_BITS[ll_code], xb_ml = ZG_ML_BITS[ml_code];
+      const int32_t q_of = (int32_t)r.x - (int32_t)of_code, q_ml = q_of - (int32_t)xb_ml, q_ll = q_ml - (int32_t)xb_ll;
+      of = zg_bits_at(bs, q_of, of_code) + (1u << of_code);
+      ml = ZG_ML_BASE[ml_code] + zg_bits_at(bs, q_ml, xb_ml);
+      ll = ZG_LL_BASE[ll_code] + zg_bits_at(bs, q_ll, xb_ll);
+    }
+    // map of this sequence (identity for lanes past the end): slots after = f(slots before)
+    ZgHistMap m = zg_map_identity();
+    bool toobig = false;
+    if (have) {
+      const uint32_t idx = of - 1u + (ll == 0u ? 1u : 0u);   // 0: keep, 1: swap01, 2: rotate slot 2 to front, 3: h0 - 1 to front
+      if (of > 3u) { toobig = of - 3u >= (1u << 30); m.s[0] = toobig ? 1u : of - 3u; m.s[1] = 1u << 30; m.s[2] = 2u << 30; }
+      else if (idx == 1) { m.s[0] = 2u << 30; m.s[1] = 1u << 30; m.s[2] = 3u << 30; }
+      else if (idx == 2) { m.s[0] = 3u << 30; m.s[1] = 1u << 30; m.s[2] = 2u << 30; }
+      else if (idx == 3) { m.s[0] = (1u << 30) | 1u; m.s[1] = 1u << 30; m.s[2] = 2u << 30; }
+    }
+    // inclusive scans inside the wave: literal lengths, output lengths, history maps
+    uint32_t sl = ll, so = ll + ml, sm = ml;
+    ZgHistMap sc = m;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t pl = __shfl_up(sl, off, 64), po = __shfl_up(so, off, 64), pm = __shfl_up(sm, off, 64);
+      ZgHistMap pmx;
+      pmx.s[0] = __shfl_up(sc.s[0], off, 64); pmx.s[1] = __shfl_up(sc.s[1], off, 64); pmx.s[2] = __shfl_up(sc.s[2], off, 64);
+      if ((int)lane >= off) { sl += pl; so += po; sm += pm; sc = zg_map_compose(pmx, sc); }
+    }
+    if (lane == 63) { s_wm[wv] = sc; s_wl[wv] = sl; s_wo[wv] = so; }
+    __syncthreads();
+    // prefix of the earlier waves of this pass
+    ZgHistMap pre = carry;
+    uint32_t pl = lit_carry, po = out_carry;
+    for (uint32_t w = 0; w < wv; w++) { pre = zg_map_compose(pre, s_wm[w]); pl += s_wl[w]; po += s_wo[w]; }
+    const ZgHistMap after = zg_map_compose(pre, sc);          // history after this sequence
+    const uint32_t lit_before = pl + sl - ll, out_before = po + so - (ll + ml);
+    if (have) {
+      const uint32_t actual = after.s[0];
+      int bad = ZG_OK;
+      if ((uint64_t)out_before + ll + ml >= (1ull << 31)) bad = ZG_UNSUPPORTED;
+      if ((uint64_t)lit_before + ll > regen) bad = ZG_EXE_NOT_ENOUGH_LITERALS;     // sequence_execution.rs:14-19
+      if (toobig) bad = ZG_EXE_OFFSET_TOO_BIG;
+      if (actual == 0) bad = ZG_EXE_ZERO_OFFSET;                                   // :28-30
+      if (bad) atomicMin(&s_err, (t << 8) | (uint32_t)bad);                        // the first failing sequence decides
+      ZgSeq q;
+      q.of = actual; q.ml = ml; q.mdst = out_before + ll; q.lit_start = lit_before;
+      out[i] = q;
+    }
+    // carries for the next pass
+    ZgHistMap tot = carry;
+    uint32_t tl = lit_carry, to = out_carry;
+    for (uint32_t w = 0; w < ZG_SP_T / 64; w++) { tot = zg_map_compose(tot, s_wm[w]); tl += s_wl[w]; to += s_wo[w]; }
+    // Σ match lengths = Σ (ll+ml) - Σ ll
+    carry = tot; lit_carry = tl; out_carry = to; ml_carry = to - tl;
+    __syncthreads();
+    if (s_err != 0xFFFFFFFFu) break;
+  }
+  if (t == 0) {
+    ZgBlockSeqOut so;
+    so.sum_ll = lit_carry; so.sum_ml = ml_carry;
+    so.hist_end[0] = carry.s[0]; so.hist_end[1] = carry.s[1]; so.hist_end[2] = carry.s[2]; so.pad = 0;
+    d.seq_out[b] = so;
+    if (s_err != 0xFFFFFFFFu) zg_set_status(d.status, b, (int)(s_err & 0xFFu));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// zg_k_scan: per frame — output position of every block and the offset history at every block start.
+// The history recurrence (sequence_execution.rs:59-118; never reset between blocks, scratch.rs:22) is a
+// composition of per-block maps on three symbolic slots, so it is scanned like a prefix sum.
+// ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) zg_k_scan(ZgBatchDev d) {
   __shared__ uint64_t s_size[256];
   __shared__ ZgHistMap s_map[256];
@@ -1215,6 +1315,9 @@ void zg_launch_huf(const ZgBatchDev& d, hipStream_t s) {
 }
 void zg_launch_seq(const ZgBatchDev& d, hipStream_t s) {
   if (d.nseq_blocks) hipLaunchKernelGGL(zg_k_seq, dim3((d.nseq_blocks + ZG_SEQ_G - 1) / ZG_SEQ_G), dim3(64), 0, s, d);
+}
+void zg_launch_seqpost(const ZgBatchDev& d, hipStream_t s) {
+  if (d.nseq_blocks) hipLaunchKernelGGL(zg_k_seqpost, dim3(d.nseq_blocks), dim3(ZG_SP_T), 0, s, d);
 }
 void zg_launch_scan(const ZgBatchDev& d, hipStream_t s) {
   hipLaunchKernelGGL(zg_k_scan, dim3(d.nframes), dim3(256), 0, s, d);

@@ -204,9 +204,9 @@ class Batch:
         return self.total_out
 
     def timings(self):
-        a = (C.c_float * 9)()
-        self.L.zgpu_batch_timings(self.h, a, 9)
-        return dict(zip(["tables", "huf", "seq", "scan", "lit", "flat", "sweep", "lz", "total"], list(a)))
+        a = (C.c_float * 10)()
+        self.L.zgpu_batch_timings(self.h, a, 10)
+        return dict(zip(["tables", "huf", "seq", "seqpost", "scan", "lit", "flat", "sweep", "lz", "total"], list(a)))
 
     def debug_timers(self):
         a = (C.c_uint64 * 1024)()
