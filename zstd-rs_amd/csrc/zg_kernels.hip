@@ -526,29 +526,33 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
 // sequence i is slot 0 of it. One workgroup per block, 256 sequences per pass.
 // ------------------------------------------------------------------------------------------------------------
 #define ZG_SP_T 256
+#define ZG_SP_S 8           // consecutive sequences per thread: the history inside them is stepped directly, only thread totals are scanned
 struct ZgHistMap { uint32_t s[3]; };
 __device__ __forceinline__ ZgHistMap zg_map_identity() { return {{1u << 30, 2u << 30, 3u << 30}}; }
+// v (a slot value relative to map A's output) expressed relative to A's input
+__device__ __forceinline__ uint32_t zg_map_apply(const ZgHistMap& A, uint32_t v) {
+  const uint32_t t = ZG_SYM_TAG(v);
+  if (!t) return v;
+  const uint32_t a = t == 1 ? A.s[0] : t == 2 ? A.s[1] : A.s[2], k = ZG_SYM_K(v);
+  if (ZG_SYM_TAG(a)) {
+    uint32_t kk = ZG_SYM_K(a) + k;
+    if (kk > 0x3FFFFFFFu) kk = 0x3FFFFFFFu;
+    return (a & 0xC0000000u) | kk;
+  }
+  return a > k ? a - k : 0;
+}
 // apply A first, then B
 __device__ __forceinline__ ZgHistMap zg_map_compose(const ZgHistMap& A, const ZgHistMap& B) {
   ZgHistMap r;
-  for (int i = 0; i < 3; i++) {
-    uint32_t v = B.s[i], t = ZG_SYM_TAG(v);
-    if (!t) { r.s[i] = v; continue; }
-    uint32_t a = A.s[t - 1], k = ZG_SYM_K(v);
-    if (ZG_SYM_TAG(a)) {
-      uint32_t kk = ZG_SYM_K(a) + k;
-      if (kk > 0x3FFFFFFFu) kk = 0x3FFFFFFFu;
-      r.s[i] = (a & 0xC0000000u) | kk;
-    } else r.s[i] = a > k ? a - k : 0;
-  }
+  r.s[0] = zg_map_apply(A, B.s[0]); r.s[1] = zg_map_apply(A, B.s[1]); r.s[2] = zg_map_apply(A, B.s[2]);
   return r;
 }
-
 
 __global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
   __shared__ ZgHistMap s_wm[ZG_SP_T / 64];
   __shared__ uint32_t s_wl[ZG_SP_T / 64], s_wo[ZG_SP_T / 64];
   __shared__ uint32_t s_err;
+  __shared__ uint32_t s_llb[36], s_mlb[53];     // base | extra bits << 24 (a constant-memory lookup is a global load here)
   const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const uint32_t b = d.seq_blocks[blockIdx.x];
   if (d.status[b]) return;                       // the bitstream (or a table) failed: nothing to post-process
@@ -558,74 +562,112 @@ __global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
   const uint2* raw = d.raw_arena + blk.seq_base;
   ZgSeq* out = d.seq_arena + blk.seq_base;
   if (t == 0) s_err = 0xFFFFFFFFu;
+  if (t < 36) s_llb[t] = ZG_LL_BASE[t] | ((uint32_t)ZG_LL_BITS[t] << 24);
+  if (t < 53) s_mlb[t] = ZG_ML_BASE[t] | ((uint32_t)ZG_ML_BITS[t] << 24);
   ZgHistMap carry = zg_map_identity();
-  uint32_t lit_carry = 0, out_carry = 0, ml_carry = 0;
+  uint32_t lit_carry = 0, out_carry = 0;
   __syncthreads();
-  for (uint32_t i0 = 0; i0 < nseq; i0 += ZG_SP_T) {
-    const uint32_t i = i0 + t;
-    const bool have = i < nseq;
-    uint32_t ll = 0, ml = 0, of = 4;
-    if (have) {
-      const uint2 r = raw[i];
-      const uint32_t ll_code = r.y & 63u, ml_code = (r.y >> 8) & 63u, of_code = (r.y >> 16) & 31u;
-      const uint32_t xb_ll = ZG_LL_BITS[ll_code], xb_ml = ZG_ML_BITS[ml_code];
-      const int32_t q_of = (int32_t)r.x - (int32_t)of_code, q_ml = q_of - (int32_t)xb_ml, q_ll = q_ml - (int32_t)xb_ll;
-      of = zg_bits_at(bs, q_of, of_code) + (1u << of_code);
-      ml = ZG_ML_BASE[ml_code] + zg_bits_at(bs, q_ml, xb_ml);
-      ll = ZG_LL_BASE[ll_code] + zg_bits_at(bs, q_ll, xb_ll);
+  for (uint32_t i0 = 0; i0 < nseq; i0 += ZG_SP_T * ZG_SP_S) {
+    const uint32_t ib = i0 + t * ZG_SP_S;
+    const uint32_t n = ib < nseq ? (nseq - ib < ZG_SP_S ? nseq - ib : ZG_SP_S) : 0u;
+    uint2 r[ZG_SP_S];
+    if (n == ZG_SP_S) {
+#pragma unroll
+      for (int j = 0; j < ZG_SP_S; j += 2) {
+        const zg_v4u v = *(const zg_gv4u*)(raw + ib + j);
+        r[j] = make_uint2(v.x, v.y); r[j + 1] = make_uint2(v.z, v.w);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < ZG_SP_S; j++) r[j] = (uint32_t)j < n ? raw[ib + j] : make_uint2(0u, 0u);
     }
-    // map of this sequence (identity for lanes past the end): slots after = f(slots before)
-    ZgHistMap m = zg_map_identity();
-    bool toobig = false;
-    if (have) {
-      const uint32_t idx = of - 1u + (ll == 0u ? 1u : 0u);   // 0: keep, 1: swap01, 2: rotate slot 2 to front, 3: h0 - 1 to front
-      if (of > 3u) { toobig = of - 3u >= (1u << 30); m.s[0] = toobig ? 1u : of - 3u; m.s[1] = 1u << 30; m.s[2] = 2u << 30; }
-      else if (idx == 1) { m.s[0] = 2u << 30; m.s[1] = 1u << 30; m.s[2] = 3u << 30; }
-      else if (idx == 2) { m.s[0] = 3u << 30; m.s[1] = 1u << 30; m.s[2] = 2u << 30; }
-      else if (idx == 3) { m.s[0] = (1u << 30) | 1u; m.s[1] = 1u << 30; m.s[2] = 2u << 30; }
+    // values: the three extra-bit fields of a sequence are adjacent, [q_ll, P), at most 63 bits: three dwords cover them
+    uint32_t ll[ZG_SP_S], ml[ZG_SP_S], of[ZG_SP_S];
+#pragma unroll
+    for (int j = 0; j < ZG_SP_S; j++) {
+      const uint32_t ll_code = r[j].y & 63u, ml_code = (r[j].y >> 8) & 63u, of_code = (r[j].y >> 16) & 31u;
+      const uint32_t vl = s_llb[ll_code < 36 ? ll_code : 0], vm = s_mlb[ml_code < 53 ? ml_code : 0];
+      const uint32_t xb_ll = vl >> 24, xb_ml = vm >> 24;
+      const uint32_t q_ll = r[j].x - of_code - xb_ml - xb_ll;            // >= 0 for every record zg_k_seq emitted
+      const uint8_t* pb = bs + (q_ll >> 3);
+      const uint32_t w0 = zg_ld32(pb), w1 = zg_ld32(pb + 4), w2 = zg_ld32(pb + 8);
+      const uint32_t sh = q_ll & 7u;
+      const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+      const uint32_t ll_add = __builtin_amdgcn_ubfe(lo, 0u, xb_ll);
+      const uint32_t ml_add = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(hi, lo, xb_ll), 0u, xb_ml);
+      const uint32_t so = xb_ll + xb_ml;                                  // <= 32
+      const uint32_t ov = so >= 32u ? hi : __builtin_amdgcn_alignbit(hi, lo, so);
+      const bool have = (uint32_t)j < n;
+      ll[j] = have ? (vl & 0xFFFFFFu) + ll_add : 0u;
+      ml[j] = have ? (vm & 0xFFFFFFu) + ml_add : 0u;
+      of[j] = have ? __builtin_amdgcn_ubfe(ov, 0u, of_code) + (1u << of_code) : 0u;   // 0 marks "no sequence"
     }
-    // inclusive scans inside the wave: literal lengths, output lengths, history maps
-    uint32_t sl = ll, so = ll + ml, sm = ml;
-    ZgHistMap sc = m;
+    // history inside the thread's run, relative to its start; thread totals
+    uint32_t h0 = 1u << 30, h1 = 2u << 30, h2 = 3u << 30, tl = 0, to = 0, act[ZG_SP_S];
+    uint32_t big = 0;
+#pragma unroll
+    for (int j = 0; j < ZG_SP_S; j++) {
+      act[j] = 1;
+      if (of[j]) {
+        const bool tb = of[j] > 3u && of[j] - 3u >= (1u << 30);
+        big |= tb ? 1u << j : 0u;
+        act[j] = zg_hist_step(tb ? 4u : of[j], ll[j], h0, h1, h2);
+      }
+      tl += ll[j]; to += ll[j] + ml[j];
+    }
+    // inclusive scans over the wave of the thread totals
+    uint32_t sl = tl, so = to;
+    ZgHistMap sc = {{h0, h1, h2}};
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t pl = __shfl_up(sl, off, 64), po = __shfl_up(so, off, 64), pm = __shfl_up(sm, off, 64);
-      ZgHistMap pmx;
-      pmx.s[0] = __shfl_up(sc.s[0], off, 64); pmx.s[1] = __shfl_up(sc.s[1], off, 64); pmx.s[2] = __shfl_up(sc.s[2], off, 64);
-      if ((int)lane >= off) { sl += pl; so += po; sm += pm; sc = zg_map_compose(pmx, sc); }
+      const uint32_t pl = __shfl_up(sl, off, 64), po = __shfl_up(so, off, 64);
+      ZgHistMap pm;
+      pm.s[0] = __shfl_up(sc.s[0], off, 64); pm.s[1] = __shfl_up(sc.s[1], off, 64); pm.s[2] = __shfl_up(sc.s[2], off, 64);
+      if ((int)lane >= off) { sl += pl; so += po; sc = zg_map_compose(pm, sc); }
     }
     if (lane == 63) { s_wm[wv] = sc; s_wl[wv] = sl; s_wo[wv] = so; }
+    // exclusive: what the lanes before this one did
+    ZgHistMap ex;
+    ex.s[0] = __shfl_up(sc.s[0], 1, 64); ex.s[1] = __shfl_up(sc.s[1], 1, 64); ex.s[2] = __shfl_up(sc.s[2], 1, 64);
+    if (lane == 0) ex = zg_map_identity();
     __syncthreads();
-    // prefix of the earlier waves of this pass
-    ZgHistMap pre = carry;
-    uint32_t pl = lit_carry, po = out_carry;
-    for (uint32_t w = 0; w < wv; w++) { pre = zg_map_compose(pre, s_wm[w]); pl += s_wl[w]; po += s_wo[w]; }
-    const ZgHistMap after = zg_map_compose(pre, sc);          // history after this sequence
-    const uint32_t lit_before = pl + sl - ll, out_before = po + so - (ll + ml);
-    if (have) {
-      const uint32_t actual = after.s[0];
-      int bad = ZG_OK;
-      if ((uint64_t)out_before + ll + ml >= (1ull << 31)) bad = ZG_UNSUPPORTED;
-      if ((uint64_t)lit_before + ll > regen) bad = ZG_EXE_NOT_ENOUGH_LITERALS;     // sequence_execution.rs:14-19
-      if (toobig) bad = ZG_EXE_OFFSET_TOO_BIG;
-      if (actual == 0) bad = ZG_EXE_ZERO_OFFSET;                                   // :28-30
-      if (bad) atomicMin(&s_err, (t << 8) | (uint32_t)bad);                        // the first failing sequence decides
-      ZgSeq q;
-      q.of = actual; q.ml = ml; q.mdst = out_before + ll; q.lit_start = lit_before;
-      out[i] = q;
+    ZgHistMap pre = carry, tot = carry;
+    uint32_t pl = lit_carry, po = out_carry, totl = lit_carry, toto = out_carry;
+#pragma unroll
+    for (uint32_t w = 0; w < ZG_SP_T / 64; w++) {
+      const ZgHistMap wm = s_wm[w];
+      const uint32_t wl = s_wl[w], wo = s_wo[w];
+      if (w < wv) { pre = zg_map_compose(pre, wm); pl += wl; po += wo; }
+      tot = zg_map_compose(tot, wm); totl += wl; toto += wo;
     }
-    // carries for the next pass
-    ZgHistMap tot = carry;
-    uint32_t tl = lit_carry, to = out_carry;
-    for (uint32_t w = 0; w < ZG_SP_T / 64; w++) { tot = zg_map_compose(tot, s_wm[w]); tl += s_wl[w]; to += s_wo[w]; }
-    // Σ match lengths = Σ (ll+ml) - Σ ll
-    carry = tot; lit_carry = tl; out_carry = to; ml_carry = to - tl;
+    pre = zg_map_compose(pre, ex);                 // history before this thread's first sequence, relative to the block start
+    uint32_t lit_pos = pl + sl - tl, out_pos = po + so - to;
+    if (n) {
+      uint32_t bad = 0xFFFFFFFFu;
+#pragma unroll
+      for (int j = 0; j < ZG_SP_S; j++) {
+        if ((uint32_t)j < n) {
+          const uint32_t actual = zg_map_apply(pre, act[j]);
+          uint32_t e = ZG_OK;
+          if ((uint64_t)out_pos + ll[j] + ml[j] >= (1ull << 31)) e = ZG_UNSUPPORTED;
+          if ((uint64_t)lit_pos + ll[j] > regen) e = ZG_EXE_NOT_ENOUGH_LITERALS;   // sequence_execution.rs:14-19
+          if ((big >> j) & 1u) e = ZG_EXE_OFFSET_TOO_BIG;
+          if (actual == 0) e = ZG_EXE_ZERO_OFFSET;                                  // :28-30
+          if (e && bad == 0xFFFFFFFFu) bad = ((t * ZG_SP_S + (uint32_t)j) << 8) | e;
+          zg_v4u q = {actual, ml[j], out_pos + ll[j], lit_pos};                     // ZgSeq {of, ml, mdst, lit_start}
+          *(zg_gv4u*)(out + ib + j) = q;
+          lit_pos += ll[j]; out_pos += ll[j] + ml[j];
+        }
+      }
+      if (bad != 0xFFFFFFFFu) atomicMin(&s_err, bad);                               // the first failing sequence decides
+    }
+    carry = tot; lit_carry = totl; out_carry = toto;
     __syncthreads();
     if (s_err != 0xFFFFFFFFu) break;
   }
   if (t == 0) {
     ZgBlockSeqOut so;
-    so.sum_ll = lit_carry; so.sum_ml = ml_carry;
+    so.sum_ll = lit_carry; so.sum_ml = out_carry - lit_carry;
     so.hist_end[0] = carry.s[0]; so.hist_end[1] = carry.s[1]; so.hist_end[2] = carry.s[2]; so.pad = 0;
     d.seq_out[b] = so;
     if (s_err != 0xFFFFFFFFu) zg_set_status(d.status, b, (int)(s_err & 0xFFu));
