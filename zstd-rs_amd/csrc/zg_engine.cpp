@@ -45,11 +45,13 @@ int Engine::create(int device, Engine** out) {
   Engine* e = new Engine();
   e->device_ = device;
   if (hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking) != hipSuccess) { delete e; return ZG_HIP_ERROR; }
+  if (hipStreamCreateWithFlags(&e->stream2_, hipStreamNonBlocking) != hipSuccess) { delete e; return ZG_HIP_ERROR; }
   *out = e;
   return ZG_OK;
 }
 Engine::~Engine() {
   if (stream_) (void)hipStreamDestroy(stream_);
+  if (stream2_) (void)hipStreamDestroy(stream2_);
 }
 
 int parse_frames(const uint8_t* src, size_t len, uint64_t max_window, BatchBuilder* bb, std::vector<FrameInfo>* info) {
@@ -113,6 +115,9 @@ Batch::~Batch() {
   for (DevBuf* b : all) b->release();
   for (auto& e : ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto& e : ev_huf)
+    if (e) (void)hipEventDestroy(e);
+  if (ev_fork) (void)hipEventDestroy(ev_fork);
 }
 
 void FrameState::reset() {
@@ -217,7 +222,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   const uint32_t nslots = bb.nslots();
   if ((st = b->d_aux.reserve((size_t)nb * sizeof(ZgBlockAux) + 16)) || (st = b->d_slot_log.reserve((size_t)nslots * 4)) ||
       (st = b->d_fse.reserve((size_t)nslots * ZG_FSE_SLOT_U32 * 4)) || (st = b->d_huf.reserve((size_t)(bb.nhuf_slots + 1) * ZG_HUF_SLOT_U16 * 2)) ||
-      (st = b->d_hufmax.reserve(bb.nhuf_slots + 16)) || (st = b->d_status.reserve((size_t)nb * 4 + 16)) ||
+      (st = b->d_hufmax.reserve(bb.nhuf_slots + 16)) || (st = b->d_status.reserve(3 * ((size_t)nb * 4 + 16))) ||
       (st = b->d_lit.reserve(bb.lit_bytes + 64)) || (st = b->d_seq.reserve((bb.seq_count + 1) * sizeof(ZgSeq))) ||
       (st = b->d_raw.reserve((bb.seq_count + 1) * 8)) ||
       (st = b->d_seqout.reserve((size_t)nb * sizeof(ZgBlockSeqOut) + 16)) || (st = b->d_pos.reserve((size_t)nb * sizeof(ZgBlockPos) + 16)) ||
@@ -237,7 +242,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   d.nslots = nslots; d.nhuf_slots = bb.nhuf_slots;
   d.aux = b->d_aux.as<ZgBlockAux>(); d.slot_log = b->d_slot_log.as<uint8_t>();
   d.fse_arena = b->d_fse.as<uint32_t>(); d.huf_arena = b->d_huf.as<uint16_t>(); d.huf_maxbits = b->d_hufmax.as<uint8_t>();
-  d.status = b->d_status.as<uint32_t>(); d.lit_arena = b->d_lit.as<uint8_t>(); d.seq_arena = b->d_seq.as<ZgSeq>(); d.raw_arena = b->d_raw.as<uint2>();
+  d.status = b->d_status.as<uint32_t>(); d.tab_status = d.status + nb + 4; d.lit_status = d.tab_status + nb + 4; d.lit_arena = b->d_lit.as<uint8_t>(); d.seq_arena = b->d_seq.as<ZgSeq>(); d.raw_arena = b->d_raw.as<uint2>();
   d.seq_out = b->d_seqout.as<ZgBlockSeqOut>(); d.pos = b->d_pos.as<ZgBlockPos>(); d.frame_out = b->d_frameout.as<ZgFrameOut>();
   if (b->fs) {
     if ((st = b->fs->d_fse.reserve(ZG_FSE_SLOT_U32 * 4)) || (st = b->fs->d_huf.reserve(ZG_HUF_SLOT_U16 * 2))) { delete b; return st; }
@@ -257,6 +262,9 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   { const char* e = getenv("ZGPU_SWEEP_T1024"); if (!e || e[0] != '0') d.flags |= 2u; }
   for (auto& e : b->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
+  for (auto& e : b->ev_huf)
+    if (hipEventCreate(&e) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
+  if (hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
   if (hipStreamSynchronize(stream_) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
   *out = b;
   return ZG_OK;
@@ -268,7 +276,7 @@ int Batch::run() {
   const ZgBatchDev& d = dev;
   if (d.nframes == 0) { ran = true; total_out = 0; return ZG_OK; }
   ZG_HIP(hipEventRecord(ev[0], s));
-  ZG_HIP(hipMemsetAsync(d.status, 0, (size_t)d.nblocks * 4 + 16, s));
+  ZG_HIP(hipMemsetAsync(d.status, 0, 3 * ((size_t)d.nblocks * 4 + 16), s));
   ZG_HIP(hipMemsetAsync(d.huf_maxbits, 0, d.nhuf_slots + 16, s));
   ZG_HIP(hipMemsetAsync(d.slot_log, 0, (size_t)d.nslots * 4, s));
   ZG_HIP(hipMemsetAsync(d.totals, 0, 64, s));
@@ -283,11 +291,20 @@ int Batch::run() {
   }
   zg_launch_tables(d, s);
   ZG_HIP(hipEventRecord(ev[1], s));
-  zg_launch_huf(d, s);
+  // literals (Huffman streams) and sequences (FSE chains) of a block are independent once the tables exist, and both
+  // kernels are latency-bound chains that leave most of the chip idle: they run side by side on two streams
+  hipStream_t s2 = eng->stream2_;
+  ZG_HIP(hipEventRecord(ev_fork, s));
+  ZG_HIP(hipStreamWaitEvent(s2, ev_fork, 0));
+  ZG_HIP(hipEventRecord(ev_huf[0], s2));
+  zg_launch_huf(d, s2);
+  ZG_HIP(hipEventRecord(ev_huf[1], s2));
   ZG_HIP(hipEventRecord(ev[2], s));
   zg_launch_seq(d, s);
   ZG_HIP(hipEventRecord(ev[3], s));
   zg_launch_seqpost(d, s);
+  ZG_HIP(hipStreamWaitEvent(s, ev_huf[1], 0));
+  zg_launch_merge(d, s);
   ZG_HIP(hipEventRecord(ev[4], s));
   zg_launch_scan(d, s);
   ZG_HIP(hipEventRecord(ev[5], s));
@@ -319,6 +336,7 @@ int Batch::sync() {
     if (hipEventElapsedTime(&m, ev[i], ev[i + 1]) == hipSuccess) ms[i] = m;
   }
   float m = 0;
+  if (hipEventElapsedTime(&m, ev_huf[0], ev_huf[1]) == hipSuccess) ms[ZG_T_HUF] = m;   // beside seq + seqpost, not in line
   if (hipEventElapsedTime(&m, ev[0], ev[ZG_T_TOTAL]) == hipSuccess) ms[ZG_T_TOTAL] = m;
   return ZG_OK;
 }

@@ -88,6 +88,7 @@ class Batch {
   DevBuf d_src, d_blocks, d_frames, d_aux, d_slot_log, d_fse, d_huf, d_hufmax, d_status, d_lit, d_seq, d_seqout, d_pos, d_frameout,
       d_dst, d_seqblocks, d_hufitems, d_hufgroups, d_totals, d_og, d_units, d_unitinfo, d_sweepwgs, d_bar, d_dbg, d_raw;
   hipEvent_t ev[ZG_T_COUNT + 1] = {};
+  hipEvent_t ev_huf[2] = {}, ev_fork = nullptr;   // zg_k_huf runs on the engine's second stream beside zg_k_seq
   bool ran = false;
   FrameState* fs = nullptr;              // streaming submit: the frame state this run reads from / writes into
 };
@@ -111,7 +112,7 @@ class Engine {
  private:
   friend class Batch;
   int device_ = 0;
-  hipStream_t stream_ = nullptr;
+  hipStream_t stream_ = nullptr, stream2_ = nullptr;
   int fail(hipError_t e, const char* what);
   int upload(Batch* b, const uint8_t* src, size_t len, Batch** out);
 };

@@ -280,7 +280,7 @@ void BatchBuilder::finish() {
     if (b.nseq) { b.seq_idx = (uint32_t)seq_blocks.size(); seq_blocks.push_back(i); }
     if (b.lit_type >= ZG_LT_COMPRESSED) {
       for (uint32_t k = 0; k < b.nstreams; k++) {
-        if (huf_groups.empty() || huf_groups.back().slot != b.huf_slot || huf_groups.back().nitems >= 256) {
+        if (huf_groups.empty() || huf_groups.back().slot != b.huf_slot || huf_groups.back().nitems >= ZG_HUF_GROUP) {
           ZgHufGroup g;
           g.slot = b.huf_slot; g.first_item = (uint32_t)huf_items.size(); g.nitems = 0; g.pad = 0;
           huf_groups.push_back(g);

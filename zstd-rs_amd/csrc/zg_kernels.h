@@ -20,6 +20,8 @@ struct ZgBatchDev {
   uint16_t* huf_arena;         // [nhuf_slots][ZG_HUF_SLOT_U16]
   uint8_t* huf_maxbits;        // [nhuf_slots]
   uint32_t* status;            // [nblocks] first error per block (ZgStatus), 0 = ok
+  uint32_t* tab_status;        // [nblocks] what zg_k_tables left in status (zg_k_huf runs beside zg_k_seq and must not see its errors)
+  uint32_t* lit_status;        // [nblocks] zg_k_huf's errors, folded into status by zg_k_merge (literals are decoded before sequences: they outrank)
   uint8_t* lit_arena;          // regenerated Huffman literals
   ZgSeq* seq_arena;            // decoded sequences
   uint2* raw_arena;            // zg_k_seq's raw records {bit position, codes}, same indexing as seq_arena
@@ -51,6 +53,7 @@ void zg_launch_tables(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_huf(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_seq(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_seqpost(const ZgBatchDev& d, hipStream_t s);
+void zg_launch_merge(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_scan(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_lit(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_flat(const ZgBatchDev& d, hipStream_t s);

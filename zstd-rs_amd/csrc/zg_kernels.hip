@@ -96,6 +96,7 @@ __global__ void __launch_bounds__(64) zg_k_tables(ZgBatchDev d) {
   }
   d.aux[b] = aux;
   zg_set_status(d.status, b, st);
+  d.tab_status[b] = (uint32_t)st;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -106,7 +107,7 @@ __global__ void __launch_bounds__(64) zg_k_tables(ZgBatchDev d) {
 // bank-conflict free) that it extends downwards with 16-byte loads landing one phase (16 symbols) later, and it
 // writes its literals 16 bytes at a time.
 // ------------------------------------------------------------------------------------------------------------
-#define ZG_HUF_T 256
+#define ZG_HUF_T ZG_HUF_GROUP   // one wave: 12 KiB of LDS, so it fits beside the zg_k_seq workgroups it runs next to
 #define ZG_HUF_RDW 32                      // ring dwords per lane
 #define ZG_HUF_CH 16                       // symbols per phase: <= 16 x 11 bits = 22 bytes of input, 16 bytes of output
 #define ZG_HUF_MARGIN 64                   // bytes kept resident below the read position (two phases + a piece)
@@ -127,10 +128,10 @@ __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
   uint32_t item = d.huf_items[grp.first_item + t];
   uint32_t b = item >> 2, k = item & 3;
   const ZgBlock blk = d.blocks[b];
-  if (max_bits == 0) { zg_set_status(d.status, b, ZG_LIT_UNINIT_HUF); return; }  // literals_section_decoder.rs:60-63
-  if (d.status[b]) return;                                                        // its own tree description failed
+  if (max_bits == 0) { zg_set_status(d.lit_status, b, ZG_LIT_UNINIT_HUF); return; }  // literals_section_decoder.rs:60-63
+  if (d.tab_status[b]) return;                                                    // its own tree description failed
   uint32_t desc = blk.lit_type == ZG_LT_COMPRESSED ? d.aux[b].huf_desc_bytes : 0;
-  if (desc > blk.lit_comp_size) { zg_set_status(d.status, b, ZG_INTERNAL); return; }
+  if (desc > blk.lit_comp_size) { zg_set_status(d.lit_status, b, ZG_INTERNAL); return; }
   const uint8_t* pay = d.src + blk.src_off + blk.lit_off + desc;
   uint32_t total = blk.lit_comp_size - desc;
   uint32_t regen = blk.regen_size;
@@ -138,10 +139,10 @@ __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
   const uint8_t* sp;
   uint32_t slen, doff, cap;
   if (blk.nstreams == 4) {
-    if (total < 6) { zg_set_status(d.status, b, ZG_LIT_MISSING_JUMP); return; }
+    if (total < 6) { zg_set_status(d.lit_status, b, ZG_LIT_MISSING_JUMP); return; }
     uint32_t j1 = zg_ld16(pay), j2 = j1 + zg_ld16(pay + 2), j3 = j2 + zg_ld16(pay + 4);
     uint32_t rest = total - 6;
-    if (rest < j3) { zg_set_status(d.status, b, ZG_LIT_MISSING_BYTES); return; }
+    if (rest < j3) { zg_set_status(d.lit_status, b, ZG_LIT_MISSING_BYTES); return; }
     uint32_t start = k == 0 ? 0 : k == 1 ? j1 : k == 2 ? j2 : j3;
     uint32_t end = k == 0 ? j1 : k == 1 ? j2 : k == 2 ? j3 : rest;
     sp = pay + 6 + start; slen = end - start;
@@ -153,7 +154,7 @@ __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
     sp = pay; slen = total; doff = 0; cap = regen;
   }
   const uint32_t lastb = slen ? sp[slen - 1] : 0;
-  if (slen == 0 || lastb == 0) { zg_set_status(d.status, b, ZG_LIT_EXTRA_PADDING); return; }  // :98-109
+  if (slen == 0 || lastb == 0) { zg_set_status(d.lit_status, b, ZG_LIT_EXTRA_PADDING); return; }  // :98-109
   const uint32_t hb = zg_hbit(lastb) - 1;                     // payload bits of the last byte (below the marker)
   const uint32_t T = (slen - 1) * 8 + hb;                     // bits of the stream
   const uint64_t A = (uint64_t)sp, A_last = A + slen - 1;
@@ -253,7 +254,7 @@ __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
   if (overflow) st = ZG_LIT_COUNT_MISMATCH;
   else if (blk.nstreams == 4 && c != T) st = ZG_LIT_BITSTREAM_MISMATCH;   // bits_remaining != -max_bits (:116-121)
   else if (n != cap) st = ZG_LIT_COUNT_MISMATCH;                           // :150-155 (per stream, spec split)
-  zg_set_status(d.status, b, st);
+  zg_set_status(d.lit_status, b, st);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -267,11 +268,13 @@ __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
 // MOVER phase in which all 64 lanes extend every lane's bitstream ring downwards with 16-byte loads (landing one
 // phase later, i.e. behind a whole decode phase) and flush the decoded sequences with coalesced 16-byte stores.
 // ------------------------------------------------------------------------------------------------------------
-#define ZG_SEQ_CH 8                                   // sequences per lane between two mover phases
-#define ZG_SEQ_CMAX 96                                // >= bytes ZG_SEQ_CH sequences can consume (8 x 89 bits)
+#define ZG_SEQ_CH 12                                  // sequences per lane between two mover phases
+#define ZG_SEQ_CMAX 144                               // >= bytes ZG_SEQ_CH sequences can consume (12 x 89 bits)
 #define ZG_SEQ_MARGIN (2 * ZG_SEQ_CMAX + 32)          // bytes of bitstream kept resident below the current position
 #define ZG_SEQ_RING 512                               // per-lane ring, indexed by the low bits of the global address
-#define ZG_SEQ_PIECES 7                               // 16-byte pieces one mover phase can add per lane (>= CMAX/16 + 1)
+#define ZG_SEQ_PIECES 10                              // 16-byte pieces one mover phase can add per lane (>= CMAX/16 + 1)
+#define ZG_SEQ_PREG ((ZG_SEQ_G * ZG_SEQ_PIECES + 63) / 64)   // piece requests per thread and phase
+#define ZG_SEQ_PRO ((ZG_SEQ_MARGIN + 16 + 8 + 15 + 15) / 16 + 1)   // pieces of the prologue fill
 
 // bits [q, q+n) of the stream (n <= 31) read from the lane's ring: two adjacent dwords + one funnel shift.
 // rbits = (stream address & (ring size - 1)) * 8; the ring has a 16-byte mirror of its start behind its end.
@@ -392,8 +395,8 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
     }
     if (t < ZG_SEQ_G) { s_fetch_hi[t] = act ? top : 0; s_fetch_lo[t] = act ? want : 0; }
     __syncthreads();
-    for (uint32_t j = t; j < ZG_SEQ_G * 20; j += 64) {        // (MARGIN + 16 + 8 + 15 + 15) / 16 + 1 <= 20 pieces per block
-      const uint32_t gg = j / 20, k = j % 20;
+    for (uint32_t j = t; j < ZG_SEQ_G * ZG_SEQ_PRO; j += 64) {
+      const uint32_t gg = j / ZG_SEQ_PRO, k = j % ZG_SEQ_PRO;
       const uint64_t hi = s_fetch_hi[gg], addr = hi - 16ull * (k + 1);
       if (hi && addr >= s_fetch_lo[gg] && addr < hi) {
         const uint4 v = *(const uint4*)addr;
@@ -413,9 +416,11 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
     P -= (int32_t)of_log; e_of = t_of[P >= 0 ? zg_ring_bits(ring32, rbits, P, of_log) : 0];
     P -= (int32_t)ml_log; { const uint32_t i = P >= 0 ? zg_ring_bits(ring32, rbits, P, ml_log) : 0; e_ml = t_ml[i]; xb_ml = x_ml[i]; }
   }
-  zg_v4u piece[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};     // ZG_SEQ_G * ZG_SEQ_PIECES = 112 requests per phase: two per lane
-  uint64_t piece_addr[2] = {0, 0};
-  uint32_t piece_g[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+  zg_v4u piece[ZG_SEQ_PREG];
+  uint64_t piece_addr[ZG_SEQ_PREG];
+  uint32_t piece_g[ZG_SEQ_PREG];
+#pragma unroll
+  for (int pi = 0; pi < ZG_SEQ_PREG; pi++) { piece[pi] = zg_v4u{0, 0, 0, 0}; piece_addr[pi] = 0; piece_g[pi] = 0xFFFFFFFFu; }
   // ---- main loop
   while (__any(act)) {
     // DECODE phase: LDS only, and one LDS round trip per sequence: the next table entries, their extra-bit counts and
@@ -433,7 +438,7 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
 #pragma unroll 1
       for (int c = 0; c < ZG_SEQ_CH; c++) {
         if (act) {
-          const uint32_t of_code = e_of >> 10, ml_code = e_ml >> 10, ll_code = e_ll >> 10;
+          const uint32_t of_code = e_of >> 10;
           const uint32_t v_ll = e_ll & 1023u, v_ml = e_ml & 1023u, v_of = e_of & 1023u;
           const uint32_t k_ll = 31u - (uint32_t)__builtin_clz(v_ll), k_ml = 31u - (uint32_t)__builtin_clz(v_ml), k_of = 31u - (uint32_t)__builtin_clz(v_of);
           const uint32_t nb_ll = ll_log - k_ll, nb_ml = ml_log - k_ml, nb_of = of_log - k_of;
@@ -442,7 +447,7 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
           // the sequence's bits, from the top: OF, ML, LL extra bits (:185), then the LL, ML, OF state bits
           const int32_t q_sof = P - (int32_t)(of_code + xb_ml + xb_ll) - (int32_t)nbs;
           const bool ok = q_sof >= 0;                               // :209-211
-          s_out[g][cnt] = make_uint2((uint32_t)P, ll_code | (ml_code << 8) | (of_code << 16));
+          s_out[g][cnt] = make_uint2((uint32_t)P | (of_code << 21), e_ll | (e_ml << 16));   // P < 2^21; entries carry the codes in [15:10]
           cnt += ok ? 1u : 0u;
           status = ok ? status : ZG_SEQ_NOT_ENOUGH_BYTES;
           // bits [q_sof, q_sof + nbs) out of the window (q_sof >= P - 89, so they are inside it)
@@ -481,7 +486,7 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
     __syncthreads();
     // (1) land the pieces requested one phase ago
 #pragma unroll
-    for (int pi = 0; pi < 2; pi++) {
+    for (int pi = 0; pi < ZG_SEQ_PREG; pi++) {
       if (piece_g[pi] != 0xFFFFFFFFu) {
         const uint32_t ro = (uint32_t)(piece_addr[pi] & (ZG_SEQ_RING - 1));
         *(zg_v4u*)(s_ring[piece_g[pi]] + ro) = piece[pi];
@@ -495,7 +500,7 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
     }
     // (3) request the next pieces
 #pragma unroll
-    for (int pi = 0; pi < 2; pi++) {
+    for (int pi = 0; pi < ZG_SEQ_PREG; pi++) {
       piece_g[pi] = 0xFFFFFFFFu;
       const uint32_t j = t + 64 * pi;
       if (j < ZG_SEQ_G * ZG_SEQ_PIECES) {
@@ -585,10 +590,10 @@ __global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
     uint32_t ll[ZG_SP_S], ml[ZG_SP_S], of[ZG_SP_S];
 #pragma unroll
     for (int j = 0; j < ZG_SP_S; j++) {
-      const uint32_t ll_code = r[j].y & 63u, ml_code = (r[j].y >> 8) & 63u, of_code = (r[j].y >> 16) & 31u;
+      const uint32_t ll_code = (r[j].y >> 10) & 63u, ml_code = r[j].y >> 26, of_code = r[j].x >> 21;
       const uint32_t vl = s_llb[ll_code < 36 ? ll_code : 0], vm = s_mlb[ml_code < 53 ? ml_code : 0];
       const uint32_t xb_ll = vl >> 24, xb_ml = vm >> 24;
-      const uint32_t q_ll = r[j].x - of_code - xb_ml - xb_ll;            // >= 0 for every record zg_k_seq emitted
+      const uint32_t q_ll = (r[j].x & 0x1FFFFFu) - of_code - xb_ml - xb_ll;            // >= 0 for every record zg_k_seq emitted
       const uint8_t* pb = bs + (q_ll >> 3);
       const uint32_t w0 = zg_ld32(pb), w1 = zg_ld32(pb + 4), w2 = zg_ld32(pb + 8);
       const uint32_t sh = q_ll & 7u;
@@ -1357,6 +1362,16 @@ void zg_launch_huf(const ZgBatchDev& d, hipStream_t s) {
 }
 void zg_launch_seq(const ZgBatchDev& d, hipStream_t s) {
   if (d.nseq_blocks) hipLaunchKernelGGL(zg_k_seq, dim3((d.nseq_blocks + ZG_SEQ_G - 1) / ZG_SEQ_G), dim3(64), 0, s, d);
+}
+// zg_k_huf ran beside zg_k_seq / zg_k_seqpost on a second stream: fold its errors into the block status. A block whose
+// tables failed keeps that error (zg_k_huf skipped it); otherwise a literals error outranks a sequence error, as the
+// literals section is decoded first (block_decoder.rs:131-150).
+__global__ void __launch_bounds__(256) zg_k_merge(ZgBatchDev d) {
+  const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+  if (b < d.nblocks && !d.tab_status[b] && d.lit_status[b]) d.status[b] = d.lit_status[b];
+}
+void zg_launch_merge(const ZgBatchDev& d, hipStream_t s) {
+  if (d.nblocks) hipLaunchKernelGGL(zg_k_merge, dim3((d.nblocks + 255) / 256), dim3(256), 0, s, d);
 }
 void zg_launch_seqpost(const ZgBatchDev& d, hipStream_t s) {
   if (d.nseq_blocks) hipLaunchKernelGGL(zg_k_seqpost, dim3(d.nseq_blocks), dim3(ZG_SP_T), 0, s, d);
