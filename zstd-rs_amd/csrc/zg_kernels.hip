@@ -902,7 +902,15 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
     const uint32_t bu0 = (uint32_t)(p.out_base - unit_abs0);      // unit-relative position of the block
     if (blk.btype != ZG_BT_COMPRESSED || blk.nseq == 0) {        // already final (zg_k_lit): nothing to resolve
       const uint32_t n = blk.regen_size;
-      for (uint32_t i = t; i < n; i += ZG_FL_T) og[bu0 + i] = 0;
+      for (uint32_t i = 4 * t; i < n; i += 4 * ZG_FL_T) {          // final (zg_k_lit wrote them): the values themselves
+        if (i + 4 <= n) {
+          const uint32_t v = zg_ld32(out_u + bu0 + i);
+          og[bu0 + i] = 0x80000000u | (v & 255u); og[bu0 + i + 1] = 0x80000000u | ((v >> 8) & 255u);
+          og[bu0 + i + 2] = 0x80000000u | ((v >> 16) & 255u); og[bu0 + i + 3] = 0x80000000u | (v >> 24);
+        } else {
+          for (uint32_t k = i; k < n; k++) og[bu0 + k] = 0x80000000u | out_u[bu0 + k];
+        }
+      }
       unit_size = bu0 + n;
       continue;
     }
@@ -1000,6 +1008,10 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
       }
       for (int round = 0; round < 40; round++) {
         if (!__syncthreads_or(unresolved != 0)) break;
+#ifdef ZG_PROFILE_FLAT
+        tc[5]++;
+        if (d.dbg) atomicAdd(&d.dbg[8], (unsigned long long)__popc(unresolved));
+#endif
         if (unresolved) {   // waves whose bytes are all resolved skip the LDS traffic
           uint16_t q[ZG_FL_PER];
 #pragma unroll
@@ -1015,50 +1027,48 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
       }
       if (__syncthreads_or(unresolved != 0)) { if (t == 0) s_err = ZG_INTERNAL; __syncthreads(); break; }  // cannot happen: depth < 2^14
       ZG_TICK(2)
-      // ---- S3: value or effective offset of every byte of the tile, written straight to their places (nobody reads
-      // s_val at match positions or og[] of the current tile during this phase). Two batches of 8 keep registers low.
+      // ---- S3: every byte of the tile becomes one word of og[]: 0x80000000 | value when the byte is known, else its
+      // effective offset (< 2^31). A byte whose root's parent lies in an earlier tile of the unit takes that byte's word
+      // (one gather: earlier tiles are final). Written straight to their places: nobody reads s_val at match positions
+      // or og[] of the current tile during this phase.
       uint32_t nun = 0;
+      {
+        uint32_t w[ZG_FL_PER];   // the word, or 0xC0000000 | unit position to look up
 #pragma unroll
-      for (int hb = 0; hb < ZG_FL_PER; hb += 8) {
-        uint32_t oo[8];
-        int32_t pu[8];      // unit position of the root's parent when it must be looked up, else -1
-        bool lit[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const int k = hb + j;
+        for (int k = 0; k < ZG_FL_PER; k++) {
           const uint32_t xr = t + k * ZG_FL_T;
-          oo[j] = 0; pu[j] = -1; lit[j] = true;
+          w[k] = 0x80000000u;
           if (t0 + xr >= t1) continue;
           const uint16_t own = s_par[xr];
-          if (own == ZG_PAR_LIT) continue;
+          if (own == ZG_PAR_LIT) { w[k] = 0x80000000u | s_val[xr]; continue; }
           const uint32_t r = own >= 0x8000u ? xr : pr[k];   // tile-relative root
           const uint16_t rp = own >= 0x8000u ? own : s_par[r];
-          if (rp == ZG_PAR_LIT) { s_val[xr] = s_val[r]; continue; }
-          lit[j] = false;
+          if (rp == ZG_PAR_LIT) { const uint8_t v = s_val[r]; s_val[xr] = v; w[k] = 0x80000000u | v; continue; }
           const uint32_t off_r = s_soff[rp & 0x7FFFu];
           const int32_t par_u = (int32_t)(tu0 + r) - (int32_t)off_r;   // unit position of the root's parent (< tu0)
-          if (par_u >= 0) pu[j] = par_u;                               // an earlier tile of this unit: already final
-          else oo[j] = (tu0 + xr) + (uint32_t)(-par_u);                // reaches before the unit
+          w[k] = par_u >= 0 ? 0xC0000000u | (uint32_t)par_u            // an earlier tile of this unit: already final
+                            : (tu0 + xr) + (uint32_t)(-par_u);         // reaches before the unit
         }
-        uint32_t o2[8];
-        uint8_t v2[8];
+        uint32_t o2[ZG_FL_PER];
 #pragma unroll
-        for (int j = 0; j < 8; j++) o2[j] = og[pu[j] >= 0 ? pu[j] : 0];      // clamped addresses: all loads issued back to back
+        for (int k = 0; k < ZG_FL_PER; k++) o2[k] = og[(w[k] >> 30) == 3u ? (w[k] & 0x3FFFFFFFu) : 0u];   // clamped addresses: all loads issued back to back
 #pragma unroll
-        for (int j = 0; j < 8; j++) v2[j] = out_u[pu[j] >= 0 ? pu[j] : 0];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const uint32_t xr = t + (hb + j) * ZG_FL_T;
+        for (int k = 0; k < ZG_FL_PER; k++) {
+          const uint32_t xr = t + k * ZG_FL_T;
           if (t0 + xr >= t1) continue;
-          if (pu[j] >= 0) {
-            if (o2[j] == 0) s_val[xr] = v2[j];
-            else oo[j] = ((tu0 + xr) - (uint32_t)pu[j]) + o2[j];
+          uint32_t v = w[k];
+          if ((v >> 30) == 3u) {
+            if (o2[k] >> 31) { v = o2[k]; s_val[xr] = (uint8_t)v; }
+            else v = ((tu0 + xr) - (v & 0x3FFFFFFFu)) + o2[k];
           }
-          og[tu0 + xr] = oo[j];
-          nun += oo[j] != 0;
+          og[tu0 + xr] = v;
+          nun += (v >> 31) ? 0u : 1u;
         }
       }
       if (nun) atomicAdd(&s_unres, nun);
+#ifdef ZG_PROFILE_FLAT
+      if (d.dbg) { if (t == 0) atomicAdd(&d.dbg[7], 1ull); int nl = 0; for (int j = 0; j < ZG_FL_PER; j++) nl += (t0 + t + j * ZG_FL_T < t1 && s_par[t + j * ZG_FL_T] != ZG_PAR_LIT) ? 1 : 0; atomicAdd(&d.dbg[9], (unsigned long long)nl); atomicAdd(&d.dbg[10], (unsigned long long)nun); }
+#endif
       __syncthreads();
       ZG_TICK(3)
       // ---- S4: publish the tile
@@ -1119,6 +1129,10 @@ __device__ __forceinline__ bool zg_frame_wait(uint32_t* bar, uint32_t step, uint
 #define ZG_SW_B 8       // groups of 4 output bytes a thread has in flight
 #define ZG_SW_UMAX 512  // units whose metadata is staged in LDS at a time
 
+// og words with bit 31 are finished bytes (0x80000000 | value): 0 = nothing to do; the others are effective offsets
+__device__ __forceinline__ uint4 zg_og_open(uint4 o) {
+  return make_uint4((uint32_t)max((int32_t)o.x, 0), (uint32_t)max((int32_t)o.y, 0), (uint32_t)max((int32_t)o.z, 0), (uint32_t)max((int32_t)o.w, 0));
+}
 struct ZgSweepUnit { uint32_t size, unresolved; uint64_t out_off, og_base; };
 
 template <int T>
@@ -1169,7 +1183,7 @@ __global__ void __launch_bounds__(T) zg_k_sweep(ZgBatchDev d) {
 #pragma unroll
       for (int k = 0; k < ZG_SW_B; k++) {
         const uint32_t g = g0 + t + k * T;
-        onext[k] = g < g1 ? *(const uint4*)(og + 4 * (uint64_t)g) : make_uint4(0, 0, 0, 0);
+        onext[k] = g < g1 ? zg_og_open(*(const uint4*)(og + 4 * (uint64_t)g)) : make_uint4(0, 0, 0, 0);
       }
     };
     uint32_t ui = next_unit(0);
@@ -1191,7 +1205,7 @@ __global__ void __launch_bounds__(T) zg_k_sweep(ZgBatchDev d) {
 #pragma unroll
           for (int k = 0; k < ZG_SW_B; k++) {
             const uint32_t g = base + k * T;
-            o[k] = g < g1 ? *(const uint4*)(og + 4 * (uint64_t)g) : make_uint4(0, 0, 0, 0);
+            o[k] = g < g1 ? zg_og_open(*(const uint4*)(og + 4 * (uint64_t)g)) : make_uint4(0, 0, 0, 0);
           }
         }
         // all loads of the batch first (sources lie before the unit: no hazards with this step's stores), then the stores
@@ -1230,7 +1244,7 @@ __global__ void __launch_bounds__(T) zg_k_sweep(ZgBatchDev d) {
       if (wg.rank == wg.wpf - 1) {          // tail bytes of the unit
         for (uint32_t x = (n4 << 2) + t; x < su.size; x += T) {
           const uint32_t o = og[x];
-          if (o) __hip_atomic_store(&out[x], out[(int64_t)x - o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((int32_t)o > 0) __hip_atomic_store(&out[x], out[(int64_t)x - o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       ZG_STICK(0)
