@@ -998,31 +998,27 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
       i_start = s_next == 0xFFFFFFFFu ? nseq + 1 : s_next;
       if (s_err) break;
       // ---- S2: pointer jumping inside the tile. Pointers are < 0x8000; 0x8000|j = parent before the tile; 0xFFFF = literal.
-      uint16_t pr[ZG_FL_PER];
+      // A byte's pointer lives in s_par only: after the phase it is the tile-relative root (or still >= 0x8000: the byte
+      // is its own root). Each round a thread visits just its still-unresolved bytes (few: most parents are before the tile).
       uint32_t unresolved = 0;
 #pragma unroll
       for (int k = 0; k < ZG_FL_PER; k++) {
         const uint32_t x = t + k * ZG_FL_T;
-        pr[k] = ZG_PAR_LIT;
-        if (t0 + x < t1) { pr[k] = s_par[x]; if (pr[k] < 0x8000u) unresolved |= 1u << k; }
+        if (t0 + x < t1 && s_par[x] < 0x8000u) unresolved |= 1u << k;
       }
       for (int round = 0; round < 40; round++) {
         if (!__syncthreads_or(unresolved != 0)) break;
 #ifdef ZG_PROFILE_FLAT
         tc[5]++;
-        if (d.dbg) atomicAdd(&d.dbg[8], (unsigned long long)__popc(unresolved));
 #endif
-        if (unresolved) {   // waves whose bytes are all resolved skip the LDS traffic
-          uint16_t q[ZG_FL_PER];
-#pragma unroll
-          for (int k = 0; k < ZG_FL_PER; k++) q[k] = (unresolved & (1u << k)) ? s_par[pr[k]] : (uint16_t)0xFFFF;
-#pragma unroll
-          for (int k = 0; k < ZG_FL_PER; k++) {
-            if (unresolved & (1u << k)) {
-              if (q[k] >= 0x8000u) unresolved &= ~(1u << k);   // pr[k] is the root
-              else { pr[k] = q[k]; s_par[t + k * ZG_FL_T] = q[k]; }
-            }
-          }
+        uint32_t m = unresolved;
+        while (m) {
+          const uint32_t k = (uint32_t)__builtin_ctz(m);
+          m &= m - 1;
+          const uint32_t x = t + k * ZG_FL_T;
+          const uint16_t q = s_par[s_par[x]];
+          if (q >= 0x8000u) unresolved &= ~(1u << k);   // s_par[x] is the root
+          else s_par[x] = q;                            // u16 stores are atomic: a reader sees the old or the new ancestor, both valid
         }
       }
       if (__syncthreads_or(unresolved != 0)) { if (t == 0) s_err = ZG_INTERNAL; __syncthreads(); break; }  // cannot happen: depth < 2^14
@@ -1041,7 +1037,7 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
           if (t0 + xr >= t1) continue;
           const uint16_t own = s_par[xr];
           if (own == ZG_PAR_LIT) { w[k] = 0x80000000u | s_val[xr]; continue; }
-          const uint32_t r = own >= 0x8000u ? xr : pr[k];   // tile-relative root
+          const uint32_t r = own >= 0x8000u ? xr : own;     // tile-relative root
           const uint16_t rp = own >= 0x8000u ? own : s_par[r];
           if (rp == ZG_PAR_LIT) { const uint8_t v = s_val[r]; s_val[xr] = v; w[k] = 0x80000000u | v; continue; }
           const uint32_t off_r = s_soff[rp & 0x7FFFu];
@@ -1067,7 +1063,7 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
       }
       if (nun) atomicAdd(&s_unres, nun);
 #ifdef ZG_PROFILE_FLAT
-      if (d.dbg) { if (t == 0) atomicAdd(&d.dbg[7], 1ull); int nl = 0; for (int j = 0; j < ZG_FL_PER; j++) nl += (t0 + t + j * ZG_FL_T < t1 && s_par[t + j * ZG_FL_T] != ZG_PAR_LIT) ? 1 : 0; atomicAdd(&d.dbg[9], (unsigned long long)nl); atomicAdd(&d.dbg[10], (unsigned long long)nun); }
+      if (d.dbg && t == 0) atomicAdd(&d.dbg[7], 1ull);
 #endif
       __syncthreads();
       ZG_TICK(3)
