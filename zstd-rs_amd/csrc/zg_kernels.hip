@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
 #define ZG_SEQ_MARGIN (2 * ZG_SEQ_CMAX + 32)          // bytes of bitstream kept resident below the current position
 #define ZG_SEQ_RING 512                               // per-lane ring, indexed by the low bits of the global address
 #define ZG_SEQ_PIECES 10                              // 16-byte pieces one mover phase can add per lane (>= CMAX/16 + 1)
-#define ZG_SEQ_PREG ((ZG_SEQ_G * ZG_SEQ_PIECES + 63) / 64)   // piece requests per thread and phase
+#define ZG_SEQ_PREG ((ZG_SEQ_PIECES + 3) / 4)         // piece requests per lane and phase: a block's four lanes share them
 #define ZG_SEQ_PRO ((ZG_SEQ_MARGIN + 16 + 8 + 15 + 15) / 16 + 1)   // pieces of the prologue fill
 
 // bits [q, q+n) of the stream (n <= 31) read from the lane's ring: two adjacent dwords + one funnel shift.
@@ -299,13 +299,11 @@ __device__ __forceinline__ uint32_t zg_sym_dec_bf(uint32_t v) {  // zg_sym_dec w
 
 __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
   // tables are re-packed to 16 bits while they are staged: [15:10] symbol, [9:0] x = (1 << (log - num_bits)) | (base_line >> num_bits)
-  __shared__ uint16_t s_tab[ZG_SEQ_G][ZG_FSE_SLOT_U32];
-  __shared__ uint8_t s_xb[ZG_SEQ_G][1024];           // extra bits of the symbol, per LL / ML state: read together with the entry
+  __shared__ uint16_t s_tab[ZG_SEQ_G][ZG_FSE_SLOT_U32 + 2];   // + the one-entry dummy table of the position lane
+  __shared__ uint8_t s_xb[ZG_SEQ_G][ZG_FSE_SLOT_U32 + 4];    // bits the state's symbol takes besides the state bits (OF: its code), read together with the entry
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[ZG_SEQ_G][ZG_SEQ_RING + 16];
-  __shared__ __attribute__((aligned(16))) uint2 s_out[ZG_SEQ_G][ZG_SEQ_CH];   // raw records: {bit position before the sequence, codes}
-  __shared__ uint64_t s_fetch_hi[ZG_SEQ_G], s_fetch_lo[ZG_SEQ_G];   // ring extension requested by each lane: [lo, hi)
-  __shared__ uint64_t s_dst[ZG_SEQ_G];                              // where each lane's chunk goes in the sequence arena
-  __shared__ uint32_t s_cnt[ZG_SEQ_G];                              // sequences of the chunk to flush
+  __shared__ __attribute__((aligned(16))) uint4 s_out[ZG_SEQ_G][ZG_SEQ_CH];   // raw records: {OF entry, ML entry, LL entry, bit position before the sequence}
+  __shared__ uint64_t s_fetch_hi[ZG_SEQ_G], s_fetch_lo[ZG_SEQ_G];   // prologue: the part of each block's stream to load, [lo, hi)
   __shared__ uint8_t s_log[ZG_SEQ_G][4];
   __shared__ int s_ok[ZG_SEQ_G];
   const uint32_t base = blockIdx.x * ZG_SEQ_G, t = threadIdx.x;
@@ -333,51 +331,52 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
           if (i < (1u << lg)) {
             const uint32_t nb = ZG_FSE_NB(v[j]);
             s_tab[g][offs[k] + i] = (uint16_t)((ZG_FSE_SYM(v[j]) << 10) | (1u << (lg - nb)) | (ZG_FSE_BL(v[j]) >> nb));
-            if (k != 1) s_xb[g][(k ? 512u : 0u) + i] = (uint8_t)(v[j] >> 26);
+            s_xb[g][offs[k] + i] = (uint8_t)(k == 1 ? ZG_FSE_SYM(v[j]) : v[j] >> 26);
           }
         }
       }
       if (t == 0) s_log[g][k] = (uint8_t)lg;
     }
-    if (t == 0) s_ok[g] = ok ? 1 : 0;
+    if (t == 0) { s_ok[g] = ok ? 1 : 0; s_tab[g][ZG_FSE_SLOT_U32] = 1; s_xb[g][ZG_FSE_SLOT_U32] = 0; }
   }
   __syncthreads();
-  // ---- per-lane setup (lanes >= ZG_SEQ_G only help moving data)
-  const uint32_t g = t < ZG_SEQ_G ? t : 0;
-  bool act = t < ZG_SEQ_G && base + t < d.nseq_blocks;
+  // ---- per-lane setup: four lanes per block. Lane role 0 follows the OF chain, 1 the ML chain, 2 the LL chain; role 3
+  // only carries the position (its "table" is the one-entry dummy: no bits). All four hold the block's scalars.
+  const uint32_t g = t >> 2, role = t & 3u;
+  const bool owner = role == 3u;
+  bool act = base + g < d.nseq_blocks;
   bool have = false;
   uint32_t b = 0, nseq = 0, done = 0, rbits = 0;
-  uint64_t bsA = 0, floorA = 0, lo = 0;
-  const uint16_t* t_ll = &s_tab[g][ZG_FSE_LL_OFF];
-  const uint16_t* t_of = &s_tab[g][ZG_FSE_OF_OFF];
-  const uint16_t* t_ml = &s_tab[g][ZG_FSE_ML_OFF];
-  uint32_t ll_log = 0, of_log = 0, ml_log = 0;
+  uint64_t bsA = 0, floorA = 0, lo = 0, dstp = 0;
+  const uint32_t toff = role == 0u ? ZG_FSE_OF_OFF : role == 1u ? ZG_FSE_ML_OFF : role == 2u ? ZG_FSE_LL_OFF : ZG_FSE_SLOT_U32;
+  const uint16_t* tab = &s_tab[g][toff];
+  const uint8_t* xtab = &s_xb[g][toff];
   const uint32_t* ring32 = (const uint32_t*)s_ring[g];
   int32_t P = 0;
-  uint32_t e_ll = 0, e_of = 0, e_ml = 0;
+  uint32_t e = 1, xb = 0, lg = 0;       // this lane's table entry, its symbol's extra bits, its table's log
   int status = ZG_OK;
   if (act) {
     b = d.seq_blocks[base + g];
     const ZgBlock blk = d.blocks[b];
     if (!s_ok[g]) {
       // FSEDecoder::init_state on a table that was never set (fse_decoder.rs:33-35), or an upstream failure
-      zg_set_status(d.status, b, ZG_FSE_UNINIT);
+      if (owner) zg_set_status(d.status, b, ZG_FSE_UNINIT);
       act = false;
     } else {
       const uint32_t bits_off = d.aux[b].seq_bits_off;
-      if (bits_off > blk.src_len) { zg_set_status(d.status, b, ZG_INTERNAL); act = false; }
+      if (bits_off > blk.src_len) { if (owner) zg_set_status(d.status, b, ZG_INTERNAL); act = false; }
       else {
         const uint8_t* bs = d.src + blk.src_off + bits_off;
         const uint32_t bs_len = blk.src_len - bits_off;
         nseq = blk.nseq;
         const uint32_t lastb = bs_len ? bs[bs_len - 1] : 0;
-        if (bs_len == 0 || lastb == 0) { zg_set_status(d.status, b, ZG_SEQ_EXTRA_PADDING); act = false; }  // :29-40
+        if (bs_len == 0 || lastb == 0) { if (owner) zg_set_status(d.status, b, ZG_SEQ_EXTRA_PADDING); act = false; }  // :29-40
         else {
           P = (int32_t)(bs_len - 1) * 8 + (int32_t)(zg_hbit(lastb) - 1);
           bsA = (uint64_t)bs;
           rbits = (uint32_t)(bsA & (ZG_SEQ_RING - 1)) * 8u;
           floorA = (bsA & ~15ull) - 16;                 // the engine keeps 64 bytes of padding in front of the buffer
-          s_dst[g] = (uint64_t)(d.raw_arena + blk.seq_base);
+          dstp = (uint64_t)(d.raw_arena + blk.seq_base);
           have = true;
         }
       }
@@ -393,7 +392,7 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
       if (want < floorA) want = floorA;
       lo = want;
     }
-    if (t < ZG_SEQ_G) { s_fetch_hi[t] = act ? top : 0; s_fetch_lo[t] = act ? want : 0; }
+    if (owner) { s_fetch_hi[g] = act ? top : 0; s_fetch_lo[g] = act ? want : 0; }
     __syncthreads();
     for (uint32_t j = t; j < ZG_SEQ_G * ZG_SEQ_PRO; j += 64) {
       const uint32_t gg = j / ZG_SEQ_PRO, k = j % ZG_SEQ_PRO;
@@ -407,26 +406,34 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
     }
     __syncthreads();
   }
-  const uint8_t* x_ll = &s_xb[g][0];
-  const uint8_t* x_ml = &s_xb[g][512];
-  uint32_t xb_ll = 0, xb_ml = 0;
   if (act) {  // initial states, order LL, OF, ML (:164-166); a negative position is reported after the first sequence
-    ll_log = s_log[g][0]; of_log = s_log[g][1]; ml_log = s_log[g][2];
-    P -= (int32_t)ll_log; { const uint32_t i = P >= 0 ? zg_ring_bits(ring32, rbits, P, ll_log) : 0; e_ll = t_ll[i]; xb_ll = x_ll[i]; }
-    P -= (int32_t)of_log; e_of = t_of[P >= 0 ? zg_ring_bits(ring32, rbits, P, of_log) : 0];
-    P -= (int32_t)ml_log; { const uint32_t i = P >= 0 ? zg_ring_bits(ring32, rbits, P, ml_log) : 0; e_ml = t_ml[i]; xb_ml = x_ml[i]; }
+    const uint32_t ll_log = s_log[g][0], of_log = s_log[g][1], ml_log = s_log[g][2];
+    lg = role == 0u ? of_log : role == 1u ? ml_log : role == 2u ? ll_log : 0u;
+    const int32_t q = P - (int32_t)(role == 2u ? ll_log : role == 0u ? ll_log + of_log : ll_log + of_log + ml_log);
+    const uint32_t i = (q >= 0 && role != 3u) ? zg_ring_bits(ring32, rbits, q, lg) : 0u;
+    e = tab[i]; xb = xtab[i];
+    P -= (int32_t)(ll_log + of_log + ml_log);
   }
   zg_v4u piece[ZG_SEQ_PREG];
   uint64_t piece_addr[ZG_SEQ_PREG];
-  uint32_t piece_g[ZG_SEQ_PREG];
+  bool piece_ok[ZG_SEQ_PREG];
 #pragma unroll
-  for (int pi = 0; pi < ZG_SEQ_PREG; pi++) { piece[pi] = zg_v4u{0, 0, 0, 0}; piece_addr[pi] = 0; piece_g[pi] = 0xFFFFFFFFu; }
+  for (int pi = 0; pi < ZG_SEQ_PREG; pi++) { piece[pi] = zg_v4u{0, 0, 0, 0}; piece_addr[pi] = 0; piece_ok[pi] = false; }
+  uint32_t* const out_base = (uint32_t*)&s_out[g][0] + (role == 3u ? 3u : role);   // record {e_of, e_ml, e_ll, position}
+#ifdef ZG_PROFILE_SEQ
+  unsigned long long tcs[3] = {0, 0, 0}, tl_ = clock64();
+#define ZG_QTICK(i) { const unsigned long long n_ = clock64(); tcs[i] += n_ - tl_; tl_ = n_; }
+#else
+#define ZG_QTICK(i)
+#endif
   // ---- main loop
   while (__any(act)) {
-    // DECODE phase: LDS only, and one LDS round trip per sequence: the next table entries, their extra-bit counts and
-    // the 128 bits of stream below the next position are all requested together; everything between is 32-bit ALU.
-    // Only the state chain is followed here (FSEDecoder::update_state, fse_decoder.rs:40-48, three times per sequence,
-    // order LL, ML, OF :204-206); the extra bits in between are skipped by their count and read by zg_k_seqpost.
+    ZG_QTICK(2)
+    // DECODE phase: LDS only, and one LDS round trip per sequence: the lane's next table entry, its extra-bit count and
+    // the 128 bits of stream below the next position are requested together; everything between is 32-bit ALU, and
+    // the three chains of a block run in three lanes that exchange their bit counts through DPP quad permutes.
+    // Only the state chains are followed here (FSEDecoder::update_state, fse_decoder.rs:40-48, order LL, ML, OF
+    // :204-206); the extra bits in between are skipped by their count and read by zg_k_seqpost.
     uint32_t cnt = 0;
     {
       uint32_t wbase = 0, w0 = 0, w1 = 0, w2 = 0, w3 = 0;
@@ -438,30 +445,29 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
 #pragma unroll 1
       for (int c = 0; c < ZG_SEQ_CH; c++) {
         if (act) {
-          const uint32_t of_code = e_of >> 10;
-          const uint32_t v_ll = e_ll & 1023u, v_ml = e_ml & 1023u, v_of = e_of & 1023u;
-          const uint32_t k_ll = 31u - (uint32_t)__builtin_clz(v_ll), k_ml = 31u - (uint32_t)__builtin_clz(v_ml), k_of = 31u - (uint32_t)__builtin_clz(v_of);
-          const uint32_t nb_ll = ll_log - k_ll, nb_ml = ml_log - k_ml, nb_of = of_log - k_of;
+          const uint32_t v = e & 1023u;
+          const uint32_t k = 31u - (uint32_t)__builtin_clz(v);
           const bool last = done + 1 == nseq;                       // no state update after the last sequence (:203)
-          const uint32_t nbs = last ? 0u : nb_ll + nb_ml + nb_of;
-          // the sequence's bits, from the top: OF, ML, LL extra bits (:185), then the LL, ML, OF state bits
-          const int32_t q_sof = P - (int32_t)(of_code + xb_ml + xb_ll) - (int32_t)nbs;
+          const uint32_t nb = last ? 0u : lg - k;
+          // pk: [7:0] all bits this lane's symbol takes from the stream, [15:8] its state bits. Quad prefix sums, lanes in
+          // stream order from the low end: OF state, ML state, LL state (then the extra bits, skipped as one count).
+          const uint32_t pk = (nb + xb) | (nb << 8);
+          const uint32_t i1 = pk + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0x93, 0xF, 0xF, false);   // quad_perm [3,0,1,2]
+          const uint32_t incl = i1 + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0x4F, 0xF, 0xF, false); // quad_perm [3,3,0,1]
+          const uint32_t tot = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0xAA, 0xF, 0xF, false);     // quad_perm [2,2,2,2]
+          const int32_t q_sof = P - (int32_t)(tot & 255u);
           const bool ok = q_sof >= 0;                               // :209-211
-          s_out[g][cnt] = make_uint2((uint32_t)P | (of_code << 21), e_ll | (e_ml << 16));   // P < 2^21; entries carry the codes in [15:10]
+          out_base[cnt * 4u] = owner ? (uint32_t)P : e;
           cnt += ok ? 1u : 0u;
           status = ok ? status : ZG_SEQ_NOT_ENOUGH_BYTES;
-          // bits [q_sof, q_sof + nbs) out of the window (q_sof >= P - 89, so they are inside it)
-          const uint32_t rel = (uint32_t)q_sof + rbits - wbase;
+          // this lane's nb state bits start (incl - pk) >> 8 bits above q_sof; q_sof >= P - 89, so they are inside the window
+          const uint32_t rel = (uint32_t)q_sof + rbits - wbase + ((incl - pk) >> 8);
           const bool up = rel >= 64u, odd = (rel & 32u) != 0u;
           const uint32_t a0 = up ? w2 : w0, a1 = up ? w3 : w1, a2 = up ? w3 : w2;
           const uint32_t d0 = odd ? a1 : a0, d1 = odd ? a2 : a1;
-          const uint32_t sb = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(d1, d0, rel & 31u), 0u, nbs);
-          const uint32_t s_of = ((v_of ^ (1u << k_of)) << nb_of) + __builtin_amdgcn_ubfe(sb, 0u, nb_of);
-          const uint32_t s_ml = ((v_ml ^ (1u << k_ml)) << nb_ml) + __builtin_amdgcn_ubfe(sb, nb_of, nb_ml);
-          const uint32_t s_ll = ((v_ll ^ (1u << k_ll)) << nb_ll) + __builtin_amdgcn_ubfe(sb, nb_of + nb_ml, nb_ll);
-          e_ll = t_ll[s_ll]; xb_ll = x_ll[s_ll];
-          e_ml = t_ml[s_ml]; xb_ml = x_ml[s_ml];
-          e_of = t_of[s_of];
+          const uint32_t bits = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(d1, d0, rel & 31u), 0u, nb);
+          const uint32_t st = ((v ^ (1u << k)) << nb) + bits;
+          e = tab[st]; xb = xtab[st];
           P = q_sof;
           wbase = (((uint32_t)P + rbits) & ~31u) - 96u;
           const uint32_t di = (wbase >> 5) & (ZG_SEQ_RING / 4 - 1);
@@ -471,52 +477,48 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
         }
       }
     }
-    // MOVER phase
-    if (t < ZG_SEQ_G) {
-      s_cnt[t] = cnt;
+    ZG_QTICK(0)
+    // MOVER phase: every quad serves its own block (position, ring bounds and output pointer are held by all four
+    // lanes), so nothing is exchanged across the workgroup and the loop has no barrier: LDS accesses of one wave are in order.
+    // (1) land the pieces requested one phase ago
+#pragma unroll
+    for (int pi = 0; pi < ZG_SEQ_PREG; pi++) {
+      if (piece_ok[pi]) {
+        const uint32_t ro = (uint32_t)(piece_addr[pi] & (ZG_SEQ_RING - 1));
+        *(zg_v4u*)(s_ring[g] + ro) = piece[pi];
+        if (ro == 0) *(zg_v4u*)(s_ring[g] + ZG_SEQ_RING) = piece[pi];
+      }
+    }
+    // (2) flush the chunk: the quad's lanes take every fourth record (16 bytes each)
+#pragma unroll
+    for (int i = 0; i < (ZG_SEQ_CH + 3) / 4; i++) {
+      const uint32_t k = role + 4u * (uint32_t)i;
+      if (k < cnt) ((zg_gv4u*)dstp)[k] = *(const zg_v4u*)&s_out[g][k];
+    }
+    dstp += (uint64_t)cnt * sizeof(uint4);
+    // (3) request the next pieces: [want, hi) just below what the ring holds
+    {
       uint64_t hi = 0, want = 0;
       if (act) {
         const uint64_t p0 = bsA + (uint64_t)(P >> 3);
         want = p0 > ZG_SEQ_MARGIN ? (p0 - ZG_SEQ_MARGIN) & ~15ull : 0;
         if (want < floorA) want = floorA;
-        if (want < lo) { hi = lo; lo = want; } else want = 0;
+        if (want < lo) { hi = lo; lo = want; }
       }
-      s_fetch_hi[t] = hi; s_fetch_lo[t] = want;
-    }
-    __syncthreads();
-    // (1) land the pieces requested one phase ago
 #pragma unroll
-    for (int pi = 0; pi < ZG_SEQ_PREG; pi++) {
-      if (piece_g[pi] != 0xFFFFFFFFu) {
-        const uint32_t ro = (uint32_t)(piece_addr[pi] & (ZG_SEQ_RING - 1));
-        *(zg_v4u*)(s_ring[piece_g[pi]] + ro) = piece[pi];
-        if (ro == 0) *(zg_v4u*)(s_ring[piece_g[pi]] + ZG_SEQ_RING) = piece[pi];
+      for (int pi = 0; pi < ZG_SEQ_PREG; pi++) {
+        const uint64_t addr = hi - 16ull * (role + 4u * (uint32_t)pi + 1u);
+        piece_ok[pi] = hi && addr >= want && addr < hi;
+        if (piece_ok[pi]) { piece[pi] = *(const zg_gv4u*)addr; piece_addr[pi] = addr; }
       }
     }
-    // (2) flush the chunk: ZG_SEQ_G x ZG_SEQ_CH records of 16 bytes
-    for (uint32_t j = t; j < ZG_SEQ_G * ZG_SEQ_CH; j += 64) {
-      const uint32_t gg = j / ZG_SEQ_CH, k = j % ZG_SEQ_CH;
-      if (k < s_cnt[gg]) ((zg_gv2u*)s_dst[gg])[k] = *(const zg_v2u*)&s_out[gg][k];
-    }
-    // (3) request the next pieces
-#pragma unroll
-    for (int pi = 0; pi < ZG_SEQ_PREG; pi++) {
-      piece_g[pi] = 0xFFFFFFFFu;
-      const uint32_t j = t + 64 * pi;
-      if (j < ZG_SEQ_G * ZG_SEQ_PIECES) {
-        const uint32_t gg = j / ZG_SEQ_PIECES, k = j % ZG_SEQ_PIECES;
-        const uint64_t hi = s_fetch_hi[gg];
-        const uint64_t addr = hi - 16ull * (k + 1);
-        if (hi && addr >= s_fetch_lo[gg] && addr < hi) {
-          piece[pi] = *(const zg_gv4u*)addr; piece_addr[pi] = addr; piece_g[pi] = gg;
-        }
-      }
-    }
-    __syncthreads();
-    if (t < ZG_SEQ_G) s_dst[t] += (uint64_t)s_cnt[t] * sizeof(uint2);
-    __syncthreads();
+    ZG_QTICK(1)
   }
-  if (have) {
+#ifdef ZG_PROFILE_SEQ
+  if (t == 0 && d.dbg) { atomicAdd(&d.dbg[16], tcs[0]); atomicAdd(&d.dbg[17], tcs[1]); atomicAdd(&d.dbg[18], 1ull); }
+#endif
+#undef ZG_QTICK
+  if (have && owner) {
     if (status == ZG_OK && P > 0) status = ZG_SEQ_EXTRA_BITS;  // :214-220
     zg_set_status(d.status, b, status);
   }
@@ -564,7 +566,7 @@ __global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
   const ZgBlock blk = d.blocks[b];
   const uint32_t nseq = blk.nseq, regen = blk.regen_size;
   const uint8_t* bs = d.src + blk.src_off + d.aux[b].seq_bits_off;
-  const uint2* raw = d.raw_arena + blk.seq_base;
+  const uint4* raw = d.raw_arena + blk.seq_base;
   ZgSeq* out = d.seq_arena + blk.seq_base;
   if (t == 0) s_err = 0xFFFFFFFFu;
   if (t < 36) s_llb[t] = ZG_LL_BASE[t] | ((uint32_t)ZG_LL_BITS[t] << 24);
@@ -575,25 +577,20 @@ __global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
   for (uint32_t i0 = 0; i0 < nseq; i0 += ZG_SP_T * ZG_SP_S) {
     const uint32_t ib = i0 + t * ZG_SP_S;
     const uint32_t n = ib < nseq ? (nseq - ib < ZG_SP_S ? nseq - ib : ZG_SP_S) : 0u;
-    uint2 r[ZG_SP_S];
-    if (n == ZG_SP_S) {
+    uint4 r[ZG_SP_S];
 #pragma unroll
-      for (int j = 0; j < ZG_SP_S; j += 2) {
-        const zg_v4u v = *(const zg_gv4u*)(raw + ib + j);
-        r[j] = make_uint2(v.x, v.y); r[j + 1] = make_uint2(v.z, v.w);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < ZG_SP_S; j++) r[j] = (uint32_t)j < n ? raw[ib + j] : make_uint2(0u, 0u);
+    for (int j = 0; j < ZG_SP_S; j++) {
+      r[j] = make_uint4(0u, 0u, 0u, 0u);
+      if ((uint32_t)j < n) { const zg_v4u v = *(const zg_gv4u*)(raw + ib + j); r[j] = make_uint4(v.x, v.y, v.z, v.w); }
     }
     // values: the three extra-bit fields of a sequence are adjacent, [q_ll, P), at most 63 bits: three dwords cover them
     uint32_t ll[ZG_SP_S], ml[ZG_SP_S], of[ZG_SP_S];
 #pragma unroll
     for (int j = 0; j < ZG_SP_S; j++) {
-      const uint32_t ll_code = (r[j].y >> 10) & 63u, ml_code = r[j].y >> 26, of_code = r[j].x >> 21;
+      const uint32_t ll_code = (r[j].z >> 10) & 63u, ml_code = (r[j].y >> 10) & 63u, of_code = (r[j].x >> 10) & 31u;
       const uint32_t vl = s_llb[ll_code < 36 ? ll_code : 0], vm = s_mlb[ml_code < 53 ? ml_code : 0];
       const uint32_t xb_ll = vl >> 24, xb_ml = vm >> 24;
-      const uint32_t q_ll = (r[j].x & 0x1FFFFFu) - of_code - xb_ml - xb_ll;            // >= 0 for every record zg_k_seq emitted
+      const uint32_t q_ll = r[j].w - of_code - xb_ml - xb_ll;            // >= 0 for every record zg_k_seq emitted
       const uint8_t* pb = bs + (q_ll >> 3);
       const uint32_t w0 = zg_ld32(pb), w1 = zg_ld32(pb + 4), w2 = zg_ld32(pb + 8);
       const uint32_t sh = q_ll & 7u;
