@@ -224,7 +224,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
       (st = b->d_fse.reserve((size_t)nslots * ZG_FSE_SLOT_U32 * 4)) || (st = b->d_huf.reserve((size_t)(bb.nhuf_slots + 1) * ZG_HUF_SLOT_U16 * 2)) ||
       (st = b->d_hufmax.reserve(bb.nhuf_slots + 16)) || (st = b->d_status.reserve(3 * ((size_t)nb * 4 + 16))) ||
       (st = b->d_lit.reserve(bb.lit_bytes + 64)) || (st = b->d_seq.reserve((bb.seq_count + 1) * sizeof(ZgSeq))) ||
-      (st = b->d_raw.reserve((bb.seq_count + 1) * 16)) ||
+      (st = b->d_raw.reserve((bb.seq_count + 2) * 8)) ||
       (st = b->d_seqout.reserve((size_t)nb * sizeof(ZgBlockSeqOut) + 16)) || (st = b->d_pos.reserve((size_t)nb * sizeof(ZgBlockPos) + 16)) ||
       (st = b->d_frameout.reserve((size_t)nf * sizeof(ZgFrameOut) + 16)) ||
       (st = b->fs ? b->fs->d_out.reserve(b->fs->base + b->fs->produced + bb.out_bound + 64, true, stream_) : b->d_dst.reserve(bb.out_bound + 64)) ||
@@ -242,7 +242,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   d.nslots = nslots; d.nhuf_slots = bb.nhuf_slots;
   d.aux = b->d_aux.as<ZgBlockAux>(); d.slot_log = b->d_slot_log.as<uint8_t>();
   d.fse_arena = b->d_fse.as<uint32_t>(); d.huf_arena = b->d_huf.as<uint16_t>(); d.huf_maxbits = b->d_hufmax.as<uint8_t>();
-  d.status = b->d_status.as<uint32_t>(); d.tab_status = d.status + nb + 4; d.lit_status = d.tab_status + nb + 4; d.lit_arena = b->d_lit.as<uint8_t>(); d.seq_arena = b->d_seq.as<ZgSeq>(); d.raw_arena = b->d_raw.as<uint4>();
+  d.status = b->d_status.as<uint32_t>(); d.tab_status = d.status + nb + 4; d.lit_status = d.tab_status + nb + 4; d.lit_arena = b->d_lit.as<uint8_t>(); d.seq_arena = b->d_seq.as<ZgSeq>(); d.raw_arena = b->d_raw.as<uint2>();
   d.seq_out = b->d_seqout.as<ZgBlockSeqOut>(); d.pos = b->d_pos.as<ZgBlockPos>(); d.frame_out = b->d_frameout.as<ZgFrameOut>();
   if (b->fs) {
     if ((st = b->fs->d_fse.reserve(ZG_FSE_SLOT_U32 * 4)) || (st = b->fs->d_huf.reserve(ZG_HUF_SLOT_U16 * 2))) { delete b; return st; }

@@ -24,7 +24,7 @@ struct ZgBatchDev {
   uint32_t* lit_status;        // [nblocks] zg_k_huf's errors, folded into status by zg_k_merge (literals are decoded before sequences: they outrank)
   uint8_t* lit_arena;          // regenerated Huffman literals
   ZgSeq* seq_arena;            // decoded sequences
-  uint4* raw_arena;            // zg_k_seq's raw records {OF, ML, LL table entries, bit position}, same indexing as seq_arena
+  uint2* raw_arena;            // zg_k_seq's raw records, 4 x u16 {OF, ML, LL table entries, bits taken}, same indexing as seq_arena
   ZgBlockSeqOut* seq_out;      // [nblocks]
   ZgBlockPos* pos;             // [nblocks]
   ZgFrameOut* frame_out;       // [nframes]

@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
   __shared__ uint16_t s_tab[ZG_SEQ_G][ZG_FSE_SLOT_U32 + 2];   // + the one-entry dummy table of the position lane
   __shared__ uint8_t s_xb[ZG_SEQ_G][ZG_FSE_SLOT_U32 + 4];    // bits the state's symbol takes besides the state bits (OF: its code), read together with the entry
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[ZG_SEQ_G][ZG_SEQ_RING + 16];
-  __shared__ __attribute__((aligned(16))) uint4 s_out[ZG_SEQ_G][ZG_SEQ_CH];   // raw records: {OF entry, ML entry, LL entry, bit position before the sequence}
+  __shared__ __attribute__((aligned(16))) uint2 s_out[ZG_SEQ_G][ZG_SEQ_CH];   // raw records, 4 x u16: {OF entry, ML entry, LL entry, bits the sequence takes}
   __shared__ uint64_t s_fetch_hi[ZG_SEQ_G], s_fetch_lo[ZG_SEQ_G];   // prologue: the part of each block's stream to load, [lo, hi)
   __shared__ uint8_t s_log[ZG_SEQ_G][4];
   __shared__ int s_ok[ZG_SEQ_G];
@@ -413,13 +413,14 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
     const uint32_t i = (q >= 0 && role != 3u) ? zg_ring_bits(ring32, rbits, q, lg) : 0u;
     e = tab[i]; xb = xtab[i];
     P -= (int32_t)(ll_log + of_log + ml_log);
+    if (owner) d.seq_out[b].pad = (uint32_t)P;   // where the first sequence starts: zg_k_seqpost rebuilds the positions from the bit counts
   }
   zg_v4u piece[ZG_SEQ_PREG];
   uint64_t piece_addr[ZG_SEQ_PREG];
   bool piece_ok[ZG_SEQ_PREG];
 #pragma unroll
   for (int pi = 0; pi < ZG_SEQ_PREG; pi++) { piece[pi] = zg_v4u{0, 0, 0, 0}; piece_addr[pi] = 0; piece_ok[pi] = false; }
-  uint32_t* const out_base = (uint32_t*)&s_out[g][0] + (role == 3u ? 3u : role);   // record {e_of, e_ml, e_ll, position}
+  uint16_t* const out_base = (uint16_t*)&s_out[g][0] + role;   // record {e_of, e_ml, e_ll, bits}: one u16 per lane
 #ifdef ZG_PROFILE_SEQ
   unsigned long long tcs[3] = {0, 0, 0}, tl_ = clock64();
 #define ZG_QTICK(i) { const unsigned long long n_ = clock64(); tcs[i] += n_ - tl_; tl_ = n_; }
@@ -457,7 +458,7 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
           const uint32_t tot = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0xAA, 0xF, 0xF, false);     // quad_perm [2,2,2,2]
           const int32_t q_sof = P - (int32_t)(tot & 255u);
           const bool ok = q_sof >= 0;                               // :209-211
-          out_base[cnt * 4u] = owner ? (uint32_t)P : e;
+          out_base[cnt * 4u] = (uint16_t)(owner ? tot & 255u : e);
           cnt += ok ? 1u : 0u;
           status = ok ? status : ZG_SEQ_NOT_ENOUGH_BYTES;
           // this lane's nb state bits start (incl - pk) >> 8 bits above q_sof; q_sof >= P - 89, so they are inside the window
@@ -489,13 +490,13 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
         if (ro == 0) *(zg_v4u*)(s_ring[g] + ZG_SEQ_RING) = piece[pi];
       }
     }
-    // (2) flush the chunk: the quad's lanes take every fourth record (16 bytes each)
+    // (2) flush the chunk: the quad's lanes take every fourth record (8 bytes each)
 #pragma unroll
     for (int i = 0; i < (ZG_SEQ_CH + 3) / 4; i++) {
       const uint32_t k = role + 4u * (uint32_t)i;
-      if (k < cnt) ((zg_gv4u*)dstp)[k] = *(const zg_v4u*)&s_out[g][k];
+      if (k < cnt) ((zg_gv2u*)dstp)[k] = *(const zg_v2u*)&s_out[g][k];
     }
-    dstp += (uint64_t)cnt * sizeof(uint4);
+    dstp += (uint64_t)cnt * sizeof(uint2);
     // (3) request the next pieces: [want, hi) just below what the ring holds
     {
       uint64_t hi = 0, want = 0;
@@ -557,7 +558,7 @@ __device__ __forceinline__ ZgHistMap zg_map_compose(const ZgHistMap& A, const Zg
 
 __global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
   __shared__ ZgHistMap s_wm[ZG_SP_T / 64];
-  __shared__ uint32_t s_wl[ZG_SP_T / 64], s_wo[ZG_SP_T / 64];
+  __shared__ uint32_t s_wl[ZG_SP_T / 64], s_wo[ZG_SP_T / 64], s_wx[ZG_SP_T / 64];
   __shared__ uint32_t s_err;
   __shared__ uint32_t s_llb[36], s_mlb[53];     // base | extra bits << 24 (a constant-memory lookup is a global load here)
   const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -566,31 +567,56 @@ __global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
   const ZgBlock blk = d.blocks[b];
   const uint32_t nseq = blk.nseq, regen = blk.regen_size;
   const uint8_t* bs = d.src + blk.src_off + d.aux[b].seq_bits_off;
-  const uint4* raw = d.raw_arena + blk.seq_base;
+  const uint2* raw = d.raw_arena + blk.seq_base;
   ZgSeq* out = d.seq_arena + blk.seq_base;
   if (t == 0) s_err = 0xFFFFFFFFu;
   if (t < 36) s_llb[t] = ZG_LL_BASE[t] | ((uint32_t)ZG_LL_BITS[t] << 24);
   if (t < 53) s_mlb[t] = ZG_ML_BASE[t] | ((uint32_t)ZG_ML_BITS[t] << 24);
   ZgHistMap carry = zg_map_identity();
   uint32_t lit_carry = 0, out_carry = 0;
+  uint32_t pos_carry = d.seq_out[b].pad;          // bit position where the next pass's first sequence starts (left by zg_k_seq)
   __syncthreads();
   for (uint32_t i0 = 0; i0 < nseq; i0 += ZG_SP_T * ZG_SP_S) {
     const uint32_t ib = i0 + t * ZG_SP_S;
     const uint32_t n = ib < nseq ? (nseq - ib < ZG_SP_S ? nseq - ib : ZG_SP_S) : 0u;
-    uint4 r[ZG_SP_S];
+    uint2 r[ZG_SP_S];
+    if (n == ZG_SP_S) {
 #pragma unroll
-    for (int j = 0; j < ZG_SP_S; j++) {
-      r[j] = make_uint4(0u, 0u, 0u, 0u);
-      if ((uint32_t)j < n) { const zg_v4u v = *(const zg_gv4u*)(raw + ib + j); r[j] = make_uint4(v.x, v.y, v.z, v.w); }
+      for (int j = 0; j < ZG_SP_S; j += 2) {
+        const zg_v4u v = *(const zg_gv4u*)(raw + ib + j);
+        r[j] = make_uint2(v.x, v.y); r[j + 1] = make_uint2(v.z, v.w);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < ZG_SP_S; j++) r[j] = (uint32_t)j < n ? raw[ib + j] : make_uint2(0u, 0u);
+    }
+    // positions: a record holds the bits its sequence takes; the position before a sequence is the block's start
+    // position minus everything taken before it (prefix sum: thread, wave, workgroup)
+    uint32_t P[ZG_SP_S];
+    {
+      uint32_t tx = 0;
+#pragma unroll
+      for (int j = 0; j < ZG_SP_S; j++) { P[j] = tx; tx += r[j].y >> 16; }
+      uint32_t sx = tx;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const uint32_t px = __shfl_up(sx, off, 64); if ((int)lane >= off) sx += px; }
+      if (lane == 63) s_wx[wv] = sx;
+      __syncthreads();
+      uint32_t before = sx - tx, all = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < ZG_SP_T / 64; w++) { const uint32_t wx = s_wx[w]; if (w < wv) before += wx; all += wx; }
+#pragma unroll
+      for (int j = 0; j < ZG_SP_S; j++) P[j] = pos_carry - before - P[j];
+      pos_carry -= all;
     }
     // values: the three extra-bit fields of a sequence are adjacent, [q_ll, P), at most 63 bits: three dwords cover them
     uint32_t ll[ZG_SP_S], ml[ZG_SP_S], of[ZG_SP_S];
 #pragma unroll
     for (int j = 0; j < ZG_SP_S; j++) {
-      const uint32_t ll_code = (r[j].z >> 10) & 63u, ml_code = (r[j].y >> 10) & 63u, of_code = (r[j].x >> 10) & 31u;
+      const uint32_t of_code = (r[j].x >> 10) & 31u, ml_code = r[j].x >> 26, ll_code = (r[j].y >> 10) & 63u;
       const uint32_t vl = s_llb[ll_code < 36 ? ll_code : 0], vm = s_mlb[ml_code < 53 ? ml_code : 0];
       const uint32_t xb_ll = vl >> 24, xb_ml = vm >> 24;
-      const uint32_t q_ll = r[j].w - of_code - xb_ml - xb_ll;            // >= 0 for every record zg_k_seq emitted
+      const uint32_t q_ll = P[j] - of_code - xb_ml - xb_ll;              // >= 0 for every record zg_k_seq emitted
       const uint8_t* pb = bs + (q_ll >> 3);
       const uint32_t w0 = zg_ld32(pb), w1 = zg_ld32(pb + 4), w2 = zg_ld32(pb + 8);
       const uint32_t sh = q_ll & 7u;
