@@ -892,6 +892,10 @@ __global__ void __launch_bounds__(256) zg_k_lit(ZgBatchDev d) {
 #define ZG_FL_LONG 48      // literal runs / matches longer than this are filled by the whole workgroup, not by one lane
 #define ZG_FL_LONGCAP 352  // > 16384 / 48 + 2
 
+// workgroup barrier that orders LDS only: unlike __syncthreads() it does not wait for this wave's global stores, so
+// the og[] / output stores of a tile drain while the next tile is being set up
+__device__ __forceinline__ void zg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
   __shared__ __attribute__((aligned(16))) uint8_t s_val[ZG_FL_TS];
   __shared__ uint16_t s_par[ZG_FL_TS];
@@ -911,7 +915,7 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
   if (t == 0) { s_err = 0; s_unres = 0; }
   uint32_t unit_size = 0;
 #ifdef ZG_PROFILE_FLAT   // per-phase cycle counters (tools/dev/flat_phases.py); costs registers, off in the product build
-  unsigned long long tc[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
+  unsigned long long tc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
 #define ZG_TICK(i) { const unsigned long long n_ = clock64(); tc[i] += n_ - tlast; tlast = n_; }
 #else
 #define ZG_TICK(i)
@@ -953,7 +957,7 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
       const uint32_t t1 = t0 + ZG_FL_TS < S ? t0 + ZG_FL_TS : S;
       const uint32_t tu0 = bu0 + t0;                             // unit-relative position of the tile
       if (t == 0) { s_next = 0xFFFFFFFFu; s_nlong = 0; }
-      __syncthreads();
+      zg_lds_barrier();
       ZG_TICK(0)
       // ---- S1: parents. Sequence i covers [mdst-ll, mdst+ml); index nseq stands for the trailing literals.
       for (uint32_t i = i_start + t; i <= nseq; i += ZG_FL_T) {
@@ -998,7 +1002,8 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
           }
         }
       }
-      __syncthreads();
+      ZG_TICK(11)
+      zg_lds_barrier();
       {  // long runs: every thread takes a stride of each
         const uint32_t nl = s_nlong < ZG_FL_LONGCAP ? s_nlong : ZG_FL_LONGCAP;
         for (uint32_t e = 0; e < nl; e++) {
@@ -1016,7 +1021,7 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
         }
         if (s_nlong > ZG_FL_LONGCAP && t == 0) s_err = ZG_INTERNAL;   // cannot happen: every entry covers > ZG_FL_LONG bytes of the tile
       }
-      __syncthreads();
+      zg_lds_barrier();
       ZG_TICK(1)
       i_start = s_next == 0xFFFFFFFFu ? nseq + 1 : s_next;
       if (s_err) break;
@@ -1029,22 +1034,26 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
         const uint32_t x = t + k * ZG_FL_T;
         if (t0 + x < t1 && s_par[x] < 0x8000u) unresolved |= 1u << k;
       }
-      for (int round = 0; round < 40; round++) {
-        if (!__syncthreads_or(unresolved != 0)) break;
-#ifdef ZG_PROFILE_FLAT
-        tc[5]++;
-#endif
-        uint32_t m = unresolved;
-        while (m) {
-          const uint32_t k = (uint32_t)__builtin_ctz(m);
-          m &= m - 1;
-          const uint32_t x = t + k * ZG_FL_T;
-          const uint16_t q = s_par[s_par[x]];
-          if (q >= 0x8000u) unresolved &= ~(1u << k);   // s_par[x] is the root
-          else s_par[x] = q;                            // u16 stores are atomic: a reader sees the old or the new ancestor, both valid
+      // Asynchronous pointer jumping: a byte's pointer only ever moves to another of its ancestors, so stale reads are
+      // harmless and no barrier is needed between rounds; a byte is done when its pointer's pointer is a root marker.
+      // Four bytes per step keep four dependent LDS read pairs in flight.
+      for (uint32_t guard = 0; unresolved && guard < (1u << 16); guard++) {
+        uint32_t m = unresolved, kk[4], pp[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { kk[j] = m ? (uint32_t)__builtin_ctz(m) : 32u; m &= m - 1; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) pp[j] = kk[j] < 32u ? s_par[t + kk[j] * ZG_FL_T] : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; j++) pp[j] = s_par[pp[j]];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (kk[j] < 32u) {
+            if (pp[j] >= 0x8000u) unresolved &= ~(1u << kk[j]);     // its pointer is the root
+            else s_par[t + kk[j] * ZG_FL_T] = (uint16_t)pp[j];     // u16 stores are atomic
+          }
         }
       }
-      if (__syncthreads_or(unresolved != 0)) { if (t == 0) s_err = ZG_INTERNAL; __syncthreads(); break; }  // cannot happen: depth < 2^14
+      if (__syncthreads_or(unresolved != 0)) { if (t == 0) s_err = ZG_INTERNAL; __syncthreads(); break; }  // cannot happen: every step moves a pointer up its chain
       ZG_TICK(2)
       // ---- S3: every byte of the tile becomes one word of og[]: 0x80000000 | value when the byte is known, else its
       // effective offset (< 2^31). A byte whose root's parent lies in an earlier tile of the unit takes that byte's word
@@ -1068,9 +1077,14 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
           w[k] = par_u >= 0 ? 0xC0000000u | (uint32_t)par_u            // an earlier tile of this unit: already final
                             : (tu0 + xr) + (uint32_t)(-par_u);         // reaches before the unit
         }
+        ZG_TICK(8)
         uint32_t o2[ZG_FL_PER];
 #pragma unroll
         for (int k = 0; k < ZG_FL_PER; k++) o2[k] = og[(w[k] >> 30) == 3u ? (w[k] & 0x3FFFFFFFu) : 0u];   // clamped addresses: all loads issued back to back
+#ifdef ZG_PROFILE_FLAT
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        ZG_TICK(9)
 #pragma unroll
         for (int k = 0; k < ZG_FL_PER; k++) {
           const uint32_t xr = t + k * ZG_FL_T;
@@ -1084,11 +1098,12 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
           nun += (v >> 31) ? 0u : 1u;
         }
       }
+      ZG_TICK(10)
       if (nun) atomicAdd(&s_unres, nun);
 #ifdef ZG_PROFILE_FLAT
       if (d.dbg && t == 0) atomicAdd(&d.dbg[7], 1ull);
 #endif
-      __syncthreads();
+      zg_lds_barrier();
       ZG_TICK(3)
       // ---- S4: publish the tile
       {
@@ -1098,7 +1113,7 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
         for (uint32_t i = t; i < n8; i += ZG_FL_T) ((zg_u64u*)(o + i * 8))->v = *(const uint64_t*)(s_val + i * 8);
         for (uint32_t i = (n8 << 3) + t; i < n; i += ZG_FL_T) o[i] = s_val[i];
       }
-      __syncthreads();  // the next tile reads og[] / out[] of this one
+      zg_lds_barrier();  // s_val / s_par are reused; this tile's og[] stores are drained by the S2 barriers of the next tile, long before its S3 reads them
       ZG_TICK(4)
     }
     if (s_err) {
@@ -1109,7 +1124,7 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
   __syncthreads();
   if (t == 0) { ZgUnitInfo ui; ui.size = unit_size; ui.unresolved = s_unres; d.unit_info[blockIdx.x] = ui; }
 #ifdef ZG_PROFILE_FLAT
-  if (t == 0 && d.dbg) for (int i = 0; i < 6; i++) atomicAdd(&d.dbg[i], tc[i]);
+  if (t == 0 && d.dbg) for (int i = 0; i < 12; i++) if (i != 7) atomicAdd(&d.dbg[i], tc[i]);
 #endif
 #undef ZG_TICK
 }
