@@ -1160,13 +1160,9 @@ __device__ __forceinline__ bool zg_frame_wait(uint32_t* bar, uint32_t step, uint
   return s_ok != 0;
 }
 
-#define ZG_SW_B 8       // groups of 4 output bytes a thread has in flight
+#define ZG_SW_B 4       // groups of 4 output bytes a thread has in flight
 #define ZG_SW_UMAX 512  // units whose metadata is staged in LDS at a time
 
-// og words with bit 31 are finished bytes (0x80000000 | value): 0 = nothing to do; the others are effective offsets
-__device__ __forceinline__ uint4 zg_og_open(uint4 o) {
-  return make_uint4((uint32_t)max((int32_t)o.x, 0), (uint32_t)max((int32_t)o.y, 0), (uint32_t)max((int32_t)o.z, 0), (uint32_t)max((int32_t)o.w, 0));
-}
 struct ZgSweepUnit { uint32_t size, unresolved; uint64_t out_off, og_base; };
 
 template <int T>
@@ -1217,7 +1213,7 @@ __global__ void __launch_bounds__(T) zg_k_sweep(ZgBatchDev d) {
 #pragma unroll
       for (int k = 0; k < ZG_SW_B; k++) {
         const uint32_t g = g0 + t + k * T;
-        onext[k] = g < g1 ? zg_og_open(*(const uint4*)(og + 4 * (uint64_t)g)) : make_uint4(0, 0, 0, 0);
+        onext[k] = g < g1 ? *(const uint4*)(og + 4 * (uint64_t)g) : make_uint4(0, 0, 0, 0);
       }
     };
     uint32_t ui = next_unit(0);
@@ -1239,40 +1235,46 @@ __global__ void __launch_bounds__(T) zg_k_sweep(ZgBatchDev d) {
 #pragma unroll
           for (int k = 0; k < ZG_SW_B; k++) {
             const uint32_t g = base + k * T;
-            o[k] = g < g1 ? zg_og_open(*(const uint4*)(og + 4 * (uint64_t)g)) : make_uint4(0, 0, 0, 0);
+            o[k] = g < g1 ? *(const uint4*)(og + 4 * (uint64_t)g) : make_uint4(0, 0, 0, 0);
           }
         }
-        // all loads of the batch first (sources lie before the unit: no hazards with this step's stores), then the stores
-        uint32_t w4[ZG_SW_B], cur[ZG_SW_B];
-        uint8_t b0[ZG_SW_B], b1[ZG_SW_B], b2[ZG_SW_B], b3[ZG_SW_B];
-        bool run[ZG_SW_B];
+        // All loads of the batch first (sources lie before the unit: no hazards with this step's stores), then the stores.
+        // A group is four output bytes at w. Byte i comes from (w + i) - o_i = (w - o_i) + i: byte i of the dword at w - o_i,
+        // so one dword load per DISTINCT offset of the group serves it (usually one or two: a match boundary), and finished
+        // bytes bring their value in their own word.
+        uint32_t lA[ZG_SW_B], lB[ZG_SW_B], lC[ZG_SW_B], lD[ZG_SW_B];
 #pragma unroll
         for (int k = 0; k < ZG_SW_B; k++) {
-          run[k] = o[k].x != 0 && o[k].x == o[k].y && o[k].x == o[k].z && o[k].x == o[k].w;
-          const uint8_t* w = out + 4 * (uint64_t)(base + k * T);
-          const bool any = (o[k].x | o[k].y | o[k].z | o[k].w) != 0;
-          w4[k] = run[k] ? zg_ld32(w - o[k].x) : 0;
-          const bool mix = any && !run[k];
-          cur[k] = mix ? zg_ld32(w) : 0;
-          b0[k] = mix && o[k].x ? w[0 - (int64_t)o[k].x] : 0;
-          b1[k] = mix && o[k].y ? w[1 - (int64_t)o[k].y] : 0;
-          b2[k] = mix && o[k].z ? w[2 - (int64_t)o[k].z] : 0;
-          b3[k] = mix && o[k].w ? w[3 - (int64_t)o[k].w] : 0;
-        }
-#pragma unroll
-        for (int k = 0; k < ZG_SW_B; k++) {
+          const uint4 q = o[k];
           const uint32_t g = base + k * T;
-          if (g >= g1 || (o[k].x | o[k].y | o[k].z | o[k].w) == 0) continue;
-          uint8_t* w = out + 4 * (uint64_t)g;
-          uint32_t v = w4[k];
-          if (!run[k]) {
-            v = cur[k];
-            if (o[k].x) v = (v & 0xFFFFFF00u) | b0[k];
-            if (o[k].y) v = (v & 0xFFFF00FFu) | ((uint32_t)b1[k] << 8);
-            if (o[k].z) v = (v & 0xFF00FFFFu) | ((uint32_t)b2[k] << 16);
-            if (o[k].w) v = (v & 0x00FFFFFFu) | ((uint32_t)b3[k] << 24);
-          }
-          __hip_atomic_store((uint32_t*)w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through store (sc1)
+          const uint8_t* w = g < g1 ? out + 4 * (uint64_t)g : out;
+          const bool ux = (int32_t)q.x > 0, uy = (int32_t)q.y > 0, uz = (int32_t)q.z > 0, uw = (int32_t)q.w > 0;
+          const bool nD = uw && !(ux && q.w == q.x);
+          const bool nB = uy && !(ux && q.y == q.x) && !(uw && q.y == q.w);
+          const bool nC = uz && !(ux && q.z == q.x) && !(uw && q.z == q.w) && !(uy && q.z == q.y);
+          lA[k] = ux ? zg_ld32(w - q.x) : 0u;
+          lD[k] = nD ? zg_ld32(w - q.w) : 0u;
+          lB[k] = nB ? zg_ld32(w - q.y) : 0u;
+          lC[k] = nC ? zg_ld32(w - q.z) : 0u;
+        }
+        // One wait for all of them here: otherwise the compiler waits (vmcnt is in order: also for the store just issued)
+        // before each group's first use, and the write-through stores complete one after the other.
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+#pragma unroll
+        for (int k = 0; k < ZG_SW_B; k++) {
+          const uint4 q = o[k];
+          const uint32_t g = base + k * T;
+          const bool ux = (int32_t)q.x > 0, uy = (int32_t)q.y > 0, uz = (int32_t)q.z > 0, uw = (int32_t)q.w > 0;
+          if (g >= g1 || !(ux || uy || uz || uw)) continue;
+          const uint32_t sw = (ux && q.w == q.x) ? lA[k] : lD[k];
+          const uint32_t sy = (ux && q.y == q.x) ? lA[k] : (uw && q.y == q.w) ? sw : lB[k];
+          const uint32_t sz = (ux && q.z == q.x) ? lA[k] : (uw && q.z == q.w) ? sw : (uy && q.z == q.y) ? sy : lC[k];
+          const uint32_t b0 = (ux ? lA[k] : q.x) & 0xFFu;
+          const uint32_t b1 = uy ? (sy >> 8) & 0xFFu : q.y & 0xFFu;
+          const uint32_t b2 = uz ? (sz >> 16) & 0xFFu : q.z & 0xFFu;
+          const uint32_t b3 = uw ? sw >> 24 : q.w & 0xFFu;
+          const uint32_t v = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+          __hip_atomic_store((uint32_t*)(out + 4 * (uint64_t)g), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through store (sc1)
         }
       }
       if (wg.rank == wg.wpf - 1) {          // tail bytes of the unit
