@@ -1163,6 +1163,12 @@ __device__ __forceinline__ bool zg_frame_wait(uint32_t* bar, uint32_t step, uint
 #define ZG_SW_B 4       // groups of 4 output bytes a thread has in flight
 #define ZG_SW_UMAX 512  // units whose metadata is staged in LDS at a time
 
+// four bytes at any address through one dword-aligned 8-byte load and a funnel shift (a misaligned dword load is split by the hardware)
+__device__ __forceinline__ uint32_t zg_ld32_fun(const uint8_t* p) {
+  const uint64_t a = (uint64_t)p;
+  const zg_v2u v = *(const zg_gv2u*)(a & ~3ull);
+  return __builtin_amdgcn_alignbit(v.y, v.x, ((uint32_t)a & 3u) * 8u);
+}
 struct ZgSweepUnit { uint32_t size, unresolved; uint64_t out_off, og_base; };
 
 template <int T>
@@ -1252,10 +1258,10 @@ __global__ void __launch_bounds__(T) zg_k_sweep(ZgBatchDev d) {
           const bool nD = uw && !(ux && q.w == q.x);
           const bool nB = uy && !(ux && q.y == q.x) && !(uw && q.y == q.w);
           const bool nC = uz && !(ux && q.z == q.x) && !(uw && q.z == q.w) && !(uy && q.z == q.y);
-          lA[k] = ux ? zg_ld32(w - q.x) : 0u;
-          lD[k] = nD ? zg_ld32(w - q.w) : 0u;
-          lB[k] = nB ? zg_ld32(w - q.y) : 0u;
-          lC[k] = nC ? zg_ld32(w - q.z) : 0u;
+          lA[k] = ux ? zg_ld32_fun(w - q.x) : 0u;
+          lD[k] = nD ? zg_ld32_fun(w - q.w) : 0u;
+          lB[k] = nB ? zg_ld32_fun(w - q.y) : 0u;
+          lC[k] = nC ? zg_ld32_fun(w - q.z) : 0u;
         }
         // One wait for all of them here: otherwise the compiler waits (vmcnt is in order: also for the store just issued)
         // before each group's first use, and the write-through stores complete one after the other.
