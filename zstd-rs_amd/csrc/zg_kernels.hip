@@ -26,6 +26,14 @@ typedef uint32_t zg_v4u __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) zg_v4u zg_gv4u;   // 16 bytes in global memory: global_load/store, not flat
 typedef uint32_t zg_v2u __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) zg_v2u zg_gv2u;
+typedef uint32_t zg_v3u __attribute__((ext_vector_type(3)));
+typedef __attribute__((address_space(1))) zg_v3u zg_gv3u;
+// four bytes at any address through one dword-aligned 8-byte load and a funnel shift (a misaligned dword load is split by the hardware)
+__device__ __forceinline__ uint32_t zg_ld32_fun(const uint8_t* p) {
+  const uint64_t a = (uint64_t)p;
+  const zg_v2u v = *(const zg_gv2u*)(a & ~3ull);
+  return __builtin_amdgcn_alignbit(v.y, v.x, ((uint32_t)a & 3u) * 8u);
+}
 
 __device__ __forceinline__ void zg_set_status(uint32_t* status, uint32_t b, int st) {
   if (st) atomicCAS(&status[b], 0u, (uint32_t)st);
@@ -617,10 +625,10 @@ __global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
       const uint32_t vl = s_llb[ll_code < 36 ? ll_code : 0], vm = s_mlb[ml_code < 53 ? ml_code : 0];
       const uint32_t xb_ll = vl >> 24, xb_ml = vm >> 24;
       const uint32_t q_ll = P[j] - of_code - xb_ml - xb_ll;              // >= 0 for every record zg_k_seq emitted
-      const uint8_t* pb = bs + (q_ll >> 3);
-      const uint32_t w0 = zg_ld32(pb), w1 = zg_ld32(pb + 4), w2 = zg_ld32(pb + 8);
-      const uint32_t sh = q_ll & 7u;
-      const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+      const uint64_t pa = (uint64_t)(bs + (q_ll >> 3));
+      const zg_v3u wv = *(const zg_gv3u*)(pa & ~3ull);                    // dword-aligned: a misaligned load is split by the hardware
+      const uint32_t sh = ((uint32_t)pa & 3u) * 8u + (q_ll & 7u);         // <= 31
+      const uint32_t lo = __builtin_amdgcn_alignbit(wv.y, wv.x, sh), hi = __builtin_amdgcn_alignbit(wv.z, wv.y, sh);
       const uint32_t ll_add = __builtin_amdgcn_ubfe(lo, 0u, xb_ll);
       const uint32_t ml_add = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(hi, lo, xb_ll), 0u, xb_ml);
       const uint32_t so = xb_ll + xb_ml;                                  // <= 32
@@ -1163,12 +1171,6 @@ __device__ __forceinline__ bool zg_frame_wait(uint32_t* bar, uint32_t step, uint
 #define ZG_SW_B 4       // groups of 4 output bytes a thread has in flight
 #define ZG_SW_UMAX 512  // units whose metadata is staged in LDS at a time
 
-// four bytes at any address through one dword-aligned 8-byte load and a funnel shift (a misaligned dword load is split by the hardware)
-__device__ __forceinline__ uint32_t zg_ld32_fun(const uint8_t* p) {
-  const uint64_t a = (uint64_t)p;
-  const zg_v2u v = *(const zg_gv2u*)(a & ~3ull);
-  return __builtin_amdgcn_alignbit(v.y, v.x, ((uint32_t)a & 3u) * 8u);
-}
 struct ZgSweepUnit { uint32_t size, unresolved; uint64_t out_off, og_base; };
 
 template <int T>
