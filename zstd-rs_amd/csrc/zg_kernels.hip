@@ -905,11 +905,13 @@ __global__ void __launch_bounds__(256) zg_k_lit(ZgBatchDev d) {
 __device__ __forceinline__ void zg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_val[ZG_FL_TS];
-  __shared__ uint16_t s_par[ZG_FL_TS];
-  __shared__ uint32_t s_soff[ZG_FL_SOFF];   // offset of the tile's j-th sequence (for bytes whose parent is before the tile)
-  __shared__ uint32_t s_next, s_err, s_unres, s_nlong;
-  __shared__ uint32_t s_long[ZG_FL_LONGCAP][4];   // runs longer than ZG_FL_LONG bytes: {x0, x1, literal source index | offset, kind<<31 | j}
+  __shared__ __attribute__((aligned(16))) uint8_t s_val[ZG_FL_TS];      // values of the bytes that are known (read by S4)
+  __shared__ __attribute__((aligned(16))) uint16_t s_par[ZG_FL_TS];    // 0xFFFF literal, 0x8000 parent before the tile, else tile-relative parent
+  __shared__ uint32_t s_bits[ZG_FL_TS / 32];                           // marks: the first tile byte of every sequence
+  __shared__ uint16_t s_cnt[ZG_FL_TS / 32];                            // marks before each word of s_bits
+  __shared__ uint32_t s_roff[ZG_FL_SOFF], s_rlit[ZG_FL_SOFF], s_rsm[ZG_FL_SOFF];   // per sequence of the tile: offset; literal source index at its first tile byte; first tile byte | first match byte << 16
+  __shared__ uint32_t s_wtot[ZG_FL_T / 64];
+  __shared__ uint32_t s_next, s_err, s_unres;
   const uint32_t t = threadIdx.x;
   const ZgUnit un = d.units[blockIdx.x];
   if (t == 0) { ZgUnitInfo ui; ui.size = 0; ui.unresolved = 0; d.unit_info[blockIdx.x] = ui; }
@@ -964,10 +966,13 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
     for (uint32_t t0 = 0; t0 < S; t0 += ZG_FL_TS) {
       const uint32_t t1 = t0 + ZG_FL_TS < S ? t0 + ZG_FL_TS : S;
       const uint32_t tu0 = bu0 + t0;                             // unit-relative position of the tile
-      if (t == 0) { s_next = 0xFFFFFFFFu; s_nlong = 0; }
+      const uint32_t n = t1 - t0;
+      if (t == 0) s_next = 0xFFFFFFFFu;
+      if (t < ZG_FL_TS / 32) s_bits[t] = 0;
       zg_lds_barrier();
       ZG_TICK(0)
-      // ---- S1: parents. Sequence i covers [mdst-ll, mdst+ml); index nseq stands for the trailing literals.
+      // ---- S1a: one thread per sequence i (index nseq stands for the trailing literals). It covers [a, m0) with literals and
+      // [m0, m1) with its match; the part inside the tile is described by one record and one mark at its first tile byte.
       for (uint32_t i = i_start + t; i <= nseq; i += ZG_FL_T) {
         uint32_t a, m0, m1, lstart, off = 0;
         if (i < nseq) {
@@ -982,58 +987,69 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
         }
         if (m1 > t1 || a >= t1) atomicMin(&s_next, i);  // first sequence that reaches beyond this tile starts the next one
         if (a >= t1) break;
-        uint32_t x0 = a > t0 ? a : t0, x1 = m0 < t1 ? m0 : t1;  // literal run (usually 0-3 bytes: fetched 4 at a time)
-        if (x1 > x0 && x1 - x0 > ZG_FL_LONG) {
-          const uint32_t e = atomicAdd(&s_nlong, 1u);
-          if (e < ZG_FL_LONGCAP) { s_long[e][0] = x0; s_long[e][1] = x1; s_long[e][2] = lstart + (x0 - a); s_long[e][3] = 0; }
-        } else if (lit_rle) {
-          for (uint32_t x = x0; x < x1; x++) { s_val[x - t0] = lit_fill; s_par[x - t0] = ZG_PAR_LIT; }
-        } else {
-          for (uint32_t x = x0; x < x1; x += 4) {
-            const uint32_t w4 = zg_ld32(lit + lstart + (x - a));   // literal buffers are padded: reading 3 bytes past the run is safe
-            const uint32_t n = x1 - x < 4 ? x1 - x : 4;
-            for (uint32_t k = 0; k < n; k++) { s_val[x + k - t0] = (uint8_t)(w4 >> (8 * k)); s_par[x + k - t0] = ZG_PAR_LIT; }
-          }
-        }
-        x0 = m0 > t0 ? m0 : t0; x1 = m1 < t1 ? m1 : t1;         // match
-        if (x0 < x1 && off) {
-          const uint32_t j = i - i_start;                       // tile-local sequence index (< ZG_FL_SOFF: matches are >= 3 bytes)
-          if (off > x0 - t0) {
-            if (j < ZG_FL_SOFF) s_soff[j] = off; else atomicCAS(&s_err, 0u, (uint32_t)ZG_INTERNAL);
-          }
-          if (x1 - x0 > ZG_FL_LONG) {
-            const uint32_t e = atomicAdd(&s_nlong, 1u);
-            if (e < ZG_FL_LONGCAP) { s_long[e][0] = x0; s_long[e][1] = x1; s_long[e][2] = off; s_long[e][3] = 0x80000000u | j; }
-          } else {
-            for (uint32_t x = x0; x < x1; x++)
-              s_par[x - t0] = (x - t0 >= off) ? (uint16_t)(x - t0 - off) : (uint16_t)(0x8000u | j);
-          }
-        }
+        const uint32_t j = i - i_start;                 // tile-local sequence index (< ZG_FL_SOFF: a sequence spans >= 3 bytes)
+        if (j >= ZG_FL_SOFF) { atomicCAS(&s_err, 0u, (uint32_t)ZG_INTERNAL); break; }
+        const uint32_t st = (a > t0 ? a : t0) - t0;
+        const uint32_t mr = (m0 > t0 ? (m0 < t1 ? m0 : t1) : t0) - t0;
+        s_roff[j] = off;
+        s_rlit[j] = lstart + (a > t0 ? 0u : t0 - a);
+        s_rsm[j] = st | (mr << 16);
+        atomicOr(&s_bits[st >> 5], 1u << (st & 31u));
       }
       ZG_TICK(11)
       zg_lds_barrier();
-      {  // long runs: every thread takes a stride of each
-        const uint32_t nl = s_nlong < ZG_FL_LONGCAP ? s_nlong : ZG_FL_LONGCAP;
-        for (uint32_t e = 0; e < nl; e++) {
-          const uint32_t x0 = s_long[e][0], x1 = s_long[e][1], v = s_long[e][2], kj = s_long[e][3];
-          if (kj >> 31) {
-            const uint32_t j = kj & 0x7FFFFFFFu;
-            for (uint32_t x = x0 + t; x < x1; x += ZG_FL_T)
-              s_par[x - t0] = (x - t0 >= v) ? (uint16_t)(x - t0 - v) : (uint16_t)(0x8000u | j);
-          } else {
-            for (uint32_t x = x0 + t; x < x1; x += ZG_FL_T) {
-              s_val[x - t0] = lit_rle ? lit_fill : lit[v + (x - x0)];
-              s_par[x - t0] = ZG_PAR_LIT;
-            }
-          }
+      // ---- S1b: marks before every word (prefix sum over the 512 words)
+      {
+        uint32_t c = 0, sc = 0;
+        if (t < ZG_FL_TS / 32) {
+          c = (uint32_t)__popc(s_bits[t]);
+          sc = c;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(sc, o, 64); if ((int)(t & 63) >= o) sc += v; }
+          if ((t & 63) == 63) s_wtot[t >> 6] = sc;
         }
-        if (s_nlong > ZG_FL_LONGCAP && t == 0) s_err = ZG_INTERNAL;   // cannot happen: every entry covers > ZG_FL_LONG bytes of the tile
+        zg_lds_barrier();
+        if (t < ZG_FL_TS / 32) {
+          uint32_t before = sc - c;
+          for (uint32_t w = 0; w < (t >> 6); w++) before += s_wtot[w];
+          s_cnt[t] = (uint16_t)before;
+        }
+        zg_lds_barrier();
+      }
+      i_start = s_next == 0xFFFFFFFFu ? nseq + 1 : s_next;
+      if (s_err) break;
+      // ---- S1c: one thread per 16 consecutive tile bytes walks them with the marks. Each byte becomes a literal (value to
+      // s_val), a match byte whose parent lies before the tile (0x8000 | its sequence), or a match byte with its parent
+      // inside the tile (pointer). 16 bytes of values and 32 bytes of pointers leave as three 16-byte LDS stores.
+      {
+        const uint32_t x0 = t * ZG_FL_PER;
+        if (x0 < n) {
+          const uint32_t word = s_bits[x0 >> 5];
+          const uint32_t bits16 = (word >> (x0 & 31u)) & 0xFFFFu;
+          int32_t j = (int32_t)s_cnt[x0 >> 5] + __popc(word & ((1u << (x0 & 31u)) - 1u)) - 1;   // sequence of byte x0 - 1
+          uint32_t r_off = 0, r_lit = 0, r_st = 0, r_m0 = 0;
+          if (j >= 0) { r_off = s_roff[j]; r_lit = s_rlit[j]; const uint32_t sm = s_rsm[j]; r_st = sm & 0xFFFFu; r_m0 = sm >> 16; }
+          uint32_t kind[ZG_FL_PER], lv[ZG_FL_PER];
+#pragma unroll
+          for (int k = 0; k < ZG_FL_PER; k++) {
+            const uint32_t x = x0 + k;
+            if ((bits16 >> k) & 1u) { j++; r_off = s_roff[j]; r_lit = s_rlit[j]; const uint32_t sm = s_rsm[j]; r_st = sm & 0xFFFFu; r_m0 = sm >> 16; }
+            const bool is_lit = x < r_m0 || x >= n;
+            lv[k] = (!is_lit || lit_rle || x >= n) ? (uint32_t)lit_fill : (uint32_t)lit[r_lit + (x - r_st)];
+            kind[k] = is_lit ? 0xFFFFu : r_off <= x ? x - r_off : 0x8000u | (uint32_t)j;
+          }
+          uint32_t vv[ZG_FL_PER / 4], pp[ZG_FL_PER / 2];
+#pragma unroll
+          for (int k = 0; k < ZG_FL_PER / 4; k++) vv[k] = (lv[4 * k] & 0xFFu) | ((lv[4 * k + 1] & 0xFFu) << 8) | ((lv[4 * k + 2] & 0xFFu) << 16) | (lv[4 * k + 3] << 24);
+#pragma unroll
+          for (int k = 0; k < ZG_FL_PER / 2; k++) pp[k] = kind[2 * k] | (kind[2 * k + 1] << 16);
+          *(zg_v4u*)&s_val[x0] = zg_v4u{vv[0], vv[1], vv[2], vv[3]};
+          *(zg_v4u*)&s_par[x0] = zg_v4u{pp[0], pp[1], pp[2], pp[3]};
+          *(zg_v4u*)&s_par[x0 + 8] = zg_v4u{pp[4], pp[5], pp[6], pp[7]};
+        }
       }
       zg_lds_barrier();
       ZG_TICK(1)
-      i_start = s_next == 0xFFFFFFFFu ? nseq + 1 : s_next;
-      if (s_err) break;
-      // ---- S2: pointer jumping inside the tile. Pointers are < 0x8000; 0x8000|j = parent before the tile; 0xFFFF = literal.
       // A byte's pointer lives in s_par only: after the phase it is the tile-relative root (or still >= 0x8000: the byte
       // is its own root). Each round a thread visits just its still-unresolved bytes (few: most parents are before the tile).
       uint32_t unresolved = 0;
@@ -1080,7 +1096,7 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
           const uint32_t r = own >= 0x8000u ? xr : own;     // tile-relative root
           const uint16_t rp = own >= 0x8000u ? own : s_par[r];
           if (rp == ZG_PAR_LIT) { const uint8_t v = s_val[r]; s_val[xr] = v; w[k] = 0x80000000u | v; continue; }
-          const uint32_t off_r = s_soff[rp & 0x7FFFu];
+          const uint32_t off_r = s_roff[rp & 0x7FFFu];
           const int32_t par_u = (int32_t)(tu0 + r) - (int32_t)off_r;   // unit position of the root's parent (< tu0)
           w[k] = par_u >= 0 ? 0xC0000000u | (uint32_t)par_u            // an earlier tile of this unit: already final
                             : (tu0 + xr) + (uint32_t)(-par_u);         // reaches before the unit
