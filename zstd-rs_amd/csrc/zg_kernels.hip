@@ -973,28 +973,39 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
       ZG_TICK(0)
       // ---- S1a: one thread per sequence i (index nseq stands for the trailing literals). It covers [a, m0) with literals and
       // [m0, m1) with its match; the part inside the tile is described by one record and one mark at its first tile byte.
-      for (uint32_t i = i_start + t; i <= nseq; i += ZG_FL_T) {
-        uint32_t a, m0, m1, lstart, off = 0;
-        if (i < nseq) {
-          const ZgSeq q = sq[i];
-          const uint32_t next = i + 1 < nseq ? sq[i + 1].lit_start : so.sum_ll;
-          lstart = q.lit_start; m0 = q.mdst; m1 = q.mdst + q.ml; a = m0 - (next - lstart);
-          off = zg_sym_resolve(q.of, p.hist_init);
-          if (off == 0) atomicCAS(&s_err, 0u, (uint32_t)ZG_EXE_ZERO_OFFSET);                     // sequence_execution.rs:28-30
-          else if ((uint64_t)off > reach + m0) atomicCAS(&s_err, 0u, (uint32_t)ZG_EXE_OFFSET_TOO_BIG);  // decode_buffer.rs:173-177
-        } else {
-          lstart = so.sum_ll; a = so.sum_ll + so.sum_ml; m0 = m1 = S;
+      {
+        auto place = [&](uint32_t i, const zg_v4u q, uint32_t next) -> bool {   // false: this and all later sequences start behind the tile
+          uint32_t a, m0, m1, lstart, off = 0;
+          if (i < nseq) {
+            lstart = q.w; m0 = q.z; m1 = q.z + q.y; a = m0 - (next - lstart);          // ZgSeq {of, ml, mdst, lit_start}
+            off = zg_sym_resolve(q.x, p.hist_init);
+            if (off == 0) atomicCAS(&s_err, 0u, (uint32_t)ZG_EXE_ZERO_OFFSET);                     // sequence_execution.rs:28-30
+            else if ((uint64_t)off > reach + m0) atomicCAS(&s_err, 0u, (uint32_t)ZG_EXE_OFFSET_TOO_BIG);  // decode_buffer.rs:173-177
+          } else {
+            lstart = so.sum_ll; a = so.sum_ll + so.sum_ml; m0 = m1 = S;
+          }
+          if (m1 > t1 || a >= t1) atomicMin(&s_next, i);  // first sequence that reaches beyond this tile starts the next one
+          if (a >= t1) return false;
+          const uint32_t j = i - i_start;                 // tile-local sequence index (< ZG_FL_SOFF: a sequence spans >= 3 bytes)
+          if (j >= ZG_FL_SOFF) { atomicCAS(&s_err, 0u, (uint32_t)ZG_INTERNAL); return false; }
+          const uint32_t st = (a > t0 ? a : t0) - t0;
+          const uint32_t mr = (m0 > t0 ? (m0 < t1 ? m0 : t1) : t0) - t0;
+          s_roff[j] = off;
+          s_rlit[j] = lstart + (a > t0 ? 0u : t0 - a);
+          s_rsm[j] = st | (mr << 16);
+          atomicOr(&s_bits[st >> 5], 1u << (st & 31u));
+          return true;
+        };
+        // two sequences per thread and round, both loaded before either is used: one memory round trip for a typical tile
+        for (uint32_t i = i_start + t; i <= nseq; i += 2 * ZG_FL_T) {
+          const uint32_t i2 = i + ZG_FL_T;
+          zg_v4u qa = {0, 0, 0, 0}, qb = {0, 0, 0, 0};
+          uint32_t na = so.sum_ll, nb = so.sum_ll;
+          if (i < nseq) { qa = *(const zg_gv4u*)(sq + i); if (i + 1 < nseq) na = sq[i + 1].lit_start; }
+          if (i2 < nseq) { qb = *(const zg_gv4u*)(sq + i2); if (i2 + 1 < nseq) nb = sq[i2 + 1].lit_start; }
+          if (!place(i, qa, na)) break;
+          if (i2 > nseq || !place(i2, qb, nb)) break;
         }
-        if (m1 > t1 || a >= t1) atomicMin(&s_next, i);  // first sequence that reaches beyond this tile starts the next one
-        if (a >= t1) break;
-        const uint32_t j = i - i_start;                 // tile-local sequence index (< ZG_FL_SOFF: a sequence spans >= 3 bytes)
-        if (j >= ZG_FL_SOFF) { atomicCAS(&s_err, 0u, (uint32_t)ZG_INTERNAL); break; }
-        const uint32_t st = (a > t0 ? a : t0) - t0;
-        const uint32_t mr = (m0 > t0 ? (m0 < t1 ? m0 : t1) : t0) - t0;
-        s_roff[j] = off;
-        s_rlit[j] = lstart + (a > t0 ? 0u : t0 - a);
-        s_rsm[j] = st | (mr << 16);
-        atomicOr(&s_bits[st >> 5], 1u << (st & 31u));
       }
       ZG_TICK(11)
       zg_lds_barrier();
