@@ -44,18 +44,35 @@ __device__ __forceinline__ void zg_set_status(uint32_t* status, uint32_t b, int 
 // Reproduces maybe_update_fse_tables (sequence_section_decoder.rs:294-410) and
 // HuffmanTable::build_decoder (huff0_decoder.rs:117-124) for the blocks that define tables.
 // ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) zg_k_tables(ZgBatchDev d) {
+#define ZG_TAB_L 32   // blocks (lanes) per workgroup: 4 KiB of LDS each
+#define ZG_TAB_HDR 384 // bytes of a section staged for parsing (three FSE descriptions are < 300 bytes, a Huffman one <= 129)
+__global__ void __launch_bounds__(ZG_TAB_L) zg_k_tables(ZgBatchDev d) {
+  // A table is built where it can be read back without touching global memory: the build loops re-read what they just
+  // wrote (fse_decoder.rs:226-262), and on gfx950 a load behind a global store waits for that store (one in-order
+  // counter). So the probabilities, the per-symbol counters, the Huffman weights and the table under construction live
+  // in LDS, one private slice per lane; a finished table leaves with plain stores.
+  __shared__ int16_t s_probs[ZG_TAB_L][256];
+  __shared__ uint16_t s_counter[ZG_TAB_L][256];
+  __shared__ uint32_t s_stage[ZG_TAB_L][512];
+  __shared__ uint32_t s_fsew[ZG_TAB_L][64];
+  __shared__ uint8_t s_weights[ZG_TAB_L][264];
+  __shared__ __attribute__((aligned(16))) uint8_t s_hdr[ZG_TAB_L][ZG_TAB_HDR + 32];   // the description being parsed (bit reads are dependent loads: from LDS, not from HBM)
+  const uint32_t ln = threadIdx.x;
   uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  int16_t probs[256];
-  uint16_t counter[256];
+  int16_t* probs = s_probs[ln];
+  uint16_t* counter = s_counter[ln];
+  uint32_t* stage = s_stage[ln];
   if (b == d.nblocks) {  // predefined tables (acc logs 6/5/6)
     uint32_t* slot = d.fse_arena + (uint64_t)d.nblocks * ZG_FSE_SLOT_U32;
     for (int i = 0; i < 36; i++) probs[i] = ZG_LL_DEFAULT[i];
-    zg_fse_build(probs, 36, 6, ZG_KIND_LL, slot + ZG_FSE_LL_OFF, counter);
+    zg_fse_build(probs, 36, 6, ZG_KIND_LL, stage, counter);
+    for (int i = 0; i < 64; i++) slot[ZG_FSE_LL_OFF + i] = stage[i];
     for (int i = 0; i < 29; i++) probs[i] = ZG_OF_DEFAULT[i];
-    zg_fse_build(probs, 29, 5, ZG_KIND_OF, slot + ZG_FSE_OF_OFF, counter);
+    zg_fse_build(probs, 29, 5, ZG_KIND_OF, stage, counter);
+    for (int i = 0; i < 32; i++) slot[ZG_FSE_OF_OFF + i] = stage[i];
     for (int i = 0; i < 53; i++) probs[i] = ZG_ML_DEFAULT[i];
-    zg_fse_build(probs, 53, 6, ZG_KIND_ML, slot + ZG_FSE_ML_OFF, counter);
+    zg_fse_build(probs, 53, 6, ZG_KIND_ML, stage, counter);
+    for (int i = 0; i < 64; i++) slot[ZG_FSE_ML_OFF + i] = stage[i];
     uint8_t* lg = d.slot_log + (uint64_t)d.nblocks * 4;
     lg[0] = 6; lg[1] = 5; lg[2] = 6; lg[3] = 0;
     return;
@@ -67,38 +84,66 @@ __global__ void __launch_bounds__(64) zg_k_tables(ZgBatchDev d) {
   ZgBlockAux aux;
   aux.seq_bits_off = blk.seq_off; aux.huf_desc_bytes = 0; aux.log[0] = aux.log[1] = aux.log[2] = 0; aux.pad = 0;
   int st = ZG_OK;
+  // copy n bytes (+8 for the bit windows) from g into the lane's LDS slice, dword-aligned 16-byte loads, 8 in flight
+  auto stage_in = [&](const uint8_t* g, uint32_t n) -> const uint8_t* {
+    const uint64_t ga = (uint64_t)g & ~3ull;
+    const uint32_t sh = (uint32_t)((uint64_t)g & 3u), nv = (n + 8 + sh + 15) / 16;
+    for (uint32_t v0 = 0; v0 < nv; v0 += 8) {
+      zg_v4u r[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) r[k] = v0 + k < nv ? *(const zg_gv4u*)(ga + 16ull * (v0 + k)) : zg_v4u{0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 8; k++) if (v0 + k < nv) *(zg_v4u*)(s_hdr[ln] + 16 * (v0 + k)) = r[k];
+    }
+    return s_hdr[ln] + sh;
+  };
   if (blk.lit_type == ZG_LT_COMPRESSED) {
-    uint8_t weights[264];
-    uint32_t fsew[64];
+    uint8_t* weights = s_weights[ln];
+    uint32_t* fsew = s_fsew[ln];
     int nw = 0, mb = 0;
     uint32_t used = 0;
-    st = zg_huf_read_weights(body + blk.lit_off, blk.lit_comp_size, weights, &nw, &used, fsew, probs, counter);
+    const uint32_t hl = blk.lit_comp_size < 136u ? blk.lit_comp_size : 136u;   // a tree description is at most 129 bytes
+    const uint8_t* hs = stage_in(body + blk.lit_off, hl);
+    st = zg_huf_read_weights(hs, hl, weights, &nw, &used, fsew, probs, counter);
     if (!st) st = zg_huf_build(weights, nw, d.huf_arena + (uint64_t)blk.huf_slot * ZG_HUF_SLOT_U16, &mb);
     if (!st) { d.huf_maxbits[blk.huf_slot] = (uint8_t)mb; aux.huf_desc_bytes = used; }
   }
   if (!st && blk.nseq > 0) {
-    const uint8_t* p = body + blk.seq_off;
-    uint32_t rem = blk.src_len - blk.seq_off;
+    const uint32_t rem_all = blk.src_len - blk.seq_off;
     uint32_t* slot = d.fse_arena + (uint64_t)b * ZG_FSE_SLOT_U32;
     // order LL, OF, ML (sequence_section_decoder.rs:305,341,376)
     const int kinds[3] = {ZG_KIND_LL, ZG_KIND_OF, ZG_KIND_ML};
     const int modes[3] = {blk.seq_modes >> 6, (blk.seq_modes >> 4) & 3, (blk.seq_modes >> 2) & 3};
     const int max_log[3] = {9, 8, 9}, max_sym[3] = {35, 31, 52};
     const uint32_t offs[3] = {ZG_FSE_LL_OFF, ZG_FSE_OF_OFF, ZG_FSE_ML_OFF};
-    for (int k = 0; k < 3 && !st; k++) {
-      if (modes[k] == ZG_MODE_FSE) {
-        int np, al;
-        uint32_t used;
-        st = zg_fse_read_probs(p, rem, max_log[k], max_sym[k], probs, &np, &al, &used);
-        if (!st) st = zg_fse_build(probs, np, al, kinds[k], slot + offs[k], counter);
-        if (!st) { aux.log[k] = (uint8_t)al; p += used; rem -= used; }
-      } else if (modes[k] == ZG_MODE_RLE) {
-        if (rem == 0) st = ZG_SEQ_RLE_BYTE;
-        else if (p[0] > max_sym[k]) st = ZG_SEQ_RLE_BYTE;
-        else { slot[offs[k]] = zg_fse_pack(kinds[k], 0, 0, p[0]); aux.log[k] = 0; p += 1; rem -= 1; }
+    uint32_t done = 0;
+    auto parse = [&](const uint8_t* p0, uint32_t lim) {   // inlined twice: once on LDS addresses, once on global ones
+      const uint8_t* p = p0;
+      uint32_t rem = lim;
+      st = ZG_OK;
+      for (int k = 0; k < 3 && !st; k++) {
+        if (modes[k] == ZG_MODE_FSE) {
+          int np, al;
+          uint32_t used;
+          st = zg_fse_read_probs(p, rem, max_log[k], max_sym[k], probs, &np, &al, &used);
+          if (!st) st = zg_fse_build(probs, np, al, kinds[k], stage, counter);
+          if (!st) {
+            for (uint32_t i = 0; i < (1u << al); i++) slot[offs[k] + i] = stage[i];
+            aux.log[k] = (uint8_t)al; p += used; rem -= used;
+          }
+        } else if (modes[k] == ZG_MODE_RLE) {
+          if (rem == 0) st = ZG_SEQ_RLE_BYTE;
+          else if (p[0] > max_sym[k]) st = ZG_SEQ_RLE_BYTE;
+          else { slot[offs[k]] = zg_fse_pack(kinds[k], 0, 0, p[0]); aux.log[k] = 0; p += 1; rem -= 1; }
+        }
       }
-    }
-    aux.seq_bits_off = (uint32_t)(p - body);
+      done = (uint32_t)(p - p0);
+    };
+    // from the staged copy; if that fails and the copy was shorter than the section, again from the section itself
+    const uint32_t lim = rem_all > ZG_TAB_HDR ? ZG_TAB_HDR : rem_all;
+    parse(stage_in(body + blk.seq_off, lim), lim);
+    if (st && lim != rem_all) parse(body + blk.seq_off, rem_all);
+    aux.seq_bits_off = blk.seq_off + done;
     uint8_t* lg = d.slot_log + (uint64_t)b * 4;
     lg[0] = aux.log[0]; lg[1] = aux.log[1]; lg[2] = aux.log[2]; lg[3] = 0;
   }
@@ -1440,7 +1485,7 @@ void zg_launch_calib(const void* src, void* dst, uint64_t bytes, hipStream_t s) 
 // ------------------------------------------------------------------------------------------------------------
 void zg_launch_tables(const ZgBatchDev& d, hipStream_t s) {
   uint32_t n = d.nblocks + 1;
-  hipLaunchKernelGGL(zg_k_tables, dim3((n + 63) / 64), dim3(64), 0, s, d);
+  hipLaunchKernelGGL(zg_k_tables, dim3((n + ZG_TAB_L - 1) / ZG_TAB_L), dim3(ZG_TAB_L), 0, s, d);
 }
 void zg_launch_huf(const ZgBatchDev& d, hipStream_t s) {
   if (d.nhuf_groups) hipLaunchKernelGGL(zg_k_huf, dim3(d.nhuf_groups), dim3(ZG_HUF_T), 0, s, d);
