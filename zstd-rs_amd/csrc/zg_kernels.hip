@@ -1296,15 +1296,13 @@ __global__ void __launch_bounds__(T) zg_k_sweep(ZgBatchDev d) {
         onext[k] = g < g1 ? *(const uint4*)(og + 4 * (uint64_t)g) : make_uint4(0, 0, 0, 0);
       }
     };
-    uint32_t ui = next_unit(0);
-    if (ui < cn) prefetch(ui);
-    while (ui < cn) {
-      const ZgSweepUnit su = s_u[ui];
+    auto sweep_unit = [&](uint32_t iu, bool prefetched) {
+      const ZgSweepUnit su = s_u[iu];
       uint8_t* out = frame_out + su.out_off;
       const uint32_t* og = d.og + su.og_base;
       const uint32_t n4 = su.size >> 2, per = (n4 + wg.wpf - 1) / wg.wpf;
       const uint32_t g0 = wg.rank * per, g1 = g0 + per < n4 ? g0 + per : n4;
-      bool first = true;
+      bool first = prefetched;
       for (uint32_t base = g0 + t; base < g1 + t; base += T * ZG_SW_B) {   // every thread runs the same number of batches
         uint4 o[ZG_SW_B];
         if (first) {
@@ -1363,6 +1361,11 @@ __global__ void __launch_bounds__(T) zg_k_sweep(ZgBatchDev d) {
           if ((int32_t)o > 0) __hip_atomic_store(&out[x], out[(int64_t)x - o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
+    };
+    uint32_t ui = next_unit(0);
+    if (ui < cn) prefetch(ui);
+    while (ui < cn) {
+      sweep_unit(ui, true);
       ZG_STICK(0)
       steps++;
       if (wg.wpf > 1) zg_frame_arrive(d.bar + (size_t)f * 16, steps, wg.rank, wg.wpf, t);
