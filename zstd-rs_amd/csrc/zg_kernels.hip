@@ -154,22 +154,26 @@ __global__ void __launch_bounds__(ZG_TAB_L) zg_k_tables(ZgBatchDev d) {
 
 // ------------------------------------------------------------------------------------------------------------
 // zg_k_huf: Huffman literal streams (literals_section_decoder.rs:40-158; HuffmanDecoder huff0_decoder.rs:25-53).
-// One workgroup per group of streams that share a table; the table (<= 2^11 x 2 B) is staged in LDS; one lane decodes
-// one stream. A stream is a serial chain (peek max_bits bits -> table -> consume num_bits), so the loop is kept free of
-// global memory like zg_k_seq's: every lane owns a 128-byte ring of its stream in LDS (dword k of lane l at [k][l]:
-// bank-conflict free) that it extends downwards with 16-byte loads landing one phase (16 symbols) later, and it
-// writes its literals 16 bytes at a time.
+// A stream is a serial chain (peek max_bits bits -> table -> consume num_bits), up to 32 K symbols long, but Huffman
+// codes SELF-SYNCHRONISE: a decoder started at a wrong bit position falls onto the true code boundaries after a few
+// symbols. So one WAVE decodes one stream, 64 x 64 bits at a time (a window): lane l guesses that a code ends exactly at
+// the top of its 64-bit chunk and decodes the chunk; then every lane whose entry differs from its upper neighbour's exit
+// decodes again from that exit, until all agree — lane 0 starts at the true position, so by induction all of them are
+// then on the true path. Most chunks converge after the second pass. Symbols are staged per lane in LDS, counted,
+// prefix-summed and written out; the exit of the last lane is the next window's true entry.
+// One workgroup = up to ZG_HUF_GROUP streams that share a table (the four streams of a block), the table staged once.
 // ------------------------------------------------------------------------------------------------------------
-#define ZG_HUF_T ZG_HUF_GROUP   // one wave: 12 KiB of LDS, so it fits beside the zg_k_seq workgroups it runs next to
-#define ZG_HUF_RDW 32                      // ring dwords per lane
-#define ZG_HUF_CH 16                       // symbols per phase: <= 16 x 11 bits = 22 bytes of input, 16 bytes of output
-#define ZG_HUF_MARGIN 64                   // bytes kept resident below the read position (two phases + a piece)
+#define ZG_HUF_T (64 * ZG_HUF_GROUP)
+#define ZG_HP_CB 64                         // bits per lane and window
+#define ZG_HP_WBYTES (64 * ZG_HP_CB / 8)    // stream bytes covered by a window
+#define ZG_HP_STAGE (ZG_HP_WBYTES + 48)     // staged: the window, 2 bytes below it (an 11-bit peek), alignment slack, 8 bytes above
 
 __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
   __shared__ uint16_t s_tab[ZG_HUF_SLOT_U16];
-  __shared__ uint32_t s_ring[ZG_HUF_RDW][ZG_HUF_T];
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[ZG_HUF_GROUP][ZG_HP_STAGE];
+  __shared__ uint8_t s_sym[ZG_HUF_GROUP][64][ZG_HP_CB];      // a chunk of 64 bits holds at most 64 symbols
   const ZgHufGroup grp = d.huf_groups[blockIdx.x];
-  const uint32_t t = threadIdx.x;
+  const uint32_t t = threadIdx.x, wv = t >> 6, lane = t & 63;
   unsigned max_bits = grp.slot >= 0 ? d.huf_maxbits[grp.slot] : 0;
   if (max_bits > 11) max_bits = 0;
   if (max_bits) {
@@ -177,137 +181,127 @@ __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
     for (uint32_t i = t; i < (1u << max_bits); i += ZG_HUF_T) s_tab[i] = g[i];
   }
   __syncthreads();
-  if (t >= grp.nitems) return;
-  uint32_t item = d.huf_items[grp.first_item + t];
-  uint32_t b = item >> 2, k = item & 3;
+  if (wv >= grp.nitems) return;                       // whole waves leave: no workgroup barrier below
+  const uint32_t item = d.huf_items[grp.first_item + wv];
+  const uint32_t b = item >> 2, k = item & 3;
   const ZgBlock blk = d.blocks[b];
-  if (max_bits == 0) { zg_set_status(d.lit_status, b, ZG_LIT_UNINIT_HUF); return; }  // literals_section_decoder.rs:60-63
-  if (d.tab_status[b]) return;                                                    // its own tree description failed
-  uint32_t desc = blk.lit_type == ZG_LT_COMPRESSED ? d.aux[b].huf_desc_bytes : 0;
-  if (desc > blk.lit_comp_size) { zg_set_status(d.lit_status, b, ZG_INTERNAL); return; }
-  const uint8_t* pay = d.src + blk.src_off + blk.lit_off + desc;
-  uint32_t total = blk.lit_comp_size - desc;
-  uint32_t regen = blk.regen_size;
-  uint8_t* lit = d.lit_arena + blk.lit_base;
-  const uint8_t* sp;
-  uint32_t slen, doff, cap;
-  if (blk.nstreams == 4) {
-    if (total < 6) { zg_set_status(d.lit_status, b, ZG_LIT_MISSING_JUMP); return; }
-    uint32_t j1 = zg_ld16(pay), j2 = j1 + zg_ld16(pay + 2), j3 = j2 + zg_ld16(pay + 4);
-    uint32_t rest = total - 6;
-    if (rest < j3) { zg_set_status(d.lit_status, b, ZG_LIT_MISSING_BYTES); return; }
-    uint32_t start = k == 0 ? 0 : k == 1 ? j1 : k == 2 ? j2 : j3;
-    uint32_t end = k == 0 ? j1 : k == 1 ? j2 : k == 2 ? j3 : rest;
-    sp = pay + 6 + start; slen = end - start;
-    uint32_t seg = (regen + 3) / 4;
-    doff = k * seg; if (doff > regen) doff = regen;
-    cap = k < 3 ? seg : regen - doff;
-    if (cap > regen - doff) cap = regen - doff;
-  } else {
-    sp = pay; slen = total; doff = 0; cap = regen;
-  }
-  const uint32_t lastb = slen ? sp[slen - 1] : 0;
-  if (slen == 0 || lastb == 0) { zg_set_status(d.lit_status, b, ZG_LIT_EXTRA_PADDING); return; }  // :98-109
-  const uint32_t hb = zg_hbit(lastb) - 1;                     // payload bits of the last byte (below the marker)
-  const uint32_t T = (slen - 1) * 8 + hb;                     // bits of the stream
-  const uint64_t A = (uint64_t)sp, A_last = A + slen - 1;
-  uint8_t* dst = lit + doff;
-  // ---- ring: prologue fill from the piece holding the last byte down to MARGIN below it
-  const uint64_t floorA = A & ~15ull;
-  uint64_t lo;
-  {
-    const uint64_t top = (A_last & ~15ull) + 16;
-    uint64_t want = A_last > ZG_HUF_MARGIN + 16 ? (A_last - ZG_HUF_MARGIN - 16) & ~15ull : 0;
-    if (want < floorA) want = floorA;
-    for (uint64_t addr = top - 16; addr + 16 > want && addr >= want; addr -= 16) {
-      const zg_v4u v = *(const zg_gv4u*)addr;
-      const uint32_t di = (uint32_t)(addr >> 2);
-      s_ring[(di + 0) & (ZG_HUF_RDW - 1)][t] = v.x; s_ring[(di + 1) & (ZG_HUF_RDW - 1)][t] = v.y;
-      s_ring[(di + 2) & (ZG_HUF_RDW - 1)][t] = v.z; s_ring[(di + 3) & (ZG_HUF_RDW - 1)][t] = v.w;
-      if (addr == 0) break;
-    }
-    lo = want;
-  }
-  // ---- bit buffer: upcoming bits sit at the top of bitbuf; dwords are popped downwards from the ring
-  uint64_t wp = A_last >> 2;                                  // absolute index of the next dword to pop
-  auto pop = [&]() -> uint32_t {
-    uint32_t v = s_ring[wp & (ZG_HUF_RDW - 1)][t];
-    const uint64_t wa = wp << 2;
-    if (wa + 4 <= A) v = 0;                                   // below the stream: zeros (bit_reader_reverse.rs:76-86)
-    else if (wa < A) v &= ~0u << (8u * (uint32_t)(A - wa));   // dword straddles the stream start
-    wp--;
-    return v;
-  };
-  uint64_t bitbuf;
-  int32_t avail;
-  {
-    const uint32_t vb = (uint32_t)(A_last & 3) + 1;           // bytes of the top dword that belong to the stream
-    uint32_t v = pop();
-    v <<= 8u * (4 - vb);                                      // last stream byte at the top
-    bitbuf = (uint64_t)v << 32;
-    bitbuf <<= (8 - hb);                                      // drop the zero padding and the marker bit
-    avail = (int32_t)(8 * vb) - (int32_t)(8 - hb);
-    if (avail <= 32) { bitbuf |= (uint64_t)pop() << (32 - avail); avail += 32; }
-  }
-  uint32_t c = 0, n = 0;                                      // bits consumed, symbols emitted
-  zg_v4u piece[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-  uint64_t piece_addr[2] = {0, 0};
-  bool piece_ok[2] = {false, false};
-  bool overflow = false;
-  while (c < T && !overflow) {
-    // ---- mover: land the pieces requested one phase ago, request the next ones
-#pragma unroll
-    for (int pi = 0; pi < 2; pi++) {
-      if (piece_ok[pi]) {
-        const uint32_t di = (uint32_t)(piece_addr[pi] >> 2);
-        s_ring[(di + 0) & (ZG_HUF_RDW - 1)][t] = piece[pi].x; s_ring[(di + 1) & (ZG_HUF_RDW - 1)][t] = piece[pi].y;
-        s_ring[(di + 2) & (ZG_HUF_RDW - 1)][t] = piece[pi].z; s_ring[(di + 3) & (ZG_HUF_RDW - 1)][t] = piece[pi].w;
-      }
-      piece_ok[pi] = false;
-    }
-    {
-      const uint64_t pos = wp << 2;
-      uint64_t want = pos > ZG_HUF_MARGIN ? (pos - ZG_HUF_MARGIN) & ~15ull : 0;
-      if (want < floorA) want = floorA;
-#pragma unroll
-      for (int pi = 0; pi < 2; pi++) {
-        if (lo > want) {
-          lo -= 16;
-          piece[pi] = *(const zg_gv4u*)lo; piece_addr[pi] = lo; piece_ok[pi] = true;
-        }
-      }
-    }
-    // ---- decode phase: LDS and registers only
-    uint32_t ow[4] = {0, 0, 0, 0};
-    uint32_t m = 0;
-#pragma unroll
-    for (int i = 0; i < ZG_HUF_CH; i++) {
-      if (c < T && !overflow) {
-        if (n + m >= cap) overflow = true;                    // more symbols than the section holds
+  // the checks of the stream header: every lane computes the same, lane 0 reports
+  int hst = ZG_OK;
+  const uint8_t* sp = nullptr;
+  uint32_t slen = 0, doff = 0, cap = 0;
+  if (max_bits == 0) hst = ZG_LIT_UNINIT_HUF;                                     // literals_section_decoder.rs:60-63
+  else if (d.tab_status[b]) return;                                                // its own tree description failed
+  else {
+    const uint32_t desc = blk.lit_type == ZG_LT_COMPRESSED ? d.aux[b].huf_desc_bytes : 0;
+    if (desc > blk.lit_comp_size) hst = ZG_INTERNAL;
+    else {
+      const uint8_t* pay = d.src + blk.src_off + blk.lit_off + desc;
+      const uint32_t total = blk.lit_comp_size - desc, regen = blk.regen_size;
+      if (blk.nstreams == 4) {
+        if (total < 6) hst = ZG_LIT_MISSING_JUMP;
         else {
-          const uint32_t e = s_tab[(uint32_t)(bitbuf >> 32) >> (32 - max_bits)];
-          const uint32_t nb = e >> 8;
-          ow[i >> 2] |= (e & 255u) << (8 * (i & 3));
-          m++;
-          bitbuf <<= nb; avail -= (int32_t)nb; c += nb;
-          if (avail <= 32) { bitbuf |= (uint64_t)pop() << (32 - avail); avail += 32; }
+          const uint32_t j1 = zg_ld16(pay), j2 = j1 + zg_ld16(pay + 2), j3 = j2 + zg_ld16(pay + 4);
+          const uint32_t rest = total - 6;
+          if (rest < j3) hst = ZG_LIT_MISSING_BYTES;
+          else {
+            const uint32_t start = k == 0 ? 0 : k == 1 ? j1 : k == 2 ? j2 : j3;
+            const uint32_t end = k == 0 ? j1 : k == 1 ? j2 : k == 2 ? j3 : rest;
+            sp = pay + 6 + start; slen = end - start;
+            const uint32_t seg = (regen + 3) / 4;
+            doff = k * seg; if (doff > regen) doff = regen;
+            cap = k < 3 ? seg : regen - doff;
+            if (cap > regen - doff) cap = regen - doff;
+          }
+        }
+      } else { sp = pay; slen = total; doff = 0; cap = regen; }
+    }
+  }
+  uint32_t lastb = 0;
+  if (!hst) {
+    lastb = slen ? sp[slen - 1] : 0;
+    if (slen == 0 || lastb == 0) hst = ZG_LIT_EXTRA_PADDING;                       // :98-109
+  }
+  if (hst) { if (lane == 0) zg_set_status(d.lit_status, b, hst); return; }
+  const uint32_t hb = zg_hbit(lastb) - 1;                     // payload bits of the last byte (below the marker)
+  const int32_t T = (int32_t)((slen - 1) * 8 + hb);           // bits of the stream; position P = bits not yet consumed
+  const int64_t A = (int64_t)(uint64_t)sp;                    // address of stream bit 0
+  uint8_t* dst = d.lit_arena + blk.lit_base + doff;
+  uint8_t* win = s_win[wv];
+  uint8_t* sym = s_sym[wv][lane];
+  const uint32_t pmask = (1u << max_bits) - 1u;
+  int32_t top = T;                                            // true entry position of the window
+  uint32_t ndone = 0;
+  bool overflow = false;
+  while (top > 0) {
+    // ---- stage the bytes that hold bits [top - 4096 - 16, top + 8): 16-byte pieces, zeros below the stream start
+    const int64_t lowbit = (int64_t)top - 64 * ZG_HP_CB - 16;
+    const int64_t wb0 = (A + (lowbit >> 3)) & ~15ll;          // address of staged byte 0 (may lie below the stream)
+    for (uint32_t pc = lane; pc < ZG_HP_STAGE / 16; pc += 64) {
+      const int64_t addr = wb0 + 16 * (int64_t)pc;
+      zg_v4u v = {0, 0, 0, 0};
+      if (addr + 16 > A) {
+        v = *(const zg_gv4u*)(uint64_t)addr;
+        if (addr < A) {                                       // piece straddles the stream start: zero the bytes below it
+          const uint32_t zb = (uint32_t)(A - addr);           // 1..15
+          uint32_t q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int i = 0; i < 4; i++) { const uint32_t lo = 4u * i; q[i] = zb >= lo + 4 ? 0u : zb > lo ? q[i] & (0xFFFFFFFFu << (8 * (zb - lo))) : q[i]; }
+          v = zg_v4u{q[0], q[1], q[2], q[3]};
         }
       }
+      *(zg_v4u*)(win + 16 * pc) = v;
     }
-    // ---- write the phase's literals
-    if (m == ZG_HUF_CH) {
-      ((zg_u64u*)(dst + n))->v = (uint64_t)ow[0] | ((uint64_t)ow[1] << 32);
-      ((zg_u64u*)(dst + n + 8))->v = (uint64_t)ow[2] | ((uint64_t)ow[3] << 32);
-    } else {
-      for (uint32_t i = 0; i < m; i++) dst[n + i] = (uint8_t)(ow[i >> 2] >> (8 * (i & 3)));
+    const int32_t wq0 = (int32_t)((wb0 - A) * 8);             // stream bit index of staged bit 0 (LDS of one wave is in order: no barrier)
+    const uint32_t* win32 = (const uint32_t*)win;
+    // one pass over the lane's chunk from position `from`: symbols to s_sym, returns the exit position
+    const int32_t U = top - (int32_t)lane * ZG_HP_CB, L = U - ZG_HP_CB > 0 ? U - ZG_HP_CB : 0;
+    uint32_t n = 0;
+    auto pass = [&](int32_t from) -> int32_t {
+      int32_t P = from;
+      n = 0;
+      while (P > L) {
+        const int32_t q = P - (int32_t)max_bits;              // >= -11: inside the staged zeros below the stream
+        const uint32_t rb = (uint32_t)(q - wq0);
+        const uint32_t d0 = win32[rb >> 5], d1 = win32[(rb >> 5) + 1];
+        const uint32_t e = s_tab[__builtin_amdgcn_alignbit(d1, d0, rb & 31u) & pmask];
+        sym[n++] = (uint8_t)e;
+        P -= (int32_t)(e >> 8);
+        if (n >= ZG_HP_CB) break;                              // cannot happen with a valid table (every code has >= 1 bit)
+      }
+      return P;
+    };
+    const bool active = U > 0;
+    int32_t entry = U, E = U;
+    if (active) E = pass(entry);                               // the guess: a code ends at the top of the chunk (true for lane 0)
+    for (int round = 0; round < 64; round++) {
+      const int32_t pe = __shfl_up(E, 1, 64);
+      const bool need = active && lane > 0 && pe != entry;
+      if (!__any(need)) break;
+      if (need) { entry = pe; E = pass(entry); }
     }
-    n += m;
+    // ---- all lanes are on the true path: count, place, write
+    uint32_t incl = active ? n : 0u;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += v; }
+    const uint32_t wtot = __shfl(incl, 63, 64);
+    const uint32_t at = ndone + incl - (active ? n : 0u);
+    if (active) {
+      for (uint32_t i = 0; i < n; i++) {
+        if (at + i < cap) dst[at + i] = sym[i];
+      }
+    }
+    if (ndone + wtot > cap) overflow = true;                   // more symbols than the section holds
+    ndone += wtot;
+    // the last active lane's exit is the next entry; it is <= 0 when that lane's chunk reaches the stream start
+    const uint32_t nact = (uint32_t)((top + ZG_HP_CB - 1) / ZG_HP_CB);
+    top = __shfl(E, (int)(nact < 64u ? nact - 1u : 63u), 64);
+    if (overflow) break;
   }
   int st = ZG_OK;
   if (overflow) st = ZG_LIT_COUNT_MISMATCH;
-  else if (blk.nstreams == 4 && c != T) st = ZG_LIT_BITSTREAM_MISMATCH;   // bits_remaining != -max_bits (:116-121)
-  else if (n != cap) st = ZG_LIT_COUNT_MISMATCH;                           // :150-155 (per stream, spec split)
-  zg_set_status(d.lit_status, b, st);
+  else if (blk.nstreams == 4 && top != 0) st = ZG_LIT_BITSTREAM_MISMATCH;   // bits_remaining != -max_bits (:116-121)
+  else if (ndone != cap) st = ZG_LIT_COUNT_MISMATCH;                        // :150-155 (per stream, spec split)
+  if (lane == 0) zg_set_status(d.lit_status, b, st);
 }
 
 // ------------------------------------------------------------------------------------------------------------
