@@ -161,17 +161,18 @@ __global__ void __launch_bounds__(ZG_TAB_L) zg_k_tables(ZgBatchDev d) {
 // decodes again from that exit, until all agree — lane 0 starts at the true position, so by induction all of them are
 // then on the true path. Most chunks converge after the second pass. Symbols are staged per lane in LDS, counted,
 // prefix-summed and written out; the exit of the last lane is the next window's true entry.
-// One workgroup = up to ZG_HUF_GROUP streams that share a table (the four streams of a block), the table staged once.
+// One workgroup = up to ZG_HUF_GROUP streams that share a table, the table staged once per workgroup.
 // ------------------------------------------------------------------------------------------------------------
 #define ZG_HUF_T (64 * ZG_HUF_GROUP)
-#define ZG_HP_CB 64                         // bits per lane and window
+#define ZG_HP_CB 128                        // bits per lane and window
+#define ZG_HP_WARM 32                       // bits a lane starts above its chunk, to be on a code boundary when it enters it
 #define ZG_HP_WBYTES (64 * ZG_HP_CB / 8)    // stream bytes covered by a window
-#define ZG_HP_STAGE (ZG_HP_WBYTES + 48)     // staged: the window, 2 bytes below it (an 11-bit peek), alignment slack, 8 bytes above
+#define ZG_HP_STAGE (ZG_HP_WBYTES + 64)     // staged: the window, 2 bytes below it (an 11-bit peek), alignment slack, 16+ bytes above
 
 __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
   __shared__ uint16_t s_tab[ZG_HUF_SLOT_U16];
   __shared__ __attribute__((aligned(16))) uint8_t s_win[ZG_HUF_GROUP][ZG_HP_STAGE];
-  __shared__ uint8_t s_sym[ZG_HUF_GROUP][64][ZG_HP_CB];      // a chunk of 64 bits holds at most 64 symbols
+  __shared__ uint8_t s_sym[ZG_HUF_GROUP][ZG_HP_CB][64];      // [symbol index][lane]: a chunk of CB bits holds at most CB symbols
   const ZgHufGroup grp = d.huf_groups[blockIdx.x];
   const uint32_t t = threadIdx.x, wv = t >> 6, lane = t & 63;
   unsigned max_bits = grp.slot >= 0 ? d.huf_maxbits[grp.slot] : 0;
@@ -227,14 +228,14 @@ __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
   const int64_t A = (int64_t)(uint64_t)sp;                    // address of stream bit 0
   uint8_t* dst = d.lit_arena + blk.lit_base + doff;
   uint8_t* win = s_win[wv];
-  uint8_t* sym = s_sym[wv][lane];
+  uint8_t* sym = &s_sym[wv][0][lane];
   const uint32_t pmask = (1u << max_bits) - 1u;
   int32_t top = T;                                            // true entry position of the window
   uint32_t ndone = 0;
   bool overflow = false;
   while (top > 0) {
     // ---- stage the bytes that hold bits [top - 4096 - 16, top + 8): 16-byte pieces, zeros below the stream start
-    const int64_t lowbit = (int64_t)top - 64 * ZG_HP_CB - 16;
+    const int64_t lowbit = (int64_t)top - 64 * ZG_HP_CB - 16;   // staged up to top + 128 bits at least (warm-up + a two-dword read)
     const int64_t wb0 = (A + (lowbit >> 3)) & ~15ll;          // address of staged byte 0 (may lie below the stream)
     for (uint32_t pc = lane; pc < ZG_HP_STAGE / 16; pc += 64) {
       const int64_t addr = wb0 + 16 * (int64_t)pc;
@@ -256,28 +257,35 @@ __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
     // one pass over the lane's chunk from position `from`: symbols to s_sym, returns the exit position
     const int32_t U = top - (int32_t)lane * ZG_HP_CB, L = U - ZG_HP_CB > 0 ? U - ZG_HP_CB : 0;
     uint32_t n = 0;
+    int32_t entry = U;                                          // where the lane's recorded symbols start
     auto pass = [&](int32_t from) -> int32_t {
       int32_t P = from;
+      while (P > U) {                                           // warm-up above the chunk: not recorded
+        const uint32_t rb = (uint32_t)(P - (int32_t)max_bits - wq0);
+        const uint32_t d0 = win32[rb >> 5], d1 = win32[(rb >> 5) + 1];
+        P -= (int32_t)(s_tab[__builtin_amdgcn_alignbit(d1, d0, rb & 31u) & pmask] >> 8);
+      }
+      entry = P;
       n = 0;
       while (P > L) {
         const int32_t q = P - (int32_t)max_bits;              // >= -11: inside the staged zeros below the stream
         const uint32_t rb = (uint32_t)(q - wq0);
         const uint32_t d0 = win32[rb >> 5], d1 = win32[(rb >> 5) + 1];
         const uint32_t e = s_tab[__builtin_amdgcn_alignbit(d1, d0, rb & 31u) & pmask];
-        sym[n++] = (uint8_t)e;
+        sym[64 * n++] = (uint8_t)e;
         P -= (int32_t)(e >> 8);
         if (n >= ZG_HP_CB) break;                              // cannot happen with a valid table (every code has >= 1 bit)
       }
       return P;
     };
     const bool active = U > 0;
-    int32_t entry = U, E = U;
-    if (active) E = pass(entry);                               // the guess: a code ends at the top of the chunk (true for lane 0)
+    int32_t E = U;
+    if (active) E = pass(lane ? U + ZG_HP_WARM : U);           // lane 0 starts at the true position
     for (int round = 0; round < 64; round++) {
       const int32_t pe = __shfl_up(E, 1, 64);
       const bool need = active && lane > 0 && pe != entry;
       if (!__any(need)) break;
-      if (need) { entry = pe; E = pass(entry); }
+      if (need) E = pass(pe);
     }
     // ---- all lanes are on the true path: count, place, write
     uint32_t incl = active ? n : 0u;
@@ -287,7 +295,7 @@ __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
     const uint32_t at = ndone + incl - (active ? n : 0u);
     if (active) {
       for (uint32_t i = 0; i < n; i++) {
-        if (at + i < cap) dst[at + i] = sym[i];
+        if (at + i < cap) dst[at + i] = sym[64 * i];
       }
     }
     if (ndone + wtot > cap) overflow = true;                   // more symbols than the section holds

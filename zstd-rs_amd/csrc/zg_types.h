@@ -72,7 +72,7 @@ enum { ZG_MODE_PREDEFINED = 0, ZG_MODE_RLE = 1, ZG_MODE_FSE = 2, ZG_MODE_REPEAT 
 #define ZG_FSE_OF_OFF 1024
 // Huffman table arena: one slot of 2048 u16 per table.
 #define ZG_HUF_SLOT_U16 2048
-#define ZG_HUF_GROUP 4           // streams (one wave each) per zg_k_huf workgroup: the four streams of a block share their table
+#define ZG_HUF_GROUP 2           // streams (one wave each) per zg_k_huf workgroup; two keep its LDS small enough to run beside zg_k_seq
 #define ZG_REF_UNINIT (-1)
 
 // Packed FSE decode entry (u32): [0,16) next-state base_line, [16,20) num_bits, [20,26) symbol (code),
