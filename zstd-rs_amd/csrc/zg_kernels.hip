@@ -498,7 +498,7 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
         const uint32_t di = (wbase >> 5) & (ZG_SEQ_RING / 4 - 1);
         w0 = ring32[di]; w1 = ring32[di + 1]; w2 = ring32[di + 2]; w3 = ring32[di + 3];
       }
-#pragma unroll 1
+#pragma unroll
       for (int c = 0; c < ZG_SEQ_CH; c++) {
         if (act) {
           const uint32_t v = e & 1023u;
