@@ -44,8 +44,12 @@ int Engine::create(int device, Engine** out) {
   if (hipSetDevice(device) != hipSuccess) return ZG_HIP_ERROR;
   Engine* e = new Engine();
   e->device_ = device;
-  if (hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking) != hipSuccess) { delete e; return ZG_HIP_ERROR; }
-  if (hipStreamCreateWithFlags(&e->stream2_, hipStreamNonBlocking) != hipSuccess) { delete e; return ZG_HIP_ERROR; }
+  // two streams: the sequences chain is the critical one (its kernels last as long as one block's serial chain), so its
+  // workgroups are dispatched first; the literals chain fills what is left
+  int prio_lo = 0, prio_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  if (hipStreamCreateWithPriority(&e->stream_, hipStreamNonBlocking, prio_hi) != hipSuccess) { delete e; return ZG_HIP_ERROR; }
+  if (hipStreamCreateWithPriority(&e->stream2_, hipStreamNonBlocking, prio_lo) != hipSuccess) { delete e; return ZG_HIP_ERROR; }
   *out = e;
   return ZG_OK;
 }
@@ -289,16 +293,18 @@ int Batch::run() {
     ZG_HIP(hipMemcpyAsync(d.huf_arena + (size_t)fr.carry_huf_slot * ZG_HUF_SLOT_U16, fs->d_huf.p, ZG_HUF_SLOT_U16 * 2, hipMemcpyDeviceToDevice, s));
     ZG_HIP(hipMemcpyAsync(d.huf_maxbits + fr.carry_huf_slot, &fs->huf_maxbits, 1, hipMemcpyHostToDevice, s));
   }
-  zg_launch_tables(d, s);
-  ZG_HIP(hipEventRecord(ev[1], s));
-  // literals (Huffman streams) and sequences (FSE chains) of a block are independent once the tables exist, and both
-  // kernels are latency-bound chains that leave most of the chip idle: they run side by side on two streams
+  // Literals (Huffman tree descriptions -> streams) and sequences (FSE descriptions -> state chains -> post-pass) of a
+  // block are independent, and all of these kernels are latency-bound chains that leave most of the chip idle: the two
+  // chains run side by side on two streams and meet again in zg_k_merge.
   hipStream_t s2 = eng->stream2_;
   ZG_HIP(hipEventRecord(ev_fork, s));
   ZG_HIP(hipStreamWaitEvent(s2, ev_fork, 0));
   ZG_HIP(hipEventRecord(ev_huf[0], s2));
+  zg_launch_tables(d, s2, 0);
   zg_launch_huf(d, s2);
   ZG_HIP(hipEventRecord(ev_huf[1], s2));
+  zg_launch_tables(d, s, 1);
+  ZG_HIP(hipEventRecord(ev[1], s));
   ZG_HIP(hipEventRecord(ev[2], s));
   zg_launch_seq(d, s);
   ZG_HIP(hipEventRecord(ev[3], s));

@@ -49,7 +49,7 @@ struct ZgBatchDev {
   uint32_t* bar;               // [nframes][16] arrival counters of the sweep's per-frame barrier: 8 groups + top (zeroed every run)
 };
 
-void zg_launch_tables(const ZgBatchDev& d, hipStream_t s);
+void zg_launch_tables(const ZgBatchDev& d, hipStream_t s, int part);   // part 0: Huffman trees, part 1: FSE tables
 void zg_launch_huf(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_seq(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_seqpost(const ZgBatchDev& d, hipStream_t s);

@@ -46,6 +46,9 @@ __device__ __forceinline__ void zg_set_status(uint32_t* status, uint32_t b, int 
 // ------------------------------------------------------------------------------------------------------------
 #define ZG_TAB_L 32   // blocks (lanes) per workgroup: 4 KiB of LDS each
 #define ZG_TAB_HDR 384 // bytes of a section staged for parsing (three FSE descriptions are < 300 bytes, a Huffman one <= 129)
+// Two instances run side by side on the engine's two streams: PART 0 = Huffman tree descriptions (feeds zg_k_huf),
+// PART 1 = FSE table descriptions and the predefined tables (feeds zg_k_seq).
+template <int PART>
 __global__ void __launch_bounds__(ZG_TAB_L) zg_k_tables(ZgBatchDev d) {
   // A table is built where it can be read back without touching global memory: the build loops re-read what they just
   // wrote (fse_decoder.rs:226-262), and on gfx950 a load behind a global store waits for that store (one in-order
@@ -63,6 +66,7 @@ __global__ void __launch_bounds__(ZG_TAB_L) zg_k_tables(ZgBatchDev d) {
   uint16_t* counter = s_counter[ln];
   uint32_t* stage = s_stage[ln];
   if (b == d.nblocks) {  // predefined tables (acc logs 6/5/6)
+    if (PART == 0) return;
     uint32_t* slot = d.fse_arena + (uint64_t)d.nblocks * ZG_FSE_SLOT_U32;
     for (int i = 0; i < 36; i++) probs[i] = ZG_LL_DEFAULT[i];
     zg_fse_build(probs, 36, 6, ZG_KIND_LL, stage, counter);
@@ -97,7 +101,7 @@ __global__ void __launch_bounds__(ZG_TAB_L) zg_k_tables(ZgBatchDev d) {
     }
     return s_hdr[ln] + sh;
   };
-  if (blk.lit_type == ZG_LT_COMPRESSED) {
+  if (PART == 0 && blk.lit_type == ZG_LT_COMPRESSED) {
     uint8_t* weights = s_weights[ln];
     uint32_t* fsew = s_fsew[ln];
     int nw = 0, mb = 0;
@@ -108,7 +112,7 @@ __global__ void __launch_bounds__(ZG_TAB_L) zg_k_tables(ZgBatchDev d) {
     if (!st) st = zg_huf_build(weights, nw, d.huf_arena + (uint64_t)blk.huf_slot * ZG_HUF_SLOT_U16, &mb);
     if (!st) { d.huf_maxbits[blk.huf_slot] = (uint8_t)mb; aux.huf_desc_bytes = used; }
   }
-  if (!st && blk.nseq > 0) {
+  if (PART == 1 && blk.nseq > 0) {
     const uint32_t rem_all = blk.src_len - blk.seq_off;
     uint32_t* slot = d.fse_arena + (uint64_t)b * ZG_FSE_SLOT_U32;
     // order LL, OF, ML (sequence_section_decoder.rs:305,341,376)
@@ -147,9 +151,14 @@ __global__ void __launch_bounds__(ZG_TAB_L) zg_k_tables(ZgBatchDev d) {
     uint8_t* lg = d.slot_log + (uint64_t)b * 4;
     lg[0] = aux.log[0]; lg[1] = aux.log[1]; lg[2] = aux.log[2]; lg[3] = 0;
   }
-  d.aux[b] = aux;
-  zg_set_status(d.status, b, st);
-  d.tab_status[b] = (uint32_t)st;
+  if (PART == 0) {
+    d.aux[b].huf_desc_bytes = aux.huf_desc_bytes;
+    d.tab_status[b] = (uint32_t)st;              // a bad tree description: zg_k_huf leaves the block alone, zg_k_merge reports it
+  } else {
+    d.aux[b].seq_bits_off = aux.seq_bits_off;
+    d.aux[b].log[0] = aux.log[0]; d.aux[b].log[1] = aux.log[1]; d.aux[b].log[2] = aux.log[2];
+    zg_set_status(d.status, b, st);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1488,9 +1497,10 @@ void zg_launch_calib(const void* src, void* dst, uint64_t bytes, hipStream_t s) 
 // ------------------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------------------
-void zg_launch_tables(const ZgBatchDev& d, hipStream_t s) {
+void zg_launch_tables(const ZgBatchDev& d, hipStream_t s, int part) {
   uint32_t n = d.nblocks + 1;
-  hipLaunchKernelGGL(zg_k_tables, dim3((n + ZG_TAB_L - 1) / ZG_TAB_L), dim3(ZG_TAB_L), 0, s, d);
+  if (part == 0) hipLaunchKernelGGL(zg_k_tables<0>, dim3((n + ZG_TAB_L - 1) / ZG_TAB_L), dim3(ZG_TAB_L), 0, s, d);
+  else hipLaunchKernelGGL(zg_k_tables<1>, dim3((n + ZG_TAB_L - 1) / ZG_TAB_L), dim3(ZG_TAB_L), 0, s, d);
 }
 void zg_launch_huf(const ZgBatchDev& d, hipStream_t s) {
   if (d.nhuf_groups) hipLaunchKernelGGL(zg_k_huf, dim3(d.nhuf_groups), dim3(ZG_HUF_T), 0, s, d);
@@ -1498,12 +1508,14 @@ void zg_launch_huf(const ZgBatchDev& d, hipStream_t s) {
 void zg_launch_seq(const ZgBatchDev& d, hipStream_t s) {
   if (d.nseq_blocks) hipLaunchKernelGGL(zg_k_seq, dim3((d.nseq_blocks + ZG_SEQ_G - 1) / ZG_SEQ_G), dim3(64), 0, s, d);
 }
-// zg_k_huf ran beside zg_k_seq / zg_k_seqpost on a second stream: fold its errors into the block status. A block whose
-// tables failed keeps that error (zg_k_huf skipped it); otherwise a literals error outranks a sequence error, as the
-// literals section is decoded first (block_decoder.rs:131-150).
+// The literals chain (Huffman tree descriptions, zg_k_huf) ran beside the sequences chain on a second stream: fold its
+// errors into the block status. The literals section is decoded first (block_decoder.rs:131-150), so its errors —
+// the tree description's, then the streams' — outrank those of the sequences section.
 __global__ void __launch_bounds__(256) zg_k_merge(ZgBatchDev d) {
   const uint32_t b = blockIdx.x * 256 + threadIdx.x;
-  if (b < d.nblocks && !d.tab_status[b] && d.lit_status[b]) d.status[b] = d.lit_status[b];
+  if (b >= d.nblocks) return;
+  if (d.tab_status[b]) d.status[b] = d.tab_status[b];
+  else if (d.lit_status[b]) d.status[b] = d.lit_status[b];
 }
 void zg_launch_merge(const ZgBatchDev& d, hipStream_t s) {
   if (d.nblocks) hipLaunchKernelGGL(zg_k_merge, dim3((d.nblocks + 255) / 256), dim3(256), 0, s, d);
