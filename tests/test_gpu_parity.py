@@ -230,6 +230,34 @@ def test_generated_large_text_and_iso(ctx):
         assert oout == plain
 
 
+def test_huffman_stream_shapes(ctx):
+    """zg_k_huf decodes a stream 64 chunks at a time and relies on the code re-synchronising: stress it with code-length
+    mixes from 1-bit codes (up to 128 symbols per 128-bit chunk) to flat 8-bit alphabets, stream lengths around the
+    window size (8192 bits), one- and four-stream sections. Inputs come from the real encoder; outputs are compared with
+    the oracle and the plaintext, block literals with the oracle's literals."""
+    try:
+        import zgdata
+        zgdata.libzstd()
+    except Exception as e:  # pragma: no cover
+        pytest.skip("libzstd not available to create inputs: %s" % e)
+    import numpy as np
+    rng = np.random.default_rng(0xF00D)
+    cases = []
+    for n in (300, 1000, 1023, 1024, 1025, 4096, 8191, 8192, 8193, 70000, 131072, 300000):
+        for probs in ((0.93, 0.04, 0.02, 0.01), (0.5, 0.25, 0.125, 0.0625, 0.0625), tuple([1 / 40.0] * 40), tuple([1 / 250.0] * 250)):
+            syms = rng.permutation(256)[:len(probs)].astype(np.uint8)
+            cases.append(bytes(rng.choice(syms, size=n, p=np.array(probs) / sum(probs))))
+    checked = 0
+    for plain in cases:
+        z = zgdata.zstd_compress(plain, level=3)
+        out = ctx.decode_all(z, len(plain))
+        assert out == plain, (len(plain), checked)
+        oout, _ = oracle.decode_frame_all(z)
+        assert oout == plain
+        checked += 1
+    assert checked == len(cases)
+
+
 def test_inorder_fallback_path(ctx, monkeypatch):
     """the in-order kernel (zg_k_lz) that serves frames with a block regenerating more than 128 KiB: forced on here"""
     monkeypatch.setenv("ZGPU_FORCE_INORDER", "1")
