@@ -297,14 +297,18 @@ int Batch::run() {
   // block are independent, and all of these kernels are latency-bound chains that leave most of the chip idle: the two
   // chains run side by side on two streams and meet again in zg_k_merge.
   hipStream_t s2 = eng->stream2_;
+  zg_launch_tables(d, s, 1);
+  ZG_HIP(hipEventRecord(ev[1], s));
+  // The literals chain starts when the FSE tables are done, i.e. together with zg_k_seq: the dispatcher then places the
+  // high-priority zg_k_seq workgroups first (all of them must be resident at once: the kernel lasts as long as one
+  // block's chain) and the Huffman workgroups fill the LDS that is left. Started earlier, they would sit in the CUs
+  // when zg_k_seq arrives and push half of its workgroups into a second round.
   ZG_HIP(hipEventRecord(ev_fork, s));
   ZG_HIP(hipStreamWaitEvent(s2, ev_fork, 0));
   ZG_HIP(hipEventRecord(ev_huf[0], s2));
   zg_launch_tables(d, s2, 0);
   zg_launch_huf(d, s2);
   ZG_HIP(hipEventRecord(ev_huf[1], s2));
-  zg_launch_tables(d, s, 1);
-  ZG_HIP(hipEventRecord(ev[1], s));
   ZG_HIP(hipEventRecord(ev[2], s));
   zg_launch_seq(d, s);
   ZG_HIP(hipEventRecord(ev[3], s));

@@ -162,6 +162,186 @@ __global__ void __launch_bounds__(ZG_TAB_L) zg_k_tables(ZgBatchDev d) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// zg_k_ftab: FSE table descriptions of the sequences sections (maybe_update_fse_tables,
+// sequence_section_decoder.rs:294-410) and the predefined tables. One WAVE per block: lane 0 parses a description
+// (read_probabilities is a bit-serial chain, fse_decoder.rs:264-332), then all 64 lanes build the table
+// (build_decoder, fse_decoder.rs:141-262):
+//   spreading   cell c of the symbol-ordered list goes to the c-th position of the walk pos -> (pos + step) & mask that
+//               is below the low-probability area; the walk is i*step & mask in closed form, so a ballot/popcount
+//               prefix over i gives c, and a search in the cumulated probabilities gives the symbol;
+//   numbering   the k-th entry (by position) of a symbol gets state prob + k: k is a running count per symbol plus the
+//               rank among equal symbols inside the current 64 positions (one ballot per distinct symbol);
+//   entries     num_bits / base_line from (prob, k) as in the serial version (zg_fse_build, zg_dev.h), written coalesced.
+// ------------------------------------------------------------------------------------------------------------
+#define ZG_FT_W 4         // blocks (waves) per workgroup
+// What one lane of a wave wrote to LDS inside a divergent branch is read by the other lanes afterwards: the compiler
+// reasons per thread and may otherwise move those reads ahead of a branch the reading lanes do not take.
+__device__ __forceinline__ void zg_wave_publish() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+struct ZgFtabLds {
+  int16_t probs[64];
+  uint16_t cum[64];
+  uint16_t base[64];
+  uint8_t symat[512];
+  uint8_t xb_ll[36], xb_ml[53];
+  __attribute__((aligned(16))) uint8_t hdr[ZG_TAB_HDR + 32 + 640];
+};
+__device__ __forceinline__ int zg_fse_build_wave(ZgFtabLds& L, int np, int al, int kind, uint32_t* out_g, uint32_t lane) {
+  const uint32_t N = 1u << al, mask = N - 1, step = (N >> 1) + (N >> 3) + 3;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  // low-probability symbols take the top positions, in symbol order (fse_decoder.rs:153-164)
+  const int p = (int)lane < np ? (int)L.probs[lane] : 0;
+  const bool isneg = p == -1;
+  const uint64_t nm = __ballot(isneg);
+  const uint32_t negcnt = (uint32_t)__popcll(nm);
+  if (negcnt > N) return ZG_INTERNAL;
+  const uint32_t neg = N - negcnt;
+  if (isneg) L.symat[N - 1 - (uint32_t)__popcll(nm & lt)] = (uint8_t)lane;
+  // cumulated positive probabilities
+  const uint32_t pp = p > 0 ? (uint32_t)p : 0u;
+  uint32_t incl = pp;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += v; }
+  L.cum[lane] = (uint16_t)(incl - pp);
+  L.base[lane] = 0;
+  if ((uint32_t)__shfl(incl, 63, 64) != neg) return ZG_INTERNAL;     // probabilities do not fill the table
+  // spreading (:166-186)
+  uint32_t cnt = 0;
+  for (uint32_t i0 = 0; i0 < N; i0 += 64) {
+    const uint32_t i = i0 + lane;
+    const uint32_t ps = (i * step) & mask;
+    const bool valid = i < N && ps < neg;
+    const uint64_t vm = __ballot(valid);
+    if (valid) {
+      const uint32_t c = cnt + (uint32_t)__popcll(vm & lt);
+      uint32_t lo = 0, hi = (uint32_t)np;                 // largest s with cum[s] <= c (its interval is not empty)
+      while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (L.cum[mid] <= c) lo = mid; else hi = mid; }
+      L.symat[ps] = (uint8_t)lo;
+    }
+    cnt += (uint32_t)__popcll(vm);
+  }
+  // numbering + entries (:188-262)
+  for (uint32_t p0 = 0; p0 < N; p0 += 64) {
+    const uint32_t pos = p0 + lane;
+    const bool in = pos < N, low = in && pos < neg;
+    const uint32_t sy = in ? (uint32_t)L.symat[pos] : 0xFFFFu;
+    uint32_t k = 0;
+    uint64_t todo = __ballot(low);
+    while (todo) {
+      const int l0 = __ffsll((unsigned long long)todo) - 1;
+      const uint32_t s0 = (uint32_t)__shfl((int)sy, l0, 64);
+      const bool mine = low && sy == s0;
+      const uint64_t mm = __ballot(mine);
+      if (mine) k = (uint32_t)L.base[s0] + (uint32_t)__popcll(mm & lt);
+      if ((int)lane == l0) L.base[s0] = (uint16_t)(L.base[s0] + (uint32_t)__popcll(mm));
+      todo &= ~mm;
+    }
+    if (in) {
+      uint32_t e;
+      const uint32_t xb = kind == ZG_KIND_LL ? L.xb_ll[sy < 36u ? sy : 0u] : kind == ZG_KIND_ML ? L.xb_ml[sy < 53u ? sy : 0u] : sy;
+      if (low) {
+        const uint32_t pr = (uint32_t)L.probs[sy];
+        const uint32_t hb = zg_hbit(pr);
+        const uint32_t sl = ((1u << (hb - 1)) == pr) ? hb - 1 : hb;       // log2 of the number of slices
+        const uint32_t slices = 1u << sl, dbl = slices - pr, single = pr - dbl, width = N >> sl;
+        uint32_t nb = (uint32_t)al - sl, bl;
+        if (k < dbl) { bl = single * width + k * width * 2; nb += 1; }
+        else bl = (k - dbl) * width;
+        e = ZG_FSE_PACK(bl, nb, sy, xb);
+      } else e = ZG_FSE_PACK(0u, (uint32_t)al, sy, xb);
+      out_g[pos] = e;
+    }
+  }
+  return ZG_OK;
+}
+
+__global__ void __launch_bounds__(64 * ZG_FT_W) zg_k_ftab(ZgBatchDev d) {
+  __shared__ ZgFtabLds s_l[ZG_FT_W];
+  const uint32_t t = threadIdx.x, wv = t >> 6, lane = t & 63;
+  const uint32_t b = blockIdx.x * ZG_FT_W + wv;
+  ZgFtabLds& L = s_l[wv];
+  if (lane < 36) L.xb_ll[lane] = ZG_LL_BITS[lane];
+  if (lane < 53) L.xb_ml[lane] = ZG_ML_BITS[lane];
+  zg_wave_publish();
+  if (b > d.nblocks) return;
+  if (b == d.nblocks) {  // predefined tables (acc logs 6/5/6)
+    uint32_t* slot = d.fse_arena + (uint64_t)d.nblocks * ZG_FSE_SLOT_U32;
+    L.probs[lane] = lane < 36 ? ZG_LL_DEFAULT[lane] : (int16_t)0;
+    zg_wave_publish();
+    zg_fse_build_wave(L, 36, 6, ZG_KIND_LL, slot + ZG_FSE_LL_OFF, lane);
+    zg_wave_publish();
+    L.probs[lane] = lane < 29 ? ZG_OF_DEFAULT[lane] : (int16_t)0;
+    zg_wave_publish();
+    zg_fse_build_wave(L, 29, 5, ZG_KIND_OF, slot + ZG_FSE_OF_OFF, lane);
+    zg_wave_publish();
+    L.probs[lane] = lane < 53 ? ZG_ML_DEFAULT[lane] : (int16_t)0;
+    zg_wave_publish();
+    zg_fse_build_wave(L, 53, 6, ZG_KIND_ML, slot + ZG_FSE_ML_OFF, lane);
+    if (lane == 0) { uint8_t* lg = d.slot_log + (uint64_t)d.nblocks * 4; lg[0] = 6; lg[1] = 5; lg[2] = 6; lg[3] = 0; }
+    return;
+  }
+  const ZgBlock blk = d.blocks[b];
+  if (blk.host_status || blk.btype != ZG_BT_COMPRESSED) return;
+  const uint8_t* body = d.src + blk.src_off;
+  uint32_t seq_bits_off = blk.seq_off;
+  uint8_t logs[3] = {0, 0, 0};
+  int st = ZG_OK;
+  if (blk.nseq > 0) {
+    const uint32_t rem_all = blk.src_len - blk.seq_off;
+    uint32_t* slot = d.fse_arena + (uint64_t)b * ZG_FSE_SLOT_U32;
+    // order LL, OF, ML (sequence_section_decoder.rs:305,341,376)
+    const int kinds[3] = {ZG_KIND_LL, ZG_KIND_OF, ZG_KIND_ML};
+    const int modes[3] = {blk.seq_modes >> 6, (blk.seq_modes >> 4) & 3, (blk.seq_modes >> 2) & 3};
+    const int max_log[3] = {9, 8, 9}, max_sym[3] = {35, 31, 52};
+    const uint32_t offs[3] = {ZG_FSE_LL_OFF, ZG_FSE_OF_OFF, ZG_FSE_ML_OFF};
+    // the descriptions are staged in LDS (bit reads are dependent loads): 1 KiB in one go, 16 bytes per lane
+    const uint32_t lim = rem_all > 1000u ? 1000u : rem_all;
+    {
+      const uint64_t ga = (uint64_t)(body + blk.seq_off) & ~3ull;
+      const uint32_t sh = (uint32_t)((uint64_t)(body + blk.seq_off) & 3u);
+      if (16 * lane < lim + 8 + sh) *(zg_v4u*)(L.hdr + 16 * lane) = *(const zg_gv4u*)(ga + 16ull * lane);
+    }
+    const uint8_t* p0 = L.hdr + ((uint64_t)(body + blk.seq_off) & 3u);
+    uint32_t done = 0;
+    auto parse = [&](const uint8_t* pb, uint32_t plim) {   // inlined twice: once on LDS addresses, once on global ones
+      uint32_t off = 0, rem = plim;
+      st = ZG_OK;
+      for (int k = 0; k < 3 && !st; k++) {
+        if (modes[k] == ZG_MODE_FSE) {
+          int np = 0, al = 0, pst = 0;
+          uint32_t used = 0;
+          if (lane == 0) {
+            pst = zg_fse_read_probs(pb + off, rem, max_log[k], max_sym[k], L.probs, &np, &al, &used);
+            for (int i = np; i < 64; i++) L.probs[i] = 0;
+          }
+          zg_wave_publish();
+          st = __shfl(pst, 0, 64); np = __shfl(np, 0, 64); al = __shfl(al, 0, 64); used = (uint32_t)__shfl((int)used, 0, 64);
+          if (!st) st = zg_fse_build_wave(L, np, al, kinds[k], slot + offs[k], lane);
+          if (!st) { logs[k] = (uint8_t)al; off += used; rem -= used; }
+        } else if (modes[k] == ZG_MODE_RLE) {
+          if (rem == 0) st = ZG_SEQ_RLE_BYTE;
+          else if (pb[off] > max_sym[k]) st = ZG_SEQ_RLE_BYTE;
+          else { if (lane == 0) slot[offs[k]] = zg_fse_pack(kinds[k], 0, 0, pb[off]); logs[k] = 0; off += 1; rem -= 1; }
+        }
+      }
+      done = off;
+    };
+    parse(p0, lim);
+    if (st && lim != rem_all) parse(body + blk.seq_off, rem_all);   // a description longer than the staged part: from the section itself
+    seq_bits_off = blk.seq_off + done;
+    if (lane == 0) { uint8_t* lg = d.slot_log + (uint64_t)b * 4; lg[0] = logs[0]; lg[1] = logs[1]; lg[2] = logs[2]; lg[3] = 0; }
+  }
+  if (lane == 0) {
+    d.aux[b].seq_bits_off = seq_bits_off;
+    d.aux[b].log[0] = logs[0]; d.aux[b].log[1] = logs[1]; d.aux[b].log[2] = logs[2];
+    zg_set_status(d.status, b, st);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // zg_k_huf: Huffman literal streams (literals_section_decoder.rs:40-158; HuffmanDecoder huff0_decoder.rs:25-53).
 // A stream is a serial chain (peek max_bits bits -> table -> consume num_bits), up to 32 K symbols long, but Huffman
 // codes SELF-SYNCHRONISE: a decoder started at a wrong bit position falls onto the true code boundaries after a few
@@ -1500,7 +1680,7 @@ void zg_launch_calib(const void* src, void* dst, uint64_t bytes, hipStream_t s) 
 void zg_launch_tables(const ZgBatchDev& d, hipStream_t s, int part) {
   uint32_t n = d.nblocks + 1;
   if (part == 0) hipLaunchKernelGGL(zg_k_tables<0>, dim3((n + ZG_TAB_L - 1) / ZG_TAB_L), dim3(ZG_TAB_L), 0, s, d);
-  else hipLaunchKernelGGL(zg_k_tables<1>, dim3((n + ZG_TAB_L - 1) / ZG_TAB_L), dim3(ZG_TAB_L), 0, s, d);
+  else hipLaunchKernelGGL(zg_k_ftab, dim3((n + ZG_FT_W - 1) / ZG_FT_W), dim3(64 * ZG_FT_W), 0, s, d);
 }
 void zg_launch_huf(const ZgBatchDev& d, hipStream_t s) {
   if (d.nhuf_groups) hipLaunchKernelGGL(zg_k_huf, dim3(d.nhuf_groups), dim3(ZG_HUF_T), 0, s, d);
