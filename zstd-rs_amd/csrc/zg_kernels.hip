@@ -1,19 +1,27 @@
 // zg_kernels.hip — gfx950 (MI355X, CDNA4, wave64) kernels of the zstd block-decode engine.
 //
-// Pipeline of one submit (all on one HIP stream, no host round trip in between):
-//   zg_k_tables   one lane per block      FSE table descriptions + Huffman tree descriptions -> table arenas
-//   zg_k_huf      one lane per stream     Huffman literal streams -> literals arena (table staged in LDS)
-//   zg_k_seq      one lane per block      FSE sequence bitstream -> ZgSeq[] (three tables per lane staged in LDS)
-//   zg_k_scan     one workgroup per frame block output positions + offset-history resolution (function-composition scan)
-//   zg_k_scanf    one workgroup           frame output positions
-//   zg_k_lit      one workgroup per block literal runs, raw and RLE blocks -> output
-//   zg_k_lz       one workgroup per frame LZ77 match copies, in order, multi-round resolution inside a batch of sequences
+// Pipeline of one submit (two HIP streams, no host round trip in between):
+//   sequences chain (high-priority stream)
+//     zg_k_ftab     one wave per block         FSE table descriptions -> FSE arena (+ the predefined tables)
+//     zg_k_seq      four lanes per block       the three FSE state chains of a block -> raw records (8 B per sequence)
+//     zg_k_seqpost  one workgroup per block    extra bits, values, positions, offset history (scans) -> ZgSeq[]
+//   literals chain (low-priority stream, beside zg_k_seq)
+//     zg_k_tables   one lane per block         Huffman tree descriptions -> Huffman arena
+//     zg_k_huf      one wave per stream        Huffman literal streams, self-synchronising -> literals arena
+//   then, on the first stream
+//     zg_k_merge    one thread per block       literals errors into the block status
+//     zg_k_scan     one workgroup per frame    block output positions + offset-history resolution (function-composition scan)
+//     zg_k_scanf    one workgroup              frame output positions
+//     zg_k_lit      one workgroup per block    raw and RLE blocks, blocks without sequences -> output
+//     zg_k_flat     one workgroup per unit     every byte of a run of blocks -> its value or its offset to before the unit
+//     zg_k_sweep    256 workgroups per frame   unit after unit: open bytes gathered from finished output
+//     zg_k_lz       one workgroup per frame    in-order fallback (blocks regenerating > 128 KiB)
 //
 // The reference functions each kernel reproduces are cited at the lane routines in zg_dev.h.
 #include "zg_kernels.h"
 #include "zg_dev.h"
 
-#define ZG_SEQ_G 16       // blocks (lanes) per workgroup in zg_k_seq: 16 x (2.5 KiB tables + ring + out) in LDS -> 3 workgroups per CU
+#define ZG_SEQ_G 16       // blocks per workgroup (one wave, four lanes per block) in zg_k_seq: 16 x (2.5 KiB tables + 1.25 KiB side tables + ring + out) in LDS -> 2 workgroups per CU
 #define ZG_LZ_T 256       // threads per frame in zg_k_lz
 #define ZG_FLAT_MAX 131072u  // largest block output the flatten path handles (Block_Maximum_Size)
 #define ZG_FL_T 1024      // threads per unit in zg_k_flat
@@ -40,58 +48,36 @@ __device__ __forceinline__ void zg_set_status(uint32_t* status, uint32_t b, int 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// zg_k_tables: table descriptions. One lane per block (+ one lane that builds the predefined tables).
-// Reproduces maybe_update_fse_tables (sequence_section_decoder.rs:294-410) and
-// HuffmanTable::build_decoder (huff0_decoder.rs:117-124) for the blocks that define tables.
+// zg_k_tables: Huffman tree descriptions (literals chain; the FSE tables of the sequences chain are zg_k_ftab's).
 // ------------------------------------------------------------------------------------------------------------
-#define ZG_TAB_L 32   // blocks (lanes) per workgroup: 4 KiB of LDS each
-#define ZG_TAB_HDR 384 // bytes of a section staged for parsing (three FSE descriptions are < 300 bytes, a Huffman one <= 129)
-// Two instances run side by side on the engine's two streams: PART 0 = Huffman tree descriptions (feeds zg_k_huf),
-// PART 1 = FSE table descriptions and the predefined tables (feeds zg_k_seq).
-template <int PART>
+#define ZG_TAB_L 32   // blocks (lanes) per workgroup: 1.7 KiB of LDS each
+#define ZG_TAB_HDR 160 // bytes of a literals section staged for parsing (a tree description is at most 129 bytes)
 __global__ void __launch_bounds__(ZG_TAB_L) zg_k_tables(ZgBatchDev d) {
-  // A table is built where it can be read back without touching global memory: the build loops re-read what they just
-  // wrote (fse_decoder.rs:226-262), and on gfx950 a load behind a global store waits for that store (one in-order
-  // counter). So the probabilities, the per-symbol counters, the Huffman weights and the table under construction live
-  // in LDS, one private slice per lane; a finished table leaves with plain stores.
+  // Huffman tree descriptions of the literals sections (HuffmanTable::build_decoder, huff0_decoder.rs:117-124 with
+  // :232-403). One lane per block. A table is built where it can be read back without touching global memory: the
+  // weights are FSE-decoded through a small table that was just built, and on gfx950 a load behind a global store waits
+  // for that store (one in-order counter). So the description being parsed, the probabilities, the per-symbol counters,
+  // the weights' FSE table and the weights live in LDS, one private slice per lane; the finished Huffman table leaves
+  // with plain stores.
   __shared__ int16_t s_probs[ZG_TAB_L][256];
   __shared__ uint16_t s_counter[ZG_TAB_L][256];
-  __shared__ uint32_t s_stage[ZG_TAB_L][512];
   __shared__ uint32_t s_fsew[ZG_TAB_L][64];
   __shared__ uint8_t s_weights[ZG_TAB_L][264];
-  __shared__ __attribute__((aligned(16))) uint8_t s_hdr[ZG_TAB_L][ZG_TAB_HDR + 32];   // the description being parsed (bit reads are dependent loads: from LDS, not from HBM)
+  __shared__ __attribute__((aligned(16))) uint8_t s_hdr[ZG_TAB_L][ZG_TAB_HDR + 32];
   const uint32_t ln = threadIdx.x;
-  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  int16_t* probs = s_probs[ln];
-  uint16_t* counter = s_counter[ln];
-  uint32_t* stage = s_stage[ln];
-  if (b == d.nblocks) {  // predefined tables (acc logs 6/5/6)
-    if (PART == 0) return;
-    uint32_t* slot = d.fse_arena + (uint64_t)d.nblocks * ZG_FSE_SLOT_U32;
-    for (int i = 0; i < 36; i++) probs[i] = ZG_LL_DEFAULT[i];
-    zg_fse_build(probs, 36, 6, ZG_KIND_LL, stage, counter);
-    for (int i = 0; i < 64; i++) slot[ZG_FSE_LL_OFF + i] = stage[i];
-    for (int i = 0; i < 29; i++) probs[i] = ZG_OF_DEFAULT[i];
-    zg_fse_build(probs, 29, 5, ZG_KIND_OF, stage, counter);
-    for (int i = 0; i < 32; i++) slot[ZG_FSE_OF_OFF + i] = stage[i];
-    for (int i = 0; i < 53; i++) probs[i] = ZG_ML_DEFAULT[i];
-    zg_fse_build(probs, 53, 6, ZG_KIND_ML, stage, counter);
-    for (int i = 0; i < 64; i++) slot[ZG_FSE_ML_OFF + i] = stage[i];
-    uint8_t* lg = d.slot_log + (uint64_t)d.nblocks * 4;
-    lg[0] = 6; lg[1] = 5; lg[2] = 6; lg[3] = 0;
-    return;
-  }
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= d.nblocks) return;
   const ZgBlock blk = d.blocks[b];
   if (blk.host_status || blk.btype != ZG_BT_COMPRESSED) return;
   const uint8_t* body = d.src + blk.src_off;
-  ZgBlockAux aux;
-  aux.seq_bits_off = blk.seq_off; aux.huf_desc_bytes = 0; aux.log[0] = aux.log[1] = aux.log[2] = 0; aux.pad = 0;
+  uint32_t desc_bytes = 0;
   int st = ZG_OK;
-  // copy n bytes (+8 for the bit windows) from g into the lane's LDS slice, dword-aligned 16-byte loads, 8 in flight
-  auto stage_in = [&](const uint8_t* g, uint32_t n) -> const uint8_t* {
+  if (blk.lit_type == ZG_LT_COMPRESSED) {
+    // copy the description (+8 bytes for the bit windows) into the lane's LDS slice: dword-aligned 16-byte loads, 8 in flight
+    const uint32_t hl = blk.lit_comp_size < 136u ? blk.lit_comp_size : 136u;   // a tree description is at most 129 bytes
+    const uint8_t* g = body + blk.lit_off;
     const uint64_t ga = (uint64_t)g & ~3ull;
-    const uint32_t sh = (uint32_t)((uint64_t)g & 3u), nv = (n + 8 + sh + 15) / 16;
+    const uint32_t sh = (uint32_t)((uint64_t)g & 3u), nv = (hl + 8 + sh + 15) / 16;
     for (uint32_t v0 = 0; v0 < nv; v0 += 8) {
       zg_v4u r[8];
 #pragma unroll
@@ -99,66 +85,14 @@ __global__ void __launch_bounds__(ZG_TAB_L) zg_k_tables(ZgBatchDev d) {
 #pragma unroll
       for (int k = 0; k < 8; k++) if (v0 + k < nv) *(zg_v4u*)(s_hdr[ln] + 16 * (v0 + k)) = r[k];
     }
-    return s_hdr[ln] + sh;
-  };
-  if (PART == 0 && blk.lit_type == ZG_LT_COMPRESSED) {
-    uint8_t* weights = s_weights[ln];
-    uint32_t* fsew = s_fsew[ln];
     int nw = 0, mb = 0;
     uint32_t used = 0;
-    const uint32_t hl = blk.lit_comp_size < 136u ? blk.lit_comp_size : 136u;   // a tree description is at most 129 bytes
-    const uint8_t* hs = stage_in(body + blk.lit_off, hl);
-    st = zg_huf_read_weights(hs, hl, weights, &nw, &used, fsew, probs, counter);
-    if (!st) st = zg_huf_build(weights, nw, d.huf_arena + (uint64_t)blk.huf_slot * ZG_HUF_SLOT_U16, &mb);
-    if (!st) { d.huf_maxbits[blk.huf_slot] = (uint8_t)mb; aux.huf_desc_bytes = used; }
+    st = zg_huf_read_weights(s_hdr[ln] + sh, hl, s_weights[ln], &nw, &used, s_fsew[ln], s_probs[ln], s_counter[ln]);
+    if (!st) st = zg_huf_build(s_weights[ln], nw, d.huf_arena + (uint64_t)blk.huf_slot * ZG_HUF_SLOT_U16, &mb);
+    if (!st) { d.huf_maxbits[blk.huf_slot] = (uint8_t)mb; desc_bytes = used; }
   }
-  if (PART == 1 && blk.nseq > 0) {
-    const uint32_t rem_all = blk.src_len - blk.seq_off;
-    uint32_t* slot = d.fse_arena + (uint64_t)b * ZG_FSE_SLOT_U32;
-    // order LL, OF, ML (sequence_section_decoder.rs:305,341,376)
-    const int kinds[3] = {ZG_KIND_LL, ZG_KIND_OF, ZG_KIND_ML};
-    const int modes[3] = {blk.seq_modes >> 6, (blk.seq_modes >> 4) & 3, (blk.seq_modes >> 2) & 3};
-    const int max_log[3] = {9, 8, 9}, max_sym[3] = {35, 31, 52};
-    const uint32_t offs[3] = {ZG_FSE_LL_OFF, ZG_FSE_OF_OFF, ZG_FSE_ML_OFF};
-    uint32_t done = 0;
-    auto parse = [&](const uint8_t* p0, uint32_t lim) {   // inlined twice: once on LDS addresses, once on global ones
-      const uint8_t* p = p0;
-      uint32_t rem = lim;
-      st = ZG_OK;
-      for (int k = 0; k < 3 && !st; k++) {
-        if (modes[k] == ZG_MODE_FSE) {
-          int np, al;
-          uint32_t used;
-          st = zg_fse_read_probs(p, rem, max_log[k], max_sym[k], probs, &np, &al, &used);
-          if (!st) st = zg_fse_build(probs, np, al, kinds[k], stage, counter);
-          if (!st) {
-            for (uint32_t i = 0; i < (1u << al); i++) slot[offs[k] + i] = stage[i];
-            aux.log[k] = (uint8_t)al; p += used; rem -= used;
-          }
-        } else if (modes[k] == ZG_MODE_RLE) {
-          if (rem == 0) st = ZG_SEQ_RLE_BYTE;
-          else if (p[0] > max_sym[k]) st = ZG_SEQ_RLE_BYTE;
-          else { slot[offs[k]] = zg_fse_pack(kinds[k], 0, 0, p[0]); aux.log[k] = 0; p += 1; rem -= 1; }
-        }
-      }
-      done = (uint32_t)(p - p0);
-    };
-    // from the staged copy; if that fails and the copy was shorter than the section, again from the section itself
-    const uint32_t lim = rem_all > ZG_TAB_HDR ? ZG_TAB_HDR : rem_all;
-    parse(stage_in(body + blk.seq_off, lim), lim);
-    if (st && lim != rem_all) parse(body + blk.seq_off, rem_all);
-    aux.seq_bits_off = blk.seq_off + done;
-    uint8_t* lg = d.slot_log + (uint64_t)b * 4;
-    lg[0] = aux.log[0]; lg[1] = aux.log[1]; lg[2] = aux.log[2]; lg[3] = 0;
-  }
-  if (PART == 0) {
-    d.aux[b].huf_desc_bytes = aux.huf_desc_bytes;
-    d.tab_status[b] = (uint32_t)st;              // a bad tree description: zg_k_huf leaves the block alone, zg_k_merge reports it
-  } else {
-    d.aux[b].seq_bits_off = aux.seq_bits_off;
-    d.aux[b].log[0] = aux.log[0]; d.aux[b].log[1] = aux.log[1]; d.aux[b].log[2] = aux.log[2];
-    zg_set_status(d.status, b, st);
-  }
+  d.aux[b].huf_desc_bytes = desc_bytes;
+  d.tab_status[b] = (uint32_t)st;              // a bad tree description: zg_k_huf leaves the block alone, zg_k_merge reports it
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -187,7 +121,7 @@ struct ZgFtabLds {
   uint16_t base[64];
   uint8_t symat[512];
   uint8_t xb_ll[36], xb_ml[53];
-  __attribute__((aligned(16))) uint8_t hdr[ZG_TAB_HDR + 32 + 640];
+  __attribute__((aligned(16))) uint8_t hdr[1024 + 32];   // the section's first KiB (three descriptions are < 300 bytes)
 };
 __device__ __forceinline__ int zg_fse_build_wave(ZgFtabLds& L, int np, int al, int kind, uint32_t* out_g, uint32_t lane) {
   const uint32_t N = 1u << al, mask = N - 1, step = (N >> 1) + (N >> 3) + 3;
@@ -1679,7 +1613,7 @@ void zg_launch_calib(const void* src, void* dst, uint64_t bytes, hipStream_t s) 
 // ------------------------------------------------------------------------------------------------------------
 void zg_launch_tables(const ZgBatchDev& d, hipStream_t s, int part) {
   uint32_t n = d.nblocks + 1;
-  if (part == 0) hipLaunchKernelGGL(zg_k_tables<0>, dim3((n + ZG_TAB_L - 1) / ZG_TAB_L), dim3(ZG_TAB_L), 0, s, d);
+  if (part == 0) hipLaunchKernelGGL(zg_k_tables, dim3((n + ZG_TAB_L - 1) / ZG_TAB_L), dim3(ZG_TAB_L), 0, s, d);
   else hipLaunchKernelGGL(zg_k_ftab, dim3((n + ZG_FT_W - 1) / ZG_FT_W), dim3(64 * ZG_FT_W), 0, s, d);
 }
 void zg_launch_huf(const ZgBatchDev& d, hipStream_t s) {
