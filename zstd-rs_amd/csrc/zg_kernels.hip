@@ -631,14 +631,13 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
           // pk: [7:0] all bits this lane's symbol takes from the stream, [15:8] its state bits. Quad prefix sums, lanes in
           // stream order from the low end: OF state, ML state, LL state (then the extra bits, skipped as one count).
           const uint32_t pk = (nb + xb) | (nb << 8);
-          const uint32_t i1 = pk + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0x93, 0xF, 0xF, false);   // quad_perm [3,0,1,2]
-          const uint32_t incl = i1 + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0x4F, 0xF, 0xF, false); // quad_perm [3,3,0,1]
-          const uint32_t tot = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0xAA, 0xF, 0xF, false);     // quad_perm [2,2,2,2]
+          const uint32_t i1 = pk + (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0x93, 0xF, 0xF, true);   // quad_perm [3,0,1,2]
+          const uint32_t incl = i1 + (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0x4F, 0xF, 0xF, true); // quad_perm [3,3,0,1]
+          const uint32_t tot = (uint32_t)__builtin_amdgcn_mov_dpp((int)incl, 0xAA, 0xF, 0xF, true);     // quad_perm [2,2,2,2]
           const int32_t q_sof = P - (int32_t)(tot & 255u);
           const bool ok = q_sof >= 0;                               // :209-211
           out_base[cnt * 4u] = (uint16_t)(owner ? tot & 255u : e);
           cnt += ok ? 1u : 0u;
-          status = ok ? status : ZG_SEQ_NOT_ENOUGH_BYTES;
           // this lane's nb state bits start (incl - pk) >> 8 bits above q_sof; q_sof >= P - 89, so they are inside the window
           const uint32_t rel = (uint32_t)q_sof + rbits - wbase + ((incl - pk) >> 8);
           const bool up = rel >= 64u, odd = (rel & 32u) != 0u;
@@ -651,7 +650,7 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
           wbase = (((uint32_t)P + rbits) & ~31u) - 96u;
           const uint32_t di = (wbase >> 5) & (ZG_SEQ_RING / 4 - 1);
           w0 = ring32[di]; w1 = ring32[di + 1]; w2 = ring32[di + 2]; w3 = ring32[di + 3];
-          done++;
+          done += ok ? 1u : 0u;                                     // done stops at the sequence that ran out of bits
           act = ok && done != nseq;
         }
       }
@@ -698,7 +697,8 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
 #endif
 #undef ZG_QTICK
   if (have && owner) {
-    if (status == ZG_OK && P > 0) status = ZG_SEQ_EXTRA_BITS;  // :214-220
+    if (done != nseq) status = ZG_SEQ_NOT_ENOUGH_BYTES;       // the loop stopped at a sequence that ran out of bits (:209-211)
+    else if (P > 0) status = ZG_SEQ_EXTRA_BITS;               // :214-220
     zg_set_status(d.status, b, status);
   }
 }
