@@ -258,6 +258,49 @@ def test_huffman_stream_shapes(ctx):
     assert checked == len(cases)
 
 
+def test_mutated_frames_agree_with_oracle(ctx):
+    """Malformed input: 480 random mutations (bit flips, byte and pair overwrites, truncations) of four valid frames.
+    The engine must decide like the oracle: same bytes when both decode, the same error leaf (errors.rs) when both fail,
+    never one without the other. The one tolerated difference: which of two errors of ONE block is reported first when
+    the reference's total_output_counter quirk (raw/RLE blocks are not counted, decode_buffer.rs:62-72) changes
+    NotEnoughBytesInDictionary into OffsetTooBig."""
+    import random
+    import zgpu
+    packs, syn = read_pack("decodecorpus.pack"), read_pack("synthetic.pack")
+    bases = [packs["z000033.zst"], packs["z000059.zst"], syn["mixed_640k_l3.zst"], packs["z000000.zst"]]
+    rng = random.Random(12345)
+    same_ok = same_err = 0
+    diffs = {}
+    for bi, base in enumerate(bases):
+        for it in range(120):
+            m = bytearray(base)
+            kind = rng.randrange(4)
+            if kind == 0:
+                i = rng.randrange(4, len(m)); m[i] ^= 1 << rng.randrange(8)
+            elif kind == 1:
+                i = rng.randrange(4, len(m)); m[i] = rng.randrange(256)
+            elif kind == 2:
+                m = m[:rng.randrange(8, len(m))]
+            else:
+                i = rng.randrange(4, len(m) - 4); m[i:i + 2] = bytes([rng.randrange(256), rng.randrange(256)])
+            m = bytes(m)
+            ost, oout = oracle.FrameDecoder().decode_all(m, 1 << 24)
+            try:
+                out, gst = ctx.decode_all(m, 1 << 24), 0
+            except zgpu.ZgpuError as e:
+                out, gst = None, e.status
+            if ost == 0 and gst == 0:
+                assert out == oout, (bi, it)
+                same_ok += 1
+            elif ost == gst:
+                same_err += 1
+            else:
+                diffs[(ost, gst)] = diffs.get((ost, gst), 0) + 1
+    allowed = {(53, 52), (52, 53)}
+    assert not (set(diffs) - allowed), diffs
+    assert same_ok > 50 and same_err > 200, (same_ok, same_err)
+
+
 def test_inorder_fallback_path(ctx, monkeypatch):
     """the in-order kernel (zg_k_lz) that serves frames with a block regenerating more than 128 KiB: forced on here"""
     monkeypatch.setenv("ZGPU_FORCE_INORDER", "1")

@@ -1150,7 +1150,8 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
             lstart = q.w; m0 = q.z; m1 = q.z + q.y; a = m0 - (next - lstart);          // ZgSeq {of, ml, mdst, lit_start}
             off = zg_sym_resolve(q.x, p.hist_init);
             if (off == 0) atomicCAS(&s_err, 0u, (uint32_t)ZG_EXE_ZERO_OFFSET);                     // sequence_execution.rs:28-30
-            else if ((uint64_t)off > reach + m0) atomicCAS(&s_err, 0u, (uint32_t)ZG_EXE_OFFSET_TOO_BIG);  // decode_buffer.rs:173-177
+            else if ((uint64_t)off > reach + m0)            // repeat_from_dict (decode_buffer.rs:144-179): which error depends on how much was output so far
+              atomicCAS(&s_err, 0u, (uint32_t)(p.out_base + fr.prior_out + m0 <= fr.window_size ? ZG_EXE_DICT_TOO_SMALL : ZG_EXE_OFFSET_TOO_BIG));
           } else {
             lstart = so.sum_ll; a = so.sum_ll + so.sum_ml; m0 = m1 = S;
           }
@@ -1564,7 +1565,7 @@ __global__ void __launch_bounds__(ZG_LZ_T) zg_k_lz(ZgBatchDev d) {
         ml = q.ml; mdst = q.mdst;
         dpos = p.out_base + mdst;
         if (off == 0) { atomicCAS(&s_err, 0u, (uint32_t)ZG_EXE_ZERO_OFFSET); }
-        else if ((uint64_t)off > dpos + fr.prior_out + fr.dict_len) { atomicCAS(&s_err, 0u, (uint32_t)ZG_EXE_OFFSET_TOO_BIG); }
+        else if ((uint64_t)off > dpos + fr.prior_out + fr.dict_len) { atomicCAS(&s_err, 0u, (uint32_t)(dpos + fr.prior_out <= fr.window_size ? ZG_EXE_DICT_TOO_SMALL : ZG_EXE_OFFSET_TOO_BIG)); }
         else pending = ml > 0;
       }
       __syncthreads();
