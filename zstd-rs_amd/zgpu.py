@@ -159,12 +159,20 @@ class Context:
 
     def decode_all(self, src, cap):
         """FrameDecoder::decode_all (frame_decoder.rs:541-577). Returns the plaintext or raises ZgpuError."""
-        buf = C.create_string_buffer(max(cap, 1))
         w = C.c_size_t()
-        st = self.L.zgpu_decode_all(self.h, src, len(src), buf, cap, C.byref(w))
-        if st:
-            raise ZgpuError(st)
-        return buf.raw[:w.value]
+        try:                                   # no zero-fill, one copy: matters for GB-sized outputs
+            import numpy as np
+            arr = np.empty(max(cap, 1), dtype=np.uint8)
+            st = self.L.zgpu_decode_all(self.h, src, len(src), arr.ctypes.data_as(C.c_void_p), cap, C.byref(w))
+            if st:
+                raise ZgpuError(st)
+            return arr[:w.value].tobytes()
+        except ImportError:
+            buf = C.create_string_buffer(max(cap, 1))
+            st = self.L.zgpu_decode_all(self.h, src, len(src), buf, cap, C.byref(w))
+            if st:
+                raise ZgpuError(st)
+            return buf.raw[:w.value]
 
     def prepare(self, src):
         return Batch(self, src)
