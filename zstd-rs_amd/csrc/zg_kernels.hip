@@ -1422,20 +1422,27 @@ __global__ void __launch_bounds__(T) zg_k_sweep(ZgBatchDev d) {
         onext[k] = g < g1 ? *(const uint4*)(og + 4 * (uint64_t)g) : make_uint4(0, 0, 0, 0);
       }
     };
-    auto sweep_unit = [&](uint32_t iu, bool prefetched) {
+    // farlim < 0: the unit's step. farlim >= 0 (in advance, while waiting at the barrier of the step before): only the
+    // prefetched batch, and in it only the groups whose open bytes all come from before frame position farlim (output
+    // that is already final); those groups are remembered in donemask and skipped when the unit's own step comes.
+    auto sweep_unit = [&](uint32_t iu, bool prefetched, int64_t farlim, uint32_t& donemask) {
       const ZgSweepUnit su = s_u[iu];
       uint8_t* out = frame_out + su.out_off;
       const uint32_t* og = d.og + su.og_base;
       const uint32_t n4 = su.size >> 2, per = (n4 + wg.wpf - 1) / wg.wpf;
       const uint32_t g0 = wg.rank * per, g1 = g0 + per < n4 ? g0 + per : n4;
       bool first = prefetched;
+      const bool advance = farlim >= 0;
+      const int64_t farrel = (int64_t)su.out_off - farlim;       // distance from the limit to the unit's first byte
       for (uint32_t base = g0 + t; base < g1 + t; base += T * ZG_SW_B) {   // every thread runs the same number of batches
         uint4 o[ZG_SW_B];
+        const bool wasfirst = first;
         if (first) {
 #pragma unroll
           for (int k = 0; k < ZG_SW_B; k++) o[k] = onext[k];
           first = false;
-        } else {
+        } else if (advance) break;
+        else {
 #pragma unroll
           for (int k = 0; k < ZG_SW_B; k++) {
             const uint32_t g = base + k * T;
@@ -1447,12 +1454,21 @@ __global__ void __launch_bounds__(T) zg_k_sweep(ZgBatchDev d) {
         // so one dword load per DISTINCT offset of the group serves it (usually one or two: a match boundary), and finished
         // bytes bring their value in their own word.
         uint32_t lA[ZG_SW_B], lB[ZG_SW_B], lC[ZG_SW_B], lD[ZG_SW_B];
+        uint32_t skipm = 0;
 #pragma unroll
         for (int k = 0; k < ZG_SW_B; k++) {
           const uint4 q = o[k];
           const uint32_t g = base + k * T;
           const uint8_t* w = g < g1 ? out + 4 * (uint64_t)g : out;
           const bool ux = (int32_t)q.x > 0, uy = (int32_t)q.y > 0, uz = (int32_t)q.z > 0, uw = (int32_t)q.w > 0;
+          if (advance) {
+            const int64_t pg = farrel + 4 * (int64_t)g;            // the group's first byte relative to the limit
+            const bool far = g < g1 && (ux || uy || uz || uw) && (!ux || (int64_t)q.x > pg) && (!uy || (int64_t)q.y > pg + 1) &&
+                             (!uz || (int64_t)q.z > pg + 2) && (!uw || (int64_t)q.w > pg + 3);
+            if (far) donemask |= 1u << k;
+            skipm |= far ? 0u : 1u << k;
+          } else if (wasfirst && ((donemask >> k) & 1u)) skipm |= 1u << k;
+          if ((skipm >> k) & 1u) { lA[k] = lB[k] = lC[k] = lD[k] = 0; continue; }
           const bool nD = uw && !(ux && q.w == q.x);
           const bool nB = uy && !(ux && q.y == q.x) && !(uw && q.y == q.w);
           const bool nC = uz && !(ux && q.z == q.x) && !(uw && q.z == q.w) && !(uy && q.z == q.y);
@@ -1469,7 +1485,7 @@ __global__ void __launch_bounds__(T) zg_k_sweep(ZgBatchDev d) {
           const uint4 q = o[k];
           const uint32_t g = base + k * T;
           const bool ux = (int32_t)q.x > 0, uy = (int32_t)q.y > 0, uz = (int32_t)q.z > 0, uw = (int32_t)q.w > 0;
-          if (g >= g1 || !(ux || uy || uz || uw)) continue;
+          if (g >= g1 || !(ux || uy || uz || uw) || ((skipm >> k) & 1u)) continue;
           const uint32_t sw = (ux && q.w == q.x) ? lA[k] : lD[k];
           const uint32_t sy = (ux && q.y == q.x) ? lA[k] : (uw && q.y == q.w) ? sw : lB[k];
           const uint32_t sz = (ux && q.z == q.x) ? lA[k] : (uw && q.z == q.w) ? sw : (uy && q.z == q.y) ? sy : lC[k];
@@ -1481,7 +1497,7 @@ __global__ void __launch_bounds__(T) zg_k_sweep(ZgBatchDev d) {
           __hip_atomic_store((uint32_t*)(out + 4 * (uint64_t)g), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through store (sc1)
         }
       }
-      if (wg.rank == wg.wpf - 1) {          // tail bytes of the unit
+      if (!advance && wg.rank == wg.wpf - 1) {          // tail bytes of the unit
         for (uint32_t x = (n4 << 2) + t; x < su.size; x += T) {
           const uint32_t o = og[x];
           if ((int32_t)o > 0) __hip_atomic_store(&out[x], out[(int64_t)x - o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1490,14 +1506,20 @@ __global__ void __launch_bounds__(T) zg_k_sweep(ZgBatchDev d) {
     };
     uint32_t ui = next_unit(0);
     if (ui < cn) prefetch(ui);
+    uint32_t donemask = 0;                     // groups of the prefetched batch that were already filled in advance
     while (ui < cn) {
-      sweep_unit(ui, true);
+      sweep_unit(ui, true, -1, donemask);
       ZG_STICK(0)
       steps++;
       if (wg.wpf > 1) zg_frame_arrive(d.bar + (size_t)f * 16, steps, wg.rank, wg.wpf, t);
       ZG_STICK(1)
       const uint32_t nx = next_unit(ui + 1);
-      if (nx < cn) prefetch(nx);            // the scratch of the next unit does not depend on this step: in flight during the wait
+      donemask = 0;
+      if (nx < cn) {
+        prefetch(nx);                       // the scratch of the next unit does not depend on this step: in flight during the wait
+        // ... and neither do its bytes that come from before THIS unit: they are filled while the barrier is waited for
+        if (wg.wpf > 1) sweep_unit(nx, true, (int64_t)s_u[ui].out_off, donemask);
+      }
       if (wg.wpf > 1) { alive = zg_frame_wait(d.bar + (size_t)f * 16, steps, wg.wpf, t); if (!alive) break; }
       else __syncthreads();                 // same CU: later loads see these stores
       ZG_STICK(2)
