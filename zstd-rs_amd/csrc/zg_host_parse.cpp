@@ -241,7 +241,7 @@ void BatchBuilder::finish() {
   if (ub == 0) {
     ub = (nb + flat_slots - 1) / flat_slots;
     if (ub < 8) ub = 8;
-    if (ub > 64) ub = 64;
+    if (ub > 256) ub = 256;   // unit-relative positions stay far below 2^30
   }
   for (uint32_t f = 0; f < frames.size(); f++) {
     ZgFrame& fr = frames[f];
