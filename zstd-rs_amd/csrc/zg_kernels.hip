@@ -886,8 +886,8 @@ __global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
 // composition of per-block maps on three symbolic slots, so it is scanned like a prefix sum.
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) zg_k_scan(ZgBatchDev d) {
-  __shared__ uint64_t s_size[256];
-  __shared__ ZgHistMap s_map[256];
+  __shared__ uint64_t s_size[4];
+  __shared__ ZgHistMap s_map[4];
   __shared__ uint32_t s_bad;       // chunk-local index of the first failing block
   __shared__ uint32_t s_badst;
   __shared__ uint32_t s_slow;      // some block regenerates more than 128 KiB (non-conforming): in-order fallback
@@ -922,22 +922,34 @@ __global__ void __launch_bounds__(256) zg_k_scan(ZgBatchDev d) {
     __syncthreads();
     const uint32_t bad = s_bad;
     if (t >= bad) { size = 0; m = zg_map_identity(); }  // the failing block and everything after it produce nothing
-    s_size[t] = size;
-    s_map[t] = m;
-    __syncthreads();
-    // inclusive Hillis-Steele scans over the chunk
-    for (uint32_t off = 1; off < 256; off <<= 1) {
-      uint64_t vs = 0;
-      ZgHistMap vm = zg_map_identity();
-      bool take = t >= off;
-      if (take) { vs = s_size[t - off]; vm = s_map[t - off]; }
-      __syncthreads();
-      if (take) { s_size[t] += vs; s_map[t] = zg_map_compose(vm, s_map[t]); }
-      __syncthreads();
+    // inclusive scans over the chunk: inside the wave with shuffles, across the four waves through LDS
+    uint64_t isz = size;
+    ZgHistMap im = m;
+    {
+      const uint32_t lane = t & 63;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t lo = __shfl_up((uint32_t)isz, off, 64), hi = __shfl_up((uint32_t)(isz >> 32), off, 64);
+        ZgHistMap pm;
+        pm.s[0] = __shfl_up(im.s[0], off, 64); pm.s[1] = __shfl_up(im.s[1], off, 64); pm.s[2] = __shfl_up(im.s[2], off, 64);
+        if ((int)lane >= off) { isz += ((uint64_t)hi << 32) | lo; im = zg_map_compose(pm, im); }
+      }
+      if (lane == 63) { s_size[t >> 6] = isz; s_map[t >> 6] = im; }
     }
+    __syncthreads();
+    uint64_t wsz = 0, tsz = 0;                    // what the earlier waves of the chunk add; the whole chunk
+    ZgHistMap wmap = zg_map_identity(), tmap = zg_map_identity();
+    for (uint32_t w = 0; w < 4; w++) {
+      if (w < (t >> 6)) { wsz += s_size[w]; wmap = zg_map_compose(wmap, s_map[w]); }
+      tsz += s_size[w]; tmap = zg_map_compose(tmap, s_map[w]);
+    }
+    // history before a block: everything before the chunk, the earlier waves, the earlier lanes of its wave
+    ZgHistMap prev;
+    prev.s[0] = __shfl_up(im.s[0], 1, 64); prev.s[1] = __shfl_up(im.s[1], 1, 64); prev.s[2] = __shfl_up(im.s[2], 1, 64);
+    if ((t & 63) == 0) prev = zg_map_identity();
     if (have) {
-      uint64_t excl = carry_size + (t ? s_size[t - 1] : 0);
-      ZgHistMap pre = t ? zg_map_compose(carry_map, s_map[t - 1]) : carry_map;
+      const uint64_t excl = carry_size + wsz + isz - size;                       // sizes before this block
+      const ZgHistMap pre = zg_map_compose(zg_map_compose(carry_map, wmap), prev);
       ZgBlockPos p;
       p.out_base = excl;
       p.hist_init[0] = zg_sym_resolve(pre.s[0], fr.hist_init);
@@ -951,14 +963,14 @@ __global__ void __launch_bounds__(256) zg_k_scan(ZgBatchDev d) {
     if (bad != 0xFFFFFFFFu) {  // sizes / maps of blocks from the failing one on are zero / identity
       good = c0 + bad;
       bad_status = s_badst;
-      carry_size += s_size[255];
-      carry_map = zg_map_compose(carry_map, s_map[255]);
+      carry_size += tsz;
+      carry_map = zg_map_compose(carry_map, tmap);
       // blocks after this chunk are inactive
       for (uint32_t j = c0 + 256 + t; j < fr.nblocks; j += 256) d.pos[fr.first_block + j].active = 0;
       break;
     }
-    carry_size += s_size[255];
-    carry_map = zg_map_compose(carry_map, s_map[255]);
+    carry_size += tsz;
+    carry_map = zg_map_compose(carry_map, tmap);
     __syncthreads();
   }
   if (t == 0) {
