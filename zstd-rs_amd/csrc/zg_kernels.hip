@@ -885,9 +885,10 @@ __global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
 // The history recurrence (sequence_execution.rs:59-118; never reset between blocks, scratch.rs:22) is a
 // composition of per-block maps on three symbolic slots, so it is scanned like a prefix sum.
 // ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) zg_k_scan(ZgBatchDev d) {
-  __shared__ uint64_t s_size[4];
-  __shared__ ZgHistMap s_map[4];
+#define ZG_SCAN_T 1024
+__global__ void __launch_bounds__(ZG_SCAN_T) zg_k_scan(ZgBatchDev d) {
+  __shared__ uint64_t s_size[ZG_SCAN_T / 64];
+  __shared__ ZgHistMap s_map[ZG_SCAN_T / 64];
   __shared__ uint32_t s_bad;       // chunk-local index of the first failing block
   __shared__ uint32_t s_badst;
   __shared__ uint32_t s_slow;      // some block regenerates more than 128 KiB (non-conforming): in-order fallback
@@ -897,7 +898,7 @@ __global__ void __launch_bounds__(256) zg_k_scan(ZgBatchDev d) {
   ZgHistMap carry_map = zg_map_identity();
   uint32_t good = fr.nblocks, bad_status = 0;
   if (t == 0) s_slow = 0;
-  for (uint32_t c0 = 0; c0 < fr.nblocks; c0 += 256) {
+  for (uint32_t c0 = 0; c0 < fr.nblocks; c0 += ZG_SCAN_T) {
     uint32_t i = c0 + t;
     bool have = i < fr.nblocks;
     uint32_t b = fr.first_block + i;
@@ -922,7 +923,7 @@ __global__ void __launch_bounds__(256) zg_k_scan(ZgBatchDev d) {
     __syncthreads();
     const uint32_t bad = s_bad;
     if (t >= bad) { size = 0; m = zg_map_identity(); }  // the failing block and everything after it produce nothing
-    // inclusive scans over the chunk: inside the wave with shuffles, across the four waves through LDS
+    // inclusive scans over the chunk: inside the wave with shuffles, across the waves through LDS
     uint64_t isz = size;
     ZgHistMap im = m;
     {
@@ -939,7 +940,7 @@ __global__ void __launch_bounds__(256) zg_k_scan(ZgBatchDev d) {
     __syncthreads();
     uint64_t wsz = 0, tsz = 0;                    // what the earlier waves of the chunk add; the whole chunk
     ZgHistMap wmap = zg_map_identity(), tmap = zg_map_identity();
-    for (uint32_t w = 0; w < 4; w++) {
+    for (uint32_t w = 0; w < ZG_SCAN_T / 64; w++) {
       if (w < (t >> 6)) { wsz += s_size[w]; wmap = zg_map_compose(wmap, s_map[w]); }
       tsz += s_size[w]; tmap = zg_map_compose(tmap, s_map[w]);
     }
@@ -966,7 +967,7 @@ __global__ void __launch_bounds__(256) zg_k_scan(ZgBatchDev d) {
       carry_size += tsz;
       carry_map = zg_map_compose(carry_map, tmap);
       // blocks after this chunk are inactive
-      for (uint32_t j = c0 + 256 + t; j < fr.nblocks; j += 256) d.pos[fr.first_block + j].active = 0;
+      for (uint32_t j = c0 + ZG_SCAN_T + t; j < fr.nblocks; j += ZG_SCAN_T) d.pos[fr.first_block + j].active = 0;
       break;
     }
     carry_size += tsz;
@@ -1673,7 +1674,7 @@ void zg_launch_seqpost(const ZgBatchDev& d, hipStream_t s) {
   if (d.nseq_blocks) hipLaunchKernelGGL(zg_k_seqpost, dim3(d.nseq_blocks), dim3(ZG_SP_T), 0, s, d);
 }
 void zg_launch_scan(const ZgBatchDev& d, hipStream_t s) {
-  hipLaunchKernelGGL(zg_k_scan, dim3(d.nframes), dim3(256), 0, s, d);
+  hipLaunchKernelGGL(zg_k_scan, dim3(d.nframes), dim3(ZG_SCAN_T), 0, s, d);
   hipLaunchKernelGGL(zg_k_scanf, dim3(1), dim3(1024), 0, s, d);
 }
 void zg_launch_lit(const ZgBatchDev& d, hipStream_t s) {
