@@ -1,12 +1,13 @@
-// zg_emu.cpp — TEST-ONLY host harness: runs the engine's lane routines (zstd-rs_amd/csrc/zg_dev.h) and the host
-// parser (zg_host_parse.cpp) lane-by-lane on the CPU, in the same order the HIP kernels do, so that the decode logic
+// zg_emu.cpp — TEST-ONLY host harness: runs the engine's host parser (zg_host_parse.cpp), the table routines and the
+// symbolic offset history of zstd-rs_amd/csrc/zg_dev.h (the code the kernels call) plus a serial model of the
+// wave-cooperative decoders (zg_emu_serial.h) on the CPU, in the order of the HIP pipeline, so that this logic
 // can be checked against the oracle and the golden fixtures without a GPU. It is NOT a fallback of the product:
 // libzgpu.so neither contains nor loads it, and it lives under tests/.
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
-#include "../../zstd-rs_amd/csrc/zg_dev.h"
+#include "zg_emu_serial.h"
 #include "../../zstd-rs_amd/csrc/zg_host_parse.h"
 
 using namespace zg;
@@ -27,7 +28,7 @@ struct EmuBatch {
   std::vector<uint8_t> hufmax;
   std::vector<uint32_t> status;
   std::vector<uint8_t> lit;
-  std::vector<ZgSeq> seq;
+  std::vector<EmuSeq> seq;
   std::vector<ZgBlockSeqOut> seqout;
   std::vector<ZgBlockPos> pos;
   std::vector<ZgFrameOut> fout;
@@ -233,9 +234,9 @@ static void k_exec(EmuBatch& e) {  // zg_k_lit + zg_k_lz, serial
       if (blk.nseq) {
         const ZgBlockSeqOut& so = e.seqout[b];
         sum_ll = so.sum_ll; sum_ml = so.sum_ml;
-        const ZgSeq* sq = e.seq.data() + blk.seq_base;
+        const EmuSeq* sq = e.seq.data() + blk.seq_base;
         for (uint32_t s = 0; s < blk.nseq && !err; s++) {
-          const ZgSeq q = sq[s];
+          const EmuSeq q = sq[s];
           uint32_t next = s + 1 < blk.nseq ? sq[s + 1].lit_start : sum_ll, ll = next - q.lit_start;
           uint8_t* o = out + (q.mdst - ll);
           for (uint32_t k = 0; k < ll; k++) o[k] = rle ? lit[0] : lit[q.lit_start + k];
@@ -299,7 +300,7 @@ int zgemu_block(void* h, uint32_t b, uint32_t* info /*[12]*/) {
   return 0;
 }
 const uint8_t* zgemu_block_literals(void* h, uint32_t b) { EmuBatch* e = (EmuBatch*)h; return e->lit.data() + e->bb.blocks[b].lit_base; }
-const ZgSeq* zgemu_block_sequences(void* h, uint32_t b) { EmuBatch* e = (EmuBatch*)h; return e->seq.data() + e->bb.blocks[b].seq_base; }
+const EmuSeq* zgemu_block_sequences(void* h, uint32_t b) { EmuBatch* e = (EmuBatch*)h; return e->seq.data() + e->bb.blocks[b].seq_base; }
 void zgemu_block_hist(void* h, uint32_t b, uint32_t* out3) { EmuBatch* e = (EmuBatch*)h; memcpy(out3, e->pos[b].hist_init, 12); }
 const uint32_t* zgemu_fse_slot(void* h, uint32_t slot, uint8_t* logs) {
   EmuBatch* e = (EmuBatch*)h; memcpy(logs, e->slot_log.data() + (size_t)slot * 4, 4); return e->fse.data() + (size_t)slot * ZG_FSE_SLOT_U32;

@@ -424,3 +424,55 @@ def test_streaming_decoder(ctx):
     with pytest.raises(zgpu.ZgpuError) as e:
         zgpu.StreamingDecoder(io.BytesIO(big), ctx=ctx)
     assert e.value.status == zgpu.E_WINDOW_SIZE_TOO_BIG
+
+
+def test_dense_sequences_cut_tiles(ctx):
+    """blocks with 3-6 output bytes per sequence (up to 42 K sequences per block): zg_k_flat's tiles end early when they
+    hold more sequences than fit (two per thread), both tile shapes"""
+    import numpy as np
+    import zgdata
+    import zgpu
+    rng = np.random.default_rng(7)
+    for tok, V, lvl in ((3, 2000, 19), (5, 2000, 3)):
+        vocab = rng.integers(0, 256, size=(V, tok), dtype=np.uint8)
+        data = vocab[rng.integers(0, V, size=(600000 // tok,))].reshape(-1).tobytes()
+        z = zgdata.zstd_compress(data, level=lvl)
+        ref, _ = oracle.decode_frame_all(z)
+        assert ref == data
+        for flat_t in ("512", "1024"):
+            os.environ["ZGPU_FLAT_T"] = flat_t
+            try:
+                c = zgpu.Context(0)
+                out = c.decode_all(z, len(data))
+                c.close()
+            finally:
+                del os.environ["ZGPU_FLAT_T"]
+            assert out == data, (tok, V, lvl, flat_t)
+
+
+@pytest.mark.parametrize("env", [{"ZGPU_FLAT_T": "1024"}, {"ZGPU_UNIT_BLOCKS": "1"}, {"ZGPU_UNIT_BLOCKS": "3", "ZGPU_FLAT_T": "1024"}])
+def test_corpus_other_shapes(env):
+    """the whole corpus in one submit with the other flatten tile shape and with tiny units (a sweep step per block:
+    every cross-block match goes through the sweep, every block start is a unit start)"""
+    import zgdata
+    import zgpu
+    pack, man = read_pack("decodecorpus.pack"), read_manifest("decodecorpus.json")
+    names = sorted(man)
+    text = zgdata.text_like(3 << 20, seed=0x77)
+    blob = b"".join(pack[n] for n in names) + zgdata.zstd_compress(text)
+    for k, v in env.items():
+        os.environ[k] = v
+    try:
+        c = zgpu.Context(0)
+        b = c.prepare(blob)
+        b.run()
+        b.sync()
+        assert b.bad_status == 0, (b.bad_frame, b.bad_status)
+        bad = [n for f, n in enumerate(names) if _sha(b.frame_bytes(f)) != man[n]["sha256"]]
+        assert not bad, bad
+        assert b.frame_bytes(len(names)) == text
+        b.close()
+        c.close()
+    finally:
+        for k in env:
+            del os.environ[k]

@@ -1,0 +1,35 @@
+"""One data set, several engine variants (environment switches read when a Context is created): kernel times side by side.
+usage: variants.py [size] [kind] -- VAR=VALUE[,VAR=VALUE] ..."""
+import hashlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "zstd-rs_amd")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import zgdata, zgpu
+
+args = sys.argv[1:]
+sep = args.index("--") if "--" in args else len(args)
+size = int(args[0]) if sep > 0 else 1000000000
+kind = args[1] if sep > 1 else "text"
+variants = args[sep + 1:] or [""]
+plain = zgdata.text_like(size) if kind == "text" else zgdata.iso_like(size)
+z = zgdata.zstd_compress(plain)
+want = hashlib.sha256(plain).digest()
+for v in variants:
+    sets = [kv.split("=") for kv in v.split(",") if kv]
+    for k, val in sets:
+        os.environ[k] = val
+    ctx = zgpu.Context(0)
+    b = ctx.prepare(z)
+    assert b.parse_status == 0
+    acc = {}
+    for i in range(4):
+        b.run(); b.sync()
+        assert b.bad_status == 0, b.bad_status
+        if i == 0:
+            ok = hashlib.sha256(b.read(0, b.total_out)).digest() == want
+        else:
+            for k, t in b.timings().items():
+                acc[k] = acc.get(k, 0.0) + t / 3
+    print("%-40s %s  %7.2f GB/s " % (v or "default", "OK " if ok else "BAD", size / acc["total"] / 1e6), {k: round(t, 3) for k, t in acc.items()}, flush=True)
+    b.close(); ctx.close()
+    for k, _ in sets:
+        del os.environ[k]

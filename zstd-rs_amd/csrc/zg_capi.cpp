@@ -207,8 +207,7 @@ int zgpu_batch_block_sequences(zgpu_batch* zb, uint32_t i, zgpu_seq* dst, size_t
   if (r) return r;
   *n = v.size();
   if (v.size() > cap) return ZGPU_E_TARGET_TOO_SMALL;
-  static_assert(sizeof(zgpu_seq) == sizeof(ZgSeq), "layout");
-  if (!v.empty()) memcpy(dst, v.data(), v.size() * sizeof(ZgSeq));
+  for (size_t k = 0; k < v.size(); k++) { dst[k].of = v[k].of; dst[k].ml = ZG_SEQ_ML(v[k]); dst[k].mdst = ZG_SEQ_MDST(v[k]); dst[k].lit_start = ZG_SEQ_LIT(v[k]); }
   return ZGPU_OK;
 }
 int zgpu_batch_debug_timers(zgpu_batch* zb, uint64_t out[1024]) { return zb->b->read_debug(out); }

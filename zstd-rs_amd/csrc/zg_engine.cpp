@@ -44,6 +44,12 @@ int Engine::create(int device, Engine** out) {
   if (hipSetDevice(device) != hipSuccess) return ZG_HIP_ERROR;
   Engine* e = new Engine();
   e->device_ = device;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->cus_ = prop.multiProcessorCount;
+    const char* v = getenv("ZGPU_FLAT_T");
+    if (v) e->flat512_ = atoi(v) == 512;
+  }
   // two streams: the sequences chain is the critical one (its kernels last as long as one block's serial chain), so its
   // workgroups are dispatched first; the literals chain fills what is left
   int prio_lo = 0, prio_hi = 0;
@@ -115,7 +121,7 @@ int parse_frames(const uint8_t* src, size_t len, uint64_t max_window, BatchBuild
 
 Batch::~Batch() {
   DevBuf* all[] = {&d_src, &d_blocks, &d_frames, &d_aux, &d_slot_log, &d_fse, &d_huf, &d_hufmax, &d_status, &d_lit, &d_seq,
-                   &d_seqout, &d_pos, &d_frameout, &d_dst, &d_seqblocks, &d_hufitems, &d_hufgroups, &d_totals, &d_og, &d_units, &d_unitinfo, &d_sweepwgs, &d_bar, &d_dbg, &d_raw};
+                   &d_seqout, &d_pos, &d_frameout, &d_dst, &d_seqblocks, &d_hufitems, &d_hufgroups, &d_totals, &d_og, &d_units, &d_unitinfo, &d_stepunits, &d_dbg, &d_raw};
   for (DevBuf* b : all) b->release();
   for (auto& e : ev)
     if (e) (void)hipEventDestroy(e);
@@ -199,7 +205,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   // a frame-layer error after some good frames: the good frames are still uploaded (callers such as the
   // FrameDecoder mirror may want them); decode_all reports parse_status.
   { const char* e = getenv("ZGPU_UNIT_BLOCKS"); if (e && atoi(e) > 0) b->bb.unit_blocks = (uint32_t)atoi(e); }
-  { const char* e = getenv("ZGPU_SWEEP_WGS"); if (e && atoi(e) > 0) b->bb.sweep_budget = (uint32_t)atoi(e); }
+  b->bb.flat_slots = (uint32_t)cus_ * (flat512_ ? 2u : 1u);   // zg_k_flat: one 1024-thread or two 512-thread workgroups per CU
   b->bb.finish();
   BatchBuilder& bb = b->bb;
   const uint32_t nb = (uint32_t)bb.blocks.size(), nf = (uint32_t)bb.frames.size();
@@ -234,8 +240,8 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
       (st = b->fs ? b->fs->d_out.reserve(b->fs->base + b->fs->produced + bb.out_bound + 64, true, stream_) : b->d_dst.reserve(bb.out_bound + 64)) ||
       (st = b->d_totals.reserve(64)) || (st = b->d_og.reserve((size_t)bb.og_count * 4 + 64)) ||
       (st = up(b->d_units, bb.units.data(), bb.units.size() * sizeof(ZgUnit))) ||
-      (st = up(b->d_sweepwgs, bb.sweep_wgs.data(), bb.sweep_wgs.size() * sizeof(ZgSweepWg))) ||
-      (st = b->d_unitinfo.reserve(bb.units.size() * sizeof(ZgUnitInfo) + 16)) || (st = b->d_bar.reserve((size_t)nf * 64 + 64)) || (st = b->d_dbg.reserve(8192))) {
+      (st = up(b->d_stepunits, bb.step_units.data(), bb.step_units.size() * 4)) ||
+      (st = b->d_unitinfo.reserve(bb.units.size() * sizeof(ZgUnitInfo) + 16)) || (st = b->d_dbg.reserve(8192))) {
     delete b;
     return st;
   }
@@ -260,10 +266,16 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   d.totals = b->d_totals.as<uint32_t>();
   d.og = b->d_og.as<uint32_t>();
   d.units = b->d_units.as<ZgUnit>(); d.nunits = (uint32_t)bb.units.size(); d.unit_info = b->d_unitinfo.as<ZgUnitInfo>();
-  d.sweep_wgs = b->d_sweepwgs.as<ZgSweepWg>(); d.nsweep_wgs = (uint32_t)bb.sweep_wgs.size(); d.bar = b->d_bar.as<uint32_t>();
+  d.step_units = b->d_stepunits.as<uint32_t>();
+  b->sweep_steps.clear();
+  for (const ZgStepRange& r : bb.steps) {
+    ZgSweepStep ss;
+    ss.list_off = r.list_off; ss.nunits = r.nunits; ss.slices = r.max_blocks * (kMaxBlockSize / 4096u); ss.pad = 0;   // zg_k_sweep: 4 KiB of output per workgroup
+    b->sweep_steps.push_back(ss);
+  }
   d.dbg = getenv("ZGPU_DEBUG_TIMERS") ? b->d_dbg.as<unsigned long long>() : nullptr;
   { const char* e = getenv("ZGPU_FORCE_INORDER"); d.flags = (e && e[0] == '1') ? 1u : 0u; }
-  { const char* e = getenv("ZGPU_SWEEP_T1024"); if (!e || e[0] != '0') d.flags |= 2u; }
+  if (flat512_) d.flags |= 4u;
   for (auto& e : b->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
   for (auto& e : b->ev_huf)
@@ -284,7 +296,6 @@ int Batch::run() {
   ZG_HIP(hipMemsetAsync(d.huf_maxbits, 0, d.nhuf_slots + 16, s));
   ZG_HIP(hipMemsetAsync(d.slot_log, 0, (size_t)d.nslots * 4, s));
   ZG_HIP(hipMemsetAsync(d.totals, 0, 64, s));
-  ZG_HIP(hipMemsetAsync(d.bar, 0, (size_t)d.nframes * 64 + 64, s));
   if (d.dbg) ZG_HIP(hipMemsetAsync(d.dbg, 0, 8192, s));
   if (fs && fs->carry_mask) {   // tables carried into this run: the frame's carry slots of the two arenas
     const ZgFrame& fr = bb.frames[0];
@@ -322,7 +333,7 @@ int Batch::run() {
   ZG_HIP(hipEventRecord(ev[6], s));
   zg_launch_flat(d, s);
   ZG_HIP(hipEventRecord(ev[7], s));
-  zg_launch_sweep(d, s);
+  zg_launch_sweep(d, s, sweep_steps.data(), (uint32_t)sweep_steps.size());
   ZG_HIP(hipEventRecord(ev[8], s));
   zg_launch_lz(d, s);   // only frames that left the flatten path (a block regenerating > 128 KiB)
   ZG_HIP(hipEventRecord(ev[9], s));

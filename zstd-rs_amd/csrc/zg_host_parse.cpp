@@ -233,16 +233,18 @@ void BatchBuilder::finish() {
     }
     if (final_.huf == kCarryHuf) final_.huf = frames[lf].carry_huf_slot;
   }
-  seq_blocks.clear(); huf_items.clear(); huf_groups.clear(); units.clear(); sweep_wgs.clear();
+  seq_blocks.clear(); huf_items.clear(); huf_groups.clear(); units.clear(); step_units.clear(); steps.clear();
   og_count = 0;
-  // blocks per unit: zg_k_flat runs about one workgroup per CU, so aim at ~flat_slots units over the whole submit
-  // (more blocks per unit = fewer sweep steps, but less parallelism in the flatten pass)
+  // blocks per unit: zg_k_flat runs flat_slots workgroups at once, one per unit, so aim at ~flat_slots units over the
+  // whole submit (more blocks per unit = fewer sweep steps, but less parallelism in the flatten pass)
   uint32_t ub = unit_blocks;
   if (ub == 0) {
-    ub = (nb + flat_slots - 1) / flat_slots;
-    if (ub < 8) ub = 8;
+    const uint32_t slots = flat_slots ? flat_slots : 1;
+    ub = (nb + slots - 1) / slots;
+    if (ub < 4) ub = 4;
     if (ub > 256) ub = 256;   // unit-relative positions stay far below 2^30
   }
+  uint32_t max_units = 0;
   for (uint32_t f = 0; f < frames.size(); f++) {
     ZgFrame& fr = frames[f];
     fr.first_unit = (uint32_t)units.size();
@@ -255,18 +257,20 @@ void BatchBuilder::finish() {
       units.push_back(u);
     }
     fr.nunits = (uint32_t)units.size() - fr.first_unit;
+    if (fr.nunits > max_units) max_units = fr.nunits;
   }
-  // workgroups of the sweep: proportional to the frame's share of the blocks, at least one, all resident at once
-  {
-    const uint64_t nbt = nb ? nb : 1;
+  // sweep steps: step s takes unit s of every frame that has one (frames are independent; units of a frame go in order)
+  for (uint32_t s = 0; s < max_units; s++) {
+    ZgStepRange r;
+    r.list_off = (uint32_t)step_units.size(); r.nunits = 0; r.max_blocks = 0;
     for (uint32_t f = 0; f < frames.size(); f++) {
-      uint64_t w = ((uint64_t)sweep_budget * frames[f].nblocks + nbt - 1) / nbt;
-      uint32_t cap = (frames[f].nblocks + 1) / 2;   // at least ~256 KiB of output per workgroup
-      if (w > cap) w = cap;
-      if (w < 1) w = 1;
-      if (w > 256) w = 256;
-      for (uint32_t r = 0; r < w; r++) { ZgSweepWg g; g.frame = f; g.rank = r; g.wpf = (uint32_t)w; g.pad = 0; sweep_wgs.push_back(g); }
+      if (frames[f].nunits <= s) continue;
+      const uint32_t u = frames[f].first_unit + s;
+      step_units.push_back(u);
+      r.nunits++;
+      if (units[u].nblocks > r.max_blocks) r.max_blocks = units[u].nblocks;
     }
+    steps.push_back(r);
   }
   for (uint32_t i = 0; i < nb; i++) {
     ZgBlock& b = blocks[i];

@@ -49,6 +49,8 @@ struct Lineage {
   int32_t ll = ZG_REF_UNINIT, of = ZG_REF_UNINIT, ml = ZG_REF_UNINIT;
 };
 
+struct ZgStepRange { uint32_t list_off, nunits, max_blocks; };
+
 // Builds the submit: appends blocks (with parsed section headers and lineage) and frames.
 class BatchBuilder {
  public:
@@ -58,11 +60,11 @@ class BatchBuilder {
   std::vector<uint32_t> huf_items;
   std::vector<ZgHufGroup> huf_groups;
   std::vector<ZgUnit> units;
-  std::vector<ZgSweepWg> sweep_wgs;
+  std::vector<uint32_t> step_units;     // concatenated unit lists of the sweep steps
+  std::vector<ZgStepRange> steps;       // sweep step s: units step_units[list_off .. list_off + nunits)
   uint64_t og_count = 0;       // flatten scratch size in u32
   uint32_t unit_blocks = 0;    // blocks per unit; 0 = choose from the submit size
-  uint32_t flat_slots = 256;   // workgroups of zg_k_flat the chip runs at once (1 per CU)
-  uint32_t sweep_budget = 256; // workgroups of zg_k_sweep over the whole submit
+  uint32_t flat_slots = 256;   // workgroups of zg_k_flat the device runs at once (engine: CUs x workgroups per CU)
   uint64_t lit_bytes = 0;      // literals arena size
   uint64_t seq_count = 0;      // sequence arena size
   uint32_t nhuf_slots = 0;

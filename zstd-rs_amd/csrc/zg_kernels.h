@@ -38,16 +38,16 @@ struct ZgBatchDev {
   const ZgHufGroup* huf_groups;
   uint32_t nhuf_groups;
   uint32_t* totals;            // [4]: [0..1] total output bytes (u64), [2] overflow flag
-  uint32_t flags;              // bit 0: force the in-order fallback for every frame (tests)
-  uint32_t* og;                // flatten scratch: one u32 "effective offset" per output byte of a unit (0 = byte already final)
+  uint32_t flags;              // bit 0: force the in-order fallback for every frame (tests); bit 2: zg_k_flat with 512-thread workgroups / 8 KiB tiles
+  uint32_t* og;                // flatten scratch: one u32 "effective offset" per output byte of a unit (0 = literal byte, final already)
   const ZgUnit* units;
   uint32_t nunits;
   ZgUnitInfo* unit_info;       // [nunits]
-  const ZgSweepWg* sweep_wgs;
-  uint32_t nsweep_wgs;
-  unsigned long long* dbg;     // [8]: phase cycle counters of zg_k_flat (summed over workgroups), diagnostics only
-  uint32_t* bar;               // [nframes][16] arrival counters of the sweep's per-frame barrier: 8 groups + top (zeroed every run)
+  const uint32_t* step_units;  // sweep step s fills the units step_units[list_off(s) ...] (unit s of every frame that has one)
+  unsigned long long* dbg;     // phase cycle counters (profiling builds), diagnostics only
 };
+// one launch of zg_k_sweep
+struct ZgSweepStep { uint32_t list_off, nunits, slices, pad; };
 
 void zg_launch_tables(const ZgBatchDev& d, hipStream_t s, int part);   // part 0: Huffman trees, part 1: FSE tables
 void zg_launch_huf(const ZgBatchDev& d, hipStream_t s);
@@ -57,6 +57,6 @@ void zg_launch_merge(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_scan(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_lit(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_flat(const ZgBatchDev& d, hipStream_t s);
-void zg_launch_sweep(const ZgBatchDev& d, hipStream_t s);
+void zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* steps, uint32_t nsteps);
 void zg_launch_lz(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_calib(const void* src, void* dst, uint64_t bytes, hipStream_t s);

@@ -13,8 +13,9 @@
 //     zg_k_scan     one workgroup per frame    block output positions + offset-history resolution (function-composition scan)
 //     zg_k_scanf    one workgroup              frame output positions
 //     zg_k_lit      one workgroup per block    raw and RLE blocks, blocks without sequences -> output
-//     zg_k_flat     one workgroup per unit     every byte of a run of blocks -> its value or its offset to before the unit
-//     zg_k_sweep    256 workgroups per frame   unit after unit: open bytes gathered from finished output
+//     zg_k_flat     one workgroup per unit     every match byte of a run of blocks -> its offset to a byte that is final before the unit is swept; literals -> output
+//     zg_k_sweep    one launch per unit index  unit after unit: match bytes gathered from finished output
+//     zg_k_fin      one thread per frame       execution errors -> frame status
 //     zg_k_lz       one workgroup per frame    in-order fallback (blocks regenerating > 128 KiB)
 //
 // The reference functions each kernel reproduces are cited at the lane routines in zg_dev.h.
@@ -24,11 +25,6 @@
 #define ZG_SEQ_G 16       // blocks per workgroup (one wave, four lanes per block) in zg_k_seq: 16 x (2.5 KiB tables + 1.25 KiB side tables + ring + out) in LDS -> 2 workgroups per CU
 #define ZG_LZ_T 256       // threads per frame in zg_k_lz
 #define ZG_FLAT_MAX 131072u  // largest block output the flatten path handles (Block_Maximum_Size)
-#define ZG_FL_T 1024      // threads per unit in zg_k_flat
-#define ZG_FL_TS 16384    // tile: bytes of block output resolved at a time in LDS
-#define ZG_FL_PER (ZG_FL_TS / ZG_FL_T)
-#define ZG_PAR_LIT 0xFFFFu   // tile byte is a literal: value in s_val
-#define ZG_PAR_EXIT 0xFFFEu  // tile byte is a match byte whose source lies before the tile
 
 typedef uint32_t zg_v4u __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) zg_v4u zg_gv4u;   // 16 bytes in global memory: global_load/store, not flat
@@ -860,8 +856,8 @@ __global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
           if ((big >> j) & 1u) e = ZG_EXE_OFFSET_TOO_BIG;
           if (actual == 0) e = ZG_EXE_ZERO_OFFSET;                                  // :28-30
           if (e && bad == 0xFFFFFFFFu) bad = ((t * ZG_SP_S + (uint32_t)j) << 8) | e;
-          zg_v4u q = {actual, ml[j], out_pos + ll[j], lit_pos};                     // ZgSeq {of, ml, mdst, lit_start}
-          *(zg_gv4u*)(out + ib + j) = q;
+          const uint32_t mdst = out_pos + ll[j];
+          *(zg_gv3u*)(out + ib + j) = zg_v3u{actual, ZG_SEQ_W1(mdst, ml[j]), ZG_SEQ_W2(lit_pos, ml[j])};   // ZgSeq
           lit_pos += ll[j]; out_pos += ll[j] + ml[j];
         }
       }
@@ -1016,8 +1012,9 @@ __global__ void __launch_bounds__(1024) zg_k_scanf(ZgBatchDev d) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// zg_k_lit: everything that does not depend on earlier output — literal runs of compressed blocks
-// (DecodeBuffer::push, decode_buffer.rs:74-77), raw blocks and RLE blocks (block_decoder.rs:55-82).
+// zg_k_lit: blocks that do not depend on earlier output at all — raw blocks, RLE blocks (block_decoder.rs:55-82) and
+// compressed blocks without sequences (block_decoder.rs:184-194: the literals are the block). Literal runs of blocks
+// WITH sequences (DecodeBuffer::push, decode_buffer.rs:74-77) are placed by zg_k_flat (flatten path) or zg_k_lz.
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void zg_wg_copy(uint8_t* dst, const uint8_t* src, uint64_t n, uint32_t t, uint32_t T) {
   uint64_t n8 = n >> 3;
@@ -1040,28 +1037,9 @@ __global__ void __launch_bounds__(256) zg_k_lit(ZgBatchDev d) {
   const uint8_t* body = d.src + blk.src_off;
   if (blk.btype == ZG_BT_RAW) { zg_wg_copy(out, body, blk.regen_size, t, 256); return; }
   if (blk.btype == ZG_BT_RLE) { zg_wg_fill(out, body[0], blk.regen_size, t, 256); return; }
-  if (blk.nseq && d.frame_out[blk.frame].fast) return;  // literals of these blocks are placed by zg_k_flat
-  const bool rle = blk.lit_type == ZG_LT_RLE;
-  const uint8_t* lit = blk.lit_type == ZG_LT_RAW ? body + blk.lit_off : blk.lit_type == ZG_LT_RLE ? body + blk.lit_off : d.lit_arena + blk.lit_base;
-  uint32_t sum_ll = 0, sum_ml = 0;
-  if (blk.nseq) {
-    const ZgBlockSeqOut so = d.seq_out[b];
-    sum_ll = so.sum_ll; sum_ml = so.sum_ml;
-    const ZgSeq* sq = d.seq_arena + blk.seq_base;
-    for (uint32_t i = t; i < blk.nseq; i += 256) {
-      const ZgSeq q = sq[i];
-      uint32_t next = i + 1 < blk.nseq ? sq[i + 1].lit_start : sum_ll;
-      uint32_t ll = next - q.lit_start;
-      uint8_t* o = out + (q.mdst - ll);
-      if (rle) { uint8_t v = lit[0]; for (uint32_t k = 0; k < ll; k++) o[k] = v; }
-      else { const uint8_t* s = lit + q.lit_start; for (uint32_t k = 0; k < ll; k++) o[k] = s[k]; }
-    }
-  }
-  // trailing literals (sequence_execution.rs:40-44) or the whole section when there are no sequences (block_decoder.rs:192)
-  uint32_t rest = blk.regen_size - sum_ll;
-  uint8_t* o = out + ((uint64_t)sum_ll + sum_ml);
-  if (rle) zg_wg_fill(o, lit[0], rest, t, 256);
-  else zg_wg_copy(o, lit + sum_ll, rest, t, 256);
+  if (blk.nseq) return;
+  if (blk.lit_type == ZG_LT_RLE) zg_wg_fill(out, body[blk.lit_off], blk.regen_size, t, 256);
+  else zg_wg_copy(out, blk.lit_type == ZG_LT_RAW ? body + blk.lit_off : d.lit_arena + blk.lit_base, blk.regen_size, t, 256);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1069,35 +1047,41 @@ __global__ void __launch_bounds__(256) zg_k_lit(ZgBatchDev d) {
 // decode_buffer.rs:79-141) without walking the frame's sequences one after the other.
 //
 // Chains of matches (a match copying the output of an earlier match ...) are what makes in-order execution slow on
-// a GPU: every hop is a memory round trip. Instead every output byte is resolved to where its value finally comes from:
-//   zg_k_flat  (all units at once; a unit = a run of consecutive blocks of a frame; one workgroup per unit) walks the
-//              unit in 16 KiB tiles held in LDS. A tile byte points to its parent byte (position - offset). Pointer
-//              jumping inside the tile (u16 pointers) shortens every chain to its tile root in O(log depth) rounds; roots
-//              are literal bytes (value known) or bytes whose parent lies before the tile. Parents in earlier tiles of
-//              the unit are already final. Result per byte: the value, or an "effective offset" o such that
-//              byte = frame[pos - o] with pos - o BEFORE the unit.
-//   zg_k_sweep (several workgroups per frame, units in order, one grid barrier per unit) fills the unresolved bytes of
-//              unit u from the finished output of units < u — a pure gather, all bytes of the unit in parallel.
+// a GPU: every hop is a memory round trip, and text has chains millions of hops deep. Instead every MATCH byte is
+// resolved to an "effective offset" e: byte[pos] = byte[pos - e], where pos - e is a byte that is final before the
+// byte's unit is swept — a literal byte anywhere, or any byte before the unit (a unit = a run of consecutive blocks of
+// one frame). Literal bytes have e = 0. No byte VALUES travel through this stage: only offsets.
+//   zg_k_flat  (all units at once, one workgroup per unit) walks the unit in tiles held in LDS. A tile byte points to
+//              its parent byte (position - offset); pointer jumping inside the tile (u16 pointers) shortens every chain
+//              to its tile root: a literal byte, or a match byte whose parent lies before the tile. Such a parent is in
+//              an earlier tile of the unit (its e is final: one gather from the scratch, e = offset + e[parent]) or
+//              before the unit (e = offset). Literal bytes are copied to the output on the way.
+//   zg_k_sweep one launch per unit index, in frame order (a kernel boundary is the cheapest chip-wide barrier there is,
+//              and needs no co-residency assumption): every match byte of the unit is one independent gather from
+//              bytes that are final by then.
 // ------------------------------------------------------------------------------------------------------------
-#define ZG_FL_SOFF 5632   // most matches that can start in / overlap one tile (match length >= 3) + slack
-#define ZG_FL_LONG 48      // literal runs / matches longer than this are filled by the whole workgroup, not by one lane
-#define ZG_FL_LONGCAP 352  // > 16384 / 48 + 2
+#define ZG_PAR_LIT 0xFFFFu   // tile byte is a literal
+#define ZG_PAR_EXIT 0x8000u  // tile byte is a match byte whose parent lies before the tile
 
-// workgroup barrier that orders LDS only: unlike __syncthreads() it does not wait for this wave's global stores, so
-// the og[] / output stores of a tile drain while the next tile is being set up
+// workgroup barrier that orders LDS only: unlike __syncthreads() it does not wait for this wave's global loads/stores
 __device__ __forceinline__ void zg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_val[ZG_FL_TS];      // values of the bytes that are known (read by S4)
-  __shared__ __attribute__((aligned(16))) uint16_t s_par[ZG_FL_TS];    // 0xFFFF literal, 0x8000 parent before the tile, else tile-relative parent
-  __shared__ uint32_t s_bits[ZG_FL_TS / 32];                           // marks: the first tile byte of every sequence
-  __shared__ uint16_t s_cnt[ZG_FL_TS / 32];                            // marks before each word of s_bits
-  __shared__ uint32_t s_roff[ZG_FL_SOFF], s_rlit[ZG_FL_SOFF], s_rsm[ZG_FL_SOFF];   // per sequence of the tile: offset; literal source index at its first tile byte; first tile byte | first match byte << 16
-  __shared__ uint32_t s_wtot[ZG_FL_T / 64];
-  __shared__ uint32_t s_next, s_err, s_unres;
+template <int T, int TS>
+__global__ void __launch_bounds__(T, 4) zg_k_flat(ZgBatchDev d) {   // 4 waves per SIMD: 128 registers, two 512-thread workgroups (or one of 1024) per CU
+  constexpr int PER = 16;                       // consecutive tile bytes a thread walks
+  static_assert(TS == T * PER, "tile = 16 bytes per thread");
+  constexpr int SOFF = 2 * T;                   // sequences a tile takes (two per thread); a denser tile is cut short
+  constexpr int NW = TS / 32;                   // words of the mark bitmap
+  __shared__ __attribute__((aligned(16))) uint16_t s_par[TS];    // 0xFFFF literal, 0x8000 parent before the tile, else tile-relative parent
+  __shared__ uint32_t s_word[TS];                                 // effective offset of the tile's roots, [byte & 15][byte >> 4]
+  __shared__ uint32_t s_bits[NW];                                 // marks: the first tile byte of every sequence
+  __shared__ uint16_t s_cnt[NW];                                  // marks before each word of s_bits
+  __shared__ uint32_t s_roff[SOFF], s_rlit[SOFF], s_rsm[SOFF];    // per sequence of the tile: offset; literal source index at its first tile byte; first tile byte | first match byte << 16
+  __shared__ uint32_t s_wtot[NW / 64];
+  __shared__ uint32_t s_next, s_cut, s_err;
   const uint32_t t = threadIdx.x;
   const ZgUnit un = d.units[blockIdx.x];
-  if (t == 0) { ZgUnitInfo ui; ui.size = 0; ui.unresolved = 0; d.unit_info[blockIdx.x] = ui; }
+  if (t == 0) { ZgUnitInfo ui; ui.size = 0; ui.pad = 0; d.unit_info[blockIdx.x] = ui; }
   if (d.totals[2]) return;
   const ZgFrameOut fo = d.frame_out[un.frame];
   if (!fo.fast) return;
@@ -1105,10 +1089,10 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
   const uint64_t unit_abs0 = d.pos[un.first_block].out_base;     // frame-relative position of the unit's first byte
   uint8_t* out_u = d.dst + fo.out_base + unit_abs0;
   uint32_t* og = d.og + un.og_base;
-  if (t == 0) { s_err = 0; s_unres = 0; }
+  if (t == 0) s_err = 0;
   uint32_t unit_size = 0;
 #ifdef ZG_PROFILE_FLAT   // per-phase cycle counters (tools/dev/flat_phases.py); costs registers, off in the product build
-  unsigned long long tc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+  unsigned long long tc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
 #define ZG_TICK(i) { const unsigned long long n_ = clock64(); tc[i] += n_ - tlast; tlast = n_; }
 #else
 #define ZG_TICK(i)
@@ -1120,17 +1104,9 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
     if (!p.active) break;
     const ZgBlock blk = d.blocks[b];
     const uint32_t bu0 = (uint32_t)(p.out_base - unit_abs0);      // unit-relative position of the block
-    if (blk.btype != ZG_BT_COMPRESSED || blk.nseq == 0) {        // already final (zg_k_lit): nothing to resolve
+    if (blk.btype != ZG_BT_COMPRESSED || blk.nseq == 0) {        // all of it is final already (zg_k_lit): effective offset 0
       const uint32_t n = blk.regen_size;
-      for (uint32_t i = 4 * t; i < n; i += 4 * ZG_FL_T) {          // final (zg_k_lit wrote them): the values themselves
-        if (i + 4 <= n) {
-          const uint32_t v = zg_ld32(out_u + bu0 + i);
-          og[bu0 + i] = 0x80000000u | (v & 255u); og[bu0 + i + 1] = 0x80000000u | ((v >> 8) & 255u);
-          og[bu0 + i + 2] = 0x80000000u | ((v >> 16) & 255u); og[bu0 + i + 3] = 0x80000000u | (v >> 24);
-        } else {
-          for (uint32_t k = i; k < n; k++) og[bu0 + k] = 0x80000000u | out_u[bu0 + k];
-        }
-      }
+      for (uint32_t i = t; i < n; i += T) og[bu0 + i] = 0u;
       unit_size = bu0 + n;
       continue;
     }
@@ -1138,29 +1114,39 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
     const uint32_t S = blk.regen_size + so.sum_ml;               // <= ZG_FLAT_MAX on this path
     unit_size = bu0 + S;
     const uint32_t nseq = blk.nseq;
-    const ZgSeq* sq = d.seq_arena + blk.seq_base;
+    const uint32_t* sq = (const uint32_t*)(d.seq_arena + blk.seq_base);
     const uint8_t* body = d.src + blk.src_off;
     const bool lit_rle = blk.lit_type == ZG_LT_RLE;
     const uint8_t* lit = blk.lit_type <= ZG_LT_RLE ? body + blk.lit_off : d.lit_arena + blk.lit_base;
-    const uint8_t lit_fill = lit_rle ? lit[0] : 0;
+    const uint32_t lit_fill = lit_rle ? lit[0] : 0u;
     // bytes of the frame (and dictionary) that exist before this block: the farthest a match may reach
     const uint64_t reach = p.out_base + fr.prior_out + fr.dict_len;
+    // the two sequences a thread places per tile travel in registers: they are requested one tile ahead
+    zg_v3u qa = {0, 0, 0}, qb = {0, 0, 0};
+    uint32_t na = 0, nb = 0;
+    auto fetch = [&](uint32_t i0) {
+      const uint32_t ia = i0 + t, ib = ia + T;
+      if (ia < nseq) { qa = *(const zg_gv3u*)(sq + 3ull * ia); na = ia + 1 < nseq ? sq[3ull * (ia + 1) + 2] & 0x1FFFFu : so.sum_ll; }
+      if (ib < nseq) { qb = *(const zg_gv3u*)(sq + 3ull * ib); nb = ib + 1 < nseq ? sq[3ull * (ib + 1) + 2] & 0x1FFFFu : so.sum_ll; }
+    };
+    fetch(0);
     uint32_t i_start = 0;
-    for (uint32_t t0 = 0; t0 < S; t0 += ZG_FL_TS) {
-      const uint32_t t1 = t0 + ZG_FL_TS < S ? t0 + ZG_FL_TS : S;
-      const uint32_t tu0 = bu0 + t0;                             // unit-relative position of the tile
-      const uint32_t n = t1 - t0;
-      if (t == 0) s_next = 0xFFFFFFFFu;
-      if (t < ZG_FL_TS / 32) s_bits[t] = 0;
+    for (uint32_t t0 = 0; t0 < S;) {
+      const uint32_t t1o = t0 + TS < S ? t0 + TS : S;            // where the tile ends unless it holds too many sequences
+      if (t == 0) { s_next = 0xFFFFFFFFu; s_cut = 0xFFFFFFFFu; }
+      if (t < NW) s_bits[t] = 0;
       zg_lds_barrier();
       ZG_TICK(0)
-      // ---- S1a: one thread per sequence i (index nseq stands for the trailing literals). It covers [a, m0) with literals and
-      // [m0, m1) with its match; the part inside the tile is described by one record and one mark at its first tile byte.
+      // ---- S1a: one thread per sequence i (index nseq stands for the trailing literals). It covers [a, m0) with literals
+      // and [m0, m1) with its match; the part inside the tile is described by one record and one mark at its first tile byte.
       {
-        auto place = [&](uint32_t i, const zg_v4u q, uint32_t next) -> bool {   // false: this and all later sequences start behind the tile
+        auto place = [&](uint32_t j, const zg_v3u q, uint32_t next) {
+          const uint32_t i = i_start + j;
+          if (i > nseq) return;
           uint32_t a, m0, m1, lstart, off = 0;
           if (i < nseq) {
-            lstart = q.w; m0 = q.z; m1 = q.z + q.y; a = m0 - (next - lstart);          // ZgSeq {of, ml, mdst, lit_start}
+            lstart = q.z & 0x1FFFFu; m0 = q.y & 0x1FFFFu; m1 = m0 + ((q.y >> 17) | (((q.z >> 17) & 7u) << 15));
+            a = m0 - ((next - lstart) & 0x1FFFFu);
             off = zg_sym_resolve(q.x, p.hist_init);
             if (off == 0) atomicCAS(&s_err, 0u, (uint32_t)ZG_EXE_ZERO_OFFSET);                     // sequence_execution.rs:28-30
             else if ((uint64_t)off > reach + m0)            // repeat_from_dict (decode_buffer.rs:144-179): which error depends on how much was output so far
@@ -1168,35 +1154,25 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
           } else {
             lstart = so.sum_ll; a = so.sum_ll + so.sum_ml; m0 = m1 = S;
           }
-          if (m1 > t1 || a >= t1) atomicMin(&s_next, i);  // first sequence that reaches beyond this tile starts the next one
-          if (a >= t1) return false;
-          const uint32_t j = i - i_start;                 // tile-local sequence index (< ZG_FL_SOFF: a sequence spans >= 3 bytes)
-          if (j >= ZG_FL_SOFF) { atomicCAS(&s_err, 0u, (uint32_t)ZG_INTERNAL); return false; }
+          if (m1 > t1o || a >= t1o) atomicMin(&s_next, i);  // first sequence that reaches beyond this tile starts the next one
+          if (a >= t1o) return;
           const uint32_t st = (a > t0 ? a : t0) - t0;
-          const uint32_t mr = (m0 > t0 ? (m0 < t1 ? m0 : t1) : t0) - t0;
+          const uint32_t mr = (m0 > t0 ? (m0 < t1o ? m0 : t1o) : t0) - t0;
           s_roff[j] = off;
           s_rlit[j] = lstart + (a > t0 ? 0u : t0 - a);
           s_rsm[j] = st | (mr << 16);
           atomicOr(&s_bits[st >> 5], 1u << (st & 31u));
-          return true;
+          // the last sequence the tile has room for, and more would start inside it: the tile ends with this one
+          if (j == SOFF - 1 && i < nseq && m1 <= t1o) s_cut = m1;
         };
-        // two sequences per thread and round, both loaded before either is used: one memory round trip for a typical tile
-        for (uint32_t i = i_start + t; i <= nseq; i += 2 * ZG_FL_T) {
-          const uint32_t i2 = i + ZG_FL_T;
-          zg_v4u qa = {0, 0, 0, 0}, qb = {0, 0, 0, 0};
-          uint32_t na = so.sum_ll, nb = so.sum_ll;
-          if (i < nseq) { qa = *(const zg_gv4u*)(sq + i); if (i + 1 < nseq) na = sq[i + 1].lit_start; }
-          if (i2 < nseq) { qb = *(const zg_gv4u*)(sq + i2); if (i2 + 1 < nseq) nb = sq[i2 + 1].lit_start; }
-          if (!place(i, qa, na)) break;
-          if (i2 > nseq || !place(i2, qb, nb)) break;
-        }
+        place(t, qa, na);
+        place(t + T, qb, nb);
       }
-      ZG_TICK(11)
       zg_lds_barrier();
-      // ---- S1b: marks before every word (prefix sum over the 512 words)
+      // ---- S1b: marks before every word (prefix sum over the words)
       {
         uint32_t c = 0, sc = 0;
-        if (t < ZG_FL_TS / 32) {
+        if (t < NW) {
           c = (uint32_t)__popc(s_bits[t]);
           sc = c;
 #pragma unroll
@@ -1204,136 +1180,140 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
           if ((t & 63) == 63) s_wtot[t >> 6] = sc;
         }
         zg_lds_barrier();
-        if (t < ZG_FL_TS / 32) {
+        if (t < NW) {
           uint32_t before = sc - c;
           for (uint32_t w = 0; w < (t >> 6); w++) before += s_wtot[w];
           s_cnt[t] = (uint16_t)before;
         }
-        zg_lds_barrier();
       }
-      i_start = s_next == 0xFFFFFFFFu ? nseq + 1 : s_next;
+      // every wave's scratch stores of the previous tile have reached memory before any wave gathers from them
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      zg_lds_barrier();
+      ZG_TICK(1)
+      const uint32_t cut = s_cut;
+      const uint32_t t1 = cut != 0xFFFFFFFFu ? cut : t1o;
+      const uint32_t i_next = cut != 0xFFFFFFFFu ? i_start + SOFF : (s_next == 0xFFFFFFFFu ? nseq + 1 : s_next);
       if (s_err) break;
-      // ---- S1c: one thread per 16 consecutive tile bytes walks them with the marks. Each byte becomes a literal (value to
-      // s_val), a match byte whose parent lies before the tile (0x8000 | its sequence), or a match byte with its parent
-      // inside the tile (pointer). 16 bytes of values and 32 bytes of pointers leave as three 16-byte LDS stores.
+      const uint32_t n = t1 - t0;
+      const uint32_t tu0 = bu0 + t0;                             // unit-relative position of the tile
+      if (t1 < S) fetch(i_next);                                  // next tile's sequences: in flight behind this tile's work
+      // ---- S1c: one thread per 16 consecutive tile bytes walks them with the marks. A byte becomes a literal, a match byte
+      // with its parent inside the tile (pointer), or a root: a match byte whose parent lies before the tile. A root's
+      // effective offset is its sequence's offset if the parent lies before the unit, else offset + e[parent], the parent's
+      // scratch word being requested here and added after the pointer jumping (the round trip hides behind it).
+      uint32_t wadd[PER];
+      uint32_t lq[4] = {0, 0, 0, 0};                             // the thread's literal bytes, packed (zeros at match positions)
+      const uint32_t x0 = t * PER;
       {
-        const uint32_t x0 = t * ZG_FL_PER;
+#pragma unroll
+        for (int k = 0; k < PER; k++) wadd[k] = 0;
+        uint32_t pp[PER / 2];
+#pragma unroll
+        for (int k = 0; k < PER / 2; k++) pp[k] = 0;
         if (x0 < n) {
           const uint32_t word = s_bits[x0 >> 5];
           const uint32_t bits16 = (word >> (x0 & 31u)) & 0xFFFFu;
           int32_t j = (int32_t)s_cnt[x0 >> 5] + __popc(word & ((1u << (x0 & 31u)) - 1u)) - 1;   // sequence of byte x0 - 1
           uint32_t r_off = 0, r_lit = 0, r_st = 0, r_m0 = 0;
           if (j >= 0) { r_off = s_roff[j]; r_lit = s_rlit[j]; const uint32_t sm = s_rsm[j]; r_st = sm & 0xFFFFu; r_m0 = sm >> 16; }
-          uint32_t kind[ZG_FL_PER], lv[ZG_FL_PER];
 #pragma unroll
-          for (int k = 0; k < ZG_FL_PER; k++) {
+          for (int k = 0; k < PER; k++) {
             const uint32_t x = x0 + k;
             if ((bits16 >> k) & 1u) { j++; r_off = s_roff[j]; r_lit = s_rlit[j]; const uint32_t sm = s_rsm[j]; r_st = sm & 0xFFFFu; r_m0 = sm >> 16; }
-            const bool is_lit = x < r_m0 || x >= n;
-            lv[k] = (!is_lit || lit_rle || x >= n) ? (uint32_t)lit_fill : (uint32_t)lit[r_lit + (x - r_st)];
-            kind[k] = is_lit ? 0xFFFFu : r_off <= x ? x - r_off : 0x8000u | (uint32_t)j;
+            const bool in = x < n;
+            const bool is_lit = x < r_m0 || !in;
+            uint32_t kind, wb = 0;
+            if (is_lit) {
+              kind = ZG_PAR_LIT;
+              const uint32_t lv = !in ? 0u : lit_rle ? lit_fill : (uint32_t)lit[r_lit + (x - r_st)];
+              lq[k >> 2] |= lv << (8 * (k & 3));
+            } else if (r_off <= x) kind = x - r_off;
+            else {
+              kind = ZG_PAR_EXIT;
+              wb = r_off;
+              const int32_t y = (int32_t)(tu0 + x) - (int32_t)r_off;       // unit position of the parent
+              if (y >= 0) wadd[k] = og[y];
+            }
+            s_word[k * T + t] = wb;
+            pp[k >> 1] |= kind << (16 * (k & 1));
           }
-          uint32_t vv[ZG_FL_PER / 4], pp[ZG_FL_PER / 2];
-#pragma unroll
-          for (int k = 0; k < ZG_FL_PER / 4; k++) vv[k] = (lv[4 * k] & 0xFFu) | ((lv[4 * k + 1] & 0xFFu) << 8) | ((lv[4 * k + 2] & 0xFFu) << 16) | (lv[4 * k + 3] << 24);
-#pragma unroll
-          for (int k = 0; k < ZG_FL_PER / 2; k++) pp[k] = kind[2 * k] | (kind[2 * k + 1] << 16);
-          *(zg_v4u*)&s_val[x0] = zg_v4u{vv[0], vv[1], vv[2], vv[3]};
           *(zg_v4u*)&s_par[x0] = zg_v4u{pp[0], pp[1], pp[2], pp[3]};
           *(zg_v4u*)&s_par[x0 + 8] = zg_v4u{pp[4], pp[5], pp[6], pp[7]};
         }
       }
       zg_lds_barrier();
-      ZG_TICK(1)
-      // A byte's pointer lives in s_par only: after the phase it is the tile-relative root (or still >= 0x8000: the byte
-      // is its own root). Each round a thread visits just its still-unresolved bytes (few: most parents are before the tile).
-      uint32_t unresolved = 0;
-#pragma unroll
-      for (int k = 0; k < ZG_FL_PER; k++) {
-        const uint32_t x = t + k * ZG_FL_T;
-        if (t0 + x < t1 && s_par[x] < 0x8000u) unresolved |= 1u << k;
-      }
-      // Asynchronous pointer jumping: a byte's pointer only ever moves to another of its ancestors, so stale reads are
-      // harmless and no barrier is needed between rounds; a byte is done when its pointer's pointer is a root marker.
-      // Four bytes per step keep four dependent LDS read pairs in flight.
-      for (uint32_t guard = 0; unresolved && guard < (1u << 16); guard++) {
-        uint32_t m = unresolved, kk[4], pp[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) { kk[j] = m ? (uint32_t)__builtin_ctz(m) : 32u; m &= m - 1; }
-#pragma unroll
-        for (int j = 0; j < 4; j++) pp[j] = kk[j] < 32u ? s_par[t + kk[j] * ZG_FL_T] : 0u;
-#pragma unroll
-        for (int j = 0; j < 4; j++) pp[j] = s_par[pp[j]];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          if (kk[j] < 32u) {
-            if (pp[j] >= 0x8000u) unresolved &= ~(1u << kk[j]);     // its pointer is the root
-            else s_par[t + kk[j] * ZG_FL_T] = (uint16_t)pp[j];     // u16 stores are atomic
-          }
-        }
-      }
-      if (__syncthreads_or(unresolved != 0)) { if (t == 0) s_err = ZG_INTERNAL; __syncthreads(); break; }  // cannot happen: every step moves a pointer up its chain
       ZG_TICK(2)
-      // ---- S3: every byte of the tile becomes one word of og[]: 0x80000000 | value when the byte is known, else its
-      // effective offset (< 2^31). A byte whose root's parent lies in an earlier tile of the unit takes that byte's word
-      // (one gather: earlier tiles are final). Written straight to their places: nobody reads s_val at match positions
-      // or og[] of the current tile during this phase.
-      uint32_t nun = 0;
+      // ---- S2: asynchronous pointer jumping. A byte's pointer only ever moves to another of its ancestors, so stale reads
+      // are harmless and no barrier is needed between rounds; a byte is done when its pointer's pointer is a root marker.
+      // Each thread visits just its still-unresolved bytes (few: most parents are before the tile), four per step.
       {
-        uint32_t w[ZG_FL_PER];   // the word, or 0xC0000000 | unit position to look up
+        uint32_t unresolved = 0;
 #pragma unroll
-        for (int k = 0; k < ZG_FL_PER; k++) {
-          const uint32_t xr = t + k * ZG_FL_T;
-          w[k] = 0x80000000u;
-          if (t0 + xr >= t1) continue;
-          const uint16_t own = s_par[xr];
-          if (own == ZG_PAR_LIT) { w[k] = 0x80000000u | s_val[xr]; continue; }
-          const uint32_t r = own >= 0x8000u ? xr : own;     // tile-relative root
-          const uint16_t rp = own >= 0x8000u ? own : s_par[r];
-          if (rp == ZG_PAR_LIT) { const uint8_t v = s_val[r]; s_val[xr] = v; w[k] = 0x80000000u | v; continue; }
-          const uint32_t off_r = s_roff[rp & 0x7FFFu];
-          const int32_t par_u = (int32_t)(tu0 + r) - (int32_t)off_r;   // unit position of the root's parent (< tu0)
-          w[k] = par_u >= 0 ? 0xC0000000u | (uint32_t)par_u            // an earlier tile of this unit: already final
-                            : (tu0 + xr) + (uint32_t)(-par_u);         // reaches before the unit
+        for (int k = 0; k < PER; k++) {
+          const uint32_t x = t + k * T;
+          if (x < n && s_par[x] < ZG_PAR_EXIT) unresolved |= 1u << k;
         }
-        ZG_TICK(8)
-        uint32_t o2[ZG_FL_PER];
+        for (uint32_t guard = 0; unresolved && guard < (1u << 16); guard++) {
+          uint32_t m = unresolved, kk[4], pp[4];
 #pragma unroll
-        for (int k = 0; k < ZG_FL_PER; k++) o2[k] = og[(w[k] >> 30) == 3u ? (w[k] & 0x3FFFFFFFu) : 0u];   // clamped addresses: all loads issued back to back
-#ifdef ZG_PROFILE_FLAT
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        ZG_TICK(9)
+          for (int j = 0; j < 4; j++) { kk[j] = m ? (uint32_t)__builtin_ctz(m) : 32u; m &= m - 1; }
 #pragma unroll
-        for (int k = 0; k < ZG_FL_PER; k++) {
-          const uint32_t xr = t + k * ZG_FL_T;
-          if (t0 + xr >= t1) continue;
-          uint32_t v = w[k];
-          if ((v >> 30) == 3u) {
-            if (o2[k] >> 31) { v = o2[k]; s_val[xr] = (uint8_t)v; }
-            else v = ((tu0 + xr) - (v & 0x3FFFFFFFu)) + o2[k];
+          for (int j = 0; j < 4; j++) pp[j] = kk[j] < 32u ? s_par[t + kk[j] * T] : 0u;
+#pragma unroll
+          for (int j = 0; j < 4; j++) pp[j] = s_par[pp[j]];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (kk[j] < 32u) {
+              if (pp[j] >= ZG_PAR_EXIT) unresolved &= ~(1u << kk[j]);     // its pointer is the root
+              else s_par[t + kk[j] * T] = (uint16_t)pp[j];               // u16 stores are atomic
+            }
           }
-          og[tu0 + xr] = v;
-          nun += (v >> 31) ? 0u : 1u;
+        }
+        if (__syncthreads_or(unresolved != 0)) { if (t == 0) s_err = ZG_INTERNAL; __syncthreads(); break; }  // cannot happen: every step moves a pointer up its chain
+      }
+      ZG_TICK(3)
+      // ---- S3a: the scratch words requested in S1c have arrived: the roots' effective offsets are complete in LDS. The
+      // tile's literal bytes go to the output (match positions get zeros: the sweep overwrites them)
+      {
+        if (x0 < n) {
+#pragma unroll
+          for (int k = 0; k < PER; k++) if (wadd[k]) s_word[k * T + t] += wadd[k];
+          uint8_t* o = out_u + tu0 + x0;
+          if (x0 + PER <= n) *(zg_gv4u*)o = zg_v4u{lq[0], lq[1], lq[2], lq[3]};
+          else {
+#pragma unroll
+            for (int k = 0; k < PER; k++) if (x0 + k < n) o[k] = (uint8_t)(lq[k >> 2] >> (8 * (k & 3)));
+          }
         }
       }
-      ZG_TICK(10)
-      if (nun) atomicAdd(&s_unres, nun);
-#ifdef ZG_PROFILE_FLAT
-      if (d.dbg && t == 0) atomicAdd(&d.dbg[7], 1ull);
-#endif
       zg_lds_barrier();
-      ZG_TICK(3)
-      // ---- S4: publish the tile
-      {
-        const uint32_t n = t1 - t0;
-        uint8_t* o = out_u + tu0;
-        const uint32_t n8 = n >> 3;
-        for (uint32_t i = t; i < n8; i += ZG_FL_T) ((zg_u64u*)(o + i * 8))->v = *(const uint64_t*)(s_val + i * 8);
-        for (uint32_t i = (n8 << 3) + t; i < n; i += ZG_FL_T) o[i] = s_val[i];
-      }
-      zg_lds_barrier();  // s_val / s_par are reused; this tile's og[] stores are drained by the S2 barriers of the next tile, long before its S3 reads them
       ZG_TICK(4)
+      // ---- S3b: every byte's effective offset = its root's + the distance to the root; four consecutive bytes per thread
+      // and step leave as one 16-byte store
+#pragma unroll
+      for (int c = 0; c < PER / 4; c++) {
+        const uint32_t xg = 4u * (t + c * T);
+        if (xg >= n) continue;
+        const zg_v2u pw = *(const zg_v2u*)&s_par[xg];
+        const uint32_t pr[4] = {pw.x & 0xFFFFu, pw.x >> 16, pw.y & 0xFFFFu, pw.y >> 16};
+        uint32_t e[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t x = xg + k;
+          const uint32_t r = pr[k] >= ZG_PAR_EXIT ? x : pr[k];
+          e[k] = s_word[(r & 15u) * T + (r >> 4)] + (x - r);     // a literal's own word is 0
+        }
+        uint32_t* w = og + tu0 + xg;
+        if (xg + 4 <= n) *(zg_gv4u*)w = zg_v4u{e[0], e[1], e[2], e[3]};
+        else {
+#pragma unroll
+          for (int k = 0; k < 4; k++) if (xg + k < n) w[k] = e[k];
+        }
+      }
+      zg_lds_barrier();  // s_par / s_word / the records are reused by the next tile
+      ZG_TICK(5)
+      t0 = t1;
+      i_start = i_next;
     }
     if (s_err) {
       if (t == 0) atomicMin(&d.frame_out[un.frame].err_packed, ((b - fr.first_block) << 8) | s_err);
@@ -1341,225 +1321,95 @@ __global__ void __launch_bounds__(ZG_FL_T) zg_k_flat(ZgBatchDev d) {
     }
   }
   __syncthreads();
-  if (t == 0) { ZgUnitInfo ui; ui.size = unit_size; ui.unresolved = s_unres; d.unit_info[blockIdx.x] = ui; }
+  if (t == 0) { ZgUnitInfo ui; ui.size = unit_size; ui.pad = 0; d.unit_info[blockIdx.x] = ui; }
 #ifdef ZG_PROFILE_FLAT
-  if (t == 0 && d.dbg) for (int i = 0; i < 12; i++) if (i != 7) atomicAdd(&d.dbg[i], tc[i]);
+  if (t == 0 && d.dbg) { for (int i = 0; i < 8; i++) atomicAdd(&d.dbg[i], tc[i]); }
 #endif
 #undef ZG_TICK
 }
 
-// per-frame barrier of the sweep: monotonic arrival counter, agent-scope release before arriving, relaxed polling,
-// one agent-scope acquire after (the per-XCD L2s and per-CU L1s are not coherent with each other).
-// Per-frame barrier of the sweep, in two halves so that the next unit's scratch loads are in flight while waiting.
-// arrive: every wave drains its own write-through (sc1) payload stores, then one lane publishes the arrival.
-// Two levels: 8 group counters (bar[0..7]) whose last arriver bumps the top counter (bar[8]) that everybody polls.
-__device__ __forceinline__ void zg_frame_arrive(uint32_t* bar, uint32_t step, uint32_t rank, uint32_t wpf, uint32_t t) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave: its payload has left before the arrival can be seen
-  __syncthreads();
-  if (t == 0) {
-    const uint32_t grp = rank & 7;
-    const uint32_t gsize = (wpf - grp + 7) / 8;
-    const uint32_t old = __hip_atomic_fetch_add(bar + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old + 1 == gsize * step) __hip_atomic_fetch_add(bar + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-__device__ __forceinline__ bool zg_frame_wait(uint32_t* bar, uint32_t step, uint32_t wpf, uint32_t t) {
-  __shared__ uint32_t s_ok;
-  if (t == 0) {
-    const uint32_t ngroups = wpf < 8 ? wpf : 8;
-    uint32_t ok = 0;
-    for (uint32_t spin = 0; spin < (1u << 24); spin++) {
-      if (__hip_atomic_load(bar + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ngroups * step) { ok = 1; break; }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // one acquire per workgroup: drops this CU's stale L1 lines
-    s_ok = ok;
-  }
-  __syncthreads();
-  return s_ok != 0;
-}
-
+// zg_k_sweep: one launch per step; step s fills unit s of every frame that has one (blockIdx.y picks the unit from the
+// step's list, blockIdx.x a 4 KiB slice of it). A group of four output bytes at w: byte i comes from (w + i) - e_i =
+// byte i of the dword at w - e_i, so one load per DISTINCT offset of the group serves it (usually one or two: a match
+// boundary); literal bytes (e = 0) are already in place and come from the dword at w itself.
+#define ZG_SW_T 256
 #define ZG_SW_B 4       // groups of 4 output bytes a thread has in flight
-#define ZG_SW_UMAX 512  // units whose metadata is staged in LDS at a time
-
-struct ZgSweepUnit { uint32_t size, unresolved; uint64_t out_off, og_base; };
-
-template <int T>
-__global__ void __launch_bounds__(T) zg_k_sweep(ZgBatchDev d) {
-  __shared__ ZgSweepUnit s_u[ZG_SW_UMAX];
+__global__ void __launch_bounds__(ZG_SW_T) zg_k_sweep(ZgBatchDev d, uint32_t list_off) {
   if (d.totals[2]) return;
-  const ZgSweepWg wg = d.sweep_wgs[blockIdx.x];
-  const uint32_t f = wg.frame, t = threadIdx.x;
-  const ZgFrameOut fo = d.frame_out[f];
+  const uint32_t u = d.step_units[list_off + blockIdx.y], t = threadIdx.x;
+  const ZgUnit un = d.units[u];
+  const ZgFrameOut fo = d.frame_out[un.frame];
   if (!fo.fast) return;
-  const ZgFrame fr = d.frames[f];
-  uint8_t* frame_out = d.dst + fo.out_base;
-  uint32_t steps = 0;
-  bool alive = true, stop = false;
-#ifdef ZG_PROFILE_SWEEP
-  unsigned long long tc[4] = {0, 0, 0, 0}, tlast = clock64();
-#define ZG_STICK(i) { const unsigned long long n_ = clock64(); tc[i] += n_ - tlast; tlast = n_; }
-#else
-#define ZG_STICK(i)
-#endif
-  for (uint32_t c0 = 0; c0 < fr.nunits && alive && !stop; c0 += ZG_SW_UMAX) {
-    const uint32_t cn = fr.nunits - c0 < ZG_SW_UMAX ? fr.nunits - c0 : ZG_SW_UMAX;
-    __syncthreads();
-    for (uint32_t i = t; i < cn; i += T) {   // unit metadata: three dependent loads each, done once and in parallel
-      const uint32_t u = fr.first_unit + c0 + i;
-      const ZgUnitInfo info = d.unit_info[u];
-      const ZgUnit un = d.units[u];
-      ZgSweepUnit su;
-      su.size = info.size; su.unresolved = info.unresolved; su.og_base = un.og_base;
-      su.out_off = d.pos[un.first_block].out_base;
-      s_u[i] = su;
-    }
-    __syncthreads();
-    // next unit of this chunk (from index i on) that has bytes to fill; cn if none; stop at the first unflattened unit
-    auto next_unit = [&](uint32_t i) -> uint32_t {
-      for (; i < cn; i++) {
-        if (s_u[i].size == 0) { stop = true; return cn; }
-        if (s_u[i].unresolved) return i;
-      }
-      return cn;
-    };
-    uint4 onext[ZG_SW_B];
-    auto prefetch = [&](uint32_t i) {
-      const ZgSweepUnit su = s_u[i];
-      const uint32_t* og = d.og + su.og_base;
-      const uint32_t n4 = su.size >> 2, per = (n4 + wg.wpf - 1) / wg.wpf;
-      const uint32_t g0 = wg.rank * per, g1 = g0 + per < n4 ? g0 + per : n4;
+  const uint32_t size = d.unit_info[u].size;
+  const uint32_t gb = blockIdx.x * (ZG_SW_T * ZG_SW_B);
+  if (4ull * gb >= size) return;
+  uint8_t* out = d.dst + fo.out_base + d.pos[un.first_block].out_base;
+  const uint32_t* og = d.og + un.og_base;
+  const uint32_t n4 = size >> 2;
+  uint4 o[ZG_SW_B];
 #pragma unroll
-      for (int k = 0; k < ZG_SW_B; k++) {
-        const uint32_t g = g0 + t + k * T;
-        onext[k] = g < g1 ? *(const uint4*)(og + 4 * (uint64_t)g) : make_uint4(0, 0, 0, 0);
-      }
-    };
-    // farlim < 0: the unit's step. farlim >= 0 (in advance, while waiting at the barrier of the step before): only the
-    // prefetched batch, and in it only the groups whose open bytes all come from before frame position farlim (output
-    // that is already final); those groups are remembered in donemask and skipped when the unit's own step comes.
-    auto sweep_unit = [&](uint32_t iu, bool prefetched, int64_t farlim, uint32_t& donemask) {
-      const ZgSweepUnit su = s_u[iu];
-      uint8_t* out = frame_out + su.out_off;
-      const uint32_t* og = d.og + su.og_base;
-      const uint32_t n4 = su.size >> 2, per = (n4 + wg.wpf - 1) / wg.wpf;
-      const uint32_t g0 = wg.rank * per, g1 = g0 + per < n4 ? g0 + per : n4;
-      bool first = prefetched;
-      const bool advance = farlim >= 0;
-      const int64_t farrel = (int64_t)su.out_off - farlim;       // distance from the limit to the unit's first byte
-      for (uint32_t base = g0 + t; base < g1 + t; base += T * ZG_SW_B) {   // every thread runs the same number of batches
-        uint4 o[ZG_SW_B];
-        const bool wasfirst = first;
-        if (first) {
-#pragma unroll
-          for (int k = 0; k < ZG_SW_B; k++) o[k] = onext[k];
-          first = false;
-        } else if (advance) break;
-        else {
-#pragma unroll
-          for (int k = 0; k < ZG_SW_B; k++) {
-            const uint32_t g = base + k * T;
-            o[k] = g < g1 ? *(const uint4*)(og + 4 * (uint64_t)g) : make_uint4(0, 0, 0, 0);
-          }
-        }
-        // All loads of the batch first (sources lie before the unit: no hazards with this step's stores), then the stores.
-        // A group is four output bytes at w. Byte i comes from (w + i) - o_i = (w - o_i) + i: byte i of the dword at w - o_i,
-        // so one dword load per DISTINCT offset of the group serves it (usually one or two: a match boundary), and finished
-        // bytes bring their value in their own word.
-        uint32_t lA[ZG_SW_B], lB[ZG_SW_B], lC[ZG_SW_B], lD[ZG_SW_B];
-        uint32_t skipm = 0;
-#pragma unroll
-        for (int k = 0; k < ZG_SW_B; k++) {
-          const uint4 q = o[k];
-          const uint32_t g = base + k * T;
-          const uint8_t* w = g < g1 ? out + 4 * (uint64_t)g : out;
-          const bool ux = (int32_t)q.x > 0, uy = (int32_t)q.y > 0, uz = (int32_t)q.z > 0, uw = (int32_t)q.w > 0;
-          if (advance) {
-            const int64_t pg = farrel + 4 * (int64_t)g;            // the group's first byte relative to the limit
-            const bool far = g < g1 && (ux || uy || uz || uw) && (!ux || (int64_t)q.x > pg) && (!uy || (int64_t)q.y > pg + 1) &&
-                             (!uz || (int64_t)q.z > pg + 2) && (!uw || (int64_t)q.w > pg + 3);
-            if (far) donemask |= 1u << k;
-            skipm |= far ? 0u : 1u << k;
-          } else if (wasfirst && ((donemask >> k) & 1u)) skipm |= 1u << k;
-          if ((skipm >> k) & 1u) { lA[k] = lB[k] = lC[k] = lD[k] = 0; continue; }
-          const bool nD = uw && !(ux && q.w == q.x);
-          const bool nB = uy && !(ux && q.y == q.x) && !(uw && q.y == q.w);
-          const bool nC = uz && !(ux && q.z == q.x) && !(uw && q.z == q.w) && !(uy && q.z == q.y);
-          lA[k] = ux ? zg_ld32_fun(w - q.x) : 0u;
-          lD[k] = nD ? zg_ld32_fun(w - q.w) : 0u;
-          lB[k] = nB ? zg_ld32_fun(w - q.y) : 0u;
-          lC[k] = nC ? zg_ld32_fun(w - q.z) : 0u;
-        }
-        // One wait for all of them here: otherwise the compiler waits (vmcnt is in order: also for the store just issued)
-        // before each group's first use, and the write-through stores complete one after the other.
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-#pragma unroll
-        for (int k = 0; k < ZG_SW_B; k++) {
-          const uint4 q = o[k];
-          const uint32_t g = base + k * T;
-          const bool ux = (int32_t)q.x > 0, uy = (int32_t)q.y > 0, uz = (int32_t)q.z > 0, uw = (int32_t)q.w > 0;
-          if (g >= g1 || !(ux || uy || uz || uw) || ((skipm >> k) & 1u)) continue;
-          const uint32_t sw = (ux && q.w == q.x) ? lA[k] : lD[k];
-          const uint32_t sy = (ux && q.y == q.x) ? lA[k] : (uw && q.y == q.w) ? sw : lB[k];
-          const uint32_t sz = (ux && q.z == q.x) ? lA[k] : (uw && q.z == q.w) ? sw : (uy && q.z == q.y) ? sy : lC[k];
-          const uint32_t b0 = (ux ? lA[k] : q.x) & 0xFFu;
-          const uint32_t b1 = uy ? (sy >> 8) & 0xFFu : q.y & 0xFFu;
-          const uint32_t b2 = uz ? (sz >> 16) & 0xFFu : q.z & 0xFFu;
-          const uint32_t b3 = uw ? sw >> 24 : q.w & 0xFFu;
-          const uint32_t v = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
-          __hip_atomic_store((uint32_t*)(out + 4 * (uint64_t)g), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through store (sc1)
-        }
-      }
-      if (!advance && wg.rank == wg.wpf - 1) {          // tail bytes of the unit
-        for (uint32_t x = (n4 << 2) + t; x < su.size; x += T) {
-          const uint32_t o = og[x];
-          if ((int32_t)o > 0) __hip_atomic_store(&out[x], out[(int64_t)x - o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-    };
-    uint32_t ui = next_unit(0);
-    if (ui < cn) prefetch(ui);
-    uint32_t donemask = 0;                     // groups of the prefetched batch that were already filled in advance
-    while (ui < cn) {
-      sweep_unit(ui, true, -1, donemask);
-      ZG_STICK(0)
-      steps++;
-      if (wg.wpf > 1) zg_frame_arrive(d.bar + (size_t)f * 16, steps, wg.rank, wg.wpf, t);
-      ZG_STICK(1)
-      const uint32_t nx = next_unit(ui + 1);
-      donemask = 0;
-      if (nx < cn) {
-        prefetch(nx);                       // the scratch of the next unit does not depend on this step: in flight during the wait
-        // ... and neither do its bytes that come from before THIS unit: they are filled while the barrier is waited for
-        if (wg.wpf > 1) sweep_unit(nx, true, (int64_t)s_u[ui].out_off, donemask);
-      }
-      if (wg.wpf > 1) { alive = zg_frame_wait(d.bar + (size_t)f * 16, steps, wg.wpf, t); if (!alive) break; }
-      else __syncthreads();                 // same CU: later loads see these stores
-      ZG_STICK(2)
-      ui = nx;
-    }
+  for (int k = 0; k < ZG_SW_B; k++) {
+    const uint32_t g = gb + t + k * ZG_SW_T;
+    o[k] = g < n4 ? *(const uint4*)(og + 4 * (uint64_t)g) : make_uint4(0, 0, 0, 0);
   }
-#ifdef ZG_PROFILE_SWEEP
-  if (t == 0 && wg.rank == 0 && d.dbg) for (int i = 0; i < 3; i++) atomicAdd(&d.dbg[i], tc[i]);
-  if (t == 0 && d.dbg && wg.rank < 500) { d.dbg[8 + wg.rank] = tc[0]; d.dbg[520 + wg.rank] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20); }
-#endif
-#undef ZG_STICK
+  uint32_t lA[ZG_SW_B], lB[ZG_SW_B], lC[ZG_SW_B], lD[ZG_SW_B], lW[ZG_SW_B];
+#pragma unroll
+  for (int k = 0; k < ZG_SW_B; k++) {
+    const uint4 q = o[k];
+    const uint32_t g = gb + t + k * ZG_SW_T;
+    const uint8_t* w = out + 4 * (uint64_t)(g < n4 ? g : 0u);
+    const bool ux = q.x != 0, uy = q.y != 0, uz = q.z != 0, uw = q.w != 0;
+    const bool any = ux || uy || uz || uw, all = ux && uy && uz && uw;
+    const bool nD = uw && !(ux && q.w == q.x);
+    const bool nB = uy && !(ux && q.y == q.x) && !(uw && q.y == q.w);
+    const bool nC = uz && !(ux && q.z == q.x) && !(uw && q.z == q.w) && !(uy && q.z == q.y);
+    lA[k] = ux ? zg_ld32_fun(w - q.x) : 0u;
+    lD[k] = nD ? zg_ld32_fun(w - q.w) : 0u;
+    lB[k] = nB ? zg_ld32_fun(w - q.y) : 0u;
+    lC[k] = nC ? zg_ld32_fun(w - q.z) : 0u;
+    lW[k] = (any && !all) ? zg_ld32_fun(w) : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < ZG_SW_B; k++) {
+    const uint4 q = o[k];
+    const uint32_t g = gb + t + k * ZG_SW_T;
+    const bool ux = q.x != 0, uy = q.y != 0, uz = q.z != 0, uw = q.w != 0;
+    if (!(ux || uy || uz || uw)) continue;                 // also g >= n4
+    const uint32_t sw = (ux && q.w == q.x) ? lA[k] : lD[k];
+    const uint32_t sy = (ux && q.y == q.x) ? lA[k] : (uw && q.y == q.w) ? sw : lB[k];
+    const uint32_t sz = (ux && q.z == q.x) ? lA[k] : (uw && q.z == q.w) ? sw : (uy && q.z == q.y) ? sy : lC[k];
+    const uint32_t v = ((ux ? lA[k] : lW[k]) & 0x000000FFu) | ((uy ? sy : lW[k]) & 0x0000FF00u) | ((uz ? sz : lW[k]) & 0x00FF0000u) |
+                       ((uw ? sw : lW[k]) & 0xFF000000u);
+    *(zg_u32u*)(out + 4 * (uint64_t)g) = zg_u32u{v};
+  }
+  // tail bytes of the unit (size not a multiple of four): by the workgroup that would hold their group
+  if ((size & 3u) && n4 >= gb && n4 < gb + ZG_SW_T * ZG_SW_B && t < (size & 3u)) {
+    const uint32_t x = (n4 << 2) + t;
+    const uint32_t e = og[x];
+    if (e) out[x] = out[(int64_t)x - (int64_t)e];
+  }
+}
+
+// after the last sweep step: an execution error found by zg_k_flat becomes the frame's status
+__global__ void __launch_bounds__(256) zg_k_fin(ZgBatchDev d) {
+  const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= d.nframes || d.totals[2]) return;
+  if (!d.frame_out[f].fast) return;
   const uint32_t ep = d.frame_out[f].err_packed;
-  if (t == 0 && wg.rank == 0) {
-    if (!alive) { d.frame_out[f].status = ZG_INTERNAL; d.frame_out[f].bad_block = 0; d.frame_out[f].good_blocks = 0; }
-    else if (ep != 0xFFFFFFFFu) {
-      d.frame_out[f].status = ep & 0xFF;
-      d.frame_out[f].bad_block = ep >> 8;
-      d.frame_out[f].good_blocks = ep >> 8;
-    }
+  if (ep != 0xFFFFFFFFu) {
+    d.frame_out[f].status = ep & 0xFF;
+    d.frame_out[f].bad_block = ep >> 8;
+    d.frame_out[f].good_blocks = ep >> 8;
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// zg_k_lz: match copies (DecodeBuffer::repeat / repeat_in_chunks, decode_buffer.rs:79-141). One workgroup walks
-// its frame in order. A batch of ZG_LZ_T consecutive sequences is resolved in rounds: every lane owns one match;
-// a match is copied once all of its source bytes lie below the high-water mark (the destination of the first
-// match of the batch that is still pending); the first pending match always qualifies, so each round progresses.
+// zg_k_lz: in-order execution (execute_sequences, sequence_execution.rs:5-54; DecodeBuffer::push / repeat,
+// decode_buffer.rs:74-141) for frames that left the flatten path (a block regenerating more than 128 KiB: not
+// conforming). One workgroup walks its frame. Positions are rebuilt here from the exact fields of the records
+// (ml, ll): a batch of ZG_LZ_T consecutive sequences is scanned, every lane places its literal run, then the matches
+// are resolved in rounds: a match is copied once all of its source bytes lie below the high-water mark (the
+// destination of the first match of the batch that is still pending); the first pending match always qualifies.
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void zg_lane_match_copy(uint8_t* dst, uint32_t off, uint32_t ml) {
   const uint8_t* src = dst - off;
@@ -1572,10 +1422,11 @@ __device__ __forceinline__ void zg_lane_match_copy(uint8_t* dst, uint32_t off, u
 
 __global__ void __launch_bounds__(ZG_LZ_T) zg_k_lz(ZgBatchDev d) {
   __shared__ uint32_t s_min[ZG_LZ_T / 64];
+  __shared__ uint32_t s_so[ZG_LZ_T / 64], s_sl[ZG_LZ_T / 64];
   __shared__ uint32_t s_err;
   __shared__ uint32_t s_errblk;
   if (d.totals[2]) return;
-  const uint32_t f = blockIdx.x, t = threadIdx.x;
+  const uint32_t f = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const ZgFrame fr = d.frames[f];
   const ZgFrameOut fo = d.frame_out[f];
   if (fo.fast) return;
@@ -1588,28 +1439,53 @@ __global__ void __launch_bounds__(ZG_LZ_T) zg_k_lz(ZgBatchDev d) {
     if (blk->btype != ZG_BT_COMPRESSED || blk->nseq == 0) continue;
     const uint32_t nseq = blk->nseq;
     const ZgBlockPos p = d.pos[b];
+    const ZgBlockSeqOut so = d.seq_out[b];
     const ZgSeq* sq = d.seq_arena + blk->seq_base;
+    const uint8_t* body = d.src + blk->src_off;
+    const bool lit_rle = blk->lit_type == ZG_LT_RLE;
+    const uint8_t* lit = blk->lit_type <= ZG_LT_RLE ? body + blk->lit_off : d.lit_arena + blk->lit_base;
+    uint32_t carry_out = 0, carry_lit = 0;      // block-relative output position / literal index before the batch
     for (uint32_t s0 = 0; s0 < nseq; s0 += ZG_LZ_T) {
       const uint32_t i = s0 + t;
       bool pending = false;
-      uint32_t off = 0, ml = 0, mdst = 0xFFFFFFFFu;
-      uint64_t dpos = 0;  // frame-relative position of the match destination
+      uint32_t off = 0, ml = 0, ll = 0, mdst = 0xFFFFFFFFu;
       if (i < nseq) {
         const ZgSeq q = sq[i];
+        const uint32_t nx = i + 1 < nseq ? ZG_SEQ_LIT(sq[i + 1]) : so.sum_ll;
+        ml = ZG_SEQ_ML(q); ll = (nx - ZG_SEQ_LIT(q)) & 0x1FFFFu;
         off = zg_sym_resolve(q.of, p.hist_init);
-        ml = q.ml; mdst = q.mdst;
+      }
+      // exclusive scans of ll + ml and ll over the batch
+      uint32_t io = ll + ml, il = ll;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t vo = __shfl_up(io, o, 64), vl = __shfl_up(il, o, 64);
+        if ((int)lane >= o) { io += vo; il += vl; }
+      }
+      if (lane == 63) { s_so[wv] = io; s_sl[wv] = il; }
+      __syncthreads();
+      uint32_t bo = carry_out, bl = carry_lit, to = carry_out, tl = carry_lit;
+      for (uint32_t w = 0; w < ZG_LZ_T / 64; w++) { if (w < wv) { bo += s_so[w]; bl += s_sl[w]; } to += s_so[w]; tl += s_sl[w]; }
+      const uint32_t lit_start = bl + il - ll;
+      uint64_t dpos = 0;  // frame-relative position of the match destination
+      if (i < nseq) {
+        mdst = bo + io - ml;
         dpos = p.out_base + mdst;
+        uint8_t* o = frame_out + dpos - ll;
+        if (lit_rle) { const uint8_t v = lit[0]; for (uint32_t k = 0; k < ll; k++) o[k] = v; }
+        else { const uint8_t* s = lit + lit_start; for (uint32_t k = 0; k < ll; k++) o[k] = s[k]; }
         if (off == 0) { atomicCAS(&s_err, 0u, (uint32_t)ZG_EXE_ZERO_OFFSET); }
         else if ((uint64_t)off > dpos + fr.prior_out + fr.dict_len) { atomicCAS(&s_err, 0u, (uint32_t)(dpos + fr.prior_out <= fr.window_size ? ZG_EXE_DICT_TOO_SMALL : ZG_EXE_OFFSET_TOO_BIG)); }
         else pending = ml > 0;
       }
+      carry_out = to; carry_lit = tl;
       __syncthreads();
       if (s_err) break;
       for (;;) {
         // high-water mark = smallest destination among pending matches of this batch
         uint32_t m = pending ? mdst : 0xFFFFFFFFu;
         for (int sh = 32; sh >= 1; sh >>= 1) { uint32_t o = __shfl_xor(m, sh, 64); m = o < m ? o : m; }
-        if ((t & 63) == 0) s_min[t >> 6] = m;
+        if (lane == 0) s_min[wv] = m;
         __syncthreads();
         uint32_t hwm = s_min[0];
         for (int w = 1; w < ZG_LZ_T / 64; w++) hwm = s_min[w] < hwm ? s_min[w] : hwm;
@@ -1627,6 +1503,14 @@ __global__ void __launch_bounds__(ZG_LZ_T) zg_k_lz(ZgBatchDev d) {
       __syncthreads();
     }
     if (s_err) { if (t == 0) s_errblk = bi; break; }
+    // trailing literals (sequence_execution.rs:40-44)
+    {
+      const uint32_t rest = blk->regen_size - so.sum_ll;
+      uint8_t* o = frame_out + p.out_base + ((uint64_t)so.sum_ll + so.sum_ml);
+      if (lit_rle) zg_wg_fill(o, lit[0], rest, t, ZG_LZ_T);
+      else zg_wg_copy(o, lit + so.sum_ll, rest, t, ZG_LZ_T);
+      __syncthreads();
+    }
   }
   __syncthreads();
   if (t == 0 && s_err) {
@@ -1681,12 +1565,14 @@ void zg_launch_lit(const ZgBatchDev& d, hipStream_t s) {
   if (d.nblocks) hipLaunchKernelGGL(zg_k_lit, dim3(d.nblocks), dim3(256), 0, s, d);
 }
 void zg_launch_flat(const ZgBatchDev& d, hipStream_t s) {
-  if (d.nunits) hipLaunchKernelGGL(zg_k_flat, dim3(d.nunits), dim3(ZG_FL_T), 0, s, d);
+  if (!d.nunits) return;
+  if (d.flags & 4u) hipLaunchKernelGGL((zg_k_flat<512, 8192>), dim3(d.nunits), dim3(512), 0, s, d);
+  else hipLaunchKernelGGL((zg_k_flat<1024, 16384>), dim3(d.nunits), dim3(1024), 0, s, d);
 }
-void zg_launch_sweep(const ZgBatchDev& d, hipStream_t s) {
-  if (!d.nsweep_wgs) return;
-  if (d.flags & 2u) hipLaunchKernelGGL(zg_k_sweep<1024>, dim3(d.nsweep_wgs), dim3(1024), 0, s, d);
-  else hipLaunchKernelGGL(zg_k_sweep<256>, dim3(d.nsweep_wgs), dim3(256), 0, s, d);
+void zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* steps, uint32_t nsteps) {
+  for (uint32_t i = 0; i < nsteps; i++)
+    hipLaunchKernelGGL(zg_k_sweep, dim3(steps[i].slices, steps[i].nunits), dim3(ZG_SW_T), 0, s, d, steps[i].list_off);
+  if (d.nframes) hipLaunchKernelGGL(zg_k_fin, dim3((d.nframes + 255) / 256), dim3(256), 0, s, d);
 }
 void zg_launch_lz(const ZgBatchDev& d, hipStream_t s) {
   hipLaunchKernelGGL(zg_k_lz, dim3(d.nframes), dim3(ZG_LZ_T), 0, s, d);

@@ -142,13 +142,19 @@ struct ZgBlockSeqOut {
   uint32_t pad;
 };
 
-// One decoded sequence, ready for execution.
+// One decoded sequence, ready for execution: 12 bytes. Positions are block-relative; on the flatten path a block
+// regenerates at most 128 KiB, so they fit 17 bits. For larger (non-conforming) blocks the position fields wrap, but
+// ml and ll = (next.lit_start - lit_start) mod 2^17 stay exact: the in-order fallback rebuilds positions from them.
 struct ZgSeq {
   uint32_t of;             // resolved offset, or symbolic reference into the block's initial offset history
-  uint32_t ml;             // match length
-  uint32_t mdst;           // block-relative output position where the match starts (= Σ earlier ll+ml, + this ll)
-  uint32_t lit_start;      // index of this sequence's first literal in the block's literals
+  uint32_t w1;             // [16:0] mdst: position where the match starts (= sum of earlier ll+ml, + this ll); [31:17] ml bits 14..0
+  uint32_t w2;             // [16:0] lit_start: index of this sequence's first literal in the block's literals; [19:17] ml bits 17..15
 };
+#define ZG_SEQ_MDST(q) ((q).w1 & 0x1FFFFu)
+#define ZG_SEQ_LIT(q) ((q).w2 & 0x1FFFFu)
+#define ZG_SEQ_ML(q) (((q).w1 >> 17) | ((((q).w2 >> 17) & 7u) << 15))
+#define ZG_SEQ_W1(mdst, ml) (((mdst) & 0x1FFFFu) | (((ml) & 0x7FFFu) << 17))
+#define ZG_SEQ_W2(lit, ml) (((lit) & 0x1FFFFu) | ((((ml) >> 15) & 7u) << 17))
 
 // Per block, after the scan.
 struct ZgBlockPos {
@@ -170,9 +176,7 @@ struct ZgFrameOut {
 
 // LZ77 execution works on units: runs of consecutive blocks of one frame that zg_k_flat resolves together.
 struct ZgUnit { uint32_t frame, first_block, nblocks, pad; uint64_t og_base; };   // og_base: offset (in u32) into the flatten scratch
-struct ZgUnitInfo { uint32_t size; uint32_t unresolved; };   // written by zg_k_flat: bytes of the unit, bytes left for the sweep
-// One workgroup of zg_k_sweep: frame it serves, its rank among the frame's workgroups, and how many there are.
-struct ZgSweepWg { uint32_t frame, rank, wpf, pad; };
+struct ZgUnitInfo { uint32_t size; uint32_t pad; };   // written by zg_k_flat: bytes of the unit
 
 // Huffman work: one group = streams that decode with the same table.
 struct ZgHufGroup { int32_t slot; uint32_t first_item; uint32_t nitems; uint32_t pad; };
