@@ -857,7 +857,9 @@ __global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
           if (actual == 0) e = ZG_EXE_ZERO_OFFSET;                                  // :28-30
           if (e && bad == 0xFFFFFFFFu) bad = ((t * ZG_SP_S + (uint32_t)j) << 8) | e;
           const uint32_t mdst = out_pos + ll[j];
-          *(zg_gv3u*)(out + ib + j) = zg_v3u{actual, ZG_SEQ_W1(mdst, ml[j]), ZG_SEQ_W2(lit_pos, ml[j])};   // ZgSeq
+          // (a three-element vector type would be stored as four dwords and clobber the next record's first field)
+          __attribute__((address_space(1))) uint32_t* qo = (__attribute__((address_space(1))) uint32_t*)(out + ib + j);
+          qo[0] = actual; qo[1] = ZG_SEQ_W1(mdst, ml[j]); qo[2] = ZG_SEQ_W2(lit_pos, ml[j]);
           lit_pos += ll[j]; out_pos += ll[j] + ml[j];
         }
       }
@@ -1339,7 +1341,7 @@ __global__ void __launch_bounds__(ZG_SW_T) zg_k_sweep(ZgBatchDev d, uint32_t lis
   const uint32_t u = d.step_units[list_off + blockIdx.y], t = threadIdx.x;
   const ZgUnit un = d.units[u];
   const ZgFrameOut fo = d.frame_out[un.frame];
-  if (!fo.fast) return;
+  if (!fo.fast || fo.err_packed != 0xFFFFFFFFu) return;   // a unit of the frame failed in zg_k_flat: its scratch is incomplete, the frame is reported as failed
   const uint32_t size = d.unit_info[u].size;
   const uint32_t gb = blockIdx.x * (ZG_SW_T * ZG_SW_B);
   if (4ull * gb >= size) return;
