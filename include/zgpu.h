@@ -135,6 +135,11 @@ int zgpu_batch_block_literals(zgpu_batch*, uint32_t block, uint8_t* dst, size_t 
 int zgpu_batch_block_sequences(zgpu_batch*, uint32_t block, zgpu_seq* dst, size_t cap, size_t* n);
 /* diagnostics: cycle counters accumulated by the kernels when ZGPU_DEBUG_TIMERS is set (all zero otherwise) */
 int zgpu_batch_debug_timers(zgpu_batch*, uint64_t out[1024]);
+/* diagnostics for the parity tests of the LZ77 stage: the units a submit was cut into, and raw reads of the flatten
+ * scratch (what = 0: one u32 effective offset per output byte of a unit, at scratch_base + position; 1: per-unit sizes) */
+uint32_t zgpu_batch_num_units(const zgpu_batch*);
+int zgpu_batch_unit(const zgpu_batch*, uint32_t unit, uint32_t* first_block, uint32_t* nblocks, uint64_t* scratch_base);
+int zgpu_batch_debug_scratch(zgpu_batch*, int what, uint64_t off, void* dst, uint64_t n);
 /* diagnostics: runs a copy kernel (zg_k_calib_copy) of exactly `bytes` read + `bytes` written, twice, to calibrate
  * the profiler's HBM byte counters on a known amount of traffic */
 int zgpu_debug_calibrate(zgpu_ctx*, uint64_t bytes);

@@ -211,6 +211,14 @@ int zgpu_batch_block_sequences(zgpu_batch* zb, uint32_t i, zgpu_seq* dst, size_t
   return ZGPU_OK;
 }
 int zgpu_batch_debug_timers(zgpu_batch* zb, uint64_t out[1024]) { return zb->b->read_debug(out); }
+int zgpu_batch_debug_scratch(zgpu_batch* zb, int what, uint64_t off, void* dst, uint64_t n) { return zb->b->read_scratch(what, off, dst, n); }
+uint32_t zgpu_batch_num_units(const zgpu_batch* zb) { return (uint32_t)zb->b->bb.units.size(); }
+int zgpu_batch_unit(const zgpu_batch* zb, uint32_t u, uint32_t* first_block, uint32_t* nblocks, uint64_t* scratch_base) {
+  if (u >= zb->b->bb.units.size()) return ZGPU_E_BAD_ARG;
+  const ZgUnit& x = zb->b->bb.units[u];
+  *first_block = x.first_block; *nblocks = x.nblocks; *scratch_base = x.og_base;
+  return ZGPU_OK;
+}
 int zgpu_debug_calibrate(zgpu_ctx* c, uint64_t bytes) {
   // profiler calibration: one device-to-device copy kernel of exactly `bytes` read + `bytes` written
   void *a = nullptr, *b = nullptr;
@@ -351,10 +359,10 @@ static int apply_dict(zgpu_decoder* d, const ZgDict& dict) {   // DecoderScratch
   FrameState& fs = d->fs;
   int st;
   if ((st = fs.d_fse.reserve(ZG_FSE_SLOT_U32 * 4)) || (st = fs.d_huf.reserve(ZG_HUF_SLOT_U16 * 2)) ||
-      (st = fs.d_out.reserve(dict.content.size() + 256))) return st;
+      (st = fs.d_out.reserve(kOutFront + dict.content.size() + 256))) return st;
   if (hipMemcpy(fs.d_fse.p, dict.fse.data(), ZG_FSE_SLOT_U32 * 4, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(fs.d_huf.p, dict.huf.data(), ZG_HUF_SLOT_U16 * 2, hipMemcpyHostToDevice) != hipSuccess ||
-      (dict.content.size() && hipMemcpy(fs.d_out.p, dict.content.data(), dict.content.size(), hipMemcpyHostToDevice) != hipSuccess))
+      (dict.content.size() && hipMemcpy(fs.out_ptr(), dict.content.data(), dict.content.size(), hipMemcpyHostToDevice) != hipSuccess))
     return ZGPU_E_HIP;
   memcpy(fs.logs, dict.logs, 4);
   fs.huf_maxbits = dict.huf_maxbits;
@@ -385,7 +393,7 @@ static int decode_run(zgpu_decoder* d, const uint8_t* src, size_t len, uint32_t 
   // bring the new bytes to the host buffer the collect/read calls drain
   const size_t old = d->buf.size();
   d->buf.resize(old + fo.out_size);
-  if (fo.out_size && hipMemcpy(d->buf.data() + old, (const uint8_t*)d->fs.d_out.p + before, fo.out_size, hipMemcpyDeviceToHost) != hipSuccess) {
+  if (fo.out_size && hipMemcpy(d->buf.data() + old, (const uint8_t*)d->fs.out_ptr() + before, fo.out_size, hipMemcpyDeviceToHost) != hipSuccess) {
     delete b;
     return ZGPU_E_HIP;
   }

@@ -237,7 +237,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
       (st = b->d_raw.reserve((bb.seq_count + 2) * 8)) ||
       (st = b->d_seqout.reserve((size_t)nb * sizeof(ZgBlockSeqOut) + 16)) || (st = b->d_pos.reserve((size_t)nb * sizeof(ZgBlockPos) + 16)) ||
       (st = b->d_frameout.reserve((size_t)nf * sizeof(ZgFrameOut) + 16)) ||
-      (st = b->fs ? b->fs->d_out.reserve(b->fs->base + b->fs->produced + bb.out_bound + 64, true, stream_) : b->d_dst.reserve(bb.out_bound + 64)) ||
+      (st = b->fs ? b->fs->d_out.reserve(kOutFront + b->fs->base + b->fs->produced + bb.out_bound + 64, true, stream_) : b->d_dst.reserve(kOutFront + bb.out_bound + 64)) ||
       (st = b->d_totals.reserve(64)) || (st = b->d_og.reserve((size_t)bb.og_count * 4 + 64)) ||
       (st = up(b->d_units, bb.units.data(), bb.units.size() * sizeof(ZgUnit))) ||
       (st = up(b->d_stepunits, bb.step_units.data(), bb.step_units.size() * 4)) ||
@@ -256,9 +256,9 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   d.seq_out = b->d_seqout.as<ZgBlockSeqOut>(); d.pos = b->d_pos.as<ZgBlockPos>(); d.frame_out = b->d_frameout.as<ZgFrameOut>();
   if (b->fs) {
     if ((st = b->fs->d_fse.reserve(ZG_FSE_SLOT_U32 * 4)) || (st = b->fs->d_huf.reserve(ZG_HUF_SLOT_U16 * 2))) { delete b; return st; }
-    d.dst = b->fs->d_out.as<uint8_t>(); d.dst_cap = b->fs->base + b->fs->produced + bb.out_bound;
+    d.dst = b->fs->out_ptr(); d.dst_cap = b->fs->base + b->fs->produced + bb.out_bound;
   } else {
-    d.dst = b->d_dst.as<uint8_t>(); d.dst_cap = bb.out_bound;
+    d.dst = b->d_dst.as<uint8_t>() + kOutFront; d.dst_cap = bb.out_bound;
   }
   d.dict = nullptr;
   d.seq_blocks = b->d_seqblocks.as<uint32_t>(); d.nseq_blocks = (uint32_t)bb.seq_blocks.size();
@@ -333,7 +333,7 @@ int Batch::run() {
   ZG_HIP(hipEventRecord(ev[6], s));
   zg_launch_flat(d, s);
   ZG_HIP(hipEventRecord(ev[7], s));
-  zg_launch_sweep(d, s, sweep_steps.data(), (uint32_t)sweep_steps.size());
+  if (!getenv("ZGPU_DEBUG_NO_SWEEP")) zg_launch_sweep(d, s, sweep_steps.data(), (uint32_t)sweep_steps.size());
   ZG_HIP(hipEventRecord(ev[8], s));
   zg_launch_lz(d, s);   // only frames that left the flatten path (a block regenerating > 128 KiB)
   ZG_HIP(hipEventRecord(ev[9], s));
@@ -423,6 +423,13 @@ int Batch::read_fse_slot(uint32_t slot, std::vector<uint32_t>* entries, uint8_t 
   entries->resize(ZG_FSE_SLOT_U32);
   ZG_HIP(hipMemcpy(entries->data(), dev.fse_arena + (size_t)slot * ZG_FSE_SLOT_U32, ZG_FSE_SLOT_U32 * 4, hipMemcpyDeviceToHost));
   ZG_HIP(hipMemcpy(logs, dev.slot_log + (size_t)slot * 4, 4, hipMemcpyDeviceToHost));
+  return ZG_OK;
+}
+int Batch::read_scratch(int what, uint64_t off, void* dst, uint64_t n) {
+  const uint8_t* base = what == 0 ? (const uint8_t*)dev.og : what == 1 ? (const uint8_t*)dev.unit_info : nullptr;
+  const uint64_t cap = what == 0 ? bb.og_count * 4 : bb.units.size() * sizeof(ZgUnitInfo);
+  if (!base || off + n > cap) return ZG_BAD_ARG;
+  if (n) ZG_HIP(hipMemcpy(dst, base + off, n, hipMemcpyDeviceToHost));
   return ZG_OK;
 }
 int Batch::read_debug(uint64_t out[1024]) {

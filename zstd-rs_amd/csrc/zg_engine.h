@@ -11,6 +11,10 @@
 
 namespace zg {
 
+// Bytes allocated in front of every output buffer: zg_k_sweep fetches the source of output byte i of a 4-byte group as
+// byte i of the dword that starts i bytes before it, so up to 3 bytes in front of the first output byte are touched.
+constexpr size_t kOutFront = 256;
+
 // growable device buffer
 struct DevBuf {
   void* p = nullptr;
@@ -45,6 +49,7 @@ struct FrameState {
   uint8_t huf_maxbits = 0;
   uint32_t carry_mask = 0;       // bit 0 Huffman, 1 LL, 2 OF, 3 ML: which tables exist
   uint64_t window_size = 0;
+  uint8_t* out_ptr() const { return (uint8_t*)d_out.p + kOutFront; }   // first byte of [dictionary content][frame output]
   void reset();
   void release();
 };
@@ -72,7 +77,7 @@ class Batch {
   bool saw_last_block = false;           // the run ended with the frame's last block
   int sync();                            // wait, download per-frame results, compute timings
   int read_output(uint64_t off, uint8_t* dst, uint64_t n);   // D2H
-  const uint8_t* device_output() const { return (const uint8_t*)d_dst.p; }
+  const uint8_t* device_output() const { return dev.dst; }
   // intermediates, for parity tests
   int read_block_status(std::vector<uint32_t>* out);
   int read_literals(uint32_t block, std::vector<uint8_t>* out);
@@ -80,6 +85,7 @@ class Batch {
   int read_fse_slot(uint32_t slot, std::vector<uint32_t>* entries, uint8_t logs[4]);
   int read_huf_slot(uint32_t slot, std::vector<uint16_t>* entries, int* max_bits);
   int read_debug(uint64_t out[1024]);
+  int read_scratch(int what, uint64_t off, void* dst, uint64_t n);   // what: 0 flatten scratch (u32 per output byte), 1 ZgUnitInfo[]
 
  private:
   friend class Engine;

@@ -1352,9 +1352,13 @@ __global__ void __launch_bounds__(ZG_SW_T) zg_k_sweep(ZgBatchDev d, uint32_t lis
 #pragma unroll
   for (int k = 0; k < ZG_SW_B; k++) {
     const uint32_t g = gb + t + k * ZG_SW_T;
-    o[k] = g < n4 ? *(const uint4*)(og + 4 * (uint64_t)g) : make_uint4(0, 0, 0, 0);
+    o[k] = *(const uint4*)(og + 4 * (uint64_t)(g < n4 ? g : 0u));     // clamped, not branched: the four loads overlap
   }
-  uint32_t lA[ZG_SW_B], lB[ZG_SW_B], lC[ZG_SW_B], lD[ZG_SW_B], lW[ZG_SW_B];
+#pragma unroll
+  for (int k = 0; k < ZG_SW_B; k++) if (gb + t + k * ZG_SW_T >= n4) o[k] = make_uint4(0, 0, 0, 0);
+  // all loads of the thread first (dword-aligned 8-byte loads; the funnel shifts come after), then the stores
+  zg_v2u rA[ZG_SW_B], rB[ZG_SW_B], rC[ZG_SW_B], rD[ZG_SW_B], rW[ZG_SW_B];
+  auto ld8 = [](const uint8_t* p) -> zg_v2u { return *(const zg_gv2u*)((uint64_t)p & ~3ull); };
 #pragma unroll
   for (int k = 0; k < ZG_SW_B; k++) {
     const uint4 q = o[k];
@@ -1365,11 +1369,14 @@ __global__ void __launch_bounds__(ZG_SW_T) zg_k_sweep(ZgBatchDev d, uint32_t lis
     const bool nD = uw && !(ux && q.w == q.x);
     const bool nB = uy && !(ux && q.y == q.x) && !(uw && q.y == q.w);
     const bool nC = uz && !(ux && q.z == q.x) && !(uw && q.z == q.w) && !(uy && q.z == q.y);
-    lA[k] = ux ? zg_ld32_fun(w - q.x) : 0u;
-    lD[k] = nD ? zg_ld32_fun(w - q.w) : 0u;
-    lB[k] = nB ? zg_ld32_fun(w - q.y) : 0u;
-    lC[k] = nC ? zg_ld32_fun(w - q.z) : 0u;
-    lW[k] = (any && !all) ? zg_ld32_fun(w) : 0u;
+    // unconditional loads from clamped addresses (w itself when a load is not needed): no branches, so all of them are
+    // issued back to back and their round trips overlap
+    (void)any; (void)all;
+    rA[k] = ld8(w - (ux ? q.x : 0u));
+    rD[k] = ld8(w - (nD ? q.w : 0u));
+    rB[k] = ld8(w - (nB ? q.y : 0u));
+    rC[k] = ld8(w - (nC ? q.z : 0u));
+    rW[k] = ld8(w);
   }
 #pragma unroll
   for (int k = 0; k < ZG_SW_B; k++) {
@@ -1377,11 +1384,14 @@ __global__ void __launch_bounds__(ZG_SW_T) zg_k_sweep(ZgBatchDev d, uint32_t lis
     const uint32_t g = gb + t + k * ZG_SW_T;
     const bool ux = q.x != 0, uy = q.y != 0, uz = q.z != 0, uw = q.w != 0;
     if (!(ux || uy || uz || uw)) continue;                 // also g >= n4
-    const uint32_t sw = (ux && q.w == q.x) ? lA[k] : lD[k];
-    const uint32_t sy = (ux && q.y == q.x) ? lA[k] : (uw && q.y == q.w) ? sw : lB[k];
-    const uint32_t sz = (ux && q.z == q.x) ? lA[k] : (uw && q.z == q.w) ? sw : (uy && q.z == q.y) ? sy : lC[k];
-    const uint32_t v = ((ux ? lA[k] : lW[k]) & 0x000000FFu) | ((uy ? sy : lW[k]) & 0x0000FF00u) | ((uz ? sz : lW[k]) & 0x00FF0000u) |
-                       ((uw ? sw : lW[k]) & 0xFF000000u);
+    const uint32_t wl = (uint32_t)(uint64_t)(out + 4 * (uint64_t)g);        // low address bits of the group
+    auto fun = [&](const zg_v2u r, uint32_t e) { return __builtin_amdgcn_alignbit(r.y, r.x, ((wl - e) & 3u) * 8u); };
+    const uint32_t lA = fun(rA[k], q.x), lD = fun(rD[k], q.w), lB = fun(rB[k], q.y), lC = fun(rC[k], q.z), lW = fun(rW[k], 0u);
+    const uint32_t sw = (ux && q.w == q.x) ? lA : lD;
+    const uint32_t sy = (ux && q.y == q.x) ? lA : (uw && q.y == q.w) ? sw : lB;
+    const uint32_t sz = (ux && q.z == q.x) ? lA : (uw && q.z == q.w) ? sw : (uy && q.z == q.y) ? sy : lC;
+    const uint32_t v = ((ux ? lA : lW) & 0x000000FFu) | ((uy ? sy : lW) & 0x0000FF00u) | ((uz ? sz : lW) & 0x00FF0000u) |
+                       ((uw ? sw : lW) & 0xFF000000u);
     *(zg_u32u*)(out + 4 * (uint64_t)g) = zg_u32u{v};
   }
   // tail bytes of the unit (size not a multiple of four): by the workgroup that would hold their group

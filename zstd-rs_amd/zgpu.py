@@ -44,7 +44,7 @@ EXPORTS = [
     "zgpu_decode_all", "zgpu_batch_prepare", "zgpu_batch_run", "zgpu_batch_sync", "zgpu_batch_num_frames", "zgpu_batch_num_blocks",
     "zgpu_batch_compressed_size", "zgpu_batch_frame_info", "zgpu_batch_read", "zgpu_batch_output_device", "zgpu_batch_timings",
     "zgpu_batch_destroy", "zgpu_batch_block_info", "zgpu_batch_block_literals", "zgpu_batch_block_sequences", "zgpu_batch_fse_slot",
-    "zgpu_batch_huf_slot", "zgpu_batch_debug_timers", "zgpu_debug_calibrate", "zgpu_add_dict", "zgpu_decoder_force_dict",
+    "zgpu_batch_huf_slot", "zgpu_batch_debug_timers", "zgpu_batch_num_units", "zgpu_batch_unit", "zgpu_batch_debug_scratch", "zgpu_debug_calibrate", "zgpu_add_dict", "zgpu_decoder_force_dict",
     "zgpu_decoder_decode_from_to", "zgpu_decoder_create", "zgpu_decoder_destroy", "zgpu_decoder_init", "zgpu_decoder_decode_blocks",
     "zgpu_decoder_can_collect", "zgpu_decoder_collect", "zgpu_decoder_read", "zgpu_decoder_is_finished", "zgpu_decoder_blocks_decoded",
     "zgpu_decoder_bytes_read_from_source", "zgpu_decoder_content_size", "zgpu_decoder_checksum_from_data",
@@ -93,6 +93,10 @@ def load_library():
     L.zgpu_batch_fse_slot.argtypes = [vp, C.c_uint32, P(C.c_uint32), P(C.c_uint8)]
     L.zgpu_batch_huf_slot.argtypes = [vp, C.c_uint32, P(C.c_uint16), P(C.c_int)]
     L.zgpu_batch_debug_timers.argtypes = [vp, P(C.c_uint64)]
+    L.zgpu_batch_num_units.argtypes = [vp]
+    L.zgpu_batch_num_units.restype = C.c_uint32
+    L.zgpu_batch_unit.argtypes = [vp, C.c_uint32, P(C.c_uint32), P(C.c_uint32), P(C.c_uint64)]
+    L.zgpu_batch_debug_scratch.argtypes = [vp, C.c_int, C.c_uint64, vp, C.c_uint64]
     L.zgpu_debug_calibrate.argtypes = [vp, C.c_uint64]
     L.zgpu_decoder_create.argtypes = [vp, P(vp)]
     L.zgpu_add_dict.argtypes = [vp, u8p, sz, P(C.c_uint32)]
@@ -220,6 +224,26 @@ class Batch:
         a = (C.c_uint64 * 1024)()
         self.L.zgpu_batch_debug_timers(self.h, a)
         return list(a)
+
+    def units(self):
+        """[(first_block, nblocks, scratch_base, size)] — the units zg_k_flat worked on (size valid after sync)"""
+        out = []
+        for u in range(self.L.zgpu_batch_num_units(self.h)):
+            fb, nb, base = C.c_uint32(), C.c_uint32(), C.c_uint64()
+            assert self.L.zgpu_batch_unit(self.h, u, C.byref(fb), C.byref(nb), C.byref(base)) == 0
+            info = (C.c_uint32 * 2)()
+            assert self.L.zgpu_batch_debug_scratch(self.h, 1, 8 * u, info, 8) == 0
+            out.append((fb.value, nb.value, base.value, info[0]))
+        return out
+
+    def scratch_words(self, base, n):
+        """n effective offsets (u32) of the flatten scratch starting at word `base`, as a numpy array"""
+        import numpy as np
+        arr = np.empty(max(n, 1), dtype=np.uint32)
+        st = self.L.zgpu_batch_debug_scratch(self.h, 0, 4 * base, arr.ctypes.data_as(C.c_void_p), 4 * n)
+        if st:
+            raise ZgpuError(st)
+        return arr[:n]
 
     def frame_info(self, f):
         fi = FrameInfo()
