@@ -121,7 +121,7 @@ int parse_frames(const uint8_t* src, size_t len, uint64_t max_window, BatchBuild
 
 Batch::~Batch() {
   DevBuf* all[] = {&d_src, &d_blocks, &d_frames, &d_aux, &d_slot_log, &d_fse, &d_huf, &d_hufmax, &d_status, &d_lit, &d_seq,
-                   &d_seqout, &d_pos, &d_frameout, &d_dst, &d_seqblocks, &d_hufitems, &d_hufgroups, &d_totals, &d_og, &d_units, &d_unitinfo, &d_stepunits, &d_dbg, &d_raw};
+                   &d_seqout, &d_pos, &d_frameout, &d_dst, &d_seqblocks, &d_hufitems, &d_hufgroups, &d_totals, &d_og, &d_units, &d_unitinfo, &d_stepunits, &d_swdesc, &d_dbg, &d_raw};
   for (DevBuf* b : all) b->release();
   for (auto& e : ev)
     if (e) (void)hipEventDestroy(e);
@@ -241,6 +241,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
       (st = b->d_totals.reserve(64)) || (st = b->d_og.reserve((size_t)bb.og_count * 4 + 64)) ||
       (st = up(b->d_units, bb.units.data(), bb.units.size() * sizeof(ZgUnit))) ||
       (st = up(b->d_stepunits, bb.step_units.data(), bb.step_units.size() * 4)) ||
+      (st = b->d_swdesc.reserve(bb.step_units.size() * sizeof(ZgSweepDesc) + 32)) ||
       (st = b->d_unitinfo.reserve(bb.units.size() * sizeof(ZgUnitInfo) + 16)) || (st = b->d_dbg.reserve(8192))) {
     delete b;
     return st;
@@ -267,6 +268,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   d.og = b->d_og.as<uint32_t>();
   d.units = b->d_units.as<ZgUnit>(); d.nunits = (uint32_t)bb.units.size(); d.unit_info = b->d_unitinfo.as<ZgUnitInfo>();
   d.step_units = b->d_stepunits.as<uint32_t>();
+  d.sweep_desc = b->d_swdesc.as<ZgSweepDesc>();
   b->sweep_steps.clear();
   for (const ZgStepRange& r : bb.steps) {
     ZgSweepStep ss;

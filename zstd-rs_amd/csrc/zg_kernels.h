@@ -43,6 +43,7 @@ struct ZgBatchDev {
   const ZgUnit* units;
   uint32_t nunits;
   ZgUnitInfo* unit_info;       // [nunits]
+  ZgSweepDesc* sweep_desc;     // one per entry of step_units, written by zg_k_swprep after zg_k_flat
   const uint32_t* step_units;  // sweep step s fills the units step_units[list_off(s) ...] (unit s of every frame that has one)
   unsigned long long* dbg;     // phase cycle counters (profiling builds), diagnostics only
 };

@@ -1068,6 +1068,16 @@ __global__ void __launch_bounds__(256) zg_k_lit(ZgBatchDev d) {
 // workgroup barrier that orders LDS only: unlike __syncthreads() it does not wait for this wave's global loads/stores
 __device__ __forceinline__ void zg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Buffer resource over [p, p + bytes): loads through it with an offset >= bytes return 0 and cause no traffic. The inputs
+// are wave-uniform; passing them through readfirstlane makes that provable to the compiler, which otherwise wraps every
+// buffer load into a "waterfall" loop (one iteration, but it serialises the loads).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t zg_make_rsrc(const void* p, uint32_t bytes) {
+  const uint64_t a = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+#define ZG_OOB 0xFFFFFFFFu   // an offset no buffer resource covers
+
 template <int T, int TS>
 __global__ void __launch_bounds__(T, 4) zg_k_flat(ZgBatchDev d) {   // 4 waves per SIMD: 128 registers, two 512-thread workgroups (or one of 1024) per CU
   constexpr int PER = 16;                       // consecutive tile bytes a thread walks
@@ -1091,6 +1101,7 @@ __global__ void __launch_bounds__(T, 4) zg_k_flat(ZgBatchDev d) {   // 4 waves p
   const uint64_t unit_abs0 = d.pos[un.first_block].out_base;     // frame-relative position of the unit's first byte
   uint8_t* out_u = d.dst + fo.out_base + unit_abs0;
   uint32_t* og = d.og + un.og_base;
+  const __amdgpu_buffer_rsrc_t og_rs = zg_make_rsrc(og, un.nblocks * (ZG_FLAT_MAX * 4u));
   if (t == 0) s_err = 0;
   uint32_t unit_size = 0;
 #ifdef ZG_PROFILE_FLAT   // per-phase cycle counters (tools/dev/flat_phases.py); costs registers, off in the product build
@@ -1121,15 +1132,22 @@ __global__ void __launch_bounds__(T, 4) zg_k_flat(ZgBatchDev d) {   // 4 waves p
     const bool lit_rle = blk.lit_type == ZG_LT_RLE;
     const uint8_t* lit = blk.lit_type <= ZG_LT_RLE ? body + blk.lit_off : d.lit_arena + blk.lit_base;
     const uint32_t lit_fill = lit_rle ? lit[0] : 0u;
+    // Loads whose need depends on the data go through buffer resources: a lane that does not need its load is given an
+    // out-of-range offset, returns 0 and causes no traffic — no branch, so all loads of a phase are in flight together
+    // (a load inside a branch is waited for right there, and vmcnt being in order, so is everything issued before it).
+    const __amdgpu_buffer_rsrc_t lit_rs = zg_make_rsrc(lit, lit_rle ? 0u : blk.regen_size);
+    const __amdgpu_buffer_rsrc_t seq_rs = zg_make_rsrc(sq, nseq * 12u);
     // bytes of the frame (and dictionary) that exist before this block: the farthest a match may reach
     const uint64_t reach = p.out_base + fr.prior_out + fr.dict_len;
     // the two sequences a thread places per tile travel in registers: they are requested one tile ahead
     zg_v3u qa = {0, 0, 0}, qb = {0, 0, 0};
-    uint32_t na = 0, nb = 0;
+    uint32_t na = 0, nb = 0;                       // third word of the record behind qa / qb (its literal index)
     auto fetch = [&](uint32_t i0) {
       const uint32_t ia = i0 + t, ib = ia + T;
-      if (ia < nseq) { qa = *(const zg_gv3u*)(sq + 3ull * ia); na = ia + 1 < nseq ? sq[3ull * (ia + 1) + 2] & 0x1FFFFu : so.sum_ll; }
-      if (ib < nseq) { qb = *(const zg_gv3u*)(sq + 3ull * ib); nb = ib + 1 < nseq ? sq[3ull * (ib + 1) + 2] & 0x1FFFFu : so.sum_ll; }
+      qa = __builtin_amdgcn_raw_buffer_load_b96(seq_rs, ia < nseq ? 12u * ia : ZG_OOB, 0, 0);
+      na = __builtin_amdgcn_raw_buffer_load_b32(seq_rs, ia + 1 < nseq ? 12u * ia + 20u : ZG_OOB, 0, 0);
+      qb = __builtin_amdgcn_raw_buffer_load_b96(seq_rs, ib < nseq ? 12u * ib : ZG_OOB, 0, 0);
+      nb = __builtin_amdgcn_raw_buffer_load_b32(seq_rs, ib + 1 < nseq ? 12u * ib + 20u : ZG_OOB, 0, 0);
     };
     fetch(0);
     uint32_t i_start = 0;
@@ -1142,14 +1160,17 @@ __global__ void __launch_bounds__(T, 4) zg_k_flat(ZgBatchDev d) {   // 4 waves p
       // ---- S1a: one thread per sequence i (index nseq stands for the trailing literals). It covers [a, m0) with literals
       // and [m0, m1) with its match; the part inside the tile is described by one record and one mark at its first tile byte.
       {
-        auto place = [&](uint32_t j, const zg_v3u q, uint32_t next) {
+        auto place = [&](uint32_t j, const zg_v3u q, uint32_t nextw) {
           const uint32_t i = i_start + j;
+          // (the prefetched registers are read on every path: a load the compiler sees unconsumed on some path makes it wait
+          // for everything in flight — vmcnt is in order — when the register is reused)
+          const uint32_t qx = q.x, qy = q.y, qz = q.z, next = i + 1 < nseq ? nextw & 0x1FFFFu : so.sum_ll;
           if (i > nseq) return;
           uint32_t a, m0, m1, lstart, off = 0;
           if (i < nseq) {
-            lstart = q.z & 0x1FFFFu; m0 = q.y & 0x1FFFFu; m1 = m0 + ((q.y >> 17) | (((q.z >> 17) & 7u) << 15));
+            lstart = qz & 0x1FFFFu; m0 = qy & 0x1FFFFu; m1 = m0 + ((qy >> 17) | (((qz >> 17) & 7u) << 15));
             a = m0 - ((next - lstart) & 0x1FFFFu);
-            off = zg_sym_resolve(q.x, p.hist_init);
+            off = zg_sym_resolve(qx, p.hist_init);
             if (off == 0) atomicCAS(&s_err, 0u, (uint32_t)ZG_EXE_ZERO_OFFSET);                     // sequence_execution.rs:28-30
             else if ((uint64_t)off > reach + m0)            // repeat_from_dict (decode_buffer.rs:144-179): which error depends on how much was output so far
               atomicCAS(&s_err, 0u, (uint32_t)(p.out_base + fr.prior_out + m0 <= fr.window_size ? ZG_EXE_DICT_TOO_SMALL : ZG_EXE_OFFSET_TOO_BIG));
@@ -1188,8 +1209,10 @@ __global__ void __launch_bounds__(T, 4) zg_k_flat(ZgBatchDev d) {   // 4 waves p
           s_cnt[t] = (uint16_t)before;
         }
       }
-      // every wave's scratch stores of the previous tile have reached memory before any wave gathers from them
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // every wave's scratch stores of the previous tile have reached memory before any wave gathers from them. (The builtin,
+      // not inline asm: the compiler then knows that nothing is in flight here, and does not protect registers of earlier
+      // loads with waits that would also cover the loads issued below.)
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
       zg_lds_barrier();
       ZG_TICK(1)
       const uint32_t cut = s_cut;
@@ -1203,42 +1226,34 @@ __global__ void __launch_bounds__(T, 4) zg_k_flat(ZgBatchDev d) {   // 4 waves p
       // with its parent inside the tile (pointer), or a root: a match byte whose parent lies before the tile. A root's
       // effective offset is its sequence's offset if the parent lies before the unit, else offset + e[parent], the parent's
       // scratch word being requested here and added after the pointer jumping (the round trip hides behind it).
-      uint32_t wadd[PER];
-      uint32_t lq[4] = {0, 0, 0, 0};                             // the thread's literal bytes, packed (zeros at match positions)
+      uint32_t wadd[PER];                                        // parents' scratch words: requested here, used in S3a
       const uint32_t x0 = t * PER;
       {
-#pragma unroll
-        for (int k = 0; k < PER; k++) wadd[k] = 0;
         uint32_t pp[PER / 2];
 #pragma unroll
         for (int k = 0; k < PER / 2; k++) pp[k] = 0;
-        if (x0 < n) {
-          const uint32_t word = s_bits[x0 >> 5];
-          const uint32_t bits16 = (word >> (x0 & 31u)) & 0xFFFFu;
-          int32_t j = (int32_t)s_cnt[x0 >> 5] + __popc(word & ((1u << (x0 & 31u)) - 1u)) - 1;   // sequence of byte x0 - 1
-          uint32_t r_off = 0, r_lit = 0, r_st = 0, r_m0 = 0;
-          if (j >= 0) { r_off = s_roff[j]; r_lit = s_rlit[j]; const uint32_t sm = s_rsm[j]; r_st = sm & 0xFFFFu; r_m0 = sm >> 16; }
+        const bool live = x0 < n;
+        const uint32_t word = s_bits[live ? x0 >> 5 : 0];
+        const uint32_t bits16 = live ? (word >> (x0 & 31u)) & 0xFFFFu : 0u;
+        int32_t j = (int32_t)s_cnt[live ? x0 >> 5 : 0] + __popc(word & ((1u << (x0 & 31u)) - 1u)) - 1;   // sequence of byte x0 - 1
+        uint32_t r_off = 0, r_lit = 0, r_st = 0, r_m0 = 0;
+        if (live && j >= 0) { r_off = s_roff[j]; r_lit = s_rlit[j]; const uint32_t sm = s_rsm[j]; r_st = sm & 0xFFFFu; r_m0 = sm >> 16; }
 #pragma unroll
-          for (int k = 0; k < PER; k++) {
-            const uint32_t x = x0 + k;
-            if ((bits16 >> k) & 1u) { j++; r_off = s_roff[j]; r_lit = s_rlit[j]; const uint32_t sm = s_rsm[j]; r_st = sm & 0xFFFFu; r_m0 = sm >> 16; }
-            const bool in = x < n;
-            const bool is_lit = x < r_m0 || !in;
-            uint32_t kind, wb = 0;
-            if (is_lit) {
-              kind = ZG_PAR_LIT;
-              const uint32_t lv = !in ? 0u : lit_rle ? lit_fill : (uint32_t)lit[r_lit + (x - r_st)];
-              lq[k >> 2] |= lv << (8 * (k & 3));
-            } else if (r_off <= x) kind = x - r_off;
-            else {
-              kind = ZG_PAR_EXIT;
-              wb = r_off;
-              const int32_t y = (int32_t)(tu0 + x) - (int32_t)r_off;       // unit position of the parent
-              if (y >= 0) wadd[k] = og[y];
-            }
-            s_word[k * T + t] = wb;
-            pp[k >> 1] |= kind << (16 * (k & 1));
-          }
+        for (int k = 0; k < PER; k++) {
+          const uint32_t x = x0 + k;
+          if ((bits16 >> k) & 1u) { j++; r_off = s_roff[j]; r_lit = s_rlit[j]; const uint32_t sm = s_rsm[j]; r_st = sm & 0xFFFFu; r_m0 = sm >> 16; }
+          const bool in = x < n;
+          const bool is_lit = x < r_m0 || !in;
+          const bool inner = !is_lit && r_off <= x;                       // parent inside the tile
+          const bool exits = !is_lit && !inner;
+          const int32_t y = (int32_t)(tu0 + x) - (int32_t)r_off;          // unit position of the parent
+          const uint32_t kind = is_lit ? ZG_PAR_LIT : inner ? x - r_off : ZG_PAR_EXIT;
+          wadd[k] = __builtin_amdgcn_raw_buffer_load_b32(og_rs, (exits && y >= 0) ? 4u * (uint32_t)y : ZG_OOB, 0, 0);
+          // a root's word: its sequence's offset; a literal's: a tag + where its value is in the block's literals (S3b fetches it)
+          if (live) s_word[k * T + t] = exits ? r_off : (is_lit && in) ? 0x80000000u | (r_lit + (x - r_st)) : 0u;
+          pp[k >> 1] |= kind << (16 * (k & 1));
+        }
+        if (live) {
           *(zg_v4u*)&s_par[x0] = zg_v4u{pp[0], pp[1], pp[2], pp[3]};
           *(zg_v4u*)&s_par[x0 + 8] = zg_v4u{pp[4], pp[5], pp[6], pp[7]};
         }
@@ -1274,42 +1289,56 @@ __global__ void __launch_bounds__(T, 4) zg_k_flat(ZgBatchDev d) {   // 4 waves p
         if (__syncthreads_or(unresolved != 0)) { if (t == 0) s_err = ZG_INTERNAL; __syncthreads(); break; }  // cannot happen: every step moves a pointer up its chain
       }
       ZG_TICK(3)
-      // ---- S3a: the scratch words requested in S1c have arrived: the roots' effective offsets are complete in LDS. The
-      // tile's literal bytes go to the output (match positions get zeros: the sweep overwrites them)
-      {
-        if (x0 < n) {
+      // ---- S3a: the scratch words requested in S1c have arrived: the roots' effective offsets are completed in LDS
 #pragma unroll
-          for (int k = 0; k < PER; k++) if (wadd[k]) s_word[k * T + t] += wadd[k];
-          uint8_t* o = out_u + tu0 + x0;
-          if (x0 + PER <= n) *(zg_gv4u*)o = zg_v4u{lq[0], lq[1], lq[2], lq[3]};
-          else {
-#pragma unroll
-            for (int k = 0; k < PER; k++) if (x0 + k < n) o[k] = (uint8_t)(lq[k >> 2] >> (8 * (k & 3)));
-          }
-        }
-      }
+      for (int k = 0; k < PER; k++) if (wadd[k]) s_word[k * T + t] += wadd[k];   // (threads behind the tile's end requested nothing: 0)
       zg_lds_barrier();
       ZG_TICK(4)
-      // ---- S3b: every byte's effective offset = its root's + the distance to the root; four consecutive bytes per thread
-      // and step leave as one 16-byte store
+      // ---- S3b: every byte's effective offset = its root's + the distance to the root (a literal root counts 0); four
+      // consecutive bytes per thread and step leave as one 16-byte store. The tile's literal bytes are fetched and go to
+      // the output (match positions of the same dword get zeros: the sweep overwrites them).
+      {
+        uint32_t lb[PER], lm = 0;
 #pragma unroll
-      for (int c = 0; c < PER / 4; c++) {
-        const uint32_t xg = 4u * (t + c * T);
-        if (xg >= n) continue;
-        const zg_v2u pw = *(const zg_v2u*)&s_par[xg];
-        const uint32_t pr[4] = {pw.x & 0xFFFFu, pw.x >> 16, pw.y & 0xFFFFu, pw.y >> 16};
-        uint32_t e[4];
+        for (int c = 0; c < PER / 4; c++) {
+          const uint32_t xg = 4u * (t + c * T);
+          const bool gl = xg < n;
+          const zg_v2u pw = *(const zg_v2u*)&s_par[gl ? xg : 0u];
+          const uint32_t pr[4] = {pw.x & 0xFFFFu, pw.x >> 16, pw.y & 0xFFFFu, pw.y >> 16};
+          uint32_t e[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const uint32_t x = xg + k;
-          const uint32_t r = pr[k] >= ZG_PAR_EXIT ? x : pr[k];
-          e[k] = s_word[(r & 15u) * T + (r >> 4)] + (x - r);     // a literal's own word is 0
+          for (int k = 0; k < 4; k++) {
+            const uint32_t x = xg + k;
+            const uint32_t r = pr[k] >= ZG_PAR_EXIT ? x : pr[k];
+            const uint32_t w = s_word[(r & 15u) * T + (r >> 4)];
+            e[k] = ((w >> 31) ? 0u : w) + (x - r);
+            const bool isl = gl && pr[k] == ZG_PAR_LIT && (w >> 31);     // a literal byte of the tile (not padding behind its end)
+            lm |= isl ? 1u << (4 * c + k) : 0u;
+            lb[4 * c + k] = __builtin_amdgcn_raw_buffer_load_b8(lit_rs, isl ? w & 0x7FFFFFFFu : ZG_OOB, 0, 0);
+          }
+          if (gl) {
+            uint32_t* w = og + tu0 + xg;
+            if (xg + 4 <= n) *(zg_gv4u*)w = zg_v4u{e[0], e[1], e[2], e[3]};
+            else {
+#pragma unroll
+              for (int k = 0; k < 4; k++) if (xg + k < n) w[k] = e[k];
+            }
+          }
         }
-        uint32_t* w = og + tu0 + xg;
-        if (xg + 4 <= n) *(zg_gv4u*)w = zg_v4u{e[0], e[1], e[2], e[3]};
-        else {
 #pragma unroll
-          for (int k = 0; k < 4; k++) if (xg + k < n) w[k] = e[k];
+        for (int c = 0; c < PER / 4; c++) {
+          const uint32_t xg = 4u * (t + c * T);
+          const uint32_t m4 = (lm >> (4 * c)) & 15u;
+          uint32_t v = 0;
+#pragma unroll
+          for (int k = 0; k < 4; k++) v |= (((m4 >> k) & 1u) ? ((lb[4 * c + k] & 0xFFu) | lit_fill) : 0u) << (8 * k);   // RLE literals: nothing fetched (0), lit_fill set
+          if (!m4) continue;
+          uint8_t* o = out_u + tu0 + xg;
+          if (xg + 4 <= n) *(zg_u32u*)o = zg_u32u{v};
+          else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) if ((m4 >> k) & 1u) o[k] = (uint8_t)(v >> (8 * k));
+          }
         }
       }
       zg_lds_barrier();  // s_par / s_word / the records are reused by the next tile
@@ -1330,69 +1359,85 @@ __global__ void __launch_bounds__(T, 4) zg_k_flat(ZgBatchDev d) {   // 4 waves p
 #undef ZG_TICK
 }
 
+// zg_k_swprep: one thread per (step, unit) entry: everything a sweep workgroup needs about its unit in one 32-byte
+// descriptor, so that a sweep launch starts with ONE dependent scalar load instead of a chain of five.
+__global__ void __launch_bounds__(256) zg_k_swprep(ZgBatchDev d, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t u = d.step_units[i];
+  const ZgUnit un = d.units[u];
+  const ZgFrameOut fo = d.frame_out[un.frame];
+  ZgSweepDesc sd;
+  sd.out = (uint64_t)(d.dst + fo.out_base + d.pos[un.first_block].out_base);
+  sd.og = (uint64_t)(d.og + un.og_base);
+  sd.size = d.unit_info[u].size;
+  // a unit of the frame failed in zg_k_flat: its scratch is incomplete; the frame is reported as failed
+  sd.live = (!d.totals[2] && fo.fast && fo.err_packed == 0xFFFFFFFFu) ? 1u : 0u;
+  sd.pad[0] = sd.pad[1] = 0;
+  d.sweep_desc[i] = sd;
+}
+
 // zg_k_sweep: one launch per step; step s fills unit s of every frame that has one (blockIdx.y picks the unit from the
 // step's list, blockIdx.x a 4 KiB slice of it). A group of four output bytes at w: byte i comes from (w + i) - e_i =
 // byte i of the dword at w - e_i, so one load per DISTINCT offset of the group serves it (usually one or two: a match
-// boundary); literal bytes (e = 0) are already in place and come from the dword at w itself.
+// boundary); literal bytes (e = 0) are already in place and come from the dword at w itself. The loads go through a
+// buffer resource: a load that is not needed gets an out-of-range offset (no traffic, no branch), so all loads of a
+// thread are in flight together.
 #define ZG_SW_T 256
 #define ZG_SW_B 4       // groups of 4 output bytes a thread has in flight
-__global__ void __launch_bounds__(ZG_SW_T) zg_k_sweep(ZgBatchDev d, uint32_t list_off) {
-  if (d.totals[2]) return;
-  const uint32_t u = d.step_units[list_off + blockIdx.y], t = threadIdx.x;
-  const ZgUnit un = d.units[u];
-  const ZgFrameOut fo = d.frame_out[un.frame];
-  if (!fo.fast || fo.err_packed != 0xFFFFFFFFu) return;   // a unit of the frame failed in zg_k_flat: its scratch is incomplete, the frame is reported as failed
-  const uint32_t size = d.unit_info[u].size;
+__global__ void __launch_bounds__(ZG_SW_T) __attribute__((amdgpu_waves_per_eu(4, 5))) zg_k_sweep(ZgBatchDev d, uint32_t list_off) {   // up to ~100 registers: all loads of a thread in flight
+  const ZgSweepDesc sd = d.sweep_desc[list_off + blockIdx.y];
+  const uint32_t t = threadIdx.x, size = sd.size;
   const uint32_t gb = blockIdx.x * (ZG_SW_T * ZG_SW_B);
-  if (4ull * gb >= size) return;
-  uint8_t* out = d.dst + fo.out_base + d.pos[un.first_block].out_base;
-  const uint32_t* og = d.og + un.og_base;
+  if (!sd.live || 4ull * gb >= size) return;
+  typedef __attribute__((address_space(1))) uint8_t zg_gu8;
+  typedef __attribute__((address_space(1))) uint32_t zg_gu32;
+  zg_gu8* out = (zg_gu8*)sd.out;                               // global, not flat, accesses
+  const zg_gu32* og = (const zg_gu32*)sd.og;
   const uint32_t n4 = size >> 2;
+  // sources lie at most 2^31 bytes before the unit's first byte (offsets < 2^30 + a unit): a resource that starts there
+  const uint32_t lowb = (uint32_t)sd.out & 3u;
+  const uint32_t rel0 = 0x80000000u + lowb;                    // resource offset of the unit's first byte
+  const __amdgpu_buffer_rsrc_t rs = zg_make_rsrc((const void*)(sd.out - lowb - 0x80000000ull), rel0 + size + 8u);
   uint4 o[ZG_SW_B];
 #pragma unroll
   for (int k = 0; k < ZG_SW_B; k++) {
     const uint32_t g = gb + t + k * ZG_SW_T;
-    o[k] = *(const uint4*)(og + 4 * (uint64_t)(g < n4 ? g : 0u));     // clamped, not branched: the four loads overlap
+    const zg_v4u v = *(const zg_gv4u*)(og + 4 * (uint64_t)(g < n4 ? g : 0u));     // clamped, not branched: the four loads overlap
+    o[k] = make_uint4(v.x, v.y, v.z, v.w);
   }
 #pragma unroll
   for (int k = 0; k < ZG_SW_B; k++) if (gb + t + k * ZG_SW_T >= n4) o[k] = make_uint4(0, 0, 0, 0);
-  // all loads of the thread first (dword-aligned 8-byte loads; the funnel shifts come after), then the stores
   zg_v2u rA[ZG_SW_B], rB[ZG_SW_B], rC[ZG_SW_B], rD[ZG_SW_B], rW[ZG_SW_B];
-  auto ld8 = [](const uint8_t* p) -> zg_v2u { return *(const zg_gv2u*)((uint64_t)p & ~3ull); };
 #pragma unroll
   for (int k = 0; k < ZG_SW_B; k++) {
     const uint4 q = o[k];
-    const uint32_t g = gb + t + k * ZG_SW_T;
-    const uint8_t* w = out + 4 * (uint64_t)(g < n4 ? g : 0u);
+    const uint32_t wrel = rel0 + 4u * (gb + t + k * ZG_SW_T);  // resource offset of the group
     const bool ux = q.x != 0, uy = q.y != 0, uz = q.z != 0, uw = q.w != 0;
     const bool any = ux || uy || uz || uw, all = ux && uy && uz && uw;
     const bool nD = uw && !(ux && q.w == q.x);
     const bool nB = uy && !(ux && q.y == q.x) && !(uw && q.y == q.w);
     const bool nC = uz && !(ux && q.z == q.x) && !(uw && q.z == q.w) && !(uy && q.z == q.y);
-    // unconditional loads from clamped addresses (w itself when a load is not needed): no branches, so all of them are
-    // issued back to back and their round trips overlap
-    (void)any; (void)all;
-    rA[k] = ld8(w - (ux ? q.x : 0u));
-    rD[k] = ld8(w - (nD ? q.w : 0u));
-    rB[k] = ld8(w - (nB ? q.y : 0u));
-    rC[k] = ld8(w - (nC ? q.z : 0u));
-    rW[k] = ld8(w);
+    rA[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, ux ? (wrel - q.x) & ~3u : ZG_OOB, 0, 0);
+    rD[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, nD ? (wrel - q.w) & ~3u : ZG_OOB, 0, 0);
+    rB[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, nB ? (wrel - q.y) & ~3u : ZG_OOB, 0, 0);
+    rC[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, nC ? (wrel - q.z) & ~3u : ZG_OOB, 0, 0);
+    rW[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, (any && !all) ? wrel & ~3u : ZG_OOB, 0, 0);
   }
 #pragma unroll
   for (int k = 0; k < ZG_SW_B; k++) {
     const uint4 q = o[k];
     const uint32_t g = gb + t + k * ZG_SW_T;
     const bool ux = q.x != 0, uy = q.y != 0, uz = q.z != 0, uw = q.w != 0;
-    if (!(ux || uy || uz || uw)) continue;                 // also g >= n4
-    const uint32_t wl = (uint32_t)(uint64_t)(out + 4 * (uint64_t)g);        // low address bits of the group
-    auto fun = [&](const zg_v2u r, uint32_t e) { return __builtin_amdgcn_alignbit(r.y, r.x, ((wl - e) & 3u) * 8u); };
+    auto fun = [&](const zg_v2u r, uint32_t e) { return __builtin_amdgcn_alignbit(r.y, r.x, ((lowb - e) & 3u) * 8u); };
     const uint32_t lA = fun(rA[k], q.x), lD = fun(rD[k], q.w), lB = fun(rB[k], q.y), lC = fun(rC[k], q.z), lW = fun(rW[k], 0u);
     const uint32_t sw = (ux && q.w == q.x) ? lA : lD;
     const uint32_t sy = (ux && q.y == q.x) ? lA : (uw && q.y == q.w) ? sw : lB;
     const uint32_t sz = (ux && q.z == q.x) ? lA : (uw && q.z == q.w) ? sw : (uy && q.z == q.y) ? sy : lC;
     const uint32_t v = ((ux ? lA : lW) & 0x000000FFu) | ((uy ? sy : lW) & 0x0000FF00u) | ((uz ? sz : lW) & 0x00FF0000u) |
                        ((uw ? sw : lW) & 0xFF000000u);
-    *(zg_u32u*)(out + 4 * (uint64_t)g) = zg_u32u{v};
+    typedef uint32_t zg_u32a1 __attribute__((aligned(1)));
+    if (ux || uy || uz || uw) *(__attribute__((address_space(1))) zg_u32a1*)(out + 4 * (uint64_t)g) = v;     // (no match byte: also g >= n4)
   }
   // tail bytes of the unit (size not a multiple of four): by the workgroup that would hold their group
   if ((size & 3u) && n4 >= gb && n4 < gb + ZG_SW_T * ZG_SW_B && t < (size & 3u)) {
@@ -1582,6 +1627,9 @@ void zg_launch_flat(const ZgBatchDev& d, hipStream_t s) {
   else hipLaunchKernelGGL((zg_k_flat<1024, 16384>), dim3(d.nunits), dim3(1024), 0, s, d);
 }
 void zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* steps, uint32_t nsteps) {
+  uint32_t n = 0;
+  for (uint32_t i = 0; i < nsteps; i++) n += steps[i].nunits;
+  if (n) hipLaunchKernelGGL(zg_k_swprep, dim3((n + 255) / 256), dim3(256), 0, s, d, n);
   for (uint32_t i = 0; i < nsteps; i++)
     hipLaunchKernelGGL(zg_k_sweep, dim3(steps[i].slices, steps[i].nunits), dim3(ZG_SW_T), 0, s, d, steps[i].list_off);
   if (d.nframes) hipLaunchKernelGGL(zg_k_fin, dim3((d.nframes + 255) / 256), dim3(256), 0, s, d);

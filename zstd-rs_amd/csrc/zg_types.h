@@ -178,5 +178,8 @@ struct ZgFrameOut {
 struct ZgUnit { uint32_t frame, first_block, nblocks, pad; uint64_t og_base; };   // og_base: offset (in u32) into the flatten scratch
 struct ZgUnitInfo { uint32_t size; uint32_t pad; };   // written by zg_k_flat: bytes of the unit
 
+// what a sweep workgroup needs to know about its unit
+struct ZgSweepDesc { uint64_t out; uint64_t og; uint32_t size; uint32_t live; uint32_t pad[2]; };
+
 // Huffman work: one group = streams that decode with the same table.
 struct ZgHufGroup { int32_t slot; uint32_t first_item; uint32_t nitems; uint32_t pad; };

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libzgpu.so")
+LIB_PATH = os.environ.get("ZGPU_LIB") or os.path.join(HERE, "libzgpu.so")   # ZGPU_LIB: a profiling build (tools/dev)
 _LIB = None
 
 STRAT_ALL, STRAT_UPTO_BLOCKS, STRAT_UPTO_BYTES = 0, 1, 2
