@@ -48,7 +48,7 @@ int Engine::create(int device, Engine** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->cus_ = prop.multiProcessorCount;
     const char* v = getenv("ZGPU_FLAT_T");
-    if (v) e->flat512_ = atoi(v) == 512;
+    if (v) e->flat_shape_ = atoi(v) == 512 ? 1 : atoi(v) == 1024 ? 0 : 2;   // "512": 512 threads x 16 bytes; "1024": 1024 x 16; else 1024 x 8
   }
   // two streams: the sequences chain is the critical one (its kernels last as long as one block's serial chain), so its
   // workgroups are dispatched first; the literals chain fills what is left
@@ -205,7 +205,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   // a frame-layer error after some good frames: the good frames are still uploaded (callers such as the
   // FrameDecoder mirror may want them); decode_all reports parse_status.
   { const char* e = getenv("ZGPU_UNIT_BLOCKS"); if (e && atoi(e) > 0) b->bb.unit_blocks = (uint32_t)atoi(e); }
-  b->bb.flat_slots = (uint32_t)cus_ * (flat512_ ? 2u : 1u);   // zg_k_flat: one 1024-thread or two 512-thread workgroups per CU
+  b->bb.flat_slots = (uint32_t)cus_ * (flat_shape_ == 0 ? 1u : 2u);   // zg_k_flat: workgroups the device holds at once
   b->bb.finish();
   BatchBuilder& bb = b->bb;
   const uint32_t nb = (uint32_t)bb.blocks.size(), nf = (uint32_t)bb.frames.size();
@@ -277,7 +277,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   }
   d.dbg = getenv("ZGPU_DEBUG_TIMERS") ? b->d_dbg.as<unsigned long long>() : nullptr;
   { const char* e = getenv("ZGPU_FORCE_INORDER"); d.flags = (e && e[0] == '1') ? 1u : 0u; }
-  if (flat512_) d.flags |= 4u;
+  d.flags |= (uint32_t)flat_shape_ << 2;
   for (auto& e : b->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
   for (auto& e : b->ev_huf)

@@ -19,6 +19,7 @@
 //     zg_k_lz       one workgroup per frame    in-order fallback (blocks regenerating > 128 KiB)
 //
 // The reference functions each kernel reproduces are cited at the lane routines in zg_dev.h.
+#include <stdlib.h>
 #include "zg_kernels.h"
 #include "zg_dev.h"
 
@@ -1078,31 +1079,36 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t zg_make_rsrc(const void* p, ui
 }
 #define ZG_OOB 0xFFFFFFFFu   // an offset no buffer resource covers
 
-template <int T, int TS>
-__global__ void __launch_bounds__(T, 4) zg_k_flat(ZgBatchDev d) {   // 4 waves per SIMD: 128 registers, two 512-thread workgroups (or one of 1024) per CU
-  constexpr int PER = 16;                       // consecutive tile bytes a thread walks
-  static_assert(TS == T * PER, "tile = 16 bytes per thread");
-  constexpr int SOFF = 2 * T;                   // sequences a tile takes (two per thread); a denser tile is cut short
+// zg_k_flat<T, TS, SPT>: T threads resolve TS-byte tiles; a thread owns the tile bytes t, t + T, t + 2T ... through all phases
+// (consecutive lanes = consecutive bytes: LDS accesses are conflict-free and, above all, the scratch gathers of adjacent
+// lanes fall into the same cache lines — bytes of one match have adjacent parents). SPT = sequences a thread places per
+// tile; a tile that would hold more than SPT * T sequences is cut short. No phase has a data-dependent branch: loads and
+// stores that depend on the data go through buffer resources with an out-of-range offset for "not needed" (no traffic).
+template <int T, int TS, int SPT>
+__global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDev d) {
+  constexpr int PER = TS / T;                   // tile bytes per thread
+  constexpr int SOFF = SPT * T;                 // sequences a tile takes; a denser tile is cut short
   constexpr int NW = TS / 32;                   // words of the mark bitmap
-  __shared__ __attribute__((aligned(16))) uint16_t s_par[TS];    // 0xFFFF literal, 0x8000 parent before the tile, else tile-relative parent
-  __shared__ uint32_t s_word[TS];                                 // effective offset of the tile's roots, [byte & 15][byte >> 4]
-  __shared__ uint32_t s_bits[NW];                                 // marks: the first tile byte of every sequence
-  __shared__ uint16_t s_cnt[NW];                                  // marks before each word of s_bits
-  __shared__ uint32_t s_roff[SOFF], s_rlit[SOFF], s_rsm[SOFF];    // per sequence of the tile: offset; literal source index at its first tile byte; first tile byte | first match byte << 16
+  static_assert(PER * T == TS && PER <= 16 && NW <= T && (NW % 64) == 0 && SPT >= 1 && SPT <= 2, "shape");
+  __shared__ uint16_t s_par[TS];                // 0xFFFF literal, 0x8000 match byte with its parent before the tile, else tile-relative parent
+  __shared__ uint32_t s_word[TS];               // a root's effective offset; a literal: tag + index of its value in the block's literals
+  __shared__ uint32_t s_bits[NW];               // marks: the first tile byte of every sequence
+  __shared__ uint16_t s_cnt[NW];                // marks before each word of s_bits
+  __shared__ __attribute__((aligned(16))) zg_v4u s_rec[SOFF];   // per sequence of the tile: {offset, first tile byte | first match byte << 16, literal index at its first tile byte, -}
   __shared__ uint32_t s_wtot[NW / 64];
   __shared__ uint32_t s_next, s_cut, s_err;
+  __shared__ unsigned long long s_bad;          // first failing sequence of the block: index << 32 | match position << 8 | provisional status
   const uint32_t t = threadIdx.x;
   const ZgUnit un = d.units[blockIdx.x];
   if (t == 0) { ZgUnitInfo ui; ui.size = 0; ui.pad = 0; d.unit_info[blockIdx.x] = ui; }
   if (d.totals[2]) return;
   const ZgFrameOut fo = d.frame_out[un.frame];
   if (!fo.fast) return;
-  const ZgFrame fr = d.frames[un.frame];
   const uint64_t unit_abs0 = d.pos[un.first_block].out_base;     // frame-relative position of the unit's first byte
   uint8_t* out_u = d.dst + fo.out_base + unit_abs0;
   uint32_t* og = d.og + un.og_base;
   const __amdgpu_buffer_rsrc_t og_rs = zg_make_rsrc(og, un.nblocks * (ZG_FLAT_MAX * 4u));
-  if (t == 0) s_err = 0;
+  if (t == 0) { s_err = 0; s_bad = ~0ull; }
   uint32_t unit_size = 0;
 #ifdef ZG_PROFILE_FLAT   // per-phase cycle counters (tools/dev/flat_phases.py); costs registers, off in the product build
   unsigned long long tc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
@@ -1127,27 +1133,27 @@ __global__ void __launch_bounds__(T, 4) zg_k_flat(ZgBatchDev d) {   // 4 waves p
     const uint32_t S = blk.regen_size + so.sum_ml;               // <= ZG_FLAT_MAX on this path
     unit_size = bu0 + S;
     const uint32_t nseq = blk.nseq;
-    const uint32_t* sq = (const uint32_t*)(d.seq_arena + blk.seq_base);
     const uint8_t* body = d.src + blk.src_off;
     const bool lit_rle = blk.lit_type == ZG_LT_RLE;
     const uint8_t* lit = blk.lit_type <= ZG_LT_RLE ? body + blk.lit_off : d.lit_arena + blk.lit_base;
     const uint32_t lit_fill = lit_rle ? lit[0] : 0u;
-    // Loads whose need depends on the data go through buffer resources: a lane that does not need its load is given an
-    // out-of-range offset, returns 0 and causes no traffic — no branch, so all loads of a phase are in flight together
-    // (a load inside a branch is waited for right there, and vmcnt being in order, so is everything issued before it).
-    const __amdgpu_buffer_rsrc_t lit_rs = zg_make_rsrc(lit, lit_rle ? 0u : blk.regen_size);
-    const __amdgpu_buffer_rsrc_t seq_rs = zg_make_rsrc(sq, nseq * 12u);
-    // bytes of the frame (and dictionary) that exist before this block: the farthest a match may reach
-    const uint64_t reach = p.out_base + fr.prior_out + fr.dict_len;
-    // the two sequences a thread places per tile travel in registers: they are requested one tile ahead
-    zg_v3u qa = {0, 0, 0}, qb = {0, 0, 0};
-    uint32_t na = 0, nb = 0;                       // third word of the record behind qa / qb (its literal index)
+    const __amdgpu_buffer_rsrc_t lit_rs = zg_make_rsrc(lit, lit_rle ? 0u : blk.regen_size);    // RLE literals: nothing is fetched (0), lit_fill is the value
+    const __amdgpu_buffer_rsrc_t seq_rs = zg_make_rsrc(d.seq_arena + blk.seq_base, nseq * 12u);
+    // bytes of the frame (and dictionary) that exist before this block: the farthest a match may reach. Offsets are < 2^30
+    // and positions in the block < 2^17: once 2^31 bytes exist every offset is in reach, else 32-bit arithmetic decides.
+    const uint64_t reach = p.out_base + d.frames[un.frame].prior_out + d.frames[un.frame].dict_len;
+    const bool reach_all = reach >= 0x80000000ull;
+    const uint32_t reach32 = (uint32_t)reach;
+    // the sequences a thread places per tile travel in registers: they are requested one tile ahead
+    zg_v3u q[SPT];
+    uint32_t qn[SPT];                               // third word of the record behind q (its literal index)
     auto fetch = [&](uint32_t i0) {
-      const uint32_t ia = i0 + t, ib = ia + T;
-      qa = __builtin_amdgcn_raw_buffer_load_b96(seq_rs, ia < nseq ? 12u * ia : ZG_OOB, 0, 0);
-      na = __builtin_amdgcn_raw_buffer_load_b32(seq_rs, ia + 1 < nseq ? 12u * ia + 20u : ZG_OOB, 0, 0);
-      qb = __builtin_amdgcn_raw_buffer_load_b96(seq_rs, ib < nseq ? 12u * ib : ZG_OOB, 0, 0);
-      nb = __builtin_amdgcn_raw_buffer_load_b32(seq_rs, ib + 1 < nseq ? 12u * ib + 20u : ZG_OOB, 0, 0);
+#pragma unroll
+      for (int s = 0; s < SPT; s++) {
+        const uint32_t i = i0 + t + s * T;
+        q[s] = __builtin_amdgcn_raw_buffer_load_b96(seq_rs, i < nseq ? 12u * i : ZG_OOB, 0, 0);
+        qn[s] = __builtin_amdgcn_raw_buffer_load_b32(seq_rs, i + 1 < nseq ? 12u * i + 20u : ZG_OOB, 0, 0);
+      }
     };
     fetch(0);
     uint32_t i_start = 0;
@@ -1159,37 +1165,33 @@ __global__ void __launch_bounds__(T, 4) zg_k_flat(ZgBatchDev d) {   // 4 waves p
       ZG_TICK(0)
       // ---- S1a: one thread per sequence i (index nseq stands for the trailing literals). It covers [a, m0) with literals
       // and [m0, m1) with its match; the part inside the tile is described by one record and one mark at its first tile byte.
-      {
-        auto place = [&](uint32_t j, const zg_v3u q, uint32_t nextw) {
-          const uint32_t i = i_start + j;
-          // (the prefetched registers are read on every path: a load the compiler sees unconsumed on some path makes it wait
-          // for everything in flight — vmcnt is in order — when the register is reused)
-          const uint32_t qx = q.x, qy = q.y, qz = q.z, next = i + 1 < nseq ? nextw & 0x1FFFFu : so.sum_ll;
-          if (i > nseq) return;
-          uint32_t a, m0, m1, lstart, off = 0;
-          if (i < nseq) {
-            lstart = qz & 0x1FFFFu; m0 = qy & 0x1FFFFu; m1 = m0 + ((qy >> 17) | (((qz >> 17) & 7u) << 15));
-            a = m0 - ((next - lstart) & 0x1FFFFu);
-            off = zg_sym_resolve(qx, p.hist_init);
-            if (off == 0) atomicCAS(&s_err, 0u, (uint32_t)ZG_EXE_ZERO_OFFSET);                     // sequence_execution.rs:28-30
-            else if ((uint64_t)off > reach + m0)            // repeat_from_dict (decode_buffer.rs:144-179): which error depends on how much was output so far
-              atomicCAS(&s_err, 0u, (uint32_t)(p.out_base + fr.prior_out + m0 <= fr.window_size ? ZG_EXE_DICT_TOO_SMALL : ZG_EXE_OFFSET_TOO_BIG));
-          } else {
-            lstart = so.sum_ll; a = so.sum_ll + so.sum_ml; m0 = m1 = S;
-          }
-          if (m1 > t1o || a >= t1o) atomicMin(&s_next, i);  // first sequence that reaches beyond this tile starts the next one
-          if (a >= t1o) return;
-          const uint32_t st = (a > t0 ? a : t0) - t0;
-          const uint32_t mr = (m0 > t0 ? (m0 < t1o ? m0 : t1o) : t0) - t0;
-          s_roff[j] = off;
-          s_rlit[j] = lstart + (a > t0 ? 0u : t0 - a);
-          s_rsm[j] = st | (mr << 16);
-          atomicOr(&s_bits[st >> 5], 1u << (st & 31u));
-          // the last sequence the tile has room for, and more would start inside it: the tile ends with this one
-          if (j == SOFF - 1 && i < nseq && m1 <= t1o) s_cut = m1;
-        };
-        place(t, qa, na);
-        place(t + T, qb, nb);
+#pragma unroll
+      for (int s = 0; s < SPT; s++) {
+        const uint32_t j = t + s * T, i = i_start + j;
+        // (the prefetched registers are read on every path: a load the compiler sees unconsumed on some path makes it wait
+        // for everything in flight — vmcnt is in order — when the register is reused)
+        const uint32_t qx = q[s].x, qy = q[s].y, qz = q[s].z, next = i + 1 < nseq ? qn[s] & 0x1FFFFu : so.sum_ll;
+        if (i > nseq) continue;
+        uint32_t a, m0, m1, lstart, off = 0;
+        if (i < nseq) {
+          lstart = qz & 0x1FFFFu; m0 = qy & 0x1FFFFu; m1 = m0 + ((qy >> 17) | (((qz >> 17) & 7u) << 15));
+          a = m0 - ((next - lstart) & 0x1FFFFu);
+          off = zg_sym_resolve(qx, p.hist_init);
+          // the first failing sequence (in order) decides, like the reference's in-order execution; which of the two
+          // "too far" errors it is (repeat_from_dict, decode_buffer.rs:144-179) is worked out off the hot path
+          if (off == 0) atomicMin(&s_bad, ((unsigned long long)i << 32) | (m0 << 8) | (uint32_t)ZG_EXE_ZERO_OFFSET);              // sequence_execution.rs:28-30
+          else if (!reach_all && off > reach32 + m0) atomicMin(&s_bad, ((unsigned long long)i << 32) | (m0 << 8) | (uint32_t)ZG_EXE_OFFSET_TOO_BIG);
+        } else {
+          lstart = so.sum_ll; a = so.sum_ll + so.sum_ml; m0 = m1 = S;
+        }
+        if (m1 > t1o || a >= t1o) atomicMin(&s_next, i);  // first sequence that reaches beyond this tile starts the next one
+        if (a >= t1o) continue;
+        const uint32_t st = (a > t0 ? a : t0) - t0;
+        const uint32_t mr = (m0 > t0 ? (m0 < t1o ? m0 : t1o) : t0) - t0;
+        s_rec[j] = zg_v4u{off, st | (mr << 16), lstart + (a > t0 ? 0u : t0 - a), 0u};
+        atomicOr(&s_bits[st >> 5], 1u << (st & 31u));
+        // the last sequence the tile has room for, and more follow: the tile ends with this one
+        if (j == SOFF - 1 && i < nseq && m1 <= t1o) s_cut = m1;
       }
       zg_lds_barrier();
       // ---- S1b: marks before every word (prefix sum over the words)
@@ -1218,44 +1220,43 @@ __global__ void __launch_bounds__(T, 4) zg_k_flat(ZgBatchDev d) {   // 4 waves p
       const uint32_t cut = s_cut;
       const uint32_t t1 = cut != 0xFFFFFFFFu ? cut : t1o;
       const uint32_t i_next = cut != 0xFFFFFFFFu ? i_start + SOFF : (s_next == 0xFFFFFFFFu ? nseq + 1 : s_next);
-      if (s_err) break;
+      if (s_bad != ~0ull) break;
       const uint32_t n = t1 - t0;
       const uint32_t tu0 = bu0 + t0;                             // unit-relative position of the tile
       if (t1 < S) fetch(i_next);                                  // next tile's sequences: in flight behind this tile's work
-      // ---- S1c: one thread per 16 consecutive tile bytes walks them with the marks. A byte becomes a literal, a match byte
-      // with its parent inside the tile (pointer), or a root: a match byte whose parent lies before the tile. A root's
-      // effective offset is its sequence's offset if the parent lies before the unit, else offset + e[parent], the parent's
-      // scratch word being requested here and added after the pointer jumping (the round trip hides behind it).
-      uint32_t wadd[PER];                                        // parents' scratch words: requested here, used in S3a
-      const uint32_t x0 = t * PER;
-      {
-        uint32_t pp[PER / 2];
+      // ---- S1c: every byte finds its sequence (rank of the marks up to it) and becomes a literal, a match byte with its
+      // parent inside the tile (pointer), or a root: a match byte whose parent lies before the tile. A root's effective
+      // offset is its sequence's offset if the parent lies before the unit, else offset + e[parent]: the parent's scratch
+      // word is requested here and added after the pointer jumping (the round trip hides behind it).
+      uint32_t wadd[PER], unresolved = 0;
+      constexpr int G = 2;                       // bytes worked on together: their LDS round trips overlap
 #pragma unroll
-        for (int k = 0; k < PER / 2; k++) pp[k] = 0;
-        const bool live = x0 < n;
-        const uint32_t word = s_bits[live ? x0 >> 5 : 0];
-        const uint32_t bits16 = live ? (word >> (x0 & 31u)) & 0xFFFFu : 0u;
-        int32_t j = (int32_t)s_cnt[live ? x0 >> 5 : 0] + __popc(word & ((1u << (x0 & 31u)) - 1u)) - 1;   // sequence of byte x0 - 1
-        uint32_t r_off = 0, r_lit = 0, r_st = 0, r_m0 = 0;
-        if (live && j >= 0) { r_off = s_roff[j]; r_lit = s_rlit[j]; const uint32_t sm = s_rsm[j]; r_st = sm & 0xFFFFu; r_m0 = sm >> 16; }
+      for (int k0 = 0; k0 < PER; k0 += G) {
+        uint32_t word[G], cnt[G];
+        zg_v4u rec[G];
 #pragma unroll
-        for (int k = 0; k < PER; k++) {
-          const uint32_t x = x0 + k;
-          if ((bits16 >> k) & 1u) { j++; r_off = s_roff[j]; r_lit = s_rlit[j]; const uint32_t sm = s_rsm[j]; r_st = sm & 0xFFFFu; r_m0 = sm >> 16; }
-          const bool in = x < n;
-          const bool is_lit = x < r_m0 || !in;
-          const bool inner = !is_lit && r_off <= x;                       // parent inside the tile
-          const bool exits = !is_lit && !inner;
-          const int32_t y = (int32_t)(tu0 + x) - (int32_t)r_off;          // unit position of the parent
-          const uint32_t kind = is_lit ? ZG_PAR_LIT : inner ? x - r_off : ZG_PAR_EXIT;
-          wadd[k] = __builtin_amdgcn_raw_buffer_load_b32(og_rs, (exits && y >= 0) ? 4u * (uint32_t)y : ZG_OOB, 0, 0);
-          // a root's word: its sequence's offset; a literal's: a tag + where its value is in the block's literals (S3b fetches it)
-          if (live) s_word[k * T + t] = exits ? r_off : (is_lit && in) ? 0x80000000u | (r_lit + (x - r_st)) : 0u;
-          pp[k >> 1] |= kind << (16 * (k & 1));
+        for (int g = 0; g < G; g++) { const uint32_t xw = (t + (k0 + g) * T) >> 5; word[g] = s_bits[xw]; cnt[g] = s_cnt[xw]; }
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+          const uint32_t x = t + (k0 + g) * T;
+          // marks up to and including x, minus one (the tile's first byte carries a mark); bytes behind the tile's end get the last sequence
+          rec[g] = s_rec[cnt[g] + (uint32_t)__popc(word[g] & (0xFFFFFFFFu >> (31u - (x & 31u)))) - 1u];
         }
-        if (live) {
-          *(zg_v4u*)&s_par[x0] = zg_v4u{pp[0], pp[1], pp[2], pp[3]};
-          *(zg_v4u*)&s_par[x0 + 8] = zg_v4u{pp[4], pp[5], pp[6], pp[7]};
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+          const int k = k0 + g;
+          const uint32_t x = t + k * T;
+          const bool live = x < n;
+          const uint32_t off = rec[g].x, st = rec[g].y & 0xFFFFu, m0 = rec[g].y >> 16;
+          const bool is_lit = x < m0;
+          const bool inner = !is_lit && off <= x;                           // parent inside the tile
+          const bool exits = !is_lit && !inner;
+          const int32_t y = (int32_t)(tu0 + x) - (int32_t)off;              // unit position of the parent
+          wadd[k] = __builtin_amdgcn_raw_buffer_load_b32(og_rs, (live && exits && y >= 0) ? 4u * (uint32_t)y : ZG_OOB, 0, 0);
+          // (bytes behind the tile's end write too: their slots are not used by anything)
+          s_par[x] = (uint16_t)(is_lit ? ZG_PAR_LIT : inner ? x - off : ZG_PAR_EXIT);
+          s_word[x] = exits ? off : is_lit ? 0x80000000u | (rec[g].z + (x - st)) : 0u;
+          unresolved |= (live && inner) ? 1u << k : 0u;
         }
       }
       zg_lds_barrier();
@@ -1264,12 +1265,6 @@ __global__ void __launch_bounds__(T, 4) zg_k_flat(ZgBatchDev d) {   // 4 waves p
       // are harmless and no barrier is needed between rounds; a byte is done when its pointer's pointer is a root marker.
       // Each thread visits just its still-unresolved bytes (few: most parents are before the tile), four per step.
       {
-        uint32_t unresolved = 0;
-#pragma unroll
-        for (int k = 0; k < PER; k++) {
-          const uint32_t x = t + k * T;
-          if (x < n && s_par[x] < ZG_PAR_EXIT) unresolved |= 1u << k;
-        }
         for (uint32_t guard = 0; unresolved && guard < (1u << 16); guard++) {
           uint32_t m = unresolved, kk[4], pp[4];
 #pragma unroll
@@ -1291,63 +1286,49 @@ __global__ void __launch_bounds__(T, 4) zg_k_flat(ZgBatchDev d) {   // 4 waves p
       ZG_TICK(3)
       // ---- S3a: the scratch words requested in S1c have arrived: the roots' effective offsets are completed in LDS
 #pragma unroll
-      for (int k = 0; k < PER; k++) if (wadd[k]) s_word[k * T + t] += wadd[k];   // (threads behind the tile's end requested nothing: 0)
+      for (int k = 0; k < PER; k++) __hip_atomic_fetch_add(&s_word[t + k * T], wadd[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_u32; 0 where nothing was requested
       zg_lds_barrier();
       ZG_TICK(4)
-      // ---- S3b: every byte's effective offset = its root's + the distance to the root (a literal root counts 0); four
-      // consecutive bytes per thread and step leave as one 16-byte store. The tile's literal bytes are fetched and go to
-      // the output (match positions of the same dword get zeros: the sweep overwrites them).
-      {
-        uint32_t lb[PER], lm = 0;
+      // ---- S3b: every byte's effective offset = its root's + the distance to the root (a literal root counts 0) -> scratch;
+      // the tile's literal bytes are fetched and go to the output
+      constexpr int H = PER < 8 ? PER : 8;                        // bytes per batch (their loads are in flight together)
 #pragma unroll
-        for (int c = 0; c < PER / 4; c++) {
-          const uint32_t xg = 4u * (t + c * T);
-          const bool gl = xg < n;
-          const zg_v2u pw = *(const zg_v2u*)&s_par[gl ? xg : 0u];
-          const uint32_t pr[4] = {pw.x & 0xFFFFu, pw.x >> 16, pw.y & 0xFFFFu, pw.y >> 16};
-          uint32_t e[4];
+      for (int k0 = 0; k0 < PER; k0 += H) {
+        uint32_t lb[H], islm = 0;
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const uint32_t x = xg + k;
-            const uint32_t r = pr[k] >= ZG_PAR_EXIT ? x : pr[k];
-            const uint32_t w = s_word[(r & 15u) * T + (r >> 4)];
-            e[k] = ((w >> 31) ? 0u : w) + (x - r);
-            const bool isl = gl && pr[k] == ZG_PAR_LIT && (w >> 31);     // a literal byte of the tile (not padding behind its end)
-            lm |= isl ? 1u << (4 * c + k) : 0u;
-            lb[4 * c + k] = __builtin_amdgcn_raw_buffer_load_b8(lit_rs, isl ? w & 0x7FFFFFFFu : ZG_OOB, 0, 0);
-          }
-          if (gl) {
-            uint32_t* w = og + tu0 + xg;
-            if (xg + 4 <= n) *(zg_gv4u*)w = zg_v4u{e[0], e[1], e[2], e[3]};
-            else {
-#pragma unroll
-              for (int k = 0; k < 4; k++) if (xg + k < n) w[k] = e[k];
-            }
-          }
+        for (int h = 0; h < H; h++) {
+          const uint32_t x = t + (k0 + h) * T;
+          const bool live = x < n;
+          const uint32_t pr = s_par[x];
+          const uint32_t r = pr >= ZG_PAR_EXIT ? x : pr;
+          const uint32_t w = s_word[r];
+          const uint32_t e = ((w >> 31) ? 0u : w) + (x - r);
+          const bool isl = live && pr == ZG_PAR_LIT;                      // a literal byte: w carries where its value is
+          lb[h] = __builtin_amdgcn_raw_buffer_load_b8(lit_rs, isl ? w & 0x7FFFFFFFu : ZG_OOB, 0, 0);
+          islm |= isl ? 1u << h : 0u;
+          __builtin_amdgcn_raw_buffer_store_b32(e, og_rs, live ? 4u * (tu0 + x) : ZG_OOB, 0, 0);
         }
 #pragma unroll
-        for (int c = 0; c < PER / 4; c++) {
-          const uint32_t xg = 4u * (t + c * T);
-          const uint32_t m4 = (lm >> (4 * c)) & 15u;
-          uint32_t v = 0;
-#pragma unroll
-          for (int k = 0; k < 4; k++) v |= (((m4 >> k) & 1u) ? ((lb[4 * c + k] & 0xFFu) | lit_fill) : 0u) << (8 * k);   // RLE literals: nothing fetched (0), lit_fill set
-          if (!m4) continue;
-          uint8_t* o = out_u + tu0 + xg;
-          if (xg + 4 <= n) *(zg_u32u*)o = zg_u32u{v};
-          else {
-#pragma unroll
-            for (int k = 0; k < 4; k++) if ((m4 >> k) & 1u) o[k] = (uint8_t)(v >> (8 * k));
-          }
-        }
+        for (int h = 0; h < H; h++)
+          __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(lb[h] | lit_fill), zg_make_rsrc(out_u, un.nblocks * ZG_FLAT_MAX), ((islm >> h) & 1u) ? tu0 + t + (k0 + h) * T : ZG_OOB, 0, 0);
       }
       zg_lds_barrier();  // s_par / s_word / the records are reused by the next tile
       ZG_TICK(5)
       t0 = t1;
       i_start = i_next;
     }
-    if (s_err) {
-      if (t == 0) atomicMin(&d.frame_out[un.frame].err_packed, ((b - fr.first_block) << 8) | s_err);
+    if (s_err || s_bad != ~0ull) {
+      if (t == 0) {
+        const ZgFrame fr = d.frames[un.frame];
+        uint32_t st = s_err;
+        if (!st) {
+          const unsigned long long bad = s_bad;
+          const uint32_t m0 = ((uint32_t)bad >> 8) & 0x1FFFFu;
+          st = (uint32_t)bad & 0xFFu;
+          if (st == (uint32_t)ZG_EXE_OFFSET_TOO_BIG && p.out_base + fr.prior_out + m0 <= fr.window_size) st = ZG_EXE_DICT_TOO_SMALL;
+        }
+        atomicMin(&d.frame_out[un.frame].err_packed, ((b - fr.first_block) << 8) | st);
+      }
       break;
     }
   }
@@ -1385,11 +1366,12 @@ __global__ void __launch_bounds__(256) zg_k_swprep(ZgBatchDev d, uint32_t n) {
 // thread are in flight together.
 #define ZG_SW_T 256
 #define ZG_SW_B 4       // groups of 4 output bytes a thread has in flight
-__global__ void __launch_bounds__(ZG_SW_T) __attribute__((amdgpu_waves_per_eu(4, 5))) zg_k_sweep(ZgBatchDev d, uint32_t list_off) {   // up to ~100 registers: all loads of a thread in flight
+__global__ void __launch_bounds__(ZG_SW_T) __attribute__((amdgpu_waves_per_eu(4, 5))) zg_k_sweep(ZgBatchDev d, uint32_t list_off, uint32_t dbgmode) {   // up to ~100 registers: all loads of a thread in flight
   const ZgSweepDesc sd = d.sweep_desc[list_off + blockIdx.y];
   const uint32_t t = threadIdx.x, size = sd.size;
   const uint32_t gb = blockIdx.x * (ZG_SW_T * ZG_SW_B);
   if (!sd.live || 4ull * gb >= size) return;
+  if (dbgmode == 1) return;                                   // timing experiments (ZGPU_SWEEP_MODE): launch floor
   typedef __attribute__((address_space(1))) uint8_t zg_gu8;
   typedef __attribute__((address_space(1))) uint32_t zg_gu32;
   zg_gu8* out = (zg_gu8*)sd.out;                               // global, not flat, accesses
@@ -1408,6 +1390,11 @@ __global__ void __launch_bounds__(ZG_SW_T) __attribute__((amdgpu_waves_per_eu(4,
   }
 #pragma unroll
   for (int k = 0; k < ZG_SW_B; k++) if (gb + t + k * ZG_SW_T >= n4) o[k] = make_uint4(0, 0, 0, 0);
+  if (dbgmode == 2) {                                         // scratch read + store only, no gathers
+#pragma unroll
+    for (int k = 0; k < ZG_SW_B; k++) if (o[k].x | o[k].y | o[k].z | o[k].w) *(__attribute__((address_space(1))) uint32_t*)(out + 4 * (uint64_t)(gb + t + k * ZG_SW_T) - lowb) = o[k].x;
+    return;
+  }
   zg_v2u rA[ZG_SW_B], rB[ZG_SW_B], rC[ZG_SW_B], rD[ZG_SW_B], rW[ZG_SW_B];
 #pragma unroll
   for (int k = 0; k < ZG_SW_B; k++) {
@@ -1623,15 +1610,18 @@ void zg_launch_lit(const ZgBatchDev& d, hipStream_t s) {
 }
 void zg_launch_flat(const ZgBatchDev& d, hipStream_t s) {
   if (!d.nunits) return;
-  if (d.flags & 4u) hipLaunchKernelGGL((zg_k_flat<512, 8192>), dim3(d.nunits), dim3(512), 0, s, d);
-  else hipLaunchKernelGGL((zg_k_flat<1024, 16384>), dim3(d.nunits), dim3(1024), 0, s, d);
+  const uint32_t shape = (d.flags >> 2) & 3u;
+  if (shape == 1) hipLaunchKernelGGL((zg_k_flat<512, 8192, 2>), dim3(d.nunits), dim3(512), 0, s, d);
+  else if (shape == 2) hipLaunchKernelGGL((zg_k_flat<1024, 8192, 1>), dim3(d.nunits), dim3(1024), 0, s, d);
+  else hipLaunchKernelGGL((zg_k_flat<1024, 16384, 2>), dim3(d.nunits), dim3(1024), 0, s, d);
 }
 void zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* steps, uint32_t nsteps) {
+  const uint32_t dbgmode = getenv("ZGPU_SWEEP_MODE") ? (uint32_t)atoi(getenv("ZGPU_SWEEP_MODE")) : 0u;   // timing experiments only
   uint32_t n = 0;
   for (uint32_t i = 0; i < nsteps; i++) n += steps[i].nunits;
   if (n) hipLaunchKernelGGL(zg_k_swprep, dim3((n + 255) / 256), dim3(256), 0, s, d, n);
   for (uint32_t i = 0; i < nsteps; i++)
-    hipLaunchKernelGGL(zg_k_sweep, dim3(steps[i].slices, steps[i].nunits), dim3(ZG_SW_T), 0, s, d, steps[i].list_off);
+    hipLaunchKernelGGL(zg_k_sweep, dim3(steps[i].slices, steps[i].nunits), dim3(ZG_SW_T), 0, s, d, steps[i].list_off, dbgmode);
   if (d.nframes) hipLaunchKernelGGL(zg_k_fin, dim3((d.nframes + 255) / 256), dim3(256), 0, s, d);
 }
 void zg_launch_lz(const ZgBatchDev& d, hipStream_t s) {
