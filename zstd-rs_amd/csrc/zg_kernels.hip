@@ -1366,68 +1366,79 @@ __global__ void __launch_bounds__(256) zg_k_swprep(ZgBatchDev d, uint32_t n) {
 // thread are in flight together.
 #define ZG_SW_T 256
 #define ZG_SW_B 4       // groups of 4 output bytes a thread has in flight
-__global__ void __launch_bounds__(ZG_SW_T) __attribute__((amdgpu_waves_per_eu(4, 5))) zg_k_sweep(ZgBatchDev d, uint32_t list_off, uint32_t dbgmode) {   // up to ~100 registers: all loads of a thread in flight
+__global__ void __launch_bounds__(ZG_SW_T) __attribute__((amdgpu_waves_per_eu(2, 3))) zg_k_sweep(ZgBatchDev d, uint32_t list_off, uint32_t nbatch, uint32_t dbgmode) {
   const ZgSweepDesc sd = d.sweep_desc[list_off + blockIdx.y];
   const uint32_t t = threadIdx.x, size = sd.size;
-  const uint32_t gb = blockIdx.x * (ZG_SW_T * ZG_SW_B);
-  if (!sd.live || 4ull * gb >= size) return;
+  constexpr uint32_t BG = ZG_SW_T * ZG_SW_B;                  // groups per batch (4 KiB of output)
+  const uint32_t b0 = blockIdx.x * nbatch;                    // the workgroup's batches: b0 .. b0 + nbatch - 1, one after the other
+  if (!sd.live || 4ull * b0 * BG >= size) return;
   if (dbgmode == 1) return;                                   // timing experiments (ZGPU_SWEEP_MODE): launch floor
   typedef __attribute__((address_space(1))) uint8_t zg_gu8;
   typedef __attribute__((address_space(1))) uint32_t zg_gu32;
   zg_gu8* out = (zg_gu8*)sd.out;                               // global, not flat, accesses
   const zg_gu32* og = (const zg_gu32*)sd.og;
   const uint32_t n4 = size >> 2;
+  const uint32_t nb_all = (n4 + BG - 1) / BG;                 // batches of the unit
+  const uint32_t nb = b0 + nbatch <= nb_all ? nbatch : (nb_all > b0 ? nb_all - b0 : 0u);
   // sources lie at most 2^31 bytes before the unit's first byte (offsets < 2^30 + a unit): a resource that starts there
   const uint32_t lowb = (uint32_t)sd.out & 3u;
   const uint32_t rel0 = 0x80000000u + lowb;                    // resource offset of the unit's first byte
   const __amdgpu_buffer_rsrc_t rs = zg_make_rsrc((const void*)(sd.out - lowb - 0x80000000ull), rel0 + size + 8u);
-  uint4 o[ZG_SW_B];
+  auto load_og = [&](uint32_t bt, uint4 (&o)[ZG_SW_B]) {      // clamped, not branched: the loads of a batch overlap
 #pragma unroll
-  for (int k = 0; k < ZG_SW_B; k++) {
-    const uint32_t g = gb + t + k * ZG_SW_T;
-    const zg_v4u v = *(const zg_gv4u*)(og + 4 * (uint64_t)(g < n4 ? g : 0u));     // clamped, not branched: the four loads overlap
-    o[k] = make_uint4(v.x, v.y, v.z, v.w);
-  }
+    for (int k = 0; k < ZG_SW_B; k++) {
+      const uint32_t g = bt * BG + t + k * ZG_SW_T;
+      const zg_v4u v = *(const zg_gv4u*)(og + 4 * (uint64_t)(g < n4 ? g : 0u));
+      o[k] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+  };
+  uint4 o[ZG_SW_B], onx[ZG_SW_B];
+  load_og(b0, o);
+  // Software pipeline over the workgroup's batches: the gathers of batch i are issued, then the scratch words of batch i + 1
+  // are requested (they stream from HBM while the gathers come back from L2), then batch i is finished.
+  for (uint32_t i = 0; i < nb; i++) {
+    const uint32_t gb = (b0 + i) * BG;
 #pragma unroll
-  for (int k = 0; k < ZG_SW_B; k++) if (gb + t + k * ZG_SW_T >= n4) o[k] = make_uint4(0, 0, 0, 0);
-  if (dbgmode == 2) {                                         // scratch read + store only, no gathers
+    for (int k = 0; k < ZG_SW_B; k++) if (gb + t + k * ZG_SW_T >= n4) o[k] = make_uint4(0, 0, 0, 0);
+    zg_v2u rA[ZG_SW_B], rB[ZG_SW_B], rC[ZG_SW_B], rD[ZG_SW_B], rW[ZG_SW_B];
 #pragma unroll
-    for (int k = 0; k < ZG_SW_B; k++) if (o[k].x | o[k].y | o[k].z | o[k].w) *(__attribute__((address_space(1))) uint32_t*)(out + 4 * (uint64_t)(gb + t + k * ZG_SW_T) - lowb) = o[k].x;
-    return;
-  }
-  zg_v2u rA[ZG_SW_B], rB[ZG_SW_B], rC[ZG_SW_B], rD[ZG_SW_B], rW[ZG_SW_B];
+    for (int k = 0; k < ZG_SW_B; k++) {
+      const uint4 q = o[k];
+      const uint32_t wrel = rel0 + 4u * (gb + t + k * ZG_SW_T);  // resource offset of the group
+      const bool ux = q.x != 0, uy = q.y != 0, uz = q.z != 0, uw = q.w != 0;
+      const bool any = ux || uy || uz || uw, all = ux && uy && uz && uw;
+      const bool nD = uw && !(ux && q.w == q.x);
+      const bool nB = uy && !(ux && q.y == q.x) && !(uw && q.y == q.w);
+      const bool nC = uz && !(ux && q.z == q.x) && !(uw && q.z == q.w) && !(uy && q.z == q.y);
+      rA[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, (dbgmode != 2 && ux) ? (wrel - q.x) & ~3u : ZG_OOB, 0, 0);
+      rD[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, (dbgmode != 2 && nD) ? (wrel - q.w) & ~3u : ZG_OOB, 0, 0);
+      rB[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, (dbgmode != 2 && nB) ? (wrel - q.y) & ~3u : ZG_OOB, 0, 0);
+      rC[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, (dbgmode != 2 && nC) ? (wrel - q.z) & ~3u : ZG_OOB, 0, 0);
+      rW[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, (dbgmode != 2 && any && !all) ? wrel & ~3u : ZG_OOB, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);                          // keep the issue order: all gathers, then the next scratch words, then the uses
+    load_og(i + 1 < nb ? b0 + i + 1 : b0 + i, onx);            // (the last batch is simply requested again: no branch)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int k = 0; k < ZG_SW_B; k++) {
-    const uint4 q = o[k];
-    const uint32_t wrel = rel0 + 4u * (gb + t + k * ZG_SW_T);  // resource offset of the group
-    const bool ux = q.x != 0, uy = q.y != 0, uz = q.z != 0, uw = q.w != 0;
-    const bool any = ux || uy || uz || uw, all = ux && uy && uz && uw;
-    const bool nD = uw && !(ux && q.w == q.x);
-    const bool nB = uy && !(ux && q.y == q.x) && !(uw && q.y == q.w);
-    const bool nC = uz && !(ux && q.z == q.x) && !(uw && q.z == q.w) && !(uy && q.z == q.y);
-    rA[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, ux ? (wrel - q.x) & ~3u : ZG_OOB, 0, 0);
-    rD[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, nD ? (wrel - q.w) & ~3u : ZG_OOB, 0, 0);
-    rB[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, nB ? (wrel - q.y) & ~3u : ZG_OOB, 0, 0);
-    rC[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, nC ? (wrel - q.z) & ~3u : ZG_OOB, 0, 0);
-    rW[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, (any && !all) ? wrel & ~3u : ZG_OOB, 0, 0);
-  }
+    for (int k = 0; k < ZG_SW_B; k++) {
+      const uint4 q = o[k];
+      const uint32_t g = gb + t + k * ZG_SW_T;
+      const bool ux = q.x != 0, uy = q.y != 0, uz = q.z != 0, uw = q.w != 0;
+      auto fun = [&](const zg_v2u r, uint32_t e) { return __builtin_amdgcn_alignbit(r.y, r.x, ((lowb - e) & 3u) * 8u); };
+      const uint32_t lA = fun(rA[k], q.x), lD = fun(rD[k], q.w), lB = fun(rB[k], q.y), lC = fun(rC[k], q.z), lW = fun(rW[k], 0u);
+      const uint32_t sw = (ux && q.w == q.x) ? lA : lD;
+      const uint32_t sy = (ux && q.y == q.x) ? lA : (uw && q.y == q.w) ? sw : lB;
+      const uint32_t sz = (ux && q.z == q.x) ? lA : (uw && q.z == q.w) ? sw : (uy && q.z == q.y) ? sy : lC;
+      const uint32_t v = ((ux ? lA : lW) & 0x000000FFu) | ((uy ? sy : lW) & 0x0000FF00u) | ((uz ? sz : lW) & 0x00FF0000u) |
+                         ((uw ? sw : lW) & 0xFF000000u);
+      // (a group without match bytes, also one behind the unit's end, stores nowhere; no branch: a branch would pull loads into it)
+      __builtin_amdgcn_raw_buffer_store_b32(v, rs, (ux || uy || uz || uw) ? rel0 + 4u * g : ZG_OOB, 0, 0);
+    }
 #pragma unroll
-  for (int k = 0; k < ZG_SW_B; k++) {
-    const uint4 q = o[k];
-    const uint32_t g = gb + t + k * ZG_SW_T;
-    const bool ux = q.x != 0, uy = q.y != 0, uz = q.z != 0, uw = q.w != 0;
-    auto fun = [&](const zg_v2u r, uint32_t e) { return __builtin_amdgcn_alignbit(r.y, r.x, ((lowb - e) & 3u) * 8u); };
-    const uint32_t lA = fun(rA[k], q.x), lD = fun(rD[k], q.w), lB = fun(rB[k], q.y), lC = fun(rC[k], q.z), lW = fun(rW[k], 0u);
-    const uint32_t sw = (ux && q.w == q.x) ? lA : lD;
-    const uint32_t sy = (ux && q.y == q.x) ? lA : (uw && q.y == q.w) ? sw : lB;
-    const uint32_t sz = (ux && q.z == q.x) ? lA : (uw && q.z == q.w) ? sw : (uy && q.z == q.y) ? sy : lC;
-    const uint32_t v = ((ux ? lA : lW) & 0x000000FFu) | ((uy ? sy : lW) & 0x0000FF00u) | ((uz ? sz : lW) & 0x00FF0000u) |
-                       ((uw ? sw : lW) & 0xFF000000u);
-    typedef uint32_t zg_u32a1 __attribute__((aligned(1)));
-    if (ux || uy || uz || uw) *(__attribute__((address_space(1))) zg_u32a1*)(out + 4 * (uint64_t)g) = v;     // (no match byte: also g >= n4)
+    for (int k = 0; k < ZG_SW_B; k++) o[k] = onx[k];
   }
   // tail bytes of the unit (size not a multiple of four): by the workgroup that would hold their group
-  if ((size & 3u) && n4 >= gb && n4 < gb + ZG_SW_T * ZG_SW_B && t < (size & 3u)) {
+  if ((size & 3u) && n4 >= b0 * BG && n4 < (b0 + nbatch) * BG && t < (size & 3u)) {
     const uint32_t x = (n4 << 2) + t;
     const uint32_t e = og[x];
     if (e) out[x] = out[(int64_t)x - (int64_t)e];
@@ -1617,11 +1628,12 @@ void zg_launch_flat(const ZgBatchDev& d, hipStream_t s) {
 }
 void zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* steps, uint32_t nsteps) {
   const uint32_t dbgmode = getenv("ZGPU_SWEEP_MODE") ? (uint32_t)atoi(getenv("ZGPU_SWEEP_MODE")) : 0u;   // timing experiments only
+  const uint32_t nbatch = getenv("ZGPU_SWEEP_NB") && atoi(getenv("ZGPU_SWEEP_NB")) > 0 ? (uint32_t)atoi(getenv("ZGPU_SWEEP_NB")) : 1u;   // 4 KiB batches per workgroup (more than one did not pay: the step is bound by its total traffic, not by a latency chain)
   uint32_t n = 0;
   for (uint32_t i = 0; i < nsteps; i++) n += steps[i].nunits;
   if (n) hipLaunchKernelGGL(zg_k_swprep, dim3((n + 255) / 256), dim3(256), 0, s, d, n);
   for (uint32_t i = 0; i < nsteps; i++)
-    hipLaunchKernelGGL(zg_k_sweep, dim3(steps[i].slices, steps[i].nunits), dim3(ZG_SW_T), 0, s, d, steps[i].list_off, dbgmode);
+    hipLaunchKernelGGL(zg_k_sweep, dim3((steps[i].slices + nbatch - 1) / nbatch, steps[i].nunits), dim3(ZG_SW_T), 0, s, d, steps[i].list_off, nbatch, dbgmode);
   if (d.nframes) hipLaunchKernelGGL(zg_k_fin, dim3((d.nframes + 255) / 256), dim3(256), 0, s, d);
 }
 void zg_launch_lz(const ZgBatchDev& d, hipStream_t s) {
