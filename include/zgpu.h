@@ -86,6 +86,31 @@ const char* zgpu_status_name(int status);
  * src holds concatenated frames (skippable frames are skipped); the plaintext of all frames is written back to
  * back into dst. ZGPU_E_TARGET_TOO_SMALL if it does not fit. H2D + kernels + D2H. */
 int zgpu_decode_all(zgpu_ctx*, const uint8_t* src, size_t len, uint8_t* dst, size_t cap, size_t* written);
+/* decode_all_to_vec (frame_decoder.rs:591-610): the library sizes the output (exactly: the size of every frame is known on
+ * the host before the LZ77 stages run). *out is malloc'ed; release it with zgpu_free. */
+int zgpu_decode_all_alloc(zgpu_ctx*, const uint8_t* src, size_t len, uint8_t** out, size_t* written);
+void zgpu_free(void*);
+
+/* ---- the same over several GPUs: frames are independent, a host-side work queue shards them (no collective) -------
+ * One worker thread + one engine (HIP streams, device buffers) per GPU inside the library. Replaces the frame loop of
+ * FrameDecoder::decode_all (frame_decoder.rs:541-577), which decodes the frames of a buffer one after the other. */
+typedef struct zgpu_pool zgpu_pool;
+int zgpu_pool_create(int n_gpus /* <= 0: all visible */, zgpu_pool** out);
+int zgpu_pool_create_on(const int* devices, int n, zgpu_pool** out);   /* explicit device ids (e.g. {LOCAL_RANK} in a one-process-per-GPU job) */
+void zgpu_pool_destroy(zgpu_pool*);
+int zgpu_pool_num_gpus(const zgpu_pool*);
+/* decode_all over the pool: the buffer is cut into frames on the host, jobs (runs of frames, >= 64 MiB of input) are queued
+ * largest first and pulled by the GPUs; plaintext back to back in input order, first error in input order wins. */
+int zgpu_pool_decode_all(zgpu_pool*, const uint8_t* src, size_t len, uint8_t* dst, size_t cap, size_t* written);
+/* The plan of the queue, host only (no GPU touched): longest-processing-time-first order of n jobs by cost and the worker
+ * each job goes to when n_workers workers pull in that order with time proportional to cost; load_out[w] = sum of w's costs. */
+int zgpu_pool_plan(const uint64_t* cost, uint32_t n, uint32_t n_workers, uint32_t* order_out, uint32_t* worker_out, uint64_t* load_out);
+/* device-resident form (bench / roofline): stage n entries (each one frame, or a run of frames) — LPT assignment, one
+ * resident submit per GPU — then run passes over them; outputs stay in HBM. */
+int zgpu_pool_stage(zgpu_pool*, const uint8_t* const* frames, const size_t* lens, uint32_t n);
+int zgpu_pool_run(zgpu_pool*, float* gpu_ms /* [num_gpus] kernel pipeline ms per GPU */, float* wall_ms);
+int zgpu_pool_frame(zgpu_pool*, uint32_t i, int* gpu, uint64_t* out_size, uint32_t* status);
+int zgpu_pool_read(zgpu_pool*, uint32_t i, uint8_t* dst, size_t cap, size_t* written);
 
 /* ---- staged form of the same path, for device-resident runs (bench / roofline) ---------------------------- */
 typedef struct {
@@ -138,7 +163,7 @@ int zgpu_batch_debug_timers(zgpu_batch*, uint64_t out[1024]);
 /* diagnostics for the parity tests of the LZ77 stage: the units a submit was cut into, and raw reads of the flatten
  * scratch (what = 0: one u32 effective offset per output byte of a unit, at scratch_base + position; 1: per-unit sizes) */
 uint32_t zgpu_batch_num_units(const zgpu_batch*);
-int zgpu_batch_unit(const zgpu_batch*, uint32_t unit, uint32_t* first_block, uint32_t* nblocks, uint64_t* scratch_base);
+int zgpu_batch_unit(zgpu_batch*, uint32_t unit, uint32_t* first_block, uint32_t* nblocks, uint64_t* scratch_base);
 int zgpu_batch_debug_scratch(zgpu_batch*, int what, uint64_t off, void* dst, uint64_t n);
 /* diagnostics: runs a copy kernel (zg_k_calib_copy) of exactly `bytes` read + `bytes` written, twice, to calibrate
  * the profiler's HBM byte counters on a known amount of traffic */
@@ -156,7 +181,8 @@ void zgpu_decoder_destroy(zgpu_decoder*);
 int zgpu_decoder_init(zgpu_decoder*, const uint8_t* src, size_t len, size_t* consumed, uint32_t* skip_magic, uint32_t* skip_len);
 /* decode_blocks (:309-377): src continues where the previous call stopped; *consumed = bytes taken. */
 int zgpu_decoder_decode_blocks(zgpu_decoder*, const uint8_t* src, size_t len, size_t* consumed, int strat, size_t n, int* frame_finished);
-/* force_dict (:229-243): use a registered dictionary although the frame header names none (before the first block) */
+/* force_dict (:229-243): use a registered dictionary although the frame header names none; like the reference, at any
+ * time (tables, offset history and dictionary content are replaced for the blocks that follow) */
 int zgpu_decoder_force_dict(zgpu_decoder*, uint32_t dict_id);
 /* decode_from_to (:439-529): consumes only whole blocks of src, then drains into dst; *read_out / *written_out as the
  * reference's (usize, usize). May be called without init: it then parses the frame header from src itself. */
@@ -164,12 +190,24 @@ int zgpu_decoder_decode_from_to(zgpu_decoder*, const uint8_t* src, size_t len, u
 size_t zgpu_decoder_can_collect(const zgpu_decoder*);                /* :410-424 */
 size_t zgpu_decoder_collect(zgpu_decoder*, uint8_t* dst, size_t cap);/* :381-389 */
 size_t zgpu_decoder_read(zgpu_decoder*, uint8_t* dst, size_t cap);   /* impl Read :615-627 */
+/* collect_to_writer (:395-407): what collect() would return goes to the writer (returns the bytes it took, io::Write::write) */
+typedef size_t (*zgpu_write_fn)(void* user, const uint8_t* data, size_t n);
+int zgpu_decoder_collect_to_writer(zgpu_decoder*, zgpu_write_fn write, void* user, size_t* written);
 int zgpu_decoder_is_finished(const zgpu_decoder*);                   /* :284-294 */
 uint64_t zgpu_decoder_blocks_decoded(const zgpu_decoder*);           /* :297 */
 uint64_t zgpu_decoder_bytes_read_from_source(const zgpu_decoder*);   /* :273 */
 uint64_t zgpu_decoder_content_size(const zgpu_decoder*);             /* :246 */
 int zgpu_decoder_checksum_from_data(const zgpu_decoder*, uint32_t* out); /* :254 — returns 1 if present */
 uint32_t zgpu_decoder_calculated_checksum(const zgpu_decoder*);      /* :263-270 XXH64 seed 0, low 32 bits */
+
+/* ---- StreamingDecoder mirror (ruzstd/src/decoding/streaming_decoder.rs:40-156): io::Read over one frame ---------------- */
+typedef struct zgpu_streaming zgpu_streaming;
+typedef size_t (*zgpu_read_fn)(void* user, uint8_t* dst, size_t n);   /* io::Read::read of the source: 0 = end of input */
+int zgpu_streaming_create(zgpu_ctx*, zgpu_read_fn read, void* user, zgpu_streaming** out);   /* new (:51-58): reads the frame header */
+void zgpu_streaming_destroy(zgpu_streaming*);
+zgpu_decoder* zgpu_streaming_decoder(zgpu_streaming*);               /* get_ref / into_frame_decoder (:66-85) */
+/* read (:119-155): whole blocks are pulled from the source as needed; *n = bytes written to dst (0 = end of frame) */
+int zgpu_streaming_read(zgpu_streaming*, uint8_t* dst, size_t cap, size_t* n);
 
 #ifdef __cplusplus
 }

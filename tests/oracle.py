@@ -115,6 +115,9 @@ class FrameDecoder:
             raise OracleError(st)
         return did.value
 
+    def force_dict(self, dict_id):
+        return self.L.zor_force_dict(self.h, dict_id)
+
     def init(self, src):
         """returns (status, consumed, skip_magic, skip_len)"""
         c, sm, sl = C.c_size_t(), C.c_uint32(), C.c_uint32()

@@ -51,6 +51,33 @@ def test_lpt_sharding_properties():
     assert zgpu_dist.shard_frames([], 2) == [[], []]
 
 
+def test_python_sharder_equals_library_queue_plan():
+    """the ranks' static shards (zgpu_dist.shard_frames) and the library's work-queue plan (zgpu_pool_plan, host only) are the same
+    LPT rule: a job that runs as N processes x 1 GPU and one that runs as 1 process x N GPUs place frames identically"""
+    import random
+    sys.path.insert(0, os.path.join(ROOT, "zstd-rs_amd"))
+    import zgpu
+    import zgpu_dist
+    rnd = random.Random(5)
+    for trial in range(40):
+        n, w = rnd.randrange(0, 40), rnd.randrange(1, 9)
+        sizes = [rnd.choice([rnd.randrange(1, 1 << 26), 12345]) for _ in range(n)]
+        order, worker, load = zgpu.plan(sizes, w)
+        sh = zgpu_dist.shard_frames(sizes, w)
+        assert [sorted(i for i in range(n) if worker[i] == r) for r in range(w)] == sh
+        assert load == [sum(sizes[i] for i in s) for s in sh]
+        assert sorted(order) == list(range(n)) and all(sizes[order[k]] >= sizes[order[k + 1]] for k in range(n - 1))
+
+
+def test_bound_of_a_run_of_frames():
+    from golden_io import read_manifest, read_pack
+    sys.path.insert(0, os.path.join(ROOT, "zstd-rs_amd"))
+    import zgpu_dist
+    pack, man = read_pack("decodecorpus.pack"), read_manifest("decodecorpus.json")
+    for n in sorted(man)[:20]:
+        assert zgpu_dist._bound(pack[n]) >= man[n]["size"]
+
+
 def test_two_ranks_gloo():
     from golden_io import read_manifest
     man = read_manifest("decodecorpus.json")

@@ -1,0 +1,176 @@
+"""GPU parity at the sizes of BASELINE.json's configs: the generator's bytes are the ground truth (sha256 of
+every frame), the oracle checks a subsample, and the size-independent property is the frame checksum (XXH64 of the
+plaintext, frame_decoder.rs:263-270) which every frame carries. Everything goes through the C ABI."""
+import hashlib
+import os
+import sys
+
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _sha(b):
+    return hashlib.sha256(b).digest()
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import zgpu
+    c = zgpu.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def text1g():
+    import zgdata
+    plain = zgdata.text_like(1000000000, seed=0xE9)
+    return plain, zgdata.zstd_compress(plain)
+
+
+def _check_batch(ctx, zs, plains, oracle_on=()):
+    b = ctx.prepare(b"".join(zs))
+    assert b.parse_status == 0 and b.nframes == len(zs)
+    b.run()
+    b.sync()
+    assert b.bad_status == 0, (b.bad_frame, b.bad_status)
+    assert b.total_out == sum(len(p) for p in plains)
+    for f, p in enumerate(plains):
+        got = b.frame_bytes(f)
+        assert len(got) == len(p) and _sha(got) == _sha(p), f
+        if f in oracle_on:
+            ref, _ = oracle.decode_frame_all(zs[f])
+            assert ref == got, f
+    b.close()
+
+
+def test_silesia_sized_12_frames_one_submit(ctx):
+    """config 3: 12 uneven frames (sizes of the Silesia files, text-like and literal-heavy content mixed), one submit"""
+    import zgdata
+    sizes = [51220480, 41458703, 33553445, 21606400, 10192446, 10085684, 9970564, 8474240, 7251944, 6627202, 6152192, 5345280]
+    plains = [zgdata.text_like(s, seed=0x51 + i) if i % 3 else zgdata.iso_like(s, seed=0x51 + i) for i, s in enumerate(sizes)]
+    zs = [zgdata.zstd_compress(p) for p in plains]
+    _check_batch(ctx, zs, plains, oracle_on=(10, 11))
+
+
+def test_2048_single_block_frames(ctx):
+    """config 4b: thousands of block-independent frames in one submit (one unit each, one sweep step for all of them)"""
+    import zgdata
+    big = zgdata.text_like(256 << 20, seed=0x4B)
+    plains = [big[i:i + (128 << 10)] for i in range(0, len(big), 128 << 10)]
+    zs = [zgdata.zstd_compress(p) for p in plains]
+    assert len(zs) == 2048
+    _check_batch(ctx, zs, plains, oracle_on=(0, 1000, 2047))
+
+
+def test_640_multi_block_frames(ctx):
+    """many more multi-unit frames than the device holds workgroups for: every sweep step serves hundreds of frames"""
+    import zgdata
+    plains = [zgdata.text_like(640 << 10, seed=0x600 + i) for i in range(640)]
+    zs = [zgdata.zstd_compress(p) for p in plains]
+    os.environ["ZGPU_UNIT_BLOCKS"] = "2"       # 3 units (sweep steps) per frame
+    try:
+        import zgpu
+        c = zgpu.Context(0)
+        _check_batch(c, zs, plains, oracle_on=(7,))
+        c.close()
+    finally:
+        del os.environ["ZGPU_UNIT_BLOCKS"]
+
+
+def test_iso_like_256mib_frame(ctx):
+    """config 5: literal-heavy (ratio 1.18) single frame: 4-stream Huffman literals of 128 KiB blocks, almost no sequences"""
+    import zgdata
+    plain = zgdata.iso_like(256 << 20, seed=0x150)
+    _check_batch(ctx, [zgdata.zstd_compress(plain)], [plain])
+
+
+def test_1e9_frame_and_checksum(ctx, text1g):
+    """config 2 at full size: the enwik9-like frame, bit-exact, and its content checksum through the FrameDecoder surface"""
+    import zgpu
+    plain, z = text1g
+    _check_batch(ctx, [z], [plain])
+    d = zgpu.FrameDecoder(ctx)
+    st, c, _, _ = d.reset(z)
+    assert st == 0
+    st, used, fin = d.decode_blocks(z[c:], zgpu.STRAT_ALL)
+    assert st == 0 and fin and d.is_finished()
+    h = hashlib.sha256()
+    while True:
+        chunk = d.read(64 << 20)
+        if not chunk:
+            break
+        h.update(chunk)
+    assert h.digest() == _sha(plain)
+    assert d.get_checksum_from_data() == d.get_calculated_checksum() is not None
+    d.close()
+
+
+def test_more_than_4gib_in_one_submit(ctx, text1g):
+    """5 frames of 1e9 bytes in one submit: output positions beyond 2^32, flatten scratch beyond 16 GiB"""
+    plain, z = text1g
+    b = ctx.prepare(z * 5)
+    b.run()
+    b.sync()
+    assert b.bad_status == 0 and b.total_out == 5 * len(plain)
+    want = _sha(plain)
+    for f in range(5):
+        fi = b.frame_info(f)
+        assert fi.out_base == f * len(plain) and fi.out_size == len(plain)
+        assert _sha(b.read(fi.out_base, fi.out_size)) == want, f
+    b.close()
+
+
+def test_single_frame_beyond_2gib(ctx):
+    """one frame of 2.6e9 bytes: frame-relative positions beyond 2^31"""
+    import zgdata
+    plain = zgdata.text_like(2600000000, seed=0x26)
+    z = zgdata.zstd_compress(plain)
+    b = ctx.prepare(z)
+    b.run()
+    b.sync()
+    assert b.bad_status == 0 and b.total_out == len(plain)
+    h = hashlib.sha256()
+    for off in range(0, len(plain), 1 << 30):
+        h.update(b.read(off, min(1 << 30, len(plain) - off)))
+    assert h.digest() == _sha(plain)
+    b.close()
+
+
+def test_pool_queue_one_gpu(ctx):
+    """the library's work queue (zgpu_pool) on the one GPU of this box: decode_all over frames of very different sizes,
+    and the staged form the bench uses"""
+    import zgdata
+    import zgpu
+    import zgpu_dist
+    plains = [zgdata.text_like(n, seed=0x700 + i) for i, n in enumerate((90 << 20, 1 << 20, 300, 17 << 20, 5 << 20, 0, 70 << 20))]
+    zs = [zgdata.zstd_compress(p) for p in plains]
+    skip = bytes([0x50, 0x2A, 0x4D, 0x18, 3, 0, 0, 0, 1, 2, 3])
+    blob = zs[0] + skip + b"".join(zs[1:])
+    pool = zgpu.Pool(devices=[0])
+    assert pool.n_gpus == 1
+    out = pool.decode_all(blob, sum(len(p) for p in plains) + 16)
+    assert _sha(out) == _sha(b"".join(plains))
+    with pytest.raises(zgpu.ZgpuError) as e:
+        pool.decode_all(blob, 1000)
+    assert e.value.status == zgpu.E_TARGET_TOO_SMALL
+    with pytest.raises(zgpu.ZgpuError):
+        pool.decode_all(blob[:-7], 1 << 30)       # the last frame is truncated: the error of the walk wins
+    pool.stage(zs)
+    for _ in range(2):
+        gms, wall = pool.run()
+        assert len(gms) == 1 and gms[0] > 0 and wall >= gms[0] * 0.5
+    for i, p in enumerate(plains):
+        gpu, size, st = pool.frame(i)
+        assert (gpu, size, st) == (0, len(p), 0)
+        assert pool.read(i, size) == p
+    pool.close()
+    fn, pool2 = zgpu_dist.gpu_decode_fn(0)
+    local = zgpu_dist.decode_sharded(zs, fn, 0, 1)
+    assert [local[i] for i in range(len(zs))] == plains
+    pool2.close()

@@ -1,5 +1,6 @@
 // zg_capi.cpp — the extern "C" boundary declared in include/zgpu.h, plus the host-side mirror of the reference's
 // FrameDecoder (ruzstd/src/decoding/frame_decoder.rs) built on the engine.
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 #include <vector>
@@ -131,7 +132,6 @@ int zgpu_batch_sync(zgpu_batch* zb, uint64_t* total_out, uint32_t* bad_frame, ui
   if (total_out) *total_out = zb->b->total_out;
   if (bad_frame) *bad_frame = bf;
   if (its_status) *its_status = bs;
-  if (zb->b->overflow && !bs) return ZGPU_E_UNSUPPORTED;  // a block regenerated more than 128 KiB (non-conforming)
   return ZGPU_OK;
 }
 uint32_t zgpu_batch_num_frames(const zgpu_batch* zb) { return (uint32_t)zb->b->bb.frames.size(); }
@@ -213,11 +213,11 @@ int zgpu_batch_block_sequences(zgpu_batch* zb, uint32_t i, zgpu_seq* dst, size_t
 int zgpu_batch_debug_timers(zgpu_batch* zb, uint64_t out[1024]) { return zb->b->read_debug(out); }
 int zgpu_batch_debug_scratch(zgpu_batch* zb, int what, uint64_t off, void* dst, uint64_t n) { return zb->b->read_scratch(what, off, dst, n); }
 uint32_t zgpu_batch_num_units(const zgpu_batch* zb) { return (uint32_t)zb->b->bb.units.size(); }
-int zgpu_batch_unit(const zgpu_batch* zb, uint32_t u, uint32_t* first_block, uint32_t* nblocks, uint64_t* scratch_base) {
+int zgpu_batch_unit(zgpu_batch* zb, uint32_t u, uint32_t* first_block, uint32_t* nblocks, uint64_t* scratch_base) {
   if (u >= zb->b->bb.units.size()) return ZGPU_E_BAD_ARG;
   const ZgUnit& x = zb->b->bb.units[u];
-  *first_block = x.first_block; *nblocks = x.nblocks; *scratch_base = x.og_base;
-  return ZGPU_OK;
+  *first_block = x.first_block; *nblocks = x.nblocks;
+  return zb->b->unit_scratch_base(u, scratch_base);
 }
 int zgpu_debug_calibrate(zgpu_ctx* c, uint64_t bytes) {
   // profiler calibration: one device-to-device copy kernel of exactly `bytes` read + `bytes` written
@@ -270,6 +270,42 @@ int zgpu_decode_all(zgpu_ctx* c, const uint8_t* src, size_t len, uint8_t* dst, s
   *written = (size_t)total;
   return ZGPU_OK;
 }
+
+// FrameDecoder::decode_all_to_vec (frame_decoder.rs:591-610): the output buffer is sized by the decoder, here exactly (the
+// size of every frame is known on the host before the LZ77 stages run). *out is malloc'ed; release it with zgpu_free.
+int zgpu_decode_all_alloc(zgpu_ctx* c, const uint8_t* src, size_t len, uint8_t** out, size_t* written) {
+  if (!c || !out || !written || (!src && len)) return ZGPU_E_BAD_ARG;
+  *out = nullptr; *written = 0;
+  zgpu_batch* zb = nullptr;
+  int st = zgpu_batch_prepare(c, src, len, &zb);
+  if (st == ZGPU_E_DICT_NOT_PROVIDED && !c->dicts.empty()) {
+    // dictionary frames go one by one through the FrameDecoder mirror: grow like Vec does
+    zgpu_batch_destroy(zb);
+    size_t cap = len * 4 + (1u << 20);
+    for (;;) {
+      uint8_t* buf = (uint8_t*)malloc(cap);
+      if (!buf) return ZGPU_E_NOMEM;
+      st = decode_all_per_frame(c, src, len, buf, cap, written);
+      if (st == ZGPU_E_TARGET_TOO_SMALL && cap < ((size_t)1 << 40)) { free(buf); cap *= 2; continue; }
+      if (st) { free(buf); return st; }
+      *out = buf;
+      return ZGPU_OK;
+    }
+  }
+  if (st) { zgpu_batch_destroy(zb); return st; }
+  uint64_t total = 0;
+  uint32_t bf = 0, bs = 0;
+  if ((st = zgpu_batch_run(zb)) || (st = zgpu_batch_sync(zb, &total, &bf, &bs))) { zgpu_batch_destroy(zb); return st; }
+  if (bs) { zgpu_batch_destroy(zb); return (int)bs; }
+  uint8_t* buf = (uint8_t*)malloc(total ? total : 1);
+  if (!buf) { zgpu_batch_destroy(zb); return ZGPU_E_NOMEM; }
+  st = zgpu_batch_read(zb, 0, buf, total);
+  zgpu_batch_destroy(zb);
+  if (st) { free(buf); return st; }
+  *out = buf; *written = (size_t)total;
+  return ZGPU_OK;
+}
+void zgpu_free(void* p) { free(p); }
 
 }  // extern "C"
 
@@ -356,14 +392,24 @@ static size_t dec_drain(zgpu_decoder* d, size_t n, uint8_t* dst) {  // DecodeBuf
 }
 
 static int apply_dict(zgpu_decoder* d, const ZgDict& dict) {   // DecoderScratch::init_from_dict scratch.rs:70-78
+  // Tables, offset history and dictionary content are replaced, whenever it is called (force_dict may come after blocks
+  // were decoded, frame_decoder.rs:229-243): the device window is rebuilt as [new dictionary content][frame bytes so far].
   FrameState& fs = d->fs;
   int st;
-  if ((st = fs.d_fse.reserve(ZG_FSE_SLOT_U32 * 4)) || (st = fs.d_huf.reserve(ZG_HUF_SLOT_U16 * 2)) ||
-      (st = fs.d_out.reserve(kOutFront + dict.content.size() + 256))) return st;
+  if ((st = fs.d_fse.reserve(ZG_FSE_SLOT_U32 * 4)) || (st = fs.d_huf.reserve(ZG_HUF_SLOT_U16 * 2))) return st;
+  const uint64_t keep = fs.have;
+  DevBuf nb;
+  if ((st = nb.reserve(kOutFront + dict.content.size() + keep + 256))) return st;
+  uint8_t* np = (uint8_t*)nb.p + kOutFront;
   if (hipMemcpy(fs.d_fse.p, dict.fse.data(), ZG_FSE_SLOT_U32 * 4, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(fs.d_huf.p, dict.huf.data(), ZG_HUF_SLOT_U16 * 2, hipMemcpyHostToDevice) != hipSuccess ||
-      (dict.content.size() && hipMemcpy(fs.out_ptr(), dict.content.data(), dict.content.size(), hipMemcpyHostToDevice) != hipSuccess))
+      (dict.content.size() && hipMemcpy(np, dict.content.data(), dict.content.size(), hipMemcpyHostToDevice) != hipSuccess) ||
+      (keep && hipMemcpy(np + dict.content.size(), fs.out_ptr() + fs.base, keep, hipMemcpyDeviceToDevice) != hipSuccess)) {
+    nb.release();
     return ZGPU_E_HIP;
+  }
+  fs.d_out.release();
+  fs.d_out = nb;
   memcpy(fs.logs, dict.logs, 4);
   fs.huf_maxbits = dict.huf_maxbits;
   fs.carry_mask = 0xF;
@@ -379,21 +425,19 @@ static int decode_run(zgpu_decoder* d, const uint8_t* src, size_t len, uint32_t 
   Batch* b = nullptr;
   size_t used = 0;
   *consumed = 0;
-  int st = eng->prepare_run(src, len, &d->fs, d->fh.content_checksum(), max_blocks, &b, &used);
+  int st = eng->prepare_run(src, len, &d->fs, d->fh.content_checksum(), max_blocks, d->held(), &b, &used);
   if (st) return st;
   const int parse_status = b->parse_status;
   const size_t nb = b->bb.blocks.size();
   if (nb == 0) { delete b; return parse_status ? parse_status : ZGPU_E_INTERNAL; }
-  const uint64_t before = d->fs.base + d->fs.produced;
   if ((st = b->run()) || (st = b->sync())) { delete b; return st; }
   if (b->frame_out.empty()) { delete b; return ZGPU_E_INTERNAL; }
   const ZgFrameOut fo = b->frame_out[0];
-  if (b->overflow) { delete b; return ZGPU_E_UNSUPPORTED; }
   if ((st = b->commit(&d->fs))) { delete b; return st; }
   // bring the new bytes to the host buffer the collect/read calls drain
   const size_t old = d->buf.size();
   d->buf.resize(old + fo.out_size);
-  if (fo.out_size && hipMemcpy(d->buf.data() + old, (const uint8_t*)d->fs.out_ptr() + before, fo.out_size, hipMemcpyDeviceToHost) != hipSuccess) {
+  if (fo.out_size && hipMemcpy(d->buf.data() + old, (const uint8_t*)d->fs.out_ptr() + fo.out_base, fo.out_size, hipMemcpyDeviceToHost) != hipSuccess) {
     delete b;
     return ZGPU_E_HIP;
   }
@@ -457,7 +501,6 @@ int zgpu_decoder_force_dict(zgpu_decoder* d, uint32_t dict_id) {   // frame_deco
   if (!d->has_state) return ZGPU_E_NOT_INITIALIZED;
   auto it = d->ctx->dicts.find(dict_id);
   if (it == d->ctx->dicts.end()) return ZGPU_E_DICT_NOT_PROVIDED;
-  if (d->fs.produced) return ZGPU_E_UNSUPPORTED;   // only before the first block (the reference allows it any time)
   return apply_dict(d, it->second);
 }
 
@@ -577,6 +620,118 @@ int zgpu_decoder_checksum_from_data(const zgpu_decoder* d, uint32_t* out) {
   return 1;
 }
 uint32_t zgpu_decoder_calculated_checksum(const zgpu_decoder* d) { return (uint32_t)d->hash.digest(); }
+
+}  // extern "C"
+
+// ---- collect_to_writer (frame_decoder.rs:395-407) and StreamingDecoder (streaming_decoder.rs:40-156) -------------------------
+struct zgpu_streaming {
+  zgpu_decoder* dec = nullptr;
+  bool owns_dec = false;
+  zgpu_read_fn read = nullptr;
+  void* user = nullptr;
+  std::vector<uint8_t> stage;
+};
+
+extern "C" {
+
+int zgpu_decoder_collect_to_writer(zgpu_decoder* d, zgpu_write_fn write, void* user, size_t* written) {
+  // drains what collect() would return into the writer, in chunks; a short write ends the call (io::Write::write semantics)
+  if (!d || !write) return ZGPU_E_BAD_ARG;
+  size_t n = zgpu_decoder_can_collect(d), done = 0;
+  while (done < n) {
+    const size_t chunk = n - done < (1u << 20) ? n - done : (1u << 20);
+    const size_t w = write(user, d->buf.data() + d->head, chunk);
+    if (w > chunk) return ZGPU_E_BAD_ARG;
+    dec_drain(d, w, nullptr);
+    done += w;
+    if (w < chunk) break;
+  }
+  if (written) *written = done;
+  return ZGPU_OK;
+}
+
+static size_t read_full(zgpu_streaming* s, uint8_t* dst, size_t n) {
+  size_t got = 0;
+  while (got < n) {
+    const size_t r = s->read(s->user, dst + got, n - got);
+    if (r == 0) break;
+    got += r;
+  }
+  return got;
+}
+
+int zgpu_streaming_create(zgpu_ctx* c, zgpu_read_fn read, void* user, zgpu_streaming** out) {
+  // StreamingDecoder::new (streaming_decoder.rs:51-58): reads the frame header from the source
+  if (!c || !read || !out) return ZGPU_E_BAD_ARG;
+  zgpu_streaming* s = new (std::nothrow) zgpu_streaming();
+  if (!s) return ZGPU_E_NOMEM;
+  s->read = read; s->user = user;
+  int st = zgpu_decoder_create(c, &s->dec);
+  if (st) { delete s; return st; }
+  s->owns_dec = true;
+  uint8_t head[18];
+  size_t have = read_full(s, head, 5);
+  if (have == 5 && head[0] == 0x28 && head[1] == 0xB5 && head[2] == 0x2F && head[3] == 0xFD) {
+    const unsigned desc = head[4], single = (desc >> 5) & 1;
+    static const unsigned kDid[4] = {0, 1, 2, 4}, kFcs[4] = {0, 2, 4, 8};
+    const unsigned extra = (single ? 0 : 1) + kDid[desc & 3] + ((desc >> 6) == 0 ? (single ? 1 : 0) : kFcs[desc >> 6]);
+    have += read_full(s, head + 5, extra);
+  } else if (have == 5) have += read_full(s, head + 5, 3);   // a skippable frame's 8-byte header
+  size_t used = 0;
+  uint32_t sm = 0, sl = 0;
+  st = zgpu_decoder_init(s->dec, head, have, &used, &sm, &sl);
+  if (st) { zgpu_decoder_destroy(s->dec); delete s; return st; }
+  *out = s;
+  return ZGPU_OK;
+}
+void zgpu_streaming_destroy(zgpu_streaming* s) {
+  if (!s) return;
+  if (s->owns_dec) zgpu_decoder_destroy(s->dec);
+  delete s;
+}
+zgpu_decoder* zgpu_streaming_decoder(zgpu_streaming* s) { return s ? s->dec : nullptr; }   // get_ref / into_frame_decoder (:66-85)
+
+int zgpu_streaming_read(zgpu_streaming* s, uint8_t* dst, size_t cap, size_t* n_out) {
+  // impl Read for StreamingDecoder (streaming_decoder.rs:119-155)
+  if (!s || !n_out) return ZGPU_E_BAD_ARG;
+  *n_out = 0;
+  zgpu_decoder* d = s->dec;
+  if (zgpu_decoder_is_finished(d) && zgpu_decoder_can_collect(d) == 0) return ZGPU_OK;      // :125-130
+  while (zgpu_decoder_can_collect(d) < cap && !zgpu_decoder_is_finished(d)) {                 // :134-150
+    const size_t need = cap - zgpu_decoder_can_collect(d);
+    // UptoBytes(need) never stops before ceil(need / 128 KiB) blocks: read that many whole blocks and hand them over as one run
+    uint32_t m = (uint32_t)((need + kMaxBlockSize - 1) / kMaxBlockSize);
+    if (m == 0) m = 1;
+    s->stage.clear();
+    for (uint32_t k = 0; k < m; k++) {
+      uint8_t hdr[3];
+      const size_t h = read_full(s, hdr, 3);
+      s->stage.insert(s->stage.end(), hdr, hdr + h);
+      if (h < 3) break;
+      BlockHeader bh;
+      if (read_block_header(hdr, &bh)) break;                 // the decoder reports the error
+      const size_t at = s->stage.size();
+      s->stage.resize(at + bh.content_size);
+      const size_t b = read_full(s, s->stage.data() + at, bh.content_size);
+      s->stage.resize(at + b);
+      if (b < bh.content_size) break;
+      if (bh.last) {
+        if (d->fh.content_checksum()) {
+          uint8_t cs[4];
+          const size_t c4 = read_full(s, cs, 4);
+          s->stage.insert(s->stage.end(), cs, cs + c4);
+        }
+        break;
+      }
+    }
+    size_t used = 0;
+    int fin = 0;
+    const int st = zgpu_decoder_decode_blocks(d, s->stage.data(), s->stage.size(), &used, ZGPU_STRAT_UPTO_BLOCKS, m, &fin);
+    if (st) return st;
+  }
+  *n_out = zgpu_decoder_read(d, dst, cap);
+  return ZGPU_OK;
+}
 
 }  // extern "C"
 

@@ -14,12 +14,15 @@ namespace zg {
 int DevBuf::reserve(size_t n, bool keep, hipStream_t s) {
   if (n <= cap && p) return 0;
   size_t ncap = n < 256 ? 256 : n;
+  if (p && ncap < cap + cap / 2) ncap = cap + cap / 2;   // a buffer that grows again: amortise
   void* np = nullptr;
   if (hipMalloc(&np, ncap) != hipSuccess) return ZG_NOMEM;
   if (p) {
     if (keep && cap) {
-      if (hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, s) != hipSuccess) return ZG_HIP_ERROR;
-      if (hipStreamSynchronize(s) != hipSuccess) return ZG_HIP_ERROR;
+      if (hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        (void)hipFree(np);
+        return ZG_HIP_ERROR;
+      }
     }
     (void)hipFree(p);
   }
@@ -31,6 +34,29 @@ void DevBuf::release() {
   if (p) (void)hipFree(p);
   p = nullptr;
   cap = 0;
+}
+
+int Scratch::init_events() {
+  if (have_events) return 0;
+  for (auto& e : ev)
+    if (hipEventCreate(&e) != hipSuccess) return ZG_HIP_ERROR;
+  for (auto& e : ev_huf)
+    if (hipEventCreate(&e) != hipSuccess) return ZG_HIP_ERROR;
+  if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return ZG_HIP_ERROR;
+  have_events = true;
+  return 0;
+}
+void Scratch::release() {
+  DevBuf* all[] = {&d_src, &d_blocks, &d_frames, &d_aux, &d_slot_log, &d_fse, &d_huf, &d_hufmax, &d_status, &d_lit, &d_seq, &d_seqout, &d_pos,
+                   &d_frameout, &d_dst, &d_seqblocks, &d_hufitems, &d_hufgroups, &d_totals, &d_og, &d_units, &d_unitinfo, &d_stepunits, &d_swdesc,
+                   &d_dbg, &d_raw};
+  for (DevBuf* b : all) b->release();
+  for (auto& e : ev)
+    if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  for (auto& e : ev_huf)
+    if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
+  have_events = false;
 }
 
 int Engine::fail(hipError_t e, const char* what) {
@@ -60,8 +86,18 @@ int Engine::create(int device, Engine** out) {
   return ZG_OK;
 }
 Engine::~Engine() {
+  (void)hipSetDevice(device_);
+  for (Scratch* s : free_) { s->release(); delete s; }
   if (stream_) (void)hipStreamDestroy(stream_);
   if (stream2_) (void)hipStreamDestroy(stream2_);
+}
+Scratch* Engine::acquire() {
+  if (!free_.empty()) { Scratch* s = free_.back(); free_.pop_back(); return s; }
+  return new Scratch();
+}
+void Engine::recycle(Scratch* s) {
+  if (free_.size() < 2) free_.push_back(s);   // what a streaming decoder or a queue worker alternates between
+  else { s->release(); delete s; }
 }
 
 int parse_frames(const uint8_t* src, size_t len, uint64_t max_window, BatchBuilder* bb, std::vector<FrameInfo>* info) {
@@ -119,22 +155,82 @@ int parse_frames(const uint8_t* src, size_t len, uint64_t max_window, BatchBuild
   return ZG_OK;
 }
 
+
+int split_frames(const uint8_t* src, size_t len, std::vector<FrameSpan>* out) {
+  // the walk of parse_frames without the section headers: frame header, then block headers up to the last block
+  size_t p = 0;
+  while (p < len) {
+    FrameHeader h;
+    size_t c;
+    uint32_t sm = 0, sl = 0;
+    FrameSpan sp;
+    sp.begin = p; sp.content_size = 0; sp.has_content_size = false; sp.skippable = false;
+    int st = read_frame_header(src + p, len - p, &h, &c, &sm, &sl);
+    if (st == ZG_SKIP_FRAME) {
+      p += c;
+      if ((size_t)sl > len - p) return ZG_FAILED_SKIP_FRAME;
+      p += sl;
+      sp.end = p; sp.skippable = true;
+      out->push_back(sp);
+      continue;
+    }
+    if (st) return st;
+    p += c;
+    for (;;) {
+      if (len - p < 3) return ZG_FAILED_READ_BLOCK_HEADER;
+      BlockHeader bh;
+      if ((st = read_block_header(src + p, &bh))) return st;
+      p += 3;
+      if (len - p < bh.content_size) return ZG_FAILED_READ_BLOCK_BODY;
+      p += bh.content_size;
+      if (bh.last) {
+        if (h.content_checksum()) {
+          if (len - p < 4) return ZG_FAILED_READ_CHECKSUM;
+          p += 4;
+        }
+        break;
+      }
+    }
+    sp.end = p; sp.content_size = h.frame_content_size; sp.has_content_size = h.has_fcs();
+    out->push_back(sp);
+  }
+  return ZG_OK;
+}
+
 Batch::~Batch() {
-  DevBuf* all[] = {&d_src, &d_blocks, &d_frames, &d_aux, &d_slot_log, &d_fse, &d_huf, &d_hufmax, &d_status, &d_lit, &d_seq,
-                   &d_seqout, &d_pos, &d_frameout, &d_dst, &d_seqblocks, &d_hufitems, &d_hufgroups, &d_totals, &d_og, &d_units, &d_unitinfo, &d_stepunits, &d_swdesc, &d_dbg, &d_raw};
-  for (DevBuf* b : all) b->release();
-  for (auto& e : ev)
-    if (e) (void)hipEventDestroy(e);
-  for (auto& e : ev_huf)
-    if (e) (void)hipEventDestroy(e);
-  if (ev_fork) (void)hipEventDestroy(ev_fork);
+  if (sc && eng) { (void)hipSetDevice(eng->device_); (void)hipStreamSynchronize(eng->stream_); eng->recycle(sc); }
 }
 
 void FrameState::reset() {
-  base = 0; produced = 0; hist[0] = 1; hist[1] = 4; hist[2] = 8;
+  base = 0; have = 0; produced = 0; hist[0] = 1; hist[1] = 4; hist[2] = 8;
   logs[0] = logs[1] = logs[2] = logs[3] = 0; huf_maxbits = 0; carry_mask = 0; window_size = 0;
 }
 void FrameState::release() { d_out.release(); d_fse.release(); d_huf.release(); }
+
+int FrameState::make_room(uint64_t extra, uint64_t keep, hipStream_t s) {
+  if (keep > have) keep = have;
+  const uint64_t need = kOutFront + base + have + extra + 64;
+  if (d_out.p && need <= d_out.cap) return 0;
+  // rebuild: [dictionary][the last `keep` frame bytes] move to a new buffer with room to grow; what the caller has drained
+  // and no match can reach any more (decode_buffer.rs:182-219) is dropped here, so the device window stays bounded
+  const uint64_t live = base + keep;
+  uint64_t ncap = kOutFront + live + extra + 64;
+  const uint64_t slack = live + extra > (8u << 20) ? (live + extra) / 2 : (4u << 20);
+  ncap += slack;
+  void* np = nullptr;
+  if (hipMalloc(&np, ncap) != hipSuccess) return ZG_NOMEM;
+  if (d_out.p) {
+    hipError_t e = hipSuccess;
+    if (base) e = hipMemcpyAsync((uint8_t*)np + kOutFront, out_ptr(), base, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess && keep) e = hipMemcpyAsync((uint8_t*)np + kOutFront + base, out_ptr() + base + (have - keep), keep, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { (void)hipFree(np); return ZG_HIP_ERROR; }
+    (void)hipFree(d_out.p);
+  }
+  d_out.p = np; d_out.cap = ncap;
+  have = keep;
+  return 0;
+}
 
 int parse_block_run(const uint8_t* src, size_t len, uint64_t window, bool has_checksum, const uint32_t hist[3], uint32_t carry_mask,
                     uint32_t max_blocks, BatchBuilder* bb, std::vector<FrameInfo>* info, size_t* consumed, bool* saw_last) {
@@ -175,6 +271,7 @@ int parse_block_run(const uint8_t* src, size_t len, uint64_t window, bool has_ch
   return st;
 }
 
+
 int Engine::prepare(const uint8_t* src, size_t len, Batch** out) {
   Batch* b = new Batch();
   b->eng = this;
@@ -183,19 +280,15 @@ int Engine::prepare(const uint8_t* src, size_t len, Batch** out) {
   return upload(b, src, len, out);
 }
 
-int Engine::prepare_run(const uint8_t* src, size_t len, FrameState* fs, bool has_checksum, uint32_t max_blocks, Batch** out, size_t* consumed) {
+int Engine::prepare_run(const uint8_t* src, size_t len, FrameState* fs, bool has_checksum, uint32_t max_blocks, uint64_t keep, Batch** out, size_t* consumed) {
   Batch* b = new Batch();
   b->eng = this;
   b->fs = fs;
+  b->keep_bytes = keep;
   b->parse_status = parse_block_run(src, len, fs->window_size, has_checksum, fs->hist, fs->carry_mask, max_blocks, &b->bb, &b->info, consumed,
                                     &b->saw_last_block);
   b->src_len = *consumed;
-  // this run continues the frame: its bytes go right behind what exists, and matches may reach back into it
-  ZgFrame& fr = b->bb.frames[0];
-  fr.fixed_base = 1;
-  fr.out_base_fixed = fs->base + fs->produced;
-  fr.prior_out = fs->produced;
-  fr.dict_len = fs->base;
+  b->bb.frames[0].fixed_base = 1;   // where its bytes go is decided in run(), when the size of the run is known
   return upload(b, src, *consumed, out);
 }
 
@@ -208,6 +301,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   b->bb.flat_slots = (uint32_t)cus_ * (flat_shape_ == 0 ? 1u : 2u);   // zg_k_flat: workgroups the device holds at once
   b->bb.finish();
   BatchBuilder& bb = b->bb;
+  Scratch* sc = b->sc = acquire();
   const uint32_t nb = (uint32_t)bb.blocks.size(), nf = (uint32_t)bb.frames.size();
   auto up = [&](DevBuf& d, const void* h, size_t bytes) -> int {
     int st = d.reserve(bytes ? bytes : 16);
@@ -218,71 +312,57 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   int st = 0;
   // compressed bytes, padded so that 8-byte bit-window loads near the end stay inside the allocation
   // ... and 64 bytes in front for the 16-byte windows of the sequence decoder
-  if ((st = b->d_src.reserve(len + 128))) { delete b; return st; }
-  (void)hipMemsetAsync(b->d_src.p, 0, 64, stream_);
-  if (len && hipMemcpyAsync((uint8_t*)b->d_src.p + 64, src, len, hipMemcpyHostToDevice, stream_) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
-  (void)hipMemsetAsync((uint8_t*)b->d_src.p + 64 + len, 0, 64, stream_);
-  if ((st = up(b->d_blocks, bb.blocks.data(), nb * sizeof(ZgBlock))) || (st = up(b->d_frames, bb.frames.data(), nf * sizeof(ZgFrame))) ||
-      (st = up(b->d_seqblocks, bb.seq_blocks.data(), bb.seq_blocks.size() * 4)) ||
-      (st = up(b->d_hufitems, bb.huf_items.data(), bb.huf_items.size() * 4)) ||
-      (st = up(b->d_hufgroups, bb.huf_groups.data(), bb.huf_groups.size() * sizeof(ZgHufGroup)))) {
-    delete b;
-    return st;
-  }
+  if ((st = sc->d_src.reserve(len + 128))) { delete b; return st; }
+  (void)hipMemsetAsync(sc->d_src.p, 0, 64, stream_);
+  if (len && hipMemcpyAsync((uint8_t*)sc->d_src.p + 64, src, len, hipMemcpyHostToDevice, stream_) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
+  (void)hipMemsetAsync((uint8_t*)sc->d_src.p + 64 + len, 0, 64, stream_);
   const uint32_t nslots = bb.nslots();
-  if ((st = b->d_aux.reserve((size_t)nb * sizeof(ZgBlockAux) + 16)) || (st = b->d_slot_log.reserve((size_t)nslots * 4)) ||
-      (st = b->d_fse.reserve((size_t)nslots * ZG_FSE_SLOT_U32 * 4)) || (st = b->d_huf.reserve((size_t)(bb.nhuf_slots + 1) * ZG_HUF_SLOT_U16 * 2)) ||
-      (st = b->d_hufmax.reserve(bb.nhuf_slots + 16)) || (st = b->d_status.reserve(3 * ((size_t)nb * 4 + 16))) ||
-      (st = b->d_lit.reserve(bb.lit_bytes + 64)) || (st = b->d_seq.reserve((bb.seq_count + 1) * sizeof(ZgSeq))) ||
-      (st = b->d_raw.reserve((bb.seq_count + 2) * 8)) ||
-      (st = b->d_seqout.reserve((size_t)nb * sizeof(ZgBlockSeqOut) + 16)) || (st = b->d_pos.reserve((size_t)nb * sizeof(ZgBlockPos) + 16)) ||
-      (st = b->d_frameout.reserve((size_t)nf * sizeof(ZgFrameOut) + 16)) ||
-      (st = b->fs ? b->fs->d_out.reserve(kOutFront + b->fs->base + b->fs->produced + bb.out_bound + 64, true, stream_) : b->d_dst.reserve(kOutFront + bb.out_bound + 64)) ||
-      (st = b->d_totals.reserve(64)) || (st = b->d_og.reserve((size_t)bb.og_count * 4 + 64)) ||
-      (st = up(b->d_units, bb.units.data(), bb.units.size() * sizeof(ZgUnit))) ||
-      (st = up(b->d_stepunits, bb.step_units.data(), bb.step_units.size() * 4)) ||
-      (st = b->d_swdesc.reserve(bb.step_units.size() * sizeof(ZgSweepDesc) + 32)) ||
-      (st = b->d_unitinfo.reserve(bb.units.size() * sizeof(ZgUnitInfo) + 16)) || (st = b->d_dbg.reserve(8192))) {
+  if ((st = up(sc->d_blocks, bb.blocks.data(), nb * sizeof(ZgBlock))) || (st = up(sc->d_frames, bb.frames.data(), nf * sizeof(ZgFrame))) ||
+      (st = up(sc->d_seqblocks, bb.seq_blocks.data(), bb.seq_blocks.size() * 4)) ||
+      (st = up(sc->d_hufitems, bb.huf_items.data(), bb.huf_items.size() * 4)) ||
+      (st = up(sc->d_hufgroups, bb.huf_groups.data(), bb.huf_groups.size() * sizeof(ZgHufGroup))) ||
+      (st = up(sc->d_units, bb.units.data(), bb.units.size() * sizeof(ZgUnit))) ||
+      (st = up(sc->d_stepunits, bb.step_units.data(), bb.step_units.size() * 4)) ||
+      (st = sc->d_aux.reserve((size_t)nb * sizeof(ZgBlockAux) + 16)) || (st = sc->d_slot_log.reserve((size_t)nslots * 4)) ||
+      (st = sc->d_fse.reserve((size_t)nslots * ZG_FSE_SLOT_U32 * 4)) || (st = sc->d_huf.reserve((size_t)(bb.nhuf_slots + 1) * ZG_HUF_SLOT_U16 * 2)) ||
+      (st = sc->d_hufmax.reserve(bb.nhuf_slots + 16)) || (st = sc->d_status.reserve(3 * ((size_t)nb * 4 + 16))) ||
+      (st = sc->d_lit.reserve(bb.lit_bytes + 64)) || (st = sc->d_seq.reserve((bb.seq_count + 2) * sizeof(ZgSeq))) ||
+      (st = sc->d_raw.reserve((bb.seq_count + 2) * 8)) ||
+      (st = sc->d_seqout.reserve((size_t)nb * sizeof(ZgBlockSeqOut) + 16)) || (st = sc->d_pos.reserve((size_t)nb * sizeof(ZgBlockPos) + 16)) ||
+      (st = sc->d_frameout.reserve((size_t)nf * sizeof(ZgFrameOut) + 16)) || (st = sc->d_totals.reserve(64)) ||
+      (st = sc->d_swdesc.reserve(bb.step_units.size() * sizeof(ZgSweepDesc) + 32)) ||
+      (st = sc->d_unitinfo.reserve(bb.units.size() * sizeof(ZgUnitInfo) + 16)) || (st = sc->d_dbg.reserve(8192)) || (st = sc->init_events())) {
     delete b;
     return st;
   }
+  // the output and the flatten scratch are sized in run(), when the exact output size of every frame is known
   ZgBatchDev& d = b->dev;
-  d.src = b->d_src.as<uint8_t>() + 64; d.src_len = len;
-  d.blocks = b->d_blocks.as<ZgBlock>(); d.nblocks = nb;
-  d.frames = b->d_frames.as<ZgFrame>(); d.nframes = nf;
+  d.src = sc->d_src.as<uint8_t>() + 64; d.src_len = len;
+  d.blocks = sc->d_blocks.as<ZgBlock>(); d.nblocks = nb;
+  d.frames = sc->d_frames.as<ZgFrame>(); d.nframes = nf;
   d.nslots = nslots; d.nhuf_slots = bb.nhuf_slots;
-  d.aux = b->d_aux.as<ZgBlockAux>(); d.slot_log = b->d_slot_log.as<uint8_t>();
-  d.fse_arena = b->d_fse.as<uint32_t>(); d.huf_arena = b->d_huf.as<uint16_t>(); d.huf_maxbits = b->d_hufmax.as<uint8_t>();
-  d.status = b->d_status.as<uint32_t>(); d.tab_status = d.status + nb + 4; d.lit_status = d.tab_status + nb + 4; d.lit_arena = b->d_lit.as<uint8_t>(); d.seq_arena = b->d_seq.as<ZgSeq>(); d.raw_arena = b->d_raw.as<uint2>();
-  d.seq_out = b->d_seqout.as<ZgBlockSeqOut>(); d.pos = b->d_pos.as<ZgBlockPos>(); d.frame_out = b->d_frameout.as<ZgFrameOut>();
-  if (b->fs) {
-    if ((st = b->fs->d_fse.reserve(ZG_FSE_SLOT_U32 * 4)) || (st = b->fs->d_huf.reserve(ZG_HUF_SLOT_U16 * 2))) { delete b; return st; }
-    d.dst = b->fs->out_ptr(); d.dst_cap = b->fs->base + b->fs->produced + bb.out_bound;
-  } else {
-    d.dst = b->d_dst.as<uint8_t>() + kOutFront; d.dst_cap = bb.out_bound;
-  }
+  d.aux = sc->d_aux.as<ZgBlockAux>(); d.slot_log = sc->d_slot_log.as<uint8_t>();
+  d.fse_arena = sc->d_fse.as<uint32_t>(); d.huf_arena = sc->d_huf.as<uint16_t>(); d.huf_maxbits = sc->d_hufmax.as<uint8_t>();
+  d.status = sc->d_status.as<uint32_t>(); d.tab_status = d.status + nb + 4; d.lit_status = d.tab_status + nb + 4;
+  d.lit_arena = sc->d_lit.as<uint8_t>(); d.seq_arena = sc->d_seq.as<ZgSeq>(); d.raw_arena = sc->d_raw.as<uint2>();
+  d.seq_out = sc->d_seqout.as<ZgBlockSeqOut>(); d.pos = sc->d_pos.as<ZgBlockPos>(); d.frame_out = sc->d_frameout.as<ZgFrameOut>();
+  d.dst = nullptr; d.dst_cap = 0; d.og = nullptr;
   d.dict = nullptr;
-  d.seq_blocks = b->d_seqblocks.as<uint32_t>(); d.nseq_blocks = (uint32_t)bb.seq_blocks.size();
-  d.huf_items = b->d_hufitems.as<uint32_t>(); d.huf_groups = b->d_hufgroups.as<ZgHufGroup>(); d.nhuf_groups = (uint32_t)bb.huf_groups.size();
-  d.totals = b->d_totals.as<uint32_t>();
-  d.og = b->d_og.as<uint32_t>();
-  d.units = b->d_units.as<ZgUnit>(); d.nunits = (uint32_t)bb.units.size(); d.unit_info = b->d_unitinfo.as<ZgUnitInfo>();
-  d.step_units = b->d_stepunits.as<uint32_t>();
-  d.sweep_desc = b->d_swdesc.as<ZgSweepDesc>();
+  d.seq_blocks = sc->d_seqblocks.as<uint32_t>(); d.nseq_blocks = (uint32_t)bb.seq_blocks.size();
+  d.huf_items = sc->d_hufitems.as<uint32_t>(); d.huf_groups = sc->d_hufgroups.as<ZgHufGroup>(); d.nhuf_groups = (uint32_t)bb.huf_groups.size();
+  d.totals = sc->d_totals.as<uint32_t>();
+  d.units = sc->d_units.as<ZgUnit>(); d.nunits = (uint32_t)bb.units.size(); d.unit_info = sc->d_unitinfo.as<ZgUnitInfo>();
+  d.step_units = sc->d_stepunits.as<uint32_t>();
+  d.sweep_desc = sc->d_swdesc.as<ZgSweepDesc>();
   b->sweep_steps.clear();
   for (const ZgStepRange& r : bb.steps) {
     ZgSweepStep ss;
     ss.list_off = r.list_off; ss.nunits = r.nunits; ss.slices = r.max_blocks * (kMaxBlockSize / 4096u); ss.pad = 0;   // zg_k_sweep: 4 KiB of output per workgroup
     b->sweep_steps.push_back(ss);
   }
-  d.dbg = getenv("ZGPU_DEBUG_TIMERS") ? b->d_dbg.as<unsigned long long>() : nullptr;
+  d.dbg = getenv("ZGPU_DEBUG_TIMERS") ? sc->d_dbg.as<unsigned long long>() : nullptr;
   { const char* e = getenv("ZGPU_FORCE_INORDER"); d.flags = (e && e[0] == '1') ? 1u : 0u; }
   d.flags |= (uint32_t)flat_shape_ << 2;
-  for (auto& e : b->ev)
-    if (hipEventCreate(&e) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
-  for (auto& e : b->ev_huf)
-    if (hipEventCreate(&e) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
-  if (hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
   if (hipStreamSynchronize(stream_) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
   *out = b;
   return ZG_OK;
@@ -291,8 +371,9 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
 int Batch::run() {
   ZG_HIP(hipSetDevice(eng->device_));
   hipStream_t s = eng->stream_;
-  const ZgBatchDev& d = dev;
+  ZgBatchDev& d = dev;
   if (d.nframes == 0) { ran = true; total_out = 0; return ZG_OK; }
+  hipEvent_t* ev = sc->ev;
   ZG_HIP(hipEventRecord(ev[0], s));
   ZG_HIP(hipMemsetAsync(d.status, 0, 3 * ((size_t)d.nblocks * 4 + 16), s));
   ZG_HIP(hipMemsetAsync(d.huf_maxbits, 0, d.nhuf_slots + 16, s));
@@ -306,9 +387,9 @@ int Batch::run() {
     ZG_HIP(hipMemcpyAsync(d.huf_arena + (size_t)fr.carry_huf_slot * ZG_HUF_SLOT_U16, fs->d_huf.p, ZG_HUF_SLOT_U16 * 2, hipMemcpyDeviceToDevice, s));
     ZG_HIP(hipMemcpyAsync(d.huf_maxbits + fr.carry_huf_slot, &fs->huf_maxbits, 1, hipMemcpyHostToDevice, s));
   }
-  // Literals (Huffman tree descriptions -> streams) and sequences (FSE descriptions -> state chains -> post-pass) of a
-  // block are independent, and all of these kernels are latency-bound chains that leave most of the chip idle: the two
-  // chains run side by side on two streams and meet again in zg_k_merge.
+  // ---- phase 1: entropy stages + scan. Literals (Huffman tree descriptions -> streams) and sequences (FSE descriptions ->
+  // state chains -> post-pass) of a block are independent, and all of these kernels are latency-bound chains that leave most
+  // of the chip idle: the two chains run side by side on two streams and meet again in zg_k_merge.
   hipStream_t s2 = eng->stream2_;
   zg_launch_tables(d, s, 1);
   ZG_HIP(hipEventRecord(ev[1], s));
@@ -316,21 +397,54 @@ int Batch::run() {
   // high-priority zg_k_seq workgroups first (all of them must be resident at once: the kernel lasts as long as one
   // block's chain) and the Huffman workgroups fill the LDS that is left. Started earlier, they would sit in the CUs
   // when zg_k_seq arrives and push half of its workgroups into a second round.
-  ZG_HIP(hipEventRecord(ev_fork, s));
-  ZG_HIP(hipStreamWaitEvent(s2, ev_fork, 0));
-  ZG_HIP(hipEventRecord(ev_huf[0], s2));
+  ZG_HIP(hipEventRecord(sc->ev_fork, s));
+  ZG_HIP(hipStreamWaitEvent(s2, sc->ev_fork, 0));
+  ZG_HIP(hipEventRecord(sc->ev_huf[0], s2));
   zg_launch_tables(d, s2, 0);
   zg_launch_huf(d, s2);
-  ZG_HIP(hipEventRecord(ev_huf[1], s2));
+  ZG_HIP(hipEventRecord(sc->ev_huf[1], s2));
   ZG_HIP(hipEventRecord(ev[2], s));
   zg_launch_seq(d, s);
   ZG_HIP(hipEventRecord(ev[3], s));
   zg_launch_seqpost(d, s);
-  ZG_HIP(hipStreamWaitEvent(s, ev_huf[1], 0));
+  ZG_HIP(hipStreamWaitEvent(s, sc->ev_huf[1], 0));
   zg_launch_merge(d, s);
   ZG_HIP(hipEventRecord(ev[4], s));
   zg_launch_scan(d, s);
   ZG_HIP(hipEventRecord(ev[5], s));
+  // ---- the one host round trip: exact output size of every frame -> output buffer and flatten scratch sized to it
+  frame_out.resize(d.nframes);
+  uint32_t totals[4] = {0, 0, 0, 0};
+  ZG_HIP(hipMemcpyAsync(frame_out.data(), d.frame_out, (size_t)d.nframes * sizeof(ZgFrameOut), hipMemcpyDeviceToHost, s));
+  ZG_HIP(hipMemcpyAsync(totals, d.totals, 16, hipMemcpyDeviceToHost, s));
+  ZG_HIP(hipStreamSynchronize(s));
+  total_out = (uint64_t)totals[0] | ((uint64_t)totals[1] << 32);
+  int st = 0;
+  bool any_fast = false;
+  for (const ZgFrameOut& fo : frame_out) any_fast |= fo.fast != 0;
+  if (fs) {
+    const uint64_t add = frame_out[0].out_size;
+    if ((st = fs->make_room(add, keep_bytes, s))) return st;
+    // this run continues the frame: its bytes go right behind what exists, and matches may reach back into it — as far as
+    // the caller still holds bytes (DecodeBuffer semantics: repeat() sees only what has not been drained)
+    ZgFrame& fr = bb.frames[0];
+    fr.prior_out = fs->produced;
+    fr.prior_reach = keep_bytes < fs->have ? keep_bytes : fs->have;
+    fr.dict_len = fs->base;
+    fr.out_base_fixed = fs->base + fs->have;
+    ZG_HIP(hipMemcpyAsync((void*)d.frames, bb.frames.data(), sizeof(ZgFrame), hipMemcpyHostToDevice, s));
+    ZG_HIP(hipMemcpyAsync(&d.frame_out[0].out_base, &fr.out_base_fixed, 8, hipMemcpyHostToDevice, s));
+    frame_out[0].out_base = fr.out_base_fixed;
+    d.dst = fs->out_ptr(); d.dst_cap = fs->base + fs->have + add;
+    og_words = add;
+  } else {
+    if ((st = sc->d_dst.reserve(kOutFront + total_out + 64))) return st;
+    d.dst = sc->d_dst.as<uint8_t>() + kOutFront; d.dst_cap = total_out;
+    og_words = total_out;
+  }
+  if (any_fast && (st = sc->d_og.reserve(og_words * 4 + 64))) return st;
+  d.og = sc->d_og.as<uint32_t>();
+  // ---- phase 2: LZ77 execution
   zg_launch_lit(d, s);
   ZG_HIP(hipEventRecord(ev[6], s));
   zg_launch_flat(d, s);
@@ -347,19 +461,15 @@ int Batch::run() {
 int Batch::sync() {
   ZG_HIP(hipSetDevice(eng->device_));
   ZG_HIP(hipStreamSynchronize(eng->stream_));
-  if (dev.nframes == 0) return ZG_OK;
-  frame_out.resize(dev.nframes);
-  uint32_t totals[4] = {0, 0, 0, 0};
+  if (dev.nframes == 0 || !ran) return ZG_OK;
   ZG_HIP(hipMemcpy(frame_out.data(), dev.frame_out, (size_t)dev.nframes * sizeof(ZgFrameOut), hipMemcpyDeviceToHost));
-  ZG_HIP(hipMemcpy(totals, dev.totals, 16, hipMemcpyDeviceToHost));
-  total_out = (uint64_t)totals[0] | ((uint64_t)totals[1] << 32);
-  overflow = totals[2] != 0;
+  hipEvent_t* ev = sc->ev;
   for (int i = 0; i < ZG_T_TOTAL; i++) {
     float m = 0;
     if (hipEventElapsedTime(&m, ev[i], ev[i + 1]) == hipSuccess) ms[i] = m;
   }
   float m = 0;
-  if (hipEventElapsedTime(&m, ev_huf[0], ev_huf[1]) == hipSuccess) ms[ZG_T_HUF] = m;   // beside seq + seqpost, not in line
+  if (hipEventElapsedTime(&m, sc->ev_huf[0], sc->ev_huf[1]) == hipSuccess) ms[ZG_T_HUF] = m;   // beside seq + seqpost, not in line
   if (hipEventElapsedTime(&m, ev[0], ev[ZG_T_TOTAL]) == hipSuccess) ms[ZG_T_TOTAL] = m;
   return ZG_OK;
 }
@@ -369,6 +479,7 @@ int Batch::commit(FrameState* st) {
   if (dev.nframes != 1 || frame_out.size() != 1) return ZG_BAD_ARG;
   const ZgFrameOut& fo = frame_out[0];
   st->produced += fo.out_size;
+  st->have += fo.out_size;
   st->hist[0] = fo.hist_end[0]; st->hist[1] = fo.hist_end[1]; st->hist[2] = fo.hist_end[2];
   if (fo.status) return ZG_OK;   // the frame failed: the caller reports it; tables are not needed any more
   const Lineage fl = bb.final_lineage();
@@ -393,8 +504,13 @@ int Batch::commit(FrameState* st) {
 }
 
 int Batch::read_output(uint64_t off, uint8_t* dst, uint64_t n) {
-  if (off + n > dev.dst_cap + 64) return ZG_BAD_ARG;
+  if (off + n > dev.dst_cap) return ZG_BAD_ARG;
   if (n) ZG_HIP(hipMemcpy(dst, dev.dst + off, n, hipMemcpyDeviceToHost));
+  return ZG_OK;
+}
+int Batch::read_output_async(uint64_t off, uint8_t* dst, uint64_t n, hipStream_t s) {
+  if (off + n > dev.dst_cap) return ZG_BAD_ARG;
+  if (n) ZG_HIP(hipMemcpyAsync(dst, dev.dst + off, n, hipMemcpyDeviceToHost, s));
   return ZG_OK;
 }
 int Batch::read_block_status(std::vector<uint32_t>* out) {
@@ -429,9 +545,18 @@ int Batch::read_fse_slot(uint32_t slot, std::vector<uint32_t>* entries, uint8_t 
 }
 int Batch::read_scratch(int what, uint64_t off, void* dst, uint64_t n) {
   const uint8_t* base = what == 0 ? (const uint8_t*)dev.og : what == 1 ? (const uint8_t*)dev.unit_info : nullptr;
-  const uint64_t cap = what == 0 ? bb.og_count * 4 : bb.units.size() * sizeof(ZgUnitInfo);
+  const uint64_t cap = what == 0 ? og_words * 4 : bb.units.size() * sizeof(ZgUnitInfo);
   if (!base || off + n > cap) return ZG_BAD_ARG;
   if (n) ZG_HIP(hipMemcpy(dst, base + off, n, hipMemcpyDeviceToHost));
+  return ZG_OK;
+}
+int Batch::unit_scratch_base(uint32_t unit, uint64_t* base) {
+  if (unit >= bb.units.size()) return ZG_BAD_ARG;
+  const ZgUnit& u = bb.units[unit];
+  ZgBlockPos p;
+  ZG_HIP(hipMemcpy(&p, dev.pos + u.first_block, sizeof p, hipMemcpyDeviceToHost));
+  if (u.frame >= frame_out.size()) return ZG_BAD_ARG;
+  *base = frame_out[u.frame].og_base + p.out_base;
   return ZG_OK;
 }
 int Batch::read_debug(uint64_t out[1024]) {

@@ -1,4 +1,4 @@
-// zg_engine.h — one engine per (GPU, HIP stream): device memory, upload of a parsed submit, the kernel
+// zg_engine.h — one engine per (GPU, pair of HIP streams): device memory, upload of a parsed submit, the kernel
 // pipeline, and result download. Host buffers never enter the kernels; torch is not involved.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -15,7 +15,7 @@ namespace zg {
 // byte i of the dword that starts i bytes before it, so up to 3 bytes in front of the first output byte are touched.
 constexpr size_t kOutFront = 256;
 
-// growable device buffer
+// growable device buffer; a buffer that is grown again grows by at least half of its size (amortised reuse)
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
@@ -36,11 +36,13 @@ struct FrameInfo {
 };
 
 // What one frame carries from one submit of its blocks to the next (the reference's DecoderScratch, scratch.rs:15-27):
-// the output so far (= the decode window; a dictionary's content sits in front of it), the offset history, and the
-// Huffman / FSE tables a later Treeless / Repeat block may decode with.
+// the decode window (a dictionary's content sits in front of it), the offset history, and the Huffman / FSE tables a
+// later Treeless / Repeat block may decode with. The device holds [front pad][dictionary content][the last `have` bytes of
+// the frame]; bytes the caller has drained and that no match may reach any more are dropped when the buffer is rebuilt.
 struct FrameState {
-  DevBuf d_out;                  // [dictionary content][frame output so far]
-  uint64_t base = 0;             // dictionary content bytes in front of the frame's first byte
+  DevBuf d_out;
+  uint64_t base = 0;             // dictionary content bytes in front of the frame bytes
+  uint64_t have = 0;             // frame bytes on the device (the most recent ones)
   uint64_t produced = 0;         // frame bytes decoded so far
   uint32_t hist[3] = {1, 4, 8};  // scratch.rs:44
   DevBuf d_fse;                  // carried FSE tables, one arena slot (ZG_FSE_SLOT_U32 packed entries)
@@ -49,12 +51,27 @@ struct FrameState {
   uint8_t huf_maxbits = 0;
   uint32_t carry_mask = 0;       // bit 0 Huffman, 1 LL, 2 OF, 3 ML: which tables exist
   uint64_t window_size = 0;
-  uint8_t* out_ptr() const { return (uint8_t*)d_out.p + kOutFront; }   // first byte of [dictionary content][frame output]
+  uint8_t* out_ptr() const { return (uint8_t*)d_out.p + kOutFront; }   // first byte of [dictionary content][frame bytes]
+  // Make room for `extra` more frame bytes. `keep` = frame bytes that must stay reachable (what the caller still holds
+  // undrained: DecodeBuffer semantics, decode_buffer.rs:79-111,182-219); older bytes are dropped when the buffer is rebuilt.
+  int make_room(uint64_t extra, uint64_t keep, hipStream_t s);
   void reset();
   void release();
 };
 
 enum { ZG_T_TABLES = 0, ZG_T_HUF, ZG_T_SEQ, ZG_T_SEQPOST, ZG_T_SCAN, ZG_T_LIT, ZG_T_FLAT, ZG_T_SWEEP, ZG_T_LZ, ZG_T_TOTAL, ZG_T_COUNT };
+
+// Device buffers and events of one submit in flight. Engines keep finished ones for reuse: a stream of submits (block runs
+// of a streaming decoder, frames pulled from a work queue) allocates once.
+struct Scratch {
+  DevBuf d_src, d_blocks, d_frames, d_aux, d_slot_log, d_fse, d_huf, d_hufmax, d_status, d_lit, d_seq, d_seqout, d_pos, d_frameout,
+      d_dst, d_seqblocks, d_hufitems, d_hufgroups, d_totals, d_og, d_units, d_unitinfo, d_stepunits, d_swdesc, d_dbg, d_raw;
+  hipEvent_t ev[ZG_T_COUNT + 1] = {};
+  hipEvent_t ev_huf[2] = {}, ev_fork = nullptr;   // zg_k_huf runs on the engine's second stream beside zg_k_seq
+  bool have_events = false;
+  int init_events();
+  void release();
+};
 
 class Engine;
 
@@ -64,19 +81,23 @@ class Batch {
   ~Batch();
   BatchBuilder bb;
   std::vector<FrameInfo> info;
-  std::vector<ZgFrameOut> frame_out;     // valid after sync()
-  uint64_t total_out = 0;                // valid after sync()
-  bool overflow = false;
+  std::vector<ZgFrameOut> frame_out;     // valid after run() (sizes) / sync() (final status)
+  uint64_t total_out = 0;                // valid after run()
   float ms[ZG_T_COUNT] = {0};
   int parse_status = 0;                  // frame-layer error that stops decode_all (first failing frame's status)
   uint64_t src_len = 0;
+  uint64_t keep_bytes = 0;               // streaming submits: frame bytes that must stay reachable on the device (FrameState::make_room)
 
-  int run();                             // enqueue the kernel pipeline on the engine's stream
+  // Enqueue the kernel pipeline on the engine's streams. Two phases with one host round trip in between: the entropy
+  // stages and the scan run first; the host reads the exact output size of every frame, sizes the output and the flatten
+  // scratch to it, and then enqueues the LZ77 stages. Returns when the second phase is enqueued.
+  int run();
   // streaming submits: after sync(), fold this run into the frame's carried state (tables, history, produced bytes)
   int commit(FrameState* fs);
   bool saw_last_block = false;           // the run ended with the frame's last block
   int sync();                            // wait, download per-frame results, compute timings
   int read_output(uint64_t off, uint8_t* dst, uint64_t n);   // D2H
+  int read_output_async(uint64_t off, uint8_t* dst, uint64_t n, hipStream_t s);
   const uint8_t* device_output() const { return dev.dst; }
   // intermediates, for parity tests
   int read_block_status(std::vector<uint32_t>* out);
@@ -86,16 +107,15 @@ class Batch {
   int read_huf_slot(uint32_t slot, std::vector<uint16_t>* entries, int* max_bits);
   int read_debug(uint64_t out[1024]);
   int read_scratch(int what, uint64_t off, void* dst, uint64_t n);   // what: 0 flatten scratch (u32 per output byte), 1 ZgUnitInfo[]
+  int unit_scratch_base(uint32_t unit, uint64_t* base);              // word index of a unit's first byte in the flatten scratch
 
  private:
   friend class Engine;
   Engine* eng = nullptr;
+  Scratch* sc = nullptr;
   ZgBatchDev dev{};
-  DevBuf d_src, d_blocks, d_frames, d_aux, d_slot_log, d_fse, d_huf, d_hufmax, d_status, d_lit, d_seq, d_seqout, d_pos, d_frameout,
-      d_dst, d_seqblocks, d_hufitems, d_hufgroups, d_totals, d_og, d_units, d_unitinfo, d_stepunits, d_swdesc, d_dbg, d_raw;
   std::vector<ZgSweepStep> sweep_steps;
-  hipEvent_t ev[ZG_T_COUNT + 1] = {};
-  hipEvent_t ev_huf[2] = {}, ev_fork = nullptr;   // zg_k_huf runs on the engine's second stream beside zg_k_seq
+  uint64_t og_words = 0;
   bool ran = false;
   FrameState* fs = nullptr;              // streaming submit: the frame state this run reads from / writes into
 };
@@ -106,14 +126,16 @@ class Engine {
   ~Engine();
   uint64_t max_window = kDefaultMaxWindow;
   // Walk `len` bytes of concatenated frames (decode_all semantics, frame_decoder.rs:541-577), upload everything.
-  // dst_cap_hint: 0 = size the output from the block walk.
   int prepare(const uint8_t* src, size_t len, Batch** out);
   // Same for a run of blocks of ONE frame that starts at a block header (the FrameDecoder mirror parsed the frame
   // header itself). *consumed = bytes of the run (block headers, bodies, checksum).
-  // max_blocks: 0 = up to the last block of the frame. fs carries the frame's state across calls.
-  int prepare_run(const uint8_t* src, size_t len, FrameState* fs, bool has_checksum, uint32_t max_blocks, Batch** out, size_t* consumed);
+  // max_blocks: 0 = up to the last block of the frame. fs carries the frame's state across calls; keep = frame bytes
+  // that must stay reachable (FrameState::make_room).
+  int prepare_run(const uint8_t* src, size_t len, FrameState* fs, bool has_checksum, uint32_t max_blocks, uint64_t keep, Batch** out, size_t* consumed);
   hipStream_t stream() const { return stream_; }
+  hipStream_t copy_stream() const { return stream2_; }
   int device() const { return device_; }
+  int compute_units() const { return cus_; }
   std::string last_error;
 
  private:
@@ -122,6 +144,9 @@ class Engine {
   int cus_ = 256;                // compute units of the device (MI355X: 256)
   int flat_shape_ = 0;           // zg_k_flat shape: 0 = 1024 threads x 16 KiB tiles (one workgroup per CU), 1 = 512 x 8 KiB (two), 2 = 1024 x 8 KiB (two)
   hipStream_t stream_ = nullptr, stream2_ = nullptr;
+  std::vector<Scratch*> free_;   // finished submits' buffers, for reuse
+  Scratch* acquire();
+  void recycle(Scratch* s);
   int fail(hipError_t e, const char* what);
   int upload(Batch* b, const uint8_t* src, size_t len, Batch** out);
 };
@@ -130,5 +155,10 @@ class Engine {
 int parse_frames(const uint8_t* src, size_t len, uint64_t max_window, BatchBuilder* bb, std::vector<FrameInfo>* info);
 int parse_block_run(const uint8_t* src, size_t len, uint64_t window, bool has_checksum, const uint32_t hist[3], uint32_t carry_mask,
                     uint32_t max_blocks, BatchBuilder* bb, std::vector<FrameInfo>* info, size_t* consumed, bool* saw_last);
+// Byte ranges of the frames (and skippable frames) of a buffer, by walking frame and block headers only: what a work queue
+// needs to hand whole frames to different GPUs. Stops at the first malformed frame (its status is returned; ranges found so
+// far stay valid).
+struct FrameSpan { uint64_t begin, end; uint64_t content_size; bool has_content_size; bool skippable; };
+int split_frames(const uint8_t* src, size_t len, std::vector<FrameSpan>* out);
 
 }  // namespace zg

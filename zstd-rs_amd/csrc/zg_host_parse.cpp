@@ -234,7 +234,6 @@ void BatchBuilder::finish() {
     if (final_.huf == kCarryHuf) final_.huf = frames[lf].carry_huf_slot;
   }
   seq_blocks.clear(); huf_items.clear(); huf_groups.clear(); units.clear(); step_units.clear(); steps.clear();
-  og_count = 0;
   // blocks per unit: zg_k_flat runs flat_slots workgroups at once, one per unit, so aim at ~flat_slots units over the
   // whole submit (more blocks per unit = fewer sweep steps, but less parallelism in the flatten pass)
   uint32_t ub = unit_blocks;
@@ -252,8 +251,6 @@ void BatchBuilder::finish() {
       ZgUnit u;
       u.frame = f; u.first_block = fr.first_block + i;
       u.nblocks = fr.nblocks - i < ub ? fr.nblocks - i : ub; u.pad = 0;
-      u.og_base = og_count;
-      og_count += (uint64_t)u.nblocks * kMaxBlockSize;
       units.push_back(u);
     }
     fr.nunits = (uint32_t)units.size() - fr.first_unit;

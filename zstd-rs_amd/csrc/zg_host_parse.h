@@ -62,7 +62,6 @@ class BatchBuilder {
   std::vector<ZgUnit> units;
   std::vector<uint32_t> step_units;     // concatenated unit lists of the sweep steps
   std::vector<ZgStepRange> steps;       // sweep step s: units step_units[list_off .. list_off + nunits)
-  uint64_t og_count = 0;       // flatten scratch size in u32
   uint32_t unit_blocks = 0;    // blocks per unit; 0 = choose from the submit size
   uint32_t flat_slots = 256;   // workgroups of zg_k_flat the device runs at once (engine: CUs x workgroups per CU)
   uint64_t lit_bytes = 0;      // literals arena size

@@ -982,11 +982,14 @@ __global__ void __launch_bounds__(ZG_SCAN_T) zg_k_scan(ZgBatchDev d) {
     fo.good_blocks = good;
     fo.fast = (s_slow || (d.flags & 1u)) ? 0u : 1u;
     fo.err_packed = 0xFFFFFFFFu;
+    fo.og_base = 0;
     d.frame_out[f] = fo;
   }
 }
 
-// frames are laid out back to back in the output, like FrameDecoder::decode_all (frame_decoder.rs:541-577)
+// frames are laid out back to back in the output, like FrameDecoder::decode_all (frame_decoder.rs:541-577). The host reads
+// the sizes after this kernel and allocates the output and the flatten scratch exactly (the scratch is indexed by output
+// position: one word per output byte).
 __global__ void __launch_bounds__(1024) zg_k_scanf(ZgBatchDev d) {
   __shared__ uint64_t s_v[1024];
   const uint32_t t = threadIdx.x;
@@ -1001,17 +1004,15 @@ __global__ void __launch_bounds__(1024) zg_k_scanf(ZgBatchDev d) {
       s_v[t] += v;
       __syncthreads();
     }
-    if (f < d.nframes) d.frame_out[f].out_base = d.frames[f].fixed_base ? d.frames[f].out_base_fixed : carry + (t ? s_v[t - 1] : 0);
+    if (f < d.nframes) {
+      const uint64_t rel = carry + (t ? s_v[t - 1] : 0);
+      d.frame_out[f].out_base = d.frames[f].fixed_base ? d.frames[f].out_base_fixed : rel;
+      d.frame_out[f].og_base = d.frames[f].fixed_base ? 0 : rel;      // (a streaming run holds exactly one frame)
+    }
     carry += s_v[1023];
     __syncthreads();
   }
-  if (t == 0) {
-    d.totals[0] = (uint32_t)carry; d.totals[1] = (uint32_t)(carry >> 32);
-    uint32_t over = carry > d.dst_cap ? 1u : 0u;
-    for (uint32_t f = 0; f < d.nframes; f++)
-      if (d.frames[f].fixed_base && d.frames[f].out_base_fixed + d.frame_out[f].out_size > d.dst_cap) over = 1u;
-    d.totals[2] = over;
-  }
+  if (t == 0) { d.totals[0] = (uint32_t)carry; d.totals[1] = (uint32_t)(carry >> 32); d.totals[2] = 0; }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1106,7 +1107,7 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
   if (!fo.fast) return;
   const uint64_t unit_abs0 = d.pos[un.first_block].out_base;     // frame-relative position of the unit's first byte
   uint8_t* out_u = d.dst + fo.out_base + unit_abs0;
-  uint32_t* og = d.og + un.og_base;
+  uint32_t* og = d.og + fo.og_base + unit_abs0;
   const __amdgpu_buffer_rsrc_t og_rs = zg_make_rsrc(og, un.nblocks * (ZG_FLAT_MAX * 4u));
   if (t == 0) { s_err = 0; s_bad = ~0ull; }
   uint32_t unit_size = 0;
@@ -1141,7 +1142,7 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
     const __amdgpu_buffer_rsrc_t seq_rs = zg_make_rsrc(d.seq_arena + blk.seq_base, nseq * 12u);
     // bytes of the frame (and dictionary) that exist before this block: the farthest a match may reach. Offsets are < 2^30
     // and positions in the block < 2^17: once 2^31 bytes exist every offset is in reach, else 32-bit arithmetic decides.
-    const uint64_t reach = p.out_base + d.frames[un.frame].prior_out + d.frames[un.frame].dict_len;
+    const uint64_t reach = p.out_base + d.frames[un.frame].prior_reach + d.frames[un.frame].dict_len;
     const bool reach_all = reach >= 0x80000000ull;
     const uint32_t reach32 = (uint32_t)reach;
     // the sequences a thread places per tile travel in registers: they are requested one tile ahead
@@ -1350,7 +1351,7 @@ __global__ void __launch_bounds__(256) zg_k_swprep(ZgBatchDev d, uint32_t n) {
   const ZgFrameOut fo = d.frame_out[un.frame];
   ZgSweepDesc sd;
   sd.out = (uint64_t)(d.dst + fo.out_base + d.pos[un.first_block].out_base);
-  sd.og = (uint64_t)(d.og + un.og_base);
+  sd.og = (uint64_t)(d.og + fo.og_base + d.pos[un.first_block].out_base);
   sd.size = d.unit_info[u].size;
   // a unit of the frame failed in zg_k_flat: its scratch is incomplete; the frame is reported as failed
   sd.live = (!d.totals[2] && fo.fast && fo.err_packed == 0xFFFFFFFFu) ? 1u : 0u;
@@ -1530,7 +1531,7 @@ __global__ void __launch_bounds__(ZG_LZ_T) zg_k_lz(ZgBatchDev d) {
         if (lit_rle) { const uint8_t v = lit[0]; for (uint32_t k = 0; k < ll; k++) o[k] = v; }
         else { const uint8_t* s = lit + lit_start; for (uint32_t k = 0; k < ll; k++) o[k] = s[k]; }
         if (off == 0) { atomicCAS(&s_err, 0u, (uint32_t)ZG_EXE_ZERO_OFFSET); }
-        else if ((uint64_t)off > dpos + fr.prior_out + fr.dict_len) { atomicCAS(&s_err, 0u, (uint32_t)(dpos + fr.prior_out <= fr.window_size ? ZG_EXE_DICT_TOO_SMALL : ZG_EXE_OFFSET_TOO_BIG)); }
+        else if ((uint64_t)off > dpos + fr.prior_reach + fr.dict_len) { atomicCAS(&s_err, 0u, (uint32_t)(dpos + fr.prior_out <= fr.window_size ? ZG_EXE_DICT_TOO_SMALL : ZG_EXE_OFFSET_TOO_BIG)); }
         else pending = ml > 0;
       }
       carry_out = to; carry_lit = tl;

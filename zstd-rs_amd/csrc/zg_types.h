@@ -123,7 +123,7 @@ struct ZgFrame {
   uint64_t window_size;
   uint64_t prior_out;              // bytes of this frame already decoded by earlier submits (streaming)
   uint64_t dict_len;               // dictionary content length reachable before the frame start
-  uint64_t dict_off;               // offset of that content in the dictionary buffer
+  uint64_t prior_reach;            // of prior_out, the most recent bytes a match may still reach: what the caller has not drained (DecodeBuffer holds nothing older)
 };
 
 // What the table kernel records per block.
@@ -172,10 +172,11 @@ struct ZgFrameOut {
   uint32_t good_blocks;
   uint32_t fast;           // 1: every block regenerates <= 128 KiB -> flatten + sweep path; 0: in-order fallback (zg_k_lz)
   uint32_t err_packed;     // (frame-relative block << 8) | status of the first execution error, 0xFFFFFFFF if none
+  uint64_t og_base;        // where the frame's flatten scratch starts (in u32): the scratch is indexed by output position
 };
 
 // LZ77 execution works on units: runs of consecutive blocks of one frame that zg_k_flat resolves together.
-struct ZgUnit { uint32_t frame, first_block, nblocks, pad; uint64_t og_base; };   // og_base: offset (in u32) into the flatten scratch
+struct ZgUnit { uint32_t frame, first_block, nblocks, pad; };
 struct ZgUnitInfo { uint32_t size; uint32_t pad; };   // written by zg_k_flat: bytes of the unit
 
 // what a sweep workgroup needs to know about its unit

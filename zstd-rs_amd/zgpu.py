@@ -48,8 +48,12 @@ EXPORTS = [
     "zgpu_decoder_decode_from_to", "zgpu_decoder_create", "zgpu_decoder_destroy", "zgpu_decoder_init", "zgpu_decoder_decode_blocks",
     "zgpu_decoder_can_collect", "zgpu_decoder_collect", "zgpu_decoder_read", "zgpu_decoder_is_finished", "zgpu_decoder_blocks_decoded",
     "zgpu_decoder_bytes_read_from_source", "zgpu_decoder_content_size", "zgpu_decoder_checksum_from_data",
-    "zgpu_decoder_calculated_checksum",
+    "zgpu_decoder_calculated_checksum", "zgpu_decode_all_alloc", "zgpu_free", "zgpu_decoder_collect_to_writer", "zgpu_streaming_create",
+    "zgpu_streaming_destroy", "zgpu_streaming_decoder", "zgpu_streaming_read", "zgpu_pool_create", "zgpu_pool_create_on", "zgpu_pool_destroy",
+    "zgpu_pool_num_gpus", "zgpu_pool_decode_all", "zgpu_pool_plan", "zgpu_pool_stage", "zgpu_pool_run", "zgpu_pool_frame", "zgpu_pool_read",
 ]
+WRITE_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
+READ_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
 
 
 def load_library():
@@ -118,6 +122,24 @@ def load_library():
     L.zgpu_decoder_checksum_from_data.argtypes = [vp, P(C.c_uint32)]
     L.zgpu_decoder_calculated_checksum.argtypes = [vp]
     L.zgpu_decoder_calculated_checksum.restype = C.c_uint32
+    L.zgpu_decode_all_alloc.argtypes = [vp, u8p, sz, P(vp), P(sz)]
+    L.zgpu_free.argtypes = [vp]
+    L.zgpu_decoder_collect_to_writer.argtypes = [vp, WRITE_FN, vp, P(sz)]
+    L.zgpu_streaming_create.argtypes = [vp, READ_FN, vp, P(vp)]
+    L.zgpu_streaming_destroy.argtypes = [vp]
+    L.zgpu_streaming_decoder.argtypes = [vp]
+    L.zgpu_streaming_decoder.restype = vp
+    L.zgpu_streaming_read.argtypes = [vp, vp, sz, P(sz)]
+    L.zgpu_pool_create.argtypes = [C.c_int, P(vp)]
+    L.zgpu_pool_create_on.argtypes = [P(C.c_int), C.c_int, P(vp)]
+    L.zgpu_pool_destroy.argtypes = [vp]
+    L.zgpu_pool_num_gpus.argtypes = [vp]
+    L.zgpu_pool_decode_all.argtypes = [vp, u8p, sz, vp, sz, P(sz)]
+    L.zgpu_pool_plan.argtypes = [P(C.c_uint64), C.c_uint32, C.c_uint32, P(C.c_uint32), P(C.c_uint32), P(C.c_uint64)]
+    L.zgpu_pool_stage.argtypes = [vp, P(C.c_char_p), P(sz), C.c_uint32]
+    L.zgpu_pool_run.argtypes = [vp, P(C.c_float), P(C.c_float)]
+    L.zgpu_pool_frame.argtypes = [vp, C.c_uint32, P(C.c_int), P(C.c_uint64), P(C.c_uint32)]
+    L.zgpu_pool_read.argtypes = [vp, C.c_uint32, vp, sz, P(sz)]
     _LIB = L
     return L
 
@@ -177,6 +199,17 @@ class Context:
             if st:
                 raise ZgpuError(st)
             return buf.raw[:w.value]
+
+    def decode_all_to_vec(self, src):
+        """FrameDecoder::decode_all_to_vec (frame_decoder.rs:591-610): the library sizes the output"""
+        out, n = C.c_void_p(), C.c_size_t()
+        st = self.L.zgpu_decode_all_alloc(self.h, src, len(src), C.byref(out), C.byref(n))
+        if st:
+            raise ZgpuError(st)
+        try:
+            return C.string_at(out, n.value)
+        finally:
+            self.L.zgpu_free(out)
 
     def prepare(self, src):
         return Batch(self, src)
@@ -387,6 +420,130 @@ class FrameDecoder:
 
     def decode_all(self, src, cap):
         return self.ctx.decode_all(src, cap)
+
+    def collect_to_writer(self, writer):
+        """collect_to_writer (frame_decoder.rs:395-407); writer.write(bytes) -> number of bytes taken"""
+        def wr(_user, data, n):
+            return writer.write(C.string_at(data, n))
+        cb = WRITE_FN(wr)
+        done = C.c_size_t()
+        st = self.L.zgpu_decoder_collect_to_writer(self.h, cb, None, C.byref(done))
+        if st:
+            raise ZgpuError(st)
+        return done.value
+
+
+def plan(costs, n_workers):
+    """the work queue's plan, host only: (LPT order, worker of every job, load per worker) — zgpu_pool_plan"""
+    L = load_library()
+    n = len(costs)
+    c = (C.c_uint64 * max(n, 1))(*costs)
+    order, worker, load = (C.c_uint32 * max(n, 1))(), (C.c_uint32 * max(n, 1))(), (C.c_uint64 * n_workers)()
+    st = L.zgpu_pool_plan(c, n, n_workers, order, worker, load)
+    if st:
+        raise ZgpuError(st)
+    return list(order)[:n], list(worker)[:n], list(load)
+
+
+class Pool:
+    """Frames over the GPUs of one node through the library's work queue (zgpu_pool): one worker thread + engine per GPU."""
+
+    def __init__(self, n_gpus=0, devices=None):
+        self.L = load_library()
+        h = C.c_void_p()
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*devices)
+            st = self.L.zgpu_pool_create_on(arr, len(devices), C.byref(h))
+        else:
+            st = self.L.zgpu_pool_create(n_gpus, C.byref(h))
+        if st:
+            raise ZgpuError(st, "zgpu_pool_create: no usable MI355X/HIP device — the engine has no CPU path")
+        self.h = h
+        self.n_gpus = self.L.zgpu_pool_num_gpus(h)
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.zgpu_pool_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def decode_all(self, src, cap):
+        import numpy as np
+        w = C.c_size_t()
+        arr = np.empty(max(cap, 1), dtype=np.uint8)
+        st = self.L.zgpu_pool_decode_all(self.h, src, len(src), arr.ctypes.data_as(C.c_void_p), cap, C.byref(w))
+        if st:
+            raise ZgpuError(st)
+        return arr[:w.value].tobytes()
+
+    def stage(self, frames):
+        n = len(frames)
+        ptrs = (C.c_char_p * max(n, 1))(*frames)
+        lens = (C.c_size_t * max(n, 1))(*[len(f) for f in frames])
+        self._keep = frames
+        st = self.L.zgpu_pool_stage(self.h, ptrs, lens, n)
+        if st:
+            raise ZgpuError(st)
+        self.nstaged = n
+
+    def run(self):
+        """one pass over everything staged; returns (per-GPU kernel ms, wall ms)"""
+        g, w = (C.c_float * self.n_gpus)(), C.c_float()
+        st = self.L.zgpu_pool_run(self.h, g, C.byref(w))
+        if st:
+            raise ZgpuError(st)
+        return list(g), w.value
+
+    def frame(self, i):
+        gpu, size, st = C.c_int(), C.c_uint64(), C.c_uint32()
+        r = self.L.zgpu_pool_frame(self.h, i, C.byref(gpu), C.byref(size), C.byref(st))
+        if r:
+            raise ZgpuError(r)
+        return gpu.value, size.value, st.value
+
+    def read(self, i, cap):
+        import numpy as np
+        arr = np.empty(max(cap, 1), dtype=np.uint8)
+        w = C.c_size_t()
+        st = self.L.zgpu_pool_read(self.h, i, arr.ctypes.data_as(C.c_void_p), cap, C.byref(w))
+        if st:
+            raise ZgpuError(st)
+        return arr[:w.value].tobytes()
+
+
+class CStreamingDecoder:
+    """zgpu_streaming (the C-ABI mirror of StreamingDecoder, streaming_decoder.rs:40-156) over a Python file-like source"""
+
+    def __init__(self, ctx, source):
+        self.L, self.source = ctx.L, source
+
+        def rd(_user, dst, n):
+            b = source.read(n)
+            C.memmove(dst, b, len(b))
+            return len(b)
+        self._cb = READ_FN(rd)
+        h = C.c_void_p()
+        st = self.L.zgpu_streaming_create(ctx.h, self._cb, None, C.byref(h))
+        if st:
+            raise ZgpuError(st)
+        self.h = h
+
+    def read(self, n):
+        buf = C.create_string_buffer(max(n, 1))
+        got = C.c_size_t()
+        st = self.L.zgpu_streaming_read(self.h, buf, n, C.byref(got))
+        if st:
+            raise ZgpuError(st)
+        return buf.raw[:got.value]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.zgpu_streaming_destroy(self.h)
+            self.h = None
+
+    __del__ = close
 
 
 class StreamingDecoder:
