@@ -289,6 +289,8 @@ int Engine::prepare_run(const uint8_t* src, size_t len, FrameState* fs, bool has
                                     &b->saw_last_block);
   b->src_len = *consumed;
   b->bb.frames[0].fixed_base = 1;   // where its bytes go is decided in run(), when the size of the run is known
+  int st;
+  if ((st = fs->d_fse.reserve(ZG_FSE_SLOT_U32 * 4)) || (st = fs->d_huf.reserve(ZG_HUF_SLOT_U16 * 2))) { delete b; return st; }   // the tables it will carry on
   return upload(b, src, *consumed, out);
 }
 
