@@ -446,6 +446,7 @@ int Batch::run() {
   }
   if (any_fast && (st = sc->d_og.reserve(og_words * 4 + 64))) return st;
   d.og = sc->d_og.as<uint32_t>();
+  d.og_words = og_words;
   // ---- phase 2: LZ77 execution
   zg_launch_lit(d, s);
   ZG_HIP(hipEventRecord(ev[6], s));
