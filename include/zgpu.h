@@ -63,7 +63,14 @@ enum zgpu_status {
   ZGPU_E_EXE_OFFSET_TOO_BIG = 52,     /* DecodeBufferError::OffsetTooBig */
   ZGPU_E_EXE_DICT_TOO_SMALL = 53,
   ZGPU_E_DICT_DECODE = 60,
-  ZGPU_E_UNSUPPORTED = 80,            /* input the reference tolerates but this engine rejects */
+  /* Input the reference tolerates but this engine rejects. No conforming encoder produces any of it:
+   *  - 4-stream Huffman literals whose first three streams do not hold (regen + 3) / 4 symbols each (the spec's split;
+   *    ruzstd only checks the total): reported as ZGPU_E_LIT_COUNT_MISMATCH;
+   *  - offsets >= 2^30 (offset codes 30, 31): reported as ZGPU_E_EXE_OFFSET_TOO_BIG — in the reference they fail the same way
+   *    unless >= 1 GiB of output is still undrained;
+   *  - a block that regenerates >= 2^31 bytes: ZGPU_E_UNSUPPORTED.
+   * Blocks regenerating more than 128 KiB (beyond Block_Maximum_Size) are decoded, by the in-order kernel. */
+  ZGPU_E_UNSUPPORTED = 80,
   ZGPU_E_INTERNAL = 90,               /* where the reference would panic */
   ZGPU_E_NOMEM = 91,
   ZGPU_E_HIP = 92,                    /* HIP runtime error / no device */
@@ -165,8 +172,8 @@ int zgpu_batch_debug_timers(zgpu_batch*, uint64_t out[1024]);
 uint32_t zgpu_batch_num_units(const zgpu_batch*);
 int zgpu_batch_unit(zgpu_batch*, uint32_t unit, uint32_t* first_block, uint32_t* nblocks, uint64_t* scratch_base);
 int zgpu_batch_debug_scratch(zgpu_batch*, int what, uint64_t off, void* dst, uint64_t n);
-/* diagnostics: runs a copy kernel (zg_k_calib_copy) of exactly `bytes` read + `bytes` written, twice, to calibrate
- * the profiler's HBM byte counters on a known amount of traffic */
+/* diagnostics: runs kernels with known traffic per access pattern (16 B/lane copy, 4 B/lane copy, random 4- and 8-byte
+ * reads) to calibrate the profiler's HBM byte counters */
 int zgpu_debug_calibrate(zgpu_ctx*, uint64_t bytes);
 int zgpu_batch_fse_slot(zgpu_batch*, uint32_t slot, uint32_t* entries /* 1280 */, uint8_t logs[4]);
 int zgpu_batch_huf_slot(zgpu_batch*, uint32_t slot, uint16_t* entries /* 2048 */, int* max_bits);

@@ -619,3 +619,16 @@ def test_streaming_window_stays_bounded(ctx):
     # linear: the last quarter does not take much longer than the second (a quadratic copy would take ~2.3x)
     assert len(marks) >= 4 and (marks[3] - marks[2]) < 1.7 * (marks[1] - marks[0]) + 0.05, marks
     s.close()
+
+
+@pytest.mark.parametrize("of_code", [29, 30, 31])
+def test_offsets_of_2_pow_30_and_more(ctx, of_code):
+    """offset codes 30 / 31: zg_k_seqpost must not take an offset >= 2^30 for a symbolic history reference"""
+    import zgpu
+    from test_lane_logic_cpu import big_offset_frame
+    z = big_offset_frame(of_code, extra=5)
+    st, _ = oracle.FrameDecoder().decode_all(z, 1 << 20)
+    assert st in (52, 53)
+    with pytest.raises(zgpu.ZgpuError) as e:
+        ctx.decode_all(z, 1 << 20)
+    assert e.value.status in (52, 53)

@@ -131,3 +131,31 @@ def test_multiframe_and_skippable():
     assert e.frame(1)[0] == man["z000088.zst"]["size"]        # frames are packed back to back
     assert emu.EmuBatch(skip[:-1]).parse_status == 13          # FailedToSkipFrame
     assert emu.EmuBatch(z1[:-5]).parse_status in (9, 10, 11)
+
+
+def big_offset_frame(of_code, extra=0):
+    """one frame, one compressed block: 4 raw literals, one sequence with offset code `of_code` in RLE mode (the predefined
+    OF table stops at code 28), LL and ML predefined. Used by the CPU and GPU tests of offsets >= 2^30."""
+    # the reversed bitstream, in read order from its top: final-bit marker, LL state (6 bits), OF state (RLE: 0 bits),
+    # ML state (6 bits), then the extra bits OF, ML, LL (state 0 of the predefined LL / ML tables carries none)
+    acc, accn = 1, 1
+    for v, w in ((0, 6), (0, 6), (extra, of_code)):
+        acc = (acc << w) | (v & ((1 << w) - 1))
+        accn += w
+    stream = acc.to_bytes((accn + 7) // 8, "little")
+    lits = b"abcd"
+    body = bytes([len(lits) << 3]) + lits + bytes([1, 0x10, of_code]) + stream     # raw literals; nseq 1, modes LL predefined / OF RLE / ML predefined, RLE symbol
+    bh = (len(body) << 3) | (2 << 1) | 1                  # last block, compressed
+    return bytes([0x28, 0xB5, 0x2F, 0xFD, 0x00, 0x50]) + bh.to_bytes(3, "little") + body   # window descriptor 0x50: 1 MiB
+
+
+@pytest.mark.parametrize("of_code", [29, 30, 31])
+def test_offsets_of_2_pow_30_and_more(of_code):
+    """offset codes 30 and 31 (offset >= 2^30) must not be taken for the symbolic history references the engine tags with the
+    top two bits: oracle and lane model both end in one of the two "offset too far" errors"""
+    z = big_offset_frame(of_code, extra=5)
+    st, _ = oracle.FrameDecoder().decode_all(z, 1 << 20)
+    e = emu.EmuBatch(z)
+    est = e.parse_status or e.frame(0)[2]
+    assert st in (52, 53), st
+    assert est in (52, 53), est

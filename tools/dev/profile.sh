@@ -1,15 +1,16 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): kernel-trace statistics and HBM byte counters of bench.py, plus a calibration of
-# the byte counters on a copy kernel with known traffic. Writes under gpurun_out/ (copied into profiles/ afterwards).
+# Runs on the GPU box (via gpurun): kernel-trace statistics and HBM byte counters of bench.py (separate passes: FETCH_SIZE and
+# WRITE_SIZE do not fit one), plus a calibration of the byte counters on kernels with known traffic per access pattern.
+# Writes under gpurun_out/prof (tools/dev/pmc_summary.py turns that into profiles/r02/).
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-SIZE=${1:-1000000000}
-timeout 600 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o trace -- python $ROOT/bench.py --size $SIZE --steps 3 --warmup 1 --no-cpu > $OUT/stats.log 2>&1
-timeout 600 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/fetch -o pmc -- python $ROOT/bench.py --size $SIZE --steps 1 --warmup 1 --no-cpu > $OUT/fetch.log 2>&1
-timeout 600 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/write -o pmc -- python $ROOT/bench.py --size $SIZE --steps 1 --warmup 1 --no-cpu > $OUT/write.log 2>&1
+ARGS=${*:-"--steps 10 --warmup 2 --no-cpu --no-e2e"}
+timeout 600 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o trace -- python $ROOT/bench.py $ARGS > $OUT/stats.log 2>&1
+timeout 600 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/fetch -o pmc -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-e2e > $OUT/fetch.log 2>&1
+timeout 600 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/write -o pmc -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-e2e > $OUT/write.log 2>&1
 cat > /tmp/calib.py <<PY
 import sys
 sys.path.insert(0, "$ROOT/zstd-rs_amd")
@@ -19,5 +20,7 @@ assert c.L.zgpu_debug_calibrate(c.h, 1 << 30) == 0
 PY
 timeout 300 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/calib_fetch -o pmc -- python /tmp/calib.py > $OUT/calib_fetch.log 2>&1
 timeout 300 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/calib_write -o pmc -- python /tmp/calib.py > $OUT/calib_write.log 2>&1
-find $OUT -name "*.csv" | head -30
-tail -2 $OUT/stats.log
+# keep what the summary needs, drop the bulky traces
+python $ROOT/tools/dev/pmc_summary.py --reduce
+find $OUT -name "*.csv" -size +2M -delete
+tail -2 $OUT/stats.log | cut -c1-400

@@ -220,12 +220,12 @@ int zgpu_batch_unit(zgpu_batch* zb, uint32_t u, uint32_t* first_block, uint32_t*
   return zb->b->unit_scratch_base(u, scratch_base);
 }
 int zgpu_debug_calibrate(zgpu_ctx* c, uint64_t bytes) {
-  // profiler calibration: one device-to-device copy kernel of exactly `bytes` read + `bytes` written
+  // profiler calibration: known traffic per access pattern — a 16 B/lane and a 4 B/lane copy of exactly `bytes` read + `bytes`
+  // written, and bytes / 64 random 4-byte and 8-byte reads spread over `bytes` (every one a cache miss)
   void *a = nullptr, *b = nullptr;
   if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) return ZGPU_E_NOMEM;
   (void)hipMemset(a, 1, bytes);
   (void)hipMemset(b, 2, bytes);
-  zg_launch_calib(a, b, bytes, c->eng->stream());
   zg_launch_calib(a, b, bytes, c->eng->stream());
   hipError_t e = hipStreamSynchronize(c->eng->stream());
   (void)hipFree(a); (void)hipFree(b);

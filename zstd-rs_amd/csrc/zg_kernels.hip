@@ -47,7 +47,7 @@ __device__ __forceinline__ void zg_set_status(uint32_t* status, uint32_t b, int 
 // ------------------------------------------------------------------------------------------------------------
 // zg_k_tables: Huffman tree descriptions (literals chain; the FSE tables of the sequences chain are zg_k_ftab's).
 // ------------------------------------------------------------------------------------------------------------
-#define ZG_TAB_L 32   // blocks (lanes) per workgroup: 1.7 KiB of LDS each
+#define ZG_TAB_L 64   // blocks (lanes) per workgroup, one full wave: 1.7 KiB of LDS each
 #define ZG_TAB_HDR 160 // bytes of a literals section staged for parsing (a tree description is at most 129 bytes)
 __global__ void __launch_bounds__(ZG_TAB_L) zg_k_tables(ZgBatchDev d) {
   // Huffman tree descriptions of the literals sections (HuffmanTable::build_decoder, huff0_decoder.rs:117-124 with
@@ -1576,12 +1576,33 @@ __global__ void __launch_bounds__(ZG_LZ_T) zg_k_lz(ZgBatchDev d) {
   }
 }
 
-// known-traffic kernel used to calibrate the profiler's HBM byte counters (tools/dev/profile.sh): copies n16 x 16 bytes
-__global__ void __launch_bounds__(256) zg_k_calib_copy(const uint4* src, uint4* dst, uint64_t n16) {
+// Known-traffic kernels that calibrate the profiler's HBM byte counters per access pattern (tools/dev/profile.sh): the
+// engine's kernels read with wide coalesced loads (16 B per lane), narrow coalesced loads (4 B per lane), random 4- and
+// 8-byte gathers, and write 4 B and 16 B per lane; FETCH_SIZE / WRITE_SIZE are only documented for the first.
+__global__ void __launch_bounds__(256) zg_k_calib_copy(const uint4* src, uint4* dst, uint64_t n16) {        // 16 B per lane, read + write
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256) dst[i] = src[i];
+}
+__global__ void __launch_bounds__(256) zg_k_calib_copy4(const uint32_t* src, uint32_t* dst, uint64_t n4) {   // 4 B per lane, read + write
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * 256) dst[i] = src[i];
+}
+// n random reads of W bytes each (W = 4 or 8, W-aligned) spread over `span` bytes (much more than all caches): every one a miss
+template <typename T>
+__global__ void __launch_bounds__(256) zg_k_calib_gather(const T* src, uint32_t* sink, uint64_t span_elems, uint64_t n) {
+  uint32_t acc = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    uint64_t z = (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27;
+    const T v = src[z % span_elems];
+    acc ^= (uint32_t)v ^ (uint32_t)((uint64_t)v >> 32);
+  }
+  if (acc == 0x12345678u) sink[0] = acc;       // keeps the loads alive
 }
 void zg_launch_calib(const void* src, void* dst, uint64_t bytes, hipStream_t s) {
   hipLaunchKernelGGL(zg_k_calib_copy, dim3(2048), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, bytes / 16);
+  hipLaunchKernelGGL(zg_k_calib_copy4, dim3(2048), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)dst, bytes / 4);
+  hipLaunchKernelGGL(zg_k_calib_gather<uint32_t>, dim3(2048), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)dst, bytes / 4, bytes / 64);
+  hipLaunchKernelGGL(zg_k_calib_gather<uint64_t>, dim3(2048), dim3(256), 0, s, (const uint64_t*)src, (uint32_t*)dst, bytes / 8, bytes / 64);
 }
 
 // ------------------------------------------------------------------------------------------------------------
