@@ -612,45 +612,47 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
     // :204-206); the extra bits in between are skipped by their count and read by zg_k_seqpost.
     uint32_t cnt = 0;
     {
-      uint32_t wbase = 0, w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-      if (act) {
-        wbase = (((uint32_t)P + rbits) & ~31u) - 96u;
-        const uint32_t di = (wbase >> 5) & (ZG_SEQ_RING / 4 - 1);
-        w0 = ring32[di]; w1 = ring32[di + 1]; w2 = ring32[di + 2]; w3 = ring32[di + 3];
-      }
+      // No branch per step: a quad whose block is finished keeps running on its frozen state (its table entry stays valid, so
+      // every LDS address stays in range) and simply does not record or advance; blocks of a wave end within a few steps of
+      // each other, so little is wasted, and the 12 steps issue as one straight line.
+      uint32_t left = nseq - done;                                  // sequences still to decode (>= 1 while act)
+      uint32_t wbase = (((uint32_t)P + rbits) & ~31u) - 96u;
+      uint32_t di0 = (wbase >> 5) & (ZG_SEQ_RING / 4 - 1);
+      uint32_t w0 = ring32[di0], w1 = ring32[di0 + 1], w2 = ring32[di0 + 2], w3 = ring32[di0 + 3];
 #pragma unroll
       for (int c = 0; c < ZG_SEQ_CH; c++) {
-        if (act) {
-          const uint32_t v = e & 1023u;
-          const uint32_t k = 31u - (uint32_t)__builtin_clz(v);
-          const bool last = done + 1 == nseq;                       // no state update after the last sequence (:203)
-          const uint32_t nb = last ? 0u : lg - k;
-          // pk: [7:0] all bits this lane's symbol takes from the stream, [15:8] its state bits. Quad prefix sums, lanes in
-          // stream order from the low end: OF state, ML state, LL state (then the extra bits, skipped as one count).
-          const uint32_t pk = (nb + xb) | (nb << 8);
-          const uint32_t i1 = pk + (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0x93, 0xF, 0xF, true);   // quad_perm [3,0,1,2]
-          const uint32_t incl = i1 + (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0x4F, 0xF, 0xF, true); // quad_perm [3,3,0,1]
-          const uint32_t tot = (uint32_t)__builtin_amdgcn_mov_dpp((int)incl, 0xAA, 0xF, 0xF, true);     // quad_perm [2,2,2,2]
-          const int32_t q_sof = P - (int32_t)(tot & 255u);
-          const bool ok = q_sof >= 0;                               // :209-211
-          out_base[cnt * 4u] = (uint16_t)(owner ? tot & 255u : e);
-          cnt += ok ? 1u : 0u;
-          // this lane's nb state bits start (incl - pk) >> 8 bits above q_sof; q_sof >= P - 89, so they are inside the window
-          const uint32_t rel = (uint32_t)q_sof + rbits - wbase + ((incl - pk) >> 8);
-          const bool up = rel >= 64u, odd = (rel & 32u) != 0u;
-          const uint32_t a0 = up ? w2 : w0, a1 = up ? w3 : w1, a2 = up ? w3 : w2;
-          const uint32_t d0 = odd ? a1 : a0, d1 = odd ? a2 : a1;
-          const uint32_t bits = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(d1, d0, rel & 31u), 0u, nb);
-          const uint32_t st = ((v ^ (1u << k)) << nb) + bits;
-          e = tab[st]; xb = xtab[st];
-          P = q_sof;
-          wbase = (((uint32_t)P + rbits) & ~31u) - 96u;
-          const uint32_t di = (wbase >> 5) & (ZG_SEQ_RING / 4 - 1);
-          w0 = ring32[di]; w1 = ring32[di + 1]; w2 = ring32[di + 2]; w3 = ring32[di + 3];
-          done += ok ? 1u : 0u;                                     // done stops at the sequence that ran out of bits
-          act = ok && done != nseq;
-        }
+        const uint32_t v = e & 1023u;
+        const uint32_t k = 31u - (uint32_t)__builtin_clz(v);
+        const uint32_t nb = left == 1u ? 0u : lg - k;                // no state update after the last sequence (:203)
+        // pk: [7:0] all bits this lane's symbol takes from the stream, [15:8] its state bits. Quad prefix sums, lanes in
+        // stream order from the low end: OF state, ML state, LL state (then the extra bits, skipped as one count).
+        const uint32_t pk = (nb + xb) | (nb << 8);
+        const uint32_t i1 = pk + (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0x93, 0xF, 0xF, true);   // quad_perm [3,0,1,2]
+        const uint32_t incl = i1 + (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0x4F, 0xF, 0xF, true); // quad_perm [3,3,0,1]
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_mov_dpp((int)incl, 0xAA, 0xF, 0xF, true);     // quad_perm [2,2,2,2]
+        const int32_t q_sof = P - (int32_t)(tot & 255u);
+        const bool ok = act && q_sof >= 0;                          // :209-211
+        out_base[cnt * 4u] = (uint16_t)(owner ? tot & 255u : e);    // (not recorded unless cnt advances)
+        cnt += ok ? 1u : 0u;
+        // this lane's nb state bits start (incl - pk) >> 8 bits above q_sof; q_sof >= P - 89, so they are inside the window
+        const uint32_t rel = (uint32_t)q_sof + rbits - wbase + ((incl - pk) >> 8);
+        const bool up = rel >= 64u, odd = (rel & 32u) != 0u;
+        const uint32_t a0 = up ? w2 : w0, a1 = up ? w3 : w1, a2 = up ? w3 : w2;
+        const uint32_t d0 = odd ? a1 : a0, d1 = odd ? a2 : a1;
+        const uint32_t bits = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(d1, d0, rel & 31u), 0u, nb);
+        const uint32_t st = ((v ^ (1u << k)) << nb) + bits;
+        // one LDS round trip per step: the next entry, its extra-bit count and the window below the next position go out together
+        P = act ? q_sof : P;
+        wbase = (((uint32_t)P + rbits) & ~31u) - 96u;
+        const uint32_t di = (wbase >> 5) & (ZG_SEQ_RING / 4 - 1);
+        const uint32_t e2 = tab[st], xb2 = xtab[st];
+        w0 = ring32[di]; w1 = ring32[di + 1]; w2 = ring32[di + 2]; w3 = ring32[di + 3];
+        __builtin_amdgcn_sched_barrier(0);
+        e = act ? e2 : e; xb = act ? xb2 : xb;
+        left -= ok ? 1u : 0u;                                       // stops at the sequence that ran out of bits
+        act = ok && left != 0u;
       }
+      done = nseq - left;
     }
     ZG_QTICK(0)
     // MOVER phase: every quad serves its own block (position, ring bounds and output pointer are held by all four
