@@ -43,6 +43,11 @@ __device__ __forceinline__ uint32_t zg_ld32_fun(const uint8_t* p) {
 __device__ __forceinline__ void zg_set_status(uint32_t* status, uint32_t b, int st) {
   if (st) atomicCAS(&status[b], 0u, (uint32_t)st);
 }
+// The streams of a block's literals run in different waves: which error is reported must not depend on who is first.
+// rank 0 is the most significant; the word keeps (255 - rank) << 8 | status, the largest wins (zg_k_merge strips the rank).
+__device__ __forceinline__ void zg_set_lit_status(uint32_t* status, uint32_t b, uint32_t rank, int st) {
+  if (st) atomicMax(&status[b], ((255u - rank) << 8) | (uint32_t)st);
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // zg_k_tables: Huffman tree descriptions (literals chain; the FSE tables of the sequences chain are zg_k_ftab's).
@@ -342,7 +347,7 @@ __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
     lastb = slen ? sp[slen - 1] : 0;
     if (slen == 0 || lastb == 0) hst = ZG_LIT_EXTRA_PADDING;                       // :98-109
   }
-  if (hst) { if (lane == 0) zg_set_status(d.lit_status, b, hst); return; }
+  if (hst) { if (lane == 0) zg_set_lit_status(d.lit_status, b, 0u, hst); return; }
   const uint32_t hb = zg_hbit(lastb) - 1;                     // payload bits of the last byte (below the marker)
   const int32_t T = (int32_t)((slen - 1) * 8 + hb);           // bits of the stream; position P = bits not yet consumed
   const int64_t A = (int64_t)(uint64_t)sp;                    // address of stream bit 0
@@ -429,7 +434,10 @@ __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
   if (overflow) st = ZG_LIT_COUNT_MISMATCH;
   else if (blk.nstreams == 4 && top != 0) st = ZG_LIT_BITSTREAM_MISMATCH;   // bits_remaining != -max_bits (:116-121)
   else if (ndone != cap) st = ZG_LIT_COUNT_MISMATCH;                        // :150-155 (per stream, spec split)
-  if (lane == 0) zg_set_status(d.lit_status, b, st);
+  // The reference decodes the streams in order and checks each one's end as it goes (:116-121); the symbol count is compared
+  // once, after the last stream (:150-155): a stream's BitstreamReadMismatch outranks any count mismatch, an earlier stream a
+  // later one.
+  if (lane == 0) zg_set_lit_status(d.lit_status, b, st == ZG_LIT_BITSTREAM_MISMATCH ? k : 8u, st);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1142,6 +1150,7 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
     const uint32_t lit_fill = lit_rle ? lit[0] : 0u;
     const __amdgpu_buffer_rsrc_t lit_rs = zg_make_rsrc(lit, lit_rle ? 0u : blk.regen_size);    // RLE literals: nothing is fetched (0), lit_fill is the value
     const __amdgpu_buffer_rsrc_t seq_rs = zg_make_rsrc(d.seq_arena + blk.seq_base, nseq * 12u);
+    const __amdgpu_buffer_rsrc_t out_rs = zg_make_rsrc(out_u, un.nblocks * ZG_FLAT_MAX);
     // bytes of the frame (and dictionary) that exist before this block: the farthest a match may reach. Offsets are < 2^30
     // and positions in the block < 2^17: once 2^31 bytes exist every offset is in reach, else 32-bit arithmetic decides.
     const uint64_t reach = p.out_base + d.frames[un.frame].prior_reach + d.frames[un.frame].dict_len;
@@ -1187,7 +1196,11 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
         } else {
           lstart = so.sum_ll; a = so.sum_ll + so.sum_ml; m0 = m1 = S;
         }
-        if (m1 > t1o || a >= t1o) atomicMin(&s_next, i);  // first sequence that reaches beyond this tile starts the next one
+        // first sequence that reaches beyond this tile starts the next one: sequences are in order along the lanes, so the
+        // lowest lane of a wave that sees one speaks for the wave (one LDS atomic per wave, not one per sequence)
+        const bool beyond = m1 > t1o || a >= t1o;
+        const unsigned long long bm = __ballot(beyond);
+        if (beyond && (t & 63u) == (uint32_t)__builtin_ctzll(bm)) atomicMin(&s_next, i);
         if (a >= t1o) continue;
         const uint32_t st = (a > t0 ? a : t0) - t0;
         const uint32_t mr = (m0 > t0 ? (m0 < t1o ? m0 : t1o) : t0) - t0;
@@ -1284,7 +1297,7 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
             }
           }
         }
-        if (__syncthreads_or(unresolved != 0)) { if (t == 0) s_err = ZG_INTERNAL; __syncthreads(); break; }  // cannot happen: every step moves a pointer up its chain
+        if (unresolved) s_err = ZG_INTERNAL;   // cannot happen: every step moves a pointer up its chain (seen by everybody behind the next barrier)
       }
       ZG_TICK(3)
       // ---- S3a: the scratch words requested in S1c have arrived: the roots' effective offsets are completed in LDS
@@ -1292,28 +1305,32 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
       for (int k = 0; k < PER; k++) __hip_atomic_fetch_add(&s_word[t + k * T], wadd[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_u32; 0 where nothing was requested
       zg_lds_barrier();
       ZG_TICK(4)
+      if (s_err) break;
       // ---- S3b: every byte's effective offset = its root's + the distance to the root (a literal root counts 0) -> scratch;
       // the tile's literal bytes are fetched and go to the output
       constexpr int H = PER < 8 ? PER : 8;                        // bytes per batch (their loads are in flight together)
 #pragma unroll
       for (int k0 = 0; k0 < PER; k0 += H) {
-        uint32_t lb[H], islm = 0;
+        uint32_t lb[H], islm = 0, pr[H], w[H];
+        // (three passes over the batch, so that its LDS reads go out together: one round trip for the pointers, one for the words)
+#pragma unroll
+        for (int h = 0; h < H; h++) pr[h] = s_par[t + (k0 + h) * T];
+#pragma unroll
+        for (int h = 0; h < H; h++) { const uint32_t x = t + (k0 + h) * T; w[h] = s_word[pr[h] >= ZG_PAR_EXIT ? x : pr[h]]; }
 #pragma unroll
         for (int h = 0; h < H; h++) {
           const uint32_t x = t + (k0 + h) * T;
           const bool live = x < n;
-          const uint32_t pr = s_par[x];
-          const uint32_t r = pr >= ZG_PAR_EXIT ? x : pr;
-          const uint32_t w = s_word[r];
-          const uint32_t e = ((w >> 31) ? 0u : w) + (x - r);
-          const bool isl = live && pr == ZG_PAR_LIT;                      // a literal byte: w carries where its value is
-          lb[h] = __builtin_amdgcn_raw_buffer_load_b8(lit_rs, isl ? w & 0x7FFFFFFFu : ZG_OOB, 0, 0);
+          const uint32_t r = pr[h] >= ZG_PAR_EXIT ? x : pr[h];
+          const uint32_t e = ((w[h] >> 31) ? 0u : w[h]) + (x - r);
+          const bool isl = live && pr[h] == ZG_PAR_LIT;                   // a literal byte: w carries where its value is
+          lb[h] = __builtin_amdgcn_raw_buffer_load_b8(lit_rs, isl ? w[h] & 0x7FFFFFFFu : ZG_OOB, 0, 0);
           islm |= isl ? 1u << h : 0u;
           __builtin_amdgcn_raw_buffer_store_b32(e, og_rs, live ? 4u * (tu0 + x) : ZG_OOB, 0, 0);
         }
 #pragma unroll
         for (int h = 0; h < H; h++)
-          __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(lb[h] | lit_fill), zg_make_rsrc(out_u, un.nblocks * ZG_FLAT_MAX), ((islm >> h) & 1u) ? tu0 + t + (k0 + h) * T : ZG_OOB, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(lb[h] | lit_fill), out_rs, ((islm >> h) & 1u) ? tu0 + t + (k0 + h) * T : ZG_OOB, 0, 0);
       }
       zg_lds_barrier();  // s_par / s_word / the records are reused by the next tile
       ZG_TICK(5)
@@ -1628,7 +1645,7 @@ __global__ void __launch_bounds__(256) zg_k_merge(ZgBatchDev d) {
   const uint32_t b = blockIdx.x * 256 + threadIdx.x;
   if (b >= d.nblocks) return;
   if (d.tab_status[b]) d.status[b] = d.tab_status[b];
-  else if (d.lit_status[b]) d.status[b] = d.lit_status[b];
+  else if (d.lit_status[b]) d.status[b] = d.lit_status[b] & 0xFFu;
 }
 void zg_launch_merge(const ZgBatchDev& d, hipStream_t s) {
   if (d.nblocks) hipLaunchKernelGGL(zg_k_merge, dim3((d.nblocks + 255) / 256), dim3(256), 0, s, d);
