@@ -442,50 +442,110 @@ __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
 
 // ------------------------------------------------------------------------------------------------------------
 // zg_k_seq: sequence sections (decode_sequences, sequence_section_decoder.rs:14-221). The bitstream of a block is
-// one serial chain, so one lane owns one block; ZG_SEQ_G lanes of a wave work on ZG_SEQ_G blocks with their
-// three tables staged in LDS.
+// one serial chain, so the kernel is bound by the length of one step of that chain: a wave issues one instruction
+// every four cycles whatever the number of active lanes, and a block has ~13 K steps. Everything that is not the
+// chain itself is therefore moved out of the step: zg_k_seq only follows the three FSE state chains and records the
+// three STATES of every sequence (8 bytes); symbols, extra bits, values and positions are rebuilt from them in
+// parallel by zg_k_seqpost. Four lanes serve one block (one per chain plus one spare), ZG_SEQ_G blocks per wave,
+// tables staged in LDS as {u16 baseline << 4 | state bits, u8 all bits the state's symbol takes}.
 //
 // gfx950 counts loads and stores in one in-order counter (vmcnt), so a store inside the decode loop would make the
 // next bitstream load wait for the store's full round trip. The loop therefore never touches global memory: the wave
-// alternates between a DECODE phase (ZG_SEQ_CH sequences per lane: tables, bitstream and output all in LDS) and a
-// MOVER phase in which all 64 lanes extend every lane's bitstream ring downwards with 16-byte loads (landing one
-// phase later, i.e. behind a whole decode phase) and flush the decoded sequences with coalesced 16-byte stores.
+// alternates between a DECODE phase (ZG_SEQ_CH sequences per block: tables, bitstream and output all in LDS) and a
+// MOVER phase in which the lanes extend every block's bitstream ring downwards with 16-byte loads (landing one
+// phase later, i.e. behind a whole decode phase) and flush the recorded states with 8-byte stores.
+//
+// A decode phase comes in two forms. While more than ZG_SEQ_CH sequences are left, none of them is the block's last
+// one (which takes no state bits, :203) and a stream that runs out of bits is corrupt, so the FAST form checks nothing
+// per step: the position only decreases, one sign test after the phase is enough, and a chain that ran past the
+// start of a corrupt stream reads ring and table addresses that stay in range by construction. The block's last
+// <= ZG_SEQ_CH sequences go through the CAREFUL form, which freezes a finished block and applies :203 and :209-211
+// per step.
 // ------------------------------------------------------------------------------------------------------------
-#define ZG_SEQ_CH 12                                  // sequences per lane between two mover phases
+#define ZG_SEQ_CH 12                                  // sequences per block between two mover phases
 #define ZG_SEQ_CMAX 144                               // >= bytes ZG_SEQ_CH sequences can consume (12 x 89 bits)
 #define ZG_SEQ_MARGIN (2 * ZG_SEQ_CMAX + 32)          // bytes of bitstream kept resident below the current position
-#define ZG_SEQ_RING 512                               // per-lane ring, indexed by the low bits of the global address
-#define ZG_SEQ_PIECES 10                              // 16-byte pieces one mover phase can add per lane (>= CMAX/16 + 1)
+#define ZG_SEQ_RING 512                               // per-block ring, indexed by the low bits of the global address
+#define ZG_SEQ_PIECES 10                              // 16-byte pieces one mover phase can add per block (>= CMAX/16 + 1)
 #define ZG_SEQ_PREG ((ZG_SEQ_PIECES + 3) / 4)         // piece requests per lane and phase: a block's four lanes share them
 #define ZG_SEQ_PRO ((ZG_SEQ_MARGIN + 16 + 8 + 15 + 15) / 16 + 1)   // pieces of the prologue fill
 
-// bits [q, q+n) of the stream (n <= 31) read from the lane's ring: two adjacent dwords + one funnel shift.
-// rbits = (stream address & (ring size - 1)) * 8; the ring has a 16-byte mirror of its start behind its end.
-__device__ __forceinline__ uint32_t zg_ring_bits(const uint32_t* ring32, uint32_t rbits, int32_t q, uint32_t n) {
-  const uint32_t rb = (uint32_t)q + rbits;
-  const uint32_t di = (rb >> 5) & (ZG_SEQ_RING / 4 - 1);
-  const uint32_t d0 = ring32[di], d1 = ring32[di + 1];
-  return __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(d1, d0, rb & 31u), 0u, n);
+// Ring storage: 16 bytes that mirror the ring's END, then the ring. The four dwords a step looks at are the ones
+// [a - 12, a + 4) around the dword a that holds the current position, so with the mirror in FRONT their address is
+// storage + 4 + a without a wrap.
+#define ZG_SEQ_RSTORE (ZG_SEQ_RING + 16)
+__device__ __forceinline__ void zg_ring_put(uint8_t* store, uint64_t addr, const zg_v4u& v) {
+  const uint32_t ro = (uint32_t)(addr & (ZG_SEQ_RING - 1));
+  *(zg_v4u*)(store + 16 + ro) = v;
+  if (ro == ZG_SEQ_RING - 16) *(zg_v4u*)store = v;
 }
-// same for n <= 32
-__device__ __forceinline__ uint32_t zg_ring_bits32(const uint32_t* ring32, uint32_t rbits, int32_t q, uint32_t n) {
-  const uint32_t rb = (uint32_t)q + rbits;
-  const uint32_t di = (rb >> 5) & (ZG_SEQ_RING / 4 - 1);
-  const uint32_t d0 = ring32[di], d1 = ring32[di + 1];
-  const uint32_t v = __builtin_amdgcn_alignbit(d1, d0, rb & 31u);
-  return n >= 32 ? v : __builtin_amdgcn_ubfe(v, 0u, n);
+// bits [pr, pr+n) of the ring (pr = stream bit position + the ring phase of the stream's first byte), n <= 31
+__device__ __forceinline__ uint32_t zg_ring_bits(const uint8_t* store, int32_t pr, uint32_t n) {
+  const uint32_t a = (((uint32_t)pr >> 5) & (ZG_SEQ_RING / 4 - 1)) * 4u;
+  const uint32_t d0 = *(const uint32_t*)(store + 16 + a), d1 = *(const uint32_t*)(store + 16 + ((a + 4) & (ZG_SEQ_RING - 1)));
+  return __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(d1, d0, (uint32_t)pr & 31u), 0u, n);
 }
-__device__ __forceinline__ uint32_t zg_sym_dec_bf(uint32_t v) {  // zg_sym_dec without branches
-  const uint32_t c = v ? v - 1 : 0u;
-  return (v >> 30) ? v + 1 : c;
+
+struct ZgSeqChain {        // one lane's view of its block's chain
+  int32_t pr;              // bit position + ring phase
+  uint32_t e, s;           // the lane's table entry: baseline << 4 | state bits; all bits its symbol takes
+  uint32_t st;             // the lane's state (what gets recorded)
+  uint32_t w0, w1, w2, w3, wlo;   // the window below the position and the bit address of its first dword plus 2^32 - 96... see zg_seq_window
+};
+// request the four dwords around the position and remember where they start
+__device__ __forceinline__ void zg_seq_window(ZgSeqChain& c, const uint8_t* store4) {
+  const uint32_t a = __builtin_amdgcn_ubfe((uint32_t)c.pr, 5u, 7u);
+  const uint32_t* w = (const uint32_t*)(store4 + a * 4u);
+  c.w0 = w[0]; c.w1 = w[1]; c.w2 = w[2]; c.w3 = w[3];
+  c.wlo = ((uint32_t)c.pr & ~31u) - 96u;
+}
+// One step of the chain. FAST: no checks (see above). Otherwise `act`, `left`, `cnt` are maintained and a finished or
+// failed block keeps its state.
+template <bool FAST>
+__device__ __forceinline__ void zg_seq_step(ZgSeqChain& c, const uint16_t* tab, const uint8_t* xtab, const uint8_t* store4, uint16_t* rec,
+                                            int32_t rbits, bool& act, uint32_t& left, uint32_t& cnt) {
+  const uint32_t nb0 = c.e & 15u;
+  uint32_t nb = nb0, pk = c.s | (nb0 << 8);          // pk: [7:0] all bits this lane's symbol takes, [15:8] its state bits
+  if (!FAST) { const bool last = left == 1u; nb = last ? 0u : nb0; pk = last ? c.s - nb0 : pk; }   // no state update after the last sequence (:203)
+  // quad prefix sums, lanes in stream order from the low end: OF state, ML state, LL state (the extra bits above them are skipped as one count)
+  const uint32_t i1 = pk + (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0x93, 0xF, 0xF, true);     // quad_perm [3,0,1,2]
+  const uint32_t incl = i1 + (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0x4F, 0xF, 0xF, true);   // quad_perm [3,3,0,1]
+  const uint32_t tot = (uint32_t)__builtin_amdgcn_mov_dpp((int)incl, 0xAA, 0xF, 0xF, true) & 255u; // quad_perm [2,2,2,2]
+  const int32_t q = c.pr - (int32_t)tot;              // where the sequence ends
+  // this lane's nb state bits start (incl - pk) >> 8 bits above q; q >= position - 89, so they are inside the window
+  const uint32_t rel = (uint32_t)q - c.wlo + ((incl - pk) >> 8);
+  const bool up = rel >= 64u, odd = (rel & 32u) != 0u;
+  const uint32_t a0 = up ? c.w2 : c.w0, a1 = up ? c.w3 : c.w1, a2 = up ? c.w3 : c.w2;
+  const uint32_t d0 = odd ? a1 : a0, d1 = odd ? a2 : a1;
+  const uint32_t bits = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(d1, d0, rel), 0u, nb);
+  const uint32_t st2 = (c.e >> 4) + bits;
+  if (FAST) {
+    *rec = (uint16_t)c.st;
+    c.pr = q; c.st = st2;
+    c.e = tab[st2]; c.s = xtab[st2];
+    zg_seq_window(c, store4);
+    __builtin_amdgcn_sched_barrier(0);
+  } else {
+    const bool ok = act && q >= rbits;                // :209-211
+    rec[cnt * 4u] = (uint16_t)c.st;                   // (not recorded unless cnt advances)
+    cnt += ok ? 1u : 0u;
+    const bool was = act;
+    left -= ok ? 1u : 0u;                             // stops at the sequence that ran out of bits
+    act = ok && left != 0u;
+    ZgSeqChain n = c;
+    n.pr = q; n.st = st2; n.e = tab[st2]; n.s = xtab[st2];
+    zg_seq_window(n, store4);
+    __builtin_amdgcn_sched_barrier(0);
+    if (was) { c.pr = n.pr; c.wlo = n.wlo; c.w0 = n.w0; c.w1 = n.w1; c.w2 = n.w2; c.w3 = n.w3; }
+    if (act) { c.st = n.st; c.e = n.e; c.s = n.s; }
+  }
 }
 
 __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
-  // tables are re-packed to 16 bits while they are staged: [15:10] symbol, [9:0] x = (1 << (log - num_bits)) | (base_line >> num_bits)
-  __shared__ uint16_t s_tab[ZG_SEQ_G][ZG_FSE_SLOT_U32 + 2];   // + the one-entry dummy table of the position lane
-  __shared__ uint8_t s_xb[ZG_SEQ_G][ZG_FSE_SLOT_U32 + 4];    // bits the state's symbol takes besides the state bits (OF: its code), read together with the entry
-  __shared__ __attribute__((aligned(16))) uint8_t s_ring[ZG_SEQ_G][ZG_SEQ_RING + 16];
-  __shared__ __attribute__((aligned(16))) uint2 s_out[ZG_SEQ_G][ZG_SEQ_CH];   // raw records, 4 x u16: {OF entry, ML entry, LL entry, bits the sequence takes}
+  __shared__ uint16_t s_tab[ZG_SEQ_G][ZG_FSE_SLOT_U32 + 2];   // + the one-entry dummy table of the spare lane
+  __shared__ uint8_t s_xb[ZG_SEQ_G][ZG_FSE_SLOT_U32 + 4];
+  __shared__ __attribute__((aligned(16))) uint8_t s_ring[ZG_SEQ_G][ZG_SEQ_RSTORE];
+  __shared__ __attribute__((aligned(16))) uint2 s_out[ZG_SEQ_G][ZG_SEQ_CH];   // records, 4 x u16: states {OF, ML, LL, 0}
   __shared__ uint64_t s_fetch_hi[ZG_SEQ_G], s_fetch_lo[ZG_SEQ_G];   // prologue: the part of each block's stream to load, [lo, hi)
   __shared__ uint8_t s_log[ZG_SEQ_G][4];
   __shared__ int s_ok[ZG_SEQ_G];
@@ -513,30 +573,31 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
           const uint32_t i = t + 64 * j;
           if (i < (1u << lg)) {
             const uint32_t nb = ZG_FSE_NB(v[j]);
-            s_tab[g][offs[k] + i] = (uint16_t)((ZG_FSE_SYM(v[j]) << 10) | (1u << (lg - nb)) | (ZG_FSE_BL(v[j]) >> nb));
-            s_xb[g][offs[k] + i] = (uint8_t)(k == 1 ? ZG_FSE_SYM(v[j]) : v[j] >> 26);
+            s_tab[g][offs[k] + i] = (uint16_t)((ZG_FSE_BL(v[j]) << 4) | nb);
+            s_xb[g][offs[k] + i] = (uint8_t)(nb + (k == 1 ? ZG_FSE_SYM(v[j]) : v[j] >> 26));   // OF: the code is the number of extra bits
           }
         }
       }
       if (t == 0) s_log[g][k] = (uint8_t)lg;
     }
-    if (t == 0) { s_ok[g] = ok ? 1 : 0; s_tab[g][ZG_FSE_SLOT_U32] = 1; s_xb[g][ZG_FSE_SLOT_U32] = 0; }
+    if (t == 0) { s_ok[g] = ok ? 1 : 0; s_tab[g][ZG_FSE_SLOT_U32] = 0; s_xb[g][ZG_FSE_SLOT_U32] = 0; }
   }
   __syncthreads();
   // ---- per-lane setup: four lanes per block. Lane role 0 follows the OF chain, 1 the ML chain, 2 the LL chain; role 3
-  // only carries the position (its "table" is the one-entry dummy: no bits). All four hold the block's scalars.
+  // is the spare (its "table" is the one-entry dummy: no bits). All four hold the block's scalars.
   const uint32_t g = t >> 2, role = t & 3u;
   const bool owner = role == 3u;
   bool act = base + g < d.nseq_blocks;
   bool have = false;
-  uint32_t b = 0, nseq = 0, done = 0, rbits = 0;
+  uint32_t b = 0, nseq = 0, left = 0;
+  int32_t rbits = 0;
   uint64_t bsA = 0, floorA = 0, lo = 0, dstp = 0;
   const uint32_t toff = role == 0u ? ZG_FSE_OF_OFF : role == 1u ? ZG_FSE_ML_OFF : role == 2u ? ZG_FSE_LL_OFF : ZG_FSE_SLOT_U32;
   const uint16_t* tab = &s_tab[g][toff];
   const uint8_t* xtab = &s_xb[g][toff];
-  const uint32_t* ring32 = (const uint32_t*)s_ring[g];
+  uint8_t* const store = s_ring[g];
+  const uint8_t* const store4 = store + 4;
   int32_t P = 0;
-  uint32_t e = 1, xb = 0, lg = 0;       // this lane's table entry, its symbol's extra bits, its table's log
   int status = ZG_OK;
   if (act) {
     b = d.seq_blocks[base + g];
@@ -557,7 +618,7 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
         else {
           P = (int32_t)(bs_len - 1) * 8 + (int32_t)(zg_hbit(lastb) - 1);
           bsA = (uint64_t)bs;
-          rbits = (uint32_t)(bsA & (ZG_SEQ_RING - 1)) * 8u;
+          rbits = (int32_t)((uint32_t)(bsA & (ZG_SEQ_RING - 1)) * 8u);
           floorA = (bsA & ~15ull) - 16;                 // the engine keeps 64 bytes of padding in front of the buffer
           dstp = (uint64_t)(d.raw_arena + blk.seq_base);
           have = true;
@@ -580,30 +641,28 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
     for (uint32_t j = t; j < ZG_SEQ_G * ZG_SEQ_PRO; j += 64) {
       const uint32_t gg = j / ZG_SEQ_PRO, k = j % ZG_SEQ_PRO;
       const uint64_t hi = s_fetch_hi[gg], addr = hi - 16ull * (k + 1);
-      if (hi && addr >= s_fetch_lo[gg] && addr < hi) {
-        const uint4 v = *(const uint4*)addr;
-        const uint32_t ro = (uint32_t)(addr & (ZG_SEQ_RING - 1));
-        *(uint4*)(s_ring[gg] + ro) = v;
-        if (ro == 0) *(uint4*)(s_ring[gg] + ZG_SEQ_RING) = v;
-      }
+      if (hi && addr >= s_fetch_lo[gg] && addr < hi) { const zg_v4u v = *(const zg_gv4u*)addr; zg_ring_put(s_ring[gg], addr, v); }
     }
     __syncthreads();
   }
+  ZgSeqChain c = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (act) {  // initial states, order LL, OF, ML (:164-166); a negative position is reported after the first sequence
     const uint32_t ll_log = s_log[g][0], of_log = s_log[g][1], ml_log = s_log[g][2];
-    lg = role == 0u ? of_log : role == 1u ? ml_log : role == 2u ? ll_log : 0u;
+    const uint32_t lg = role == 0u ? of_log : role == 1u ? ml_log : role == 2u ? ll_log : 0u;
     const int32_t q = P - (int32_t)(role == 2u ? ll_log : role == 0u ? ll_log + of_log : ll_log + of_log + ml_log);
-    const uint32_t i = (q >= 0 && role != 3u) ? zg_ring_bits(ring32, rbits, q, lg) : 0u;
-    e = tab[i]; xb = xtab[i];
+    c.st = (q >= 0 && role != 3u) ? zg_ring_bits(store, q + rbits, lg) : 0u;
+    c.e = tab[c.st]; c.s = xtab[c.st];
     P -= (int32_t)(ll_log + of_log + ml_log);
     if (owner) d.seq_out[b].pad = (uint32_t)P;   // where the first sequence starts: zg_k_seqpost rebuilds the positions from the bit counts
+    left = nseq;
   }
+  c.pr = P + rbits;
   zg_v4u piece[ZG_SEQ_PREG];
   uint64_t piece_addr[ZG_SEQ_PREG];
   bool piece_ok[ZG_SEQ_PREG];
 #pragma unroll
   for (int pi = 0; pi < ZG_SEQ_PREG; pi++) { piece[pi] = zg_v4u{0, 0, 0, 0}; piece_addr[pi] = 0; piece_ok[pi] = false; }
-  uint16_t* const out_base = (uint16_t*)&s_out[g][0] + role;   // record {e_of, e_ml, e_ll, bits}: one u16 per lane
+  uint16_t* const out_base = (uint16_t*)&s_out[g][0] + role;   // record {OF, ML, LL state, spare}: one u16 per lane
 #ifdef ZG_PROFILE_SEQ
   unsigned long long tcs[3] = {0, 0, 0}, tl_ = clock64();
 #define ZG_QTICK(i) { const unsigned long long n_ = clock64(); tcs[i] += n_ - tl_; tl_ = n_; }
@@ -613,67 +672,28 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
   // ---- main loop
   while (__any(act)) {
     ZG_QTICK(2)
-    // DECODE phase: LDS only, and one LDS round trip per sequence: the lane's next table entry, its extra-bit count and
-    // the 128 bits of stream below the next position are requested together; everything between is 32-bit ALU, and
-    // the three chains of a block run in three lanes that exchange their bit counts through DPP quad permutes.
-    // Only the state chains are followed here (FSEDecoder::update_state, fse_decoder.rs:40-48, order LL, ML, OF
-    // :204-206); the extra bits in between are skipped by their count and read by zg_k_seqpost.
+    // DECODE phase: LDS only, and one LDS round trip per sequence: the lane's next table entry, its bit count and the
+    // 128 bits of stream below the next position are requested together; everything between is 32-bit ALU, and the
+    // three chains of a block run in three lanes that exchange their bit counts through DPP quad permutes
+    // (FSEDecoder::update_state, fse_decoder.rs:40-48, order LL, ML, OF :204-206).
     uint32_t cnt = 0;
-    {
-      // No branch per step: a quad whose block is finished keeps running on its frozen state (its table entry stays valid, so
-      // every LDS address stays in range) and simply does not record or advance; blocks of a wave end within a few steps of
-      // each other, so little is wasted, and the 12 steps issue as one straight line.
-      uint32_t left = nseq - done;                                  // sequences still to decode (>= 1 while act)
-      uint32_t wbase = (((uint32_t)P + rbits) & ~31u) - 96u;
-      uint32_t di0 = (wbase >> 5) & (ZG_SEQ_RING / 4 - 1);
-      uint32_t w0 = ring32[di0], w1 = ring32[di0 + 1], w2 = ring32[di0 + 2], w3 = ring32[di0 + 3];
+    if (act) zg_seq_window(c, store4);
+    if (act && left > ZG_SEQ_CH) {
 #pragma unroll
-      for (int c = 0; c < ZG_SEQ_CH; c++) {
-        const uint32_t v = e & 1023u;
-        const uint32_t k = 31u - (uint32_t)__builtin_clz(v);
-        const uint32_t nb = left == 1u ? 0u : lg - k;                // no state update after the last sequence (:203)
-        // pk: [7:0] all bits this lane's symbol takes from the stream, [15:8] its state bits. Quad prefix sums, lanes in
-        // stream order from the low end: OF state, ML state, LL state (then the extra bits, skipped as one count).
-        const uint32_t pk = (nb + xb) | (nb << 8);
-        const uint32_t i1 = pk + (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0x93, 0xF, 0xF, true);   // quad_perm [3,0,1,2]
-        const uint32_t incl = i1 + (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0x4F, 0xF, 0xF, true); // quad_perm [3,3,0,1]
-        const uint32_t tot = (uint32_t)__builtin_amdgcn_mov_dpp((int)incl, 0xAA, 0xF, 0xF, true);     // quad_perm [2,2,2,2]
-        const int32_t q_sof = P - (int32_t)(tot & 255u);
-        const bool ok = act && q_sof >= 0;                          // :209-211
-        out_base[cnt * 4u] = (uint16_t)(owner ? tot & 255u : e);    // (not recorded unless cnt advances)
-        cnt += ok ? 1u : 0u;
-        // this lane's nb state bits start (incl - pk) >> 8 bits above q_sof; q_sof >= P - 89, so they are inside the window
-        const uint32_t rel = (uint32_t)q_sof + rbits - wbase + ((incl - pk) >> 8);
-        const bool up = rel >= 64u, odd = (rel & 32u) != 0u;
-        const uint32_t a0 = up ? w2 : w0, a1 = up ? w3 : w1, a2 = up ? w3 : w2;
-        const uint32_t d0 = odd ? a1 : a0, d1 = odd ? a2 : a1;
-        const uint32_t bits = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(d1, d0, rel & 31u), 0u, nb);
-        const uint32_t st = ((v ^ (1u << k)) << nb) + bits;
-        // one LDS round trip per step: the next entry, its extra-bit count and the window below the next position go out together
-        P = act ? q_sof : P;
-        wbase = (((uint32_t)P + rbits) & ~31u) - 96u;
-        const uint32_t di = (wbase >> 5) & (ZG_SEQ_RING / 4 - 1);
-        const uint32_t e2 = tab[st], xb2 = xtab[st];
-        w0 = ring32[di]; w1 = ring32[di + 1]; w2 = ring32[di + 2]; w3 = ring32[di + 3];
-        __builtin_amdgcn_sched_barrier(0);
-        e = act ? e2 : e; xb = act ? xb2 : xb;
-        left -= ok ? 1u : 0u;                                       // stops at the sequence that ran out of bits
-        act = ok && left != 0u;
-      }
-      done = nseq - left;
+      for (int k = 0; k < ZG_SEQ_CH; k++) zg_seq_step<true>(c, tab, xtab, store4, out_base + 4 * k, rbits, act, left, cnt);
+      cnt = ZG_SEQ_CH; left -= ZG_SEQ_CH;
+      if (c.pr < rbits) act = false;                               // ran out of bits with sequences left (:209-211)
+    } else if (act) {
+#pragma unroll
+      for (int k = 0; k < ZG_SEQ_CH; k++) zg_seq_step<false>(c, tab, xtab, store4, out_base, rbits, act, left, cnt);
     }
+    P = c.pr - rbits;
     ZG_QTICK(0)
     // MOVER phase: every quad serves its own block (position, ring bounds and output pointer are held by all four
     // lanes), so nothing is exchanged across the workgroup and the loop has no barrier: LDS accesses of one wave are in order.
     // (1) land the pieces requested one phase ago
 #pragma unroll
-    for (int pi = 0; pi < ZG_SEQ_PREG; pi++) {
-      if (piece_ok[pi]) {
-        const uint32_t ro = (uint32_t)(piece_addr[pi] & (ZG_SEQ_RING - 1));
-        *(zg_v4u*)(s_ring[g] + ro) = piece[pi];
-        if (ro == 0) *(zg_v4u*)(s_ring[g] + ZG_SEQ_RING) = piece[pi];
-      }
-    }
+    for (int pi = 0; pi < ZG_SEQ_PREG; pi++) if (piece_ok[pi]) zg_ring_put(store, piece_addr[pi], piece[pi]);
     // (2) flush the chunk: the quad's lanes take every fourth record (8 bytes each)
 #pragma unroll
     for (int i = 0; i < (ZG_SEQ_CH + 3) / 4; i++) {
@@ -704,15 +724,16 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
 #endif
 #undef ZG_QTICK
   if (have && owner) {
-    if (done != nseq) status = ZG_SEQ_NOT_ENOUGH_BYTES;       // the loop stopped at a sequence that ran out of bits (:209-211)
+    if (left != 0) status = ZG_SEQ_NOT_ENOUGH_BYTES;          // the loop stopped at a sequence that ran out of bits (:209-211)
     else if (P > 0) status = ZG_SEQ_EXTRA_BITS;               // :214-220
     zg_set_status(d.status, b, status);
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// zg_k_seqpost: everything about a block's sequences that is not the serial state chain, done in parallel over the raw
-// records of zg_k_seq: extra bits read from the bitstream (get_bits_triple, bit_reader_reverse.rs:151-162), values
+// zg_k_seqpost: everything about a block's sequences that is not the serial state chain, done in parallel over the
+// states zg_k_seq recorded: symbols and bit counts (the block's three tables, staged in LDS), extra bits read from the
+// bitstream (get_bits_triple, bit_reader_reverse.rs:151-162), values
 // (lookup_ll_code / lookup_ml_code, sequence_section_decoder.rs:227-284), the output position of every sequence
 // (prefix sums, sequence_execution.rs:6-39) and the offset history (do_offset_history :59-118) as a scan of symbolic
 // maps: the history after sequence i is the composition of the maps of sequences 0..i, and the actual offset of
@@ -746,10 +767,20 @@ __global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
   __shared__ uint32_t s_wl[ZG_SP_T / 64], s_wo[ZG_SP_T / 64], s_wx[ZG_SP_T / 64];
   __shared__ uint32_t s_err;
   __shared__ uint32_t s_llb[36], s_mlb[53];     // base | extra bits << 24 (a constant-memory lookup is a global load here)
+  __shared__ uint16_t s_t[ZG_FSE_SLOT_U32];      // per state: symbol << 4 | state bits
   const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const uint32_t b = d.seq_blocks[blockIdx.x];
   if (d.status[b]) return;                       // the bitstream (or a table) failed: nothing to post-process
   const ZgBlock blk = d.blocks[b];
+  {
+    const int32_t sl[3] = {blk.ll_slot, blk.ml_slot, blk.of_slot};          // in the order of the slot layout (LL, ML, OF)
+    const uint32_t offs[4] = {ZG_FSE_LL_OFF, ZG_FSE_ML_OFF, ZG_FSE_OF_OFF, ZG_FSE_SLOT_U32};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const uint32_t* g_t = d.fse_arena + (uint64_t)sl[k] * ZG_FSE_SLOT_U32;   // (the block passed zg_k_seq: all three slots are set)
+      for (uint32_t i = offs[k] + t; i < offs[k + 1]; i += ZG_SP_T) { const uint32_t v = g_t[i]; s_t[i] = (uint16_t)((ZG_FSE_SYM(v) << 4) | ZG_FSE_NB(v)); }
+    }
+  }
   const uint32_t nseq = blk.nseq, regen = blk.regen_size;
   const uint8_t* bs = d.src + blk.src_off + d.aux[b].seq_bits_off;
   const uint2* raw = d.raw_arena + blk.seq_base;
@@ -775,13 +806,24 @@ __global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
 #pragma unroll
       for (int j = 0; j < ZG_SP_S; j++) r[j] = (uint32_t)j < n ? raw[ib + j] : make_uint2(0u, 0u);
     }
-    // positions: a record holds the bits its sequence takes; the position before a sequence is the block's start
-    // position minus everything taken before it (prefix sum: thread, wave, workgroup)
+    // symbols and bit counts from the recorded states: a sequence takes its three codes' extra bits and, unless it is the
+    // block's last one, the three state updates (:203-206)
+    uint32_t codes[ZG_SP_S], xbv[ZG_SP_S];         // codes: of | ml << 8 | ll << 16; xbv: xb_ll | xb_ml << 8
     uint32_t P[ZG_SP_S];
     {
       uint32_t tx = 0;
 #pragma unroll
-      for (int j = 0; j < ZG_SP_S; j++) { P[j] = tx; tx += r[j].y >> 16; }
+      for (int j = 0; j < ZG_SP_S; j++) {
+        const uint32_t e_of = s_t[ZG_FSE_OF_OFF + (r[j].x & 255u)], e_ml = s_t[ZG_FSE_ML_OFF + ((r[j].x >> 16) & 511u)], e_ll = s_t[ZG_FSE_LL_OFF + (r[j].y & 511u)];
+        const uint32_t of_code = (e_of >> 4) & 31u, ml_code = e_ml >> 4, ll_code = e_ll >> 4;
+        const uint32_t vl = s_llb[ll_code < 36 ? ll_code : 0], vm = s_mlb[ml_code < 53 ? ml_code : 0];
+        const uint32_t upd = ib + (uint32_t)j + 1u == nseq ? 0u : (e_of & 15u) + (e_ml & 15u) + (e_ll & 15u);
+        const bool have = (uint32_t)j < n;             // (a slot past the end takes no bits: its reads below stay at the last position)
+        codes[j] = have ? of_code | (ml_code << 8) | (ll_code << 16) : 0u;
+        xbv[j] = have ? (vl >> 24) | ((vm >> 24) << 8) : 0u;
+        P[j] = tx;
+        tx += have ? of_code + (vl >> 24) + (vm >> 24) + upd : 0u;
+      }
       uint32_t sx = tx;
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) { const uint32_t px = __shfl_up(sx, off, 64); if ((int)lane >= off) sx += px; }
@@ -798,9 +840,9 @@ __global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
     uint32_t ll[ZG_SP_S], ml[ZG_SP_S], of[ZG_SP_S];
 #pragma unroll
     for (int j = 0; j < ZG_SP_S; j++) {
-      const uint32_t of_code = (r[j].x >> 10) & 31u, ml_code = r[j].x >> 26, ll_code = (r[j].y >> 10) & 63u;
+      const uint32_t of_code = codes[j] & 255u, ml_code = (codes[j] >> 8) & 255u, ll_code = codes[j] >> 16;
       const uint32_t vl = s_llb[ll_code < 36 ? ll_code : 0], vm = s_mlb[ml_code < 53 ? ml_code : 0];
-      const uint32_t xb_ll = vl >> 24, xb_ml = vm >> 24;
+      const uint32_t xb_ll = xbv[j] & 255u, xb_ml = xbv[j] >> 8;
       const uint32_t q_ll = P[j] - of_code - xb_ml - xb_ll;              // >= 0 for every record zg_k_seq emitted
       const uint64_t pa = (uint64_t)(bs + (q_ll >> 3));
       const zg_v3u wv = *(const zg_gv3u*)(pa & ~3ull);                    // dword-aligned: a misaligned load is split by the hardware
