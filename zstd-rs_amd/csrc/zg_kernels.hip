@@ -449,11 +449,11 @@ __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
 // parallel by zg_k_seqpost. Four lanes serve one block (one per chain plus one spare), ZG_SEQ_G blocks per wave,
 // tables staged in LDS as {u16 baseline << 4 | state bits, u8 all bits the state's symbol takes}.
 //
-// gfx950 counts loads and stores in one in-order counter (vmcnt), so a store inside the decode loop would make the
-// next bitstream load wait for the store's full round trip. The loop therefore never touches global memory: the wave
-// alternates between a DECODE phase (ZG_SEQ_CH sequences per block: tables, bitstream and output all in LDS) and a
-// MOVER phase in which the lanes extend every block's bitstream ring downwards with 16-byte loads (landing one
-// phase later, i.e. behind a whole decode phase) and flush the recorded states with 8-byte stores.
+// The chain never touches global memory. A workgroup is two waves: the DECODER wave works in LDS only (tables,
+// a 512-byte ring of each block's bitstream, the recorded states), ZG_SEQ_CH sequences per block and phase; the MOVER
+// wave, one barrier behind, flushes the states of the phase just finished with 8-byte stores and extends every ring
+// downwards with 16-byte loads that it lands one phase later, so neither wave ever waits for a load it just issued and
+// the decoder only meets the mover at the barrier that ends a phase.
 //
 // A decode phase comes in two forms. While more than ZG_SEQ_CH sequences are left, none of them is the block's last
 // one (which takes no state bits, :203) and a stream that runs out of bits is corrupt, so the FAST form checks nothing
@@ -464,10 +464,14 @@ __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
 // ------------------------------------------------------------------------------------------------------------
 #define ZG_SEQ_CH 12                                  // sequences per block between two mover phases
 #define ZG_SEQ_CMAX 144                               // >= bytes ZG_SEQ_CH sequences can consume (12 x 89 bits)
-#define ZG_SEQ_MARGIN (2 * ZG_SEQ_CMAX + 32)          // bytes of bitstream kept resident below the current position
+// Bytes of bitstream kept resident below the position a request is based on. A piece requested after phase k (position
+// P_k) lands during phase k+2's decode and is first read in phase k+3, which reaches down to P_k - 3 CMAX - 16; and what it
+// overwrites, 512 bytes further up, must be above everything phase k+2 reads (<= P_k + 8): MARGIN + 16 + 8 < 512.
+#define ZG_SEQ_MARGIN (3 * ZG_SEQ_CMAX + 32)
 #define ZG_SEQ_RING 512                               // per-block ring, indexed by the low bits of the global address
 #define ZG_SEQ_PIECES 10                              // 16-byte pieces one mover phase can add per block (>= CMAX/16 + 1)
-#define ZG_SEQ_PREG ((ZG_SEQ_PIECES + 3) / 4)         // piece requests per lane and phase: a block's four lanes share them
+#define ZG_SEQ_PREG ((ZG_SEQ_PIECES + 3) / 4)         // piece requests per lane and phase: a block's four mover lanes share them
+static_assert(ZG_SEQ_MARGIN + 16 + 8 < ZG_SEQ_RING, "ring too small for the margin");
 #define ZG_SEQ_PRO ((ZG_SEQ_MARGIN + 16 + 8 + 15 + 15) / 16 + 1)   // pieces of the prologue fill
 
 // Ring storage: 16 bytes that mirror the ring's END, then the ring. The four dwords a step looks at are the ones
@@ -541,15 +545,19 @@ __device__ __forceinline__ void zg_seq_step(ZgSeqChain& c, const uint16_t* tab, 
   }
 }
 
-__global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
+__global__ void __launch_bounds__(128) zg_k_seq(ZgBatchDev d) {
   __shared__ uint16_t s_tab[ZG_SEQ_G][ZG_FSE_SLOT_U32 + 2];   // + the one-entry dummy table of the spare lane
   __shared__ uint8_t s_xb[ZG_SEQ_G][ZG_FSE_SLOT_U32 + 4];
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[ZG_SEQ_G][ZG_SEQ_RSTORE];
-  __shared__ __attribute__((aligned(16))) uint2 s_out[ZG_SEQ_G][ZG_SEQ_CH];   // records, 4 x u16: states {OF, ML, LL, 0}
+  __shared__ __attribute__((aligned(16))) uint2 s_out[2][ZG_SEQ_G][ZG_SEQ_CH];   // records, 4 x u16: states {OF, ML, LL, 0}; one buffer per phase parity
+  __shared__ int32_t s_pos[2][ZG_SEQ_G];            // decoder -> mover, per phase parity: the block's position after the phase,
+  __shared__ uint32_t s_cnt[2][ZG_SEQ_G];           //   records of the phase | still active << 8
+  __shared__ uint32_t s_more[2];                    //   any block of the workgroup still active
   __shared__ uint64_t s_fetch_hi[ZG_SEQ_G], s_fetch_lo[ZG_SEQ_G];   // prologue: the part of each block's stream to load, [lo, hi)
   __shared__ uint8_t s_log[ZG_SEQ_G][4];
   __shared__ int s_ok[ZG_SEQ_G];
   const uint32_t base = blockIdx.x * ZG_SEQ_G, t = threadIdx.x;
+  const bool mover = t >= 64u;
   for (uint32_t g = 0; g < ZG_SEQ_G; g++) {
     uint32_t idx = base + g;
     if (idx >= d.nseq_blocks) break;
@@ -564,13 +572,13 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
       unsigned lg = d.slot_log[(uint64_t)sl[k] * 4 + k];
       if (lg > 9) { ok = false; continue; }
       const uint32_t* g_t = d.fse_arena + (uint64_t)sl[k] * ZG_FSE_SLOT_U32 + offs[k];
-      {  // <= 512 entries: every lane loads its (up to 8) entries first, then stores them
-        uint32_t v[8];
+      {  // <= 512 entries: every lane loads its (up to 4) entries first, then stores them
+        uint32_t v[4];
 #pragma unroll
-        for (int j = 0; j < 8; j++) { const uint32_t i = t + 64 * j; v[j] = i < (1u << lg) ? g_t[i] : 0u; }
+        for (int j = 0; j < 4; j++) { const uint32_t i = t + 128 * j; v[j] = i < (1u << lg) ? g_t[i] : 0u; }
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const uint32_t i = t + 64 * j;
+        for (int j = 0; j < 4; j++) {
+          const uint32_t i = t + 128 * j;
           if (i < (1u << lg)) {
             const uint32_t nb = ZG_FSE_NB(v[j]);
             s_tab[g][offs[k] + i] = (uint16_t)((ZG_FSE_BL(v[j]) << 4) | nb);
@@ -583,9 +591,9 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
     if (t == 0) { s_ok[g] = ok ? 1 : 0; s_tab[g][ZG_FSE_SLOT_U32] = 0; s_xb[g][ZG_FSE_SLOT_U32] = 0; }
   }
   __syncthreads();
-  // ---- per-lane setup: four lanes per block. Lane role 0 follows the OF chain, 1 the ML chain, 2 the LL chain; role 3
-  // is the spare (its "table" is the one-entry dummy: no bits). All four hold the block's scalars.
-  const uint32_t g = t >> 2, role = t & 3u;
+  // ---- per-lane setup: four lanes per block in either wave. Decoder: lane role 0 follows the OF chain, 1 the ML chain,
+  // 2 the LL chain; role 3 is the spare (its "table" is the one-entry dummy: no bits). All four hold the block's scalars.
+  const uint32_t g = (t & 63u) >> 2, role = t & 3u;
   const bool owner = role == 3u;
   bool act = base + g < d.nseq_blocks;
   bool have = false;
@@ -604,17 +612,17 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
     const ZgBlock blk = d.blocks[b];
     if (!s_ok[g]) {
       // FSEDecoder::init_state on a table that was never set (fse_decoder.rs:33-35), or an upstream failure
-      if (owner) zg_set_status(d.status, b, ZG_FSE_UNINIT);
+      if (owner && !mover) zg_set_status(d.status, b, ZG_FSE_UNINIT);
       act = false;
     } else {
       const uint32_t bits_off = d.aux[b].seq_bits_off;
-      if (bits_off > blk.src_len) { if (owner) zg_set_status(d.status, b, ZG_INTERNAL); act = false; }
+      if (bits_off > blk.src_len) { if (owner && !mover) zg_set_status(d.status, b, ZG_INTERNAL); act = false; }
       else {
         const uint8_t* bs = d.src + blk.src_off + bits_off;
         const uint32_t bs_len = blk.src_len - bits_off;
         nseq = blk.nseq;
         const uint32_t lastb = bs_len ? bs[bs_len - 1] : 0;
-        if (bs_len == 0 || lastb == 0) { if (owner) zg_set_status(d.status, b, ZG_SEQ_EXTRA_PADDING); act = false; }  // :29-40
+        if (bs_len == 0 || lastb == 0) { if (owner && !mover) zg_set_status(d.status, b, ZG_SEQ_EXTRA_PADDING); act = false; }  // :29-40
         else {
           P = (int32_t)(bs_len - 1) * 8 + (int32_t)(zg_hbit(lastb) - 1);
           bsA = (uint64_t)bs;
@@ -636,9 +644,9 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
       if (want < floorA) want = floorA;
       lo = want;
     }
-    if (owner) { s_fetch_hi[g] = act ? top : 0; s_fetch_lo[g] = act ? want : 0; }
+    if (owner && !mover) { s_fetch_hi[g] = act ? top : 0; s_fetch_lo[g] = act ? want : 0; }
     __syncthreads();
-    for (uint32_t j = t; j < ZG_SEQ_G * ZG_SEQ_PRO; j += 64) {
+    for (uint32_t j = t; j < ZG_SEQ_G * ZG_SEQ_PRO; j += 128) {
       const uint32_t gg = j / ZG_SEQ_PRO, k = j % ZG_SEQ_PRO;
       const uint64_t hi = s_fetch_hi[gg], addr = hi - 16ull * (k + 1);
       if (hi && addr >= s_fetch_lo[gg] && addr < hi) { const zg_v4u v = *(const zg_gv4u*)addr; zg_ring_put(s_ring[gg], addr, v); }
@@ -653,81 +661,98 @@ __global__ void __launch_bounds__(64) zg_k_seq(ZgBatchDev d) {
     c.st = (q >= 0 && role != 3u) ? zg_ring_bits(store, q + rbits, lg) : 0u;
     c.e = tab[c.st]; c.s = xtab[c.st];
     P -= (int32_t)(ll_log + of_log + ml_log);
-    if (owner) d.seq_out[b].pad = (uint32_t)P;   // where the first sequence starts: zg_k_seqpost rebuilds the positions from the bit counts
+    if (owner && !mover) d.seq_out[b].pad = (uint32_t)P;   // where the first sequence starts: zg_k_seqpost rebuilds the positions from the bit counts
     left = nseq;
   }
   c.pr = P + rbits;
-  zg_v4u piece[ZG_SEQ_PREG];
-  uint64_t piece_addr[ZG_SEQ_PREG];
-  bool piece_ok[ZG_SEQ_PREG];
-#pragma unroll
-  for (int pi = 0; pi < ZG_SEQ_PREG; pi++) { piece[pi] = zg_v4u{0, 0, 0, 0}; piece_addr[pi] = 0; piece_ok[pi] = false; }
-  uint16_t* const out_base = (uint16_t*)&s_out[g][0] + role;   // record {OF, ML, LL state, spare}: one u16 per lane
 #ifdef ZG_PROFILE_SEQ
   unsigned long long tcs[3] = {0, 0, 0}, tl_ = clock64();
 #define ZG_QTICK(i) { const unsigned long long n_ = clock64(); tcs[i] += n_ - tl_; tl_ = n_; }
 #else
 #define ZG_QTICK(i)
 #endif
-  // ---- main loop
-  while (__any(act)) {
-    ZG_QTICK(2)
-    // DECODE phase: LDS only, and one LDS round trip per sequence: the lane's next table entry, its bit count and the
+  if (!mover) {
+    if (act) zg_seq_window(c, store4);   // every step requests the next one's window; the mover only writes far below it, so it stays valid across phases
+    // ---- DECODER wave: LDS only, and one LDS round trip per sequence: the lane's next table entry, its bit count and the
     // 128 bits of stream below the next position are requested together; everything between is 32-bit ALU, and the
     // three chains of a block run in three lanes that exchange their bit counts through DPP quad permutes
     // (FSEDecoder::update_state, fse_decoder.rs:40-48, order LL, ML, OF :204-206).
-    uint32_t cnt = 0;
-    if (act) zg_seq_window(c, store4);
-    if (act && left > ZG_SEQ_CH) {
+    for (uint32_t par = 0;; par ^= 1u) {
+      uint16_t* const out_base = (uint16_t*)&s_out[par][g][0] + role;   // record {OF, ML, LL state, spare}: one u16 per lane
+      uint32_t cnt = 0;
+      if (act && left > ZG_SEQ_CH) {
 #pragma unroll
-      for (int k = 0; k < ZG_SEQ_CH; k++) zg_seq_step<true>(c, tab, xtab, store4, out_base + 4 * k, rbits, act, left, cnt);
-      cnt = ZG_SEQ_CH; left -= ZG_SEQ_CH;
-      if (c.pr < rbits) act = false;                               // ran out of bits with sequences left (:209-211)
-    } else if (act) {
+        for (int k = 0; k < ZG_SEQ_CH; k++) zg_seq_step<true>(c, tab, xtab, store4, out_base + 4 * k, rbits, act, left, cnt);
+        cnt = ZG_SEQ_CH; left -= ZG_SEQ_CH;
+        if (c.pr < rbits) act = false;                             // ran out of bits with sequences left (:209-211)
+      } else if (act) {
 #pragma unroll
-      for (int k = 0; k < ZG_SEQ_CH; k++) zg_seq_step<false>(c, tab, xtab, store4, out_base, rbits, act, left, cnt);
-    }
-    P = c.pr - rbits;
-    ZG_QTICK(0)
-    // MOVER phase: every quad serves its own block (position, ring bounds and output pointer are held by all four
-    // lanes), so nothing is exchanged across the workgroup and the loop has no barrier: LDS accesses of one wave are in order.
-    // (1) land the pieces requested one phase ago
-#pragma unroll
-    for (int pi = 0; pi < ZG_SEQ_PREG; pi++) if (piece_ok[pi]) zg_ring_put(store, piece_addr[pi], piece[pi]);
-    // (2) flush the chunk: the quad's lanes take every fourth record (8 bytes each)
-#pragma unroll
-    for (int i = 0; i < (ZG_SEQ_CH + 3) / 4; i++) {
-      const uint32_t k = role + 4u * (uint32_t)i;
-      if (k < cnt) ((zg_gv2u*)dstp)[k] = *(const zg_v2u*)&s_out[g][k];
-    }
-    dstp += (uint64_t)cnt * sizeof(uint2);
-    // (3) request the next pieces: [want, hi) just below what the ring holds
-    {
-      uint64_t hi = 0, want = 0;
-      if (act) {
-        const uint64_t p0 = bsA + (uint64_t)(P >> 3);
-        want = p0 > ZG_SEQ_MARGIN ? (p0 - ZG_SEQ_MARGIN) & ~15ull : 0;
-        if (want < floorA) want = floorA;
-        if (want < lo) { hi = lo; lo = want; }
+        for (int k = 0; k < ZG_SEQ_CH; k++) zg_seq_step<false>(c, tab, xtab, store4, out_base, rbits, act, left, cnt);
       }
-#pragma unroll
-      for (int pi = 0; pi < ZG_SEQ_PREG; pi++) {
-        const uint64_t addr = hi - 16ull * (role + 4u * (uint32_t)pi + 1u);
-        piece_ok[pi] = hi && addr >= want && addr < hi;
-        if (piece_ok[pi]) { piece[pi] = *(const zg_gv4u*)addr; piece_addr[pi] = addr; }
-      }
+      P = c.pr - rbits;
+      const bool more = __any(act);
+      if (owner) { s_pos[par][g] = P; s_cnt[par][g] = cnt | (act ? 256u : 0u); }
+      if (t == 0) s_more[par] = more ? 1u : 0u;
+      ZG_QTICK(0)
+      __syncthreads();
+      ZG_QTICK(1)
+      if (!more) break;
     }
-    ZG_QTICK(1)
+    if (have && owner) {
+      if (left != 0) status = ZG_SEQ_NOT_ENOUGH_BYTES;        // the loop stopped at a sequence that ran out of bits (:209-211)
+      else if (P > 0) status = ZG_SEQ_EXTRA_BITS;             // :214-220
+      zg_set_status(d.status, b, status);
+    }
+  } else {
+    // ---- MOVER wave: every quad serves its own block (ring bounds and output pointer are held by all four lanes)
+    zg_v4u piece[ZG_SEQ_PREG];
+    uint64_t piece_addr[ZG_SEQ_PREG];
+    bool piece_ok[ZG_SEQ_PREG];
+#pragma unroll
+    for (int pi = 0; pi < ZG_SEQ_PREG; pi++) { piece[pi] = zg_v4u{0, 0, 0, 0}; piece_addr[pi] = 0; piece_ok[pi] = false; }
+    for (uint32_t par = 0;; par ^= 1u) {
+      __syncthreads();                                             // the phase's records and positions are in LDS
+      const uint32_t cw = s_cnt[par][g], cnt = cw & 255u;
+      const bool live = have && (cw >> 8) != 0u;
+      const int32_t pos = s_pos[par][g];
+      const bool more = s_more[par] != 0u;
+      // (1) the records of the phase: the quad's lanes take every fourth one (8 bytes each)
+      zg_v2u rec[(ZG_SEQ_CH + 3) / 4];
+#pragma unroll
+      for (int i = 0; i < (ZG_SEQ_CH + 3) / 4; i++) rec[i] = *(const zg_v2u*)&s_out[par][g][role + 4u * (uint32_t)i];
+      // (2) land the pieces requested one phase ago (they are older than every store below)
+#pragma unroll
+      for (int pi = 0; pi < ZG_SEQ_PREG; pi++) if (piece_ok[pi]) zg_ring_put(store, piece_addr[pi], piece[pi]);
+      // (3) request the next pieces: [want, hi) just below what the ring holds or has been promised
+      {
+        uint64_t hi = 0, want = 0;
+        if (live) {
+          const uint64_t p0 = bsA + (uint64_t)(pos >> 3);
+          want = p0 > ZG_SEQ_MARGIN ? (p0 - ZG_SEQ_MARGIN) & ~15ull : 0;
+          if (want < floorA) want = floorA;
+          if (want < lo) { hi = lo; lo = want; }
+        }
+#pragma unroll
+        for (int pi = 0; pi < ZG_SEQ_PREG; pi++) {
+          const uint64_t addr = hi - 16ull * (role + 4u * (uint32_t)pi + 1u);
+          piece_ok[pi] = hi && addr >= want && addr < hi;
+          if (piece_ok[pi]) { piece[pi] = *(const zg_gv4u*)addr; piece_addr[pi] = addr; }
+        }
+      }
+      // (4) flush
+#pragma unroll
+      for (int i = 0; i < (ZG_SEQ_CH + 3) / 4; i++) {
+        const uint32_t k = role + 4u * (uint32_t)i;
+        if (k < cnt) ((zg_gv2u*)dstp)[k] = rec[i];
+      }
+      dstp += (uint64_t)cnt * sizeof(uint2);
+      if (!more) break;
+    }
   }
 #ifdef ZG_PROFILE_SEQ
   if (t == 0 && d.dbg) { atomicAdd(&d.dbg[16], tcs[0]); atomicAdd(&d.dbg[17], tcs[1]); atomicAdd(&d.dbg[18], 1ull); }
 #endif
 #undef ZG_QTICK
-  if (have && owner) {
-    if (left != 0) status = ZG_SEQ_NOT_ENOUGH_BYTES;          // the loop stopped at a sequence that ran out of bits (:209-211)
-    else if (P > 0) status = ZG_SEQ_EXTRA_BITS;               // :214-220
-    zg_set_status(d.status, b, status);
-  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -808,7 +833,7 @@ __global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
     }
     // symbols and bit counts from the recorded states: a sequence takes its three codes' extra bits and, unless it is the
     // block's last one, the three state updates (:203-206)
-    uint32_t codes[ZG_SP_S], xbv[ZG_SP_S];         // codes: of | ml << 8 | ll << 16; xbv: xb_ll | xb_ml << 8
+    uint32_t codes[ZG_SP_S];                       // of | ml << 8 | ll << 16
     uint32_t P[ZG_SP_S];
     {
       uint32_t tx = 0;
@@ -820,7 +845,6 @@ __global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
         const uint32_t upd = ib + (uint32_t)j + 1u == nseq ? 0u : (e_of & 15u) + (e_ml & 15u) + (e_ll & 15u);
         const bool have = (uint32_t)j < n;             // (a slot past the end takes no bits: its reads below stay at the last position)
         codes[j] = have ? of_code | (ml_code << 8) | (ll_code << 16) : 0u;
-        xbv[j] = have ? (vl >> 24) | ((vm >> 24) << 8) : 0u;
         P[j] = tx;
         tx += have ? of_code + (vl >> 24) + (vm >> 24) + upd : 0u;
       }
@@ -842,7 +866,7 @@ __global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
     for (int j = 0; j < ZG_SP_S; j++) {
       const uint32_t of_code = codes[j] & 255u, ml_code = (codes[j] >> 8) & 255u, ll_code = codes[j] >> 16;
       const uint32_t vl = s_llb[ll_code < 36 ? ll_code : 0], vm = s_mlb[ml_code < 53 ? ml_code : 0];
-      const uint32_t xb_ll = xbv[j] & 255u, xb_ml = xbv[j] >> 8;
+      const uint32_t xb_ll = vl >> 24, xb_ml = vm >> 24;
       const uint32_t q_ll = P[j] - of_code - xb_ml - xb_ll;              // >= 0 for every record zg_k_seq emitted
       const uint64_t pa = (uint64_t)(bs + (q_ll >> 3));
       const zg_v3u wv = *(const zg_gv3u*)(pa & ~3ull);                    // dword-aligned: a misaligned load is split by the hardware
@@ -1678,7 +1702,7 @@ void zg_launch_huf(const ZgBatchDev& d, hipStream_t s) {
   if (d.nhuf_groups) hipLaunchKernelGGL(zg_k_huf, dim3(d.nhuf_groups), dim3(ZG_HUF_T), 0, s, d);
 }
 void zg_launch_seq(const ZgBatchDev& d, hipStream_t s) {
-  if (d.nseq_blocks) hipLaunchKernelGGL(zg_k_seq, dim3((d.nseq_blocks + ZG_SEQ_G - 1) / ZG_SEQ_G), dim3(64), 0, s, d);
+  if (d.nseq_blocks) hipLaunchKernelGGL(zg_k_seq, dim3((d.nseq_blocks + ZG_SEQ_G - 1) / ZG_SEQ_G), dim3(128), 0, s, d);
 }
 // The literals chain (Huffman tree descriptions, zg_k_huf) ran beside the sequences chain on a second stream: fold its
 // errors into the block status. The literals section is decoded first (block_decoder.rs:131-150), so its errors —
