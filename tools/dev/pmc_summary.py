@@ -70,7 +70,6 @@ def main():
     f4 = cal["zg_k_calib_copy4"]["read_factor"] or 1.0
     fg = cal["zg_k_calib_gather<unsigned long>"]["read_factor"] or 1.0
     w16 = cal["zg_k_calib_copy"]["write_factor"] or 1.0
-    passes = 3.0     # bench.py --steps 2 --warmup 1 under the profiler, + 7 passes of the per-kernel timing leg: use launches instead
     D = bench["config"]["plaintext_bytes_job"]
     res = {"kernels_sha256": hashlib.sha256(open(os.path.join(ROOT, "zstd-rs_amd", "csrc", "zg_kernels.hip"), "rb").read()).hexdigest(),
            "workload": bench["config"]["name"], "plaintext_bytes": D,
