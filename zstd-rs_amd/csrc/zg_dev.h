@@ -273,9 +273,9 @@ ZG_HD int zg_huf_build(const uint8_t* weights, int nweights, uint16_t* out, int*
 // sequences in parallel before the previous block's final history is known; the scan kernel resolves the symbols.
 #define ZG_SYM_TAG(v) ((v) >> 30)
 #define ZG_SYM_K(v) ((v) & 0x3FFFFFFFu)
-ZG_HD uint32_t zg_sym_dec(uint32_t v) {  // saturating "minus one" (sequence_execution.rs:74)
-  if (ZG_SYM_TAG(v)) return v + 1;
-  return v ? v - 1 : 0;
+ZG_HD uint32_t zg_sym_dec(uint32_t v) {  // saturating "minus one" (sequence_execution.rs:74); selects only (the callers are wave code)
+  const uint32_t c = v ? v - 1 : 0u;
+  return ZG_SYM_TAG(v) ? v + 1 : c;
 }
 ZG_HD uint32_t zg_sym_resolve(uint32_t v, const uint32_t* h) {
   uint32_t t = ZG_SYM_TAG(v);
@@ -285,15 +285,16 @@ ZG_HD uint32_t zg_sym_resolve(uint32_t v, const uint32_t* h) {
 }
 // do_offset_history (sequence_execution.rs:59-118) on symbolic slots h0..h2; returns the (symbolic) actual offset.
 ZG_HD uint32_t zg_hist_step(uint32_t of, uint32_t ll, uint32_t& h0, uint32_t& h1, uint32_t& h2) {
-  uint32_t actual;
-  if (ll > 0) {
-    if (of == 1) return h0;
-    if (of == 2) { actual = h1; h1 = h0; h0 = actual; return actual; }
-    actual = of == 3 ? h2 : of - 3;
-  } else {
-    if (of == 1) { actual = h1; h1 = h0; h0 = actual; return actual; }
-    actual = of == 2 ? h2 : of == 3 ? zg_sym_dec(h0) : of - 3;
-  }
-  h2 = h1; h1 = h0; h0 = actual;
+  // Without literals the repeat codes shift by one (:68-81): c is the code as if literals were present, 4 = "slot 0 minus one".
+  // Written with selects: every lane of a wave takes the same instructions.
+  const bool isnew = of > 3u;
+  const uint32_t c = ll ? of : of + 1u;
+  const uint32_t rep = c == 1u ? h0 : c == 2u ? h1 : c == 3u ? h2 : zg_sym_dec(h0);
+  const uint32_t actual = isnew ? of - 3u : rep;
+  const bool rot = isnew || c >= 3u;                  // slots move down by one, the offset enters at the front
+  const bool moved = rot || c == 2u;                  // c == 2: slots 0 and 1 swap; c == 1: nothing changes (actual == h0)
+  h2 = rot ? h1 : h2;
+  h1 = moved ? h0 : h1;
+  h0 = actual;
   return actual;
 }

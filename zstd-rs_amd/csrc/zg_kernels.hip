@@ -770,6 +770,8 @@ struct ZgHistMap { uint32_t s[3]; };
 __device__ __forceinline__ ZgHistMap zg_map_identity() { return {{1u << 30, 2u << 30, 3u << 30}}; }
 // v (a slot value relative to map A's output) expressed relative to A's input
 __device__ __forceinline__ uint32_t zg_map_apply(const ZgHistMap& A, uint32_t v) {
+  // (branches on purpose: almost every slot is a constant, and a wave whose lanes all hold constants skips the rest;
+  //  a select-only version was measured slower in zg_k_seqpost and zg_k_scan)
   const uint32_t t = ZG_SYM_TAG(v);
   if (!t) return v;
   const uint32_t a = t == 1 ? A.s[0] : t == 2 ? A.s[1] : A.s[2], k = ZG_SYM_K(v);
@@ -900,9 +902,13 @@ __global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const uint32_t pl = __shfl_up(sl, off, 64), po = __shfl_up(so, off, 64);
+      if ((int)lane >= off) { sl += pl; so += po; }
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
       ZgHistMap pm;
       pm.s[0] = __shfl_up(sc.s[0], off, 64); pm.s[1] = __shfl_up(sc.s[1], off, 64); pm.s[2] = __shfl_up(sc.s[2], off, 64);
-      if ((int)lane >= off) { sl += pl; so += po; sc = zg_map_compose(pm, sc); }
+      if ((int)lane >= off) sc = zg_map_compose(pm, sc);
     }
     if (lane == 63) { s_wm[wv] = sc; s_wl[wv] = sl; s_wo[wv] = so; }
     // exclusive: what the lanes before this one did
@@ -910,13 +916,14 @@ __global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
     ex.s[0] = __shfl_up(sc.s[0], 1, 64); ex.s[1] = __shfl_up(sc.s[1], 1, 64); ex.s[2] = __shfl_up(sc.s[2], 1, 64);
     if (lane == 0) ex = zg_map_identity();
     __syncthreads();
-    ZgHistMap pre = carry, tot = carry;
+    ZgHistMap pre = carry, tot = carry;           // tot runs through the waves' maps; pre is its value in front of this wave
     uint32_t pl = lit_carry, po = out_carry, totl = lit_carry, toto = out_carry;
 #pragma unroll
     for (uint32_t w = 0; w < ZG_SP_T / 64; w++) {
       const ZgHistMap wm = s_wm[w];
       const uint32_t wl = s_wl[w], wo = s_wo[w];
-      if (w < wv) { pre = zg_map_compose(pre, wm); pl += wl; po += wo; }
+      if (w == wv) pre = tot;
+      if (w < wv) { pl += wl; po += wo; }
       tot = zg_map_compose(tot, wm); totl += wl; toto += wo;
     }
     pre = zg_map_compose(pre, ex);                 // history before this thread's first sequence, relative to the block start
