@@ -170,6 +170,7 @@ int zgpu_batch_debug_timers(zgpu_batch*, uint64_t out[1024]);
 /* diagnostics for the parity tests of the LZ77 stage: the units a submit was cut into, and raw reads of the flatten
  * scratch (what = 0: one u32 effective offset per output byte of a unit, at scratch_base + position; 1: per-unit sizes) */
 uint32_t zgpu_batch_num_units(const zgpu_batch*);
+uint32_t zgpu_batch_debug_sweep_mode(const zgpu_batch*);   /* after sync: 0 plain chain of sweep steps, 1 split (tails / heads), 2 split, then repeated plain */
 int zgpu_batch_unit(zgpu_batch*, uint32_t unit, uint32_t* first_block, uint32_t* nblocks, uint64_t* scratch_base);
 int zgpu_batch_debug_scratch(zgpu_batch*, int what, uint64_t off, void* dst, uint64_t n);
 /* diagnostics: runs kernels with known traffic per access pattern (16 B/lane copy, 4 B/lane copy, random 4- and 8-byte

@@ -632,3 +632,52 @@ def test_offsets_of_2_pow_30_and_more(ctx, of_code):
     with pytest.raises(zgpu.ZgpuError) as e:
         ctx.decode_all(z, 1 << 20)
     assert e.value.status in (52, 53)
+
+
+def _run_batch(z, env):
+    import zgpu
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        c = zgpu.Context(0)
+        b = c.prepare(z)
+        assert b.parse_status == 0
+        b.run(); b.sync()
+        out, mode, bad = b.read(0, b.total_out), b.sweep_mode(), b.bad_status
+        b.close(); c.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    return out, mode, bad
+
+
+def test_split_sweep_tails_and_heads():
+    """a frame whose window (128 KiB) is much shorter than its units (512 KiB): only the last window of every unit is in
+    the chain of sweep steps, the heads are filled beside it; same bytes as the plain chain and as the generator"""
+    import zgdata
+    data = zgdata.text_like(24 << 20, seed=0x5EE)
+    z = zgdata.zstd_compress(data, window_log=17)
+    out, mode, bad = _run_batch(z, {})
+    assert bad == 0 and mode == 1 and out == data
+    out, mode, bad = _run_batch(z, {"ZGPU_SWEEP_SPLIT": "0"})
+    assert bad == 0 and mode == 0 and out == data
+    # several frames of different lengths in one submit: a step holds the k-th unit of every frame that has one
+    parts = [zgdata.text_like(n, seed=0x600 + i) for i, n in enumerate((9 << 20, 3 << 20, 700000, 5 << 20))]
+    zz = b"".join(zgdata.zstd_compress(p, window_log=17) for p in parts)
+    out, mode, bad = _run_batch(zz, {})
+    assert bad == 0 and mode == 1 and out == b"".join(parts)
+
+
+def test_split_sweep_is_repeated_when_a_match_exceeds_the_window():
+    """the split relies on matches not reaching beyond the window; the engine is told a window shorter than the real one,
+    zg_k_seqpost reports the longer matches and the sweep is repeated as a plain chain: right bytes either way"""
+    import zgdata
+    data = zgdata.text_like(24 << 20, seed=0x5EF)
+    z = zgdata.zstd_compress(data)                     # window 2 MiB or more, units of 1 MiB
+    out, mode, bad = _run_batch(z, {"ZGPU_UNIT_BLOCKS": "8", "ZGPU_SWEEP_W": "131072"})
+    assert bad == 0 and mode == 2 and out == data
+    out, mode, bad = _run_batch(z, {"ZGPU_UNIT_BLOCKS": "8"})
+    assert bad == 0 and mode == 0 and out == data      # units shorter than the window: nothing to split

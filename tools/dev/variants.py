@@ -1,5 +1,5 @@
 """One data set, several engine variants (environment switches read when a Context is created): kernel times side by side.
-usage: variants.py [size] [kind] -- VAR=VALUE[,VAR=VALUE] ..."""
+usage: variants.py [size] [text|iso|blocks] -- VAR=VALUE[,VAR=VALUE] ..."""
 import hashlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "zstd-rs_amd")); sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -10,8 +10,14 @@ sep = args.index("--") if "--" in args else len(args)
 size = int(args[0]) if sep > 0 else 1000000000
 kind = args[1] if sep > 1 else "text"
 variants = args[sep + 1:] or [""]
-plain = zgdata.text_like(size) if kind == "text" else zgdata.iso_like(size)
-z = zgdata.zstd_compress(plain)
+if kind == "blocks":     # single-block frames: every unit is a first unit, the sweep is one launch
+    parts = [zgdata.text_like(128 << 10, seed=0x900 + i) for i in range(max(size >> 17, 1))]
+    plain = b"".join(parts)
+    z = b"".join(zgdata.zstd_compress(q) for q in parts)
+    size = len(plain)
+else:
+    plain = zgdata.text_like(size) if kind == "text" else zgdata.iso_like(size)
+    z = zgdata.zstd_compress(plain)
 want = hashlib.sha256(plain).digest()
 for v in variants:
     sets = [kv.split("=") for kv in v.split(",") if kv]

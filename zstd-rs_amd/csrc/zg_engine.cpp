@@ -43,6 +43,8 @@ int Scratch::init_events() {
   for (auto& e : ev_huf)
     if (hipEventCreate(&e) != hipSuccess) return ZG_HIP_ERROR;
   if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return ZG_HIP_ERROR;
+  for (auto& e : ev_sw)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return ZG_HIP_ERROR;
   have_events = true;
   return 0;
 }
@@ -56,6 +58,8 @@ void Scratch::release() {
   for (auto& e : ev_huf)
     if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
+  for (auto& e : ev_sw)
+    if (e) { (void)hipEventDestroy(e); e = nullptr; }
   have_events = false;
 }
 
@@ -365,6 +369,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   d.dbg = getenv("ZGPU_DEBUG_TIMERS") ? sc->d_dbg.as<unsigned long long>() : nullptr;
   { const char* e = getenv("ZGPU_FORCE_INORDER"); d.flags = (e && e[0] == '1') ? 1u : 0u; }
   d.flags |= (uint32_t)flat_shape_ << 2;
+  { const char* e = getenv("ZGPU_SWEEP_W"); d.sweep_window = (e && atoi(e) > 0) ? (uint32_t)atoi(e) : 0u; }
   if (hipStreamSynchronize(stream_) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
   *out = b;
   return ZG_OK;
@@ -393,6 +398,7 @@ int Batch::run() {
   // state chains -> post-pass) of a block are independent, and all of these kernels are latency-bound chains that leave most
   // of the chip idle: the two chains run side by side on two streams and meet again in zg_k_merge.
   hipStream_t s2 = eng->stream2_;
+  ZG_HIP(hipMemsetAsync(d.totals + 3, 0, 4, s));   // "a match reaches beyond its frame's window" (zg_k_seqpost)
   zg_launch_tables(d, s, 1);
   ZG_HIP(hipEventRecord(ev[1], s));
   // The literals chain starts when the FSE tables are done, i.e. together with zg_k_seq: the dispatcher then places the
@@ -452,7 +458,8 @@ int Batch::run() {
   ZG_HIP(hipEventRecord(ev[6], s));
   zg_launch_flat(d, s);
   ZG_HIP(hipEventRecord(ev[7], s));
-  if (!getenv("ZGPU_DEBUG_NO_SWEEP")) zg_launch_sweep(d, s, sweep_steps.data(), (uint32_t)sweep_steps.size());
+  sweep_mode = 0;
+  if (!getenv("ZGPU_DEBUG_NO_SWEEP")) launch_sweep(true);
   ZG_HIP(hipEventRecord(ev[8], s));
   zg_launch_lz(d, s);   // only frames that left the flatten path (a block regenerating > 128 KiB)
   ZG_HIP(hipEventRecord(ev[9], s));
@@ -461,10 +468,38 @@ int Batch::run() {
   return ZG_OK;
 }
 
+// The sweep. split: tails on the main stream, heads beside them on the second one, which is right as long as no match
+// reaches further back than its frame's window (zg_k_flat reports one that does: sync() then repeats the sweep the plain way).
+void Batch::launch_sweep(bool split) {
+  const char* e = getenv("ZGPU_SWEEP_SPLIT");
+  if (e && e[0] == '0') split = false;
+  uint64_t wmax = 0;
+  for (const ZgFrame& fr : bb.frames) {
+    wmax = fr.window_size > wmax ? fr.window_size : wmax;
+    // an initial history other than the format's (dictionary, continued frame) may hold offsets nobody checked against the window
+    if (fr.hist_init[0] != 1 || fr.hist_init[1] != 4 || fr.hist_init[2] != 8 || fr.dict_len || fr.prior_out) split = false;
+  }
+  if (dev.sweep_window) wmax = dev.sweep_window;
+  if (wmax > 0x7FFFFFFFull) wmax = 0x7FFFFFFFull;
+  split_sweep = zg_launch_sweep(dev, eng->stream_, sweep_steps.data(), (uint32_t)sweep_steps.size(), eng->stream2_, sc->ev_sw, split ? 20u : 0u,
+                                bb.unit_blocks_used * kMaxBlockSize, (uint32_t)wmax);
+  sweep_mode = split_sweep ? 1u : sweep_mode;
+}
+
 int Batch::sync() {
   ZG_HIP(hipSetDevice(eng->device_));
   ZG_HIP(hipStreamSynchronize(eng->stream_));
   if (dev.nframes == 0 || !ran) return ZG_OK;
+  if (split_sweep) {
+    uint32_t far = 0;
+    ZG_HIP(hipMemcpy(&far, dev.totals + 3, 4, hipMemcpyDeviceToHost));
+    if (far) {   // a match longer than the window: the heads may have copied bytes that were not final yet
+      launch_sweep(false);
+      ZG_HIP(hipStreamSynchronize(eng->stream_));
+      sweep_mode = 2;
+    }
+    split_sweep = false;
+  }
   ZG_HIP(hipMemcpy(frame_out.data(), dev.frame_out, (size_t)dev.nframes * sizeof(ZgFrameOut), hipMemcpyDeviceToHost));
   hipEvent_t* ev = sc->ev;
   for (int i = 0; i < ZG_T_TOTAL; i++) {

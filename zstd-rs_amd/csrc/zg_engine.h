@@ -68,6 +68,7 @@ struct Scratch {
       d_dst, d_seqblocks, d_hufitems, d_hufgroups, d_totals, d_og, d_units, d_unitinfo, d_stepunits, d_swdesc, d_dbg, d_raw;
   hipEvent_t ev[ZG_T_COUNT + 1] = {};
   hipEvent_t ev_huf[2] = {}, ev_fork = nullptr;   // zg_k_huf runs on the engine's second stream beside zg_k_seq
+  hipEvent_t ev_sw[20] = {};                      // split sweep: heads on the second stream (zg_launch_sweep)
   bool have_events = false;
   int init_events();
   void release();
@@ -96,6 +97,9 @@ class Batch {
   int commit(FrameState* fs);
   bool saw_last_block = false;           // the run ended with the frame's last block
   int sync();                            // wait, download per-frame results, compute timings
+  void launch_sweep(bool split);
+  bool split_sweep = false;              // the last run used the split sweep: sync() checks that it was entitled to
+  uint32_t sweep_mode = 0;               // of the last run: 0 plain chain of steps, 1 split, 2 split and then repeated as a plain chain (tests)
   int read_output(uint64_t off, uint8_t* dst, uint64_t n);   // D2H
   int read_output_async(uint64_t off, uint8_t* dst, uint64_t n, hipStream_t s);
   const uint8_t* device_output() const { return dev.dst; }

@@ -243,6 +243,7 @@ void BatchBuilder::finish() {
     if (ub < 4) ub = 4;
     if (ub > 256) ub = 256;   // unit-relative positions stay far below 2^30
   }
+  unit_blocks_used = ub;
   uint32_t max_units = 0;
   for (uint32_t f = 0; f < frames.size(); f++) {
     ZgFrame& fr = frames[f];

@@ -37,7 +37,8 @@ struct ZgBatchDev {
   const uint32_t* huf_items;   // (block << 2) | stream
   const ZgHufGroup* huf_groups;
   uint32_t nhuf_groups;
-  uint32_t* totals;            // [4]: [0..1] total output bytes (u64), [2] overflow flag
+  uint32_t* totals;            // [4]: [0..1] total output bytes (u64), [2] overflow flag, [3] a match reaches further back than its frame's window (zg_k_flat)
+  uint32_t sweep_window;       // 0: a frame's window size bounds its matches (checked); else this many bytes instead (tests)
   uint32_t flags;              // bit 0: force the in-order fallback for every frame (tests); bits 2-3: shape of zg_k_flat (0: 1024 threads x 16 KiB tiles, 1: 512 x 8 KiB, 2: 1024 x 8 KiB)
   uint64_t og_words;           // size of the flatten scratch in u32
   uint32_t* og;                // flatten scratch: one u32 "effective offset" per output byte of a unit (0 = literal byte, final already)
@@ -59,6 +60,7 @@ void zg_launch_merge(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_scan(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_lit(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_flat(const ZgBatchDev& d, hipStream_t s);
-void zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* steps, uint32_t nsteps);
+bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* steps, uint32_t nsteps, hipStream_t s2, hipEvent_t* evs, uint32_t nev,
+                     uint32_t unit_bytes, uint32_t window_max);   // s2 / evs: the side stream of the split sweep (nev == 0: one stream, step by step); returns whether it split
 void zg_launch_lz(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_calib(const void* src, void* dst, uint64_t bytes, hipStream_t s);

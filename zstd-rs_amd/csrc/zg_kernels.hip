@@ -45,6 +45,10 @@ __device__ __forceinline__ void zg_set_status(uint32_t* status, uint32_t b, int 
 }
 // The streams of a block's literals run in different waves: which error is reported must not depend on who is first.
 // rank 0 is the most significant; the word keeps (255 - rank) << 8 | status, the largest wins (zg_k_merge strips the rank).
+// how far back a match of the frame may reach as far as the split sweep is concerned (zg_k_flat reports a longer one)
+__device__ __forceinline__ uint32_t zg_sweep_window(const ZgBatchDev& d, const ZgFrame& fr) {
+  return d.sweep_window ? d.sweep_window : (fr.window_size > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)fr.window_size);
+}
 __device__ __forceinline__ void zg_set_lit_status(uint32_t* status, uint32_t b, uint32_t rank, int st) {
   if (st) atomicMax(&status[b], ((255u - rank) << 8) | (uint32_t)st);
 }
@@ -809,6 +813,7 @@ __global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
     }
   }
   const uint32_t nseq = blk.nseq, regen = blk.regen_size;
+  const uint32_t wlim = zg_sweep_window(d, d.frames[blk.frame]);
   const uint8_t* bs = d.src + blk.src_off + d.aux[b].seq_bits_off;
   const uint2* raw = d.raw_arena + blk.seq_base;
   ZgSeq* out = d.seq_arena + blk.seq_base;
@@ -886,12 +891,14 @@ __global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
     // history inside the thread's run, relative to its start; thread totals
     uint32_t h0 = 1u << 30, h1 = 2u << 30, h2 = 3u << 30, tl = 0, to = 0, act[ZG_SP_S];
     uint32_t big = 0;
+    bool far = false;
 #pragma unroll
     for (int j = 0; j < ZG_SP_S; j++) {
       act[j] = 1;
       if (of[j]) {
         const bool tb = of[j] > 3u && of[j] - 3u >= (1u << 30);
         big |= tb ? 1u << j : 0u;
+        far = far || (of[j] > 3u && of[j] - 3u > wlim);
         act[j] = zg_hist_step(tb ? 4u : of[j], ll[j], h0, h1, h2);
       }
       tl += ll[j]; to += ll[j] + ml[j];
@@ -949,6 +956,9 @@ __global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
       }
       if (bad != 0xFFFFFFFFu) atomicMin(&s_err, bad);                               // the first failing sequence decides
     }
+    // a new offset beyond the frame's window: legal here, but no encoder emits one and the split sweep relies on their absence
+    // (repeat codes only repeat what a new offset set, or the frame's initial history, which the host checks)
+    if (far) d.totals[3] = 1u;
     carry = tot; lit_carry = totl; out_carry = toto;
     __syncthreads();
     if (s_err != 0xFFFFFFFFu) break;
@@ -1433,6 +1443,8 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
 #undef ZG_TICK
 }
 
+#define ZG_SW_T 256
+#define ZG_SW_B 4       // groups of 4 output bytes a sweep thread has in flight
 // zg_k_swprep: one thread per (step, unit) entry: everything a sweep workgroup needs about its unit in one 32-byte
 // descriptor, so that a sweep launch starts with ONE dependent scalar load instead of a chain of five.
 __global__ void __launch_bounds__(256) zg_k_swprep(ZgBatchDev d, uint32_t n) {
@@ -1445,9 +1457,11 @@ __global__ void __launch_bounds__(256) zg_k_swprep(ZgBatchDev d, uint32_t n) {
   sd.out = (uint64_t)(d.dst + fo.out_base + d.pos[un.first_block].out_base);
   sd.og = (uint64_t)(d.og + fo.og_base + d.pos[un.first_block].out_base);
   sd.size = d.unit_info[u].size;
+  const uint32_t w = zg_sweep_window(d, d.frames[un.frame]);
+  sd.head = sd.size > w ? (sd.size - w) / (4u * ZG_SW_T * ZG_SW_B) : 0u;
   // a unit of the frame failed in zg_k_flat: its scratch is incomplete; the frame is reported as failed
   sd.live = (!d.totals[2] && fo.fast && fo.err_packed == 0xFFFFFFFFu) ? 1u : 0u;
-  sd.pad[0] = sd.pad[1] = 0;
+  sd.pad = 0;
   d.sweep_desc[i] = sd;
 }
 
@@ -1457,21 +1471,24 @@ __global__ void __launch_bounds__(256) zg_k_swprep(ZgBatchDev d, uint32_t n) {
 // boundary); literal bytes (e = 0) are already in place and come from the dword at w itself. The loads go through a
 // buffer resource: a load that is not needed gets an out-of-range offset (no traffic, no branch), so all loads of a
 // thread are in flight together.
-#define ZG_SW_T 256
-#define ZG_SW_B 4       // groups of 4 output bytes a thread has in flight
-__global__ void __launch_bounds__(ZG_SW_T) __attribute__((amdgpu_waves_per_eu(2, 3))) zg_k_sweep(ZgBatchDev d, uint32_t list_off, uint32_t nbatch, uint32_t dbgmode) {
+//
+// The split sweep (part 1 / 2): a match reaches at most `window` bytes back, so everything a later unit can copy from is
+// the TAIL of the units in front of it. Only the tails (part 1) form the chain of steps; the heads (part 2) are filled
+// beside it, many units per launch, on the engine's second stream. part 0 is the whole unit.
+__global__ void __launch_bounds__(ZG_SW_T) __attribute__((amdgpu_waves_per_eu(2, 3))) zg_k_sweep(ZgBatchDev d, uint32_t list_off, uint32_t nbatch, uint32_t dbgmode, uint32_t part) {
   const ZgSweepDesc sd = d.sweep_desc[list_off + blockIdx.y];
   const uint32_t t = threadIdx.x, size = sd.size;
   constexpr uint32_t BG = ZG_SW_T * ZG_SW_B;                  // groups per batch (4 KiB of output)
-  const uint32_t b0 = blockIdx.x * nbatch;                    // the workgroup's batches: b0 .. b0 + nbatch - 1, one after the other
+  const uint32_t b0 = blockIdx.x * nbatch + (part == 1u ? sd.head : 0u);   // the workgroup's batches: b0 .. b0 + nbatch - 1, one after the other
   if (!sd.live || 4ull * b0 * BG >= size) return;
+  if (part == 2u && b0 >= sd.head) return;
   if (dbgmode == 1) return;                                   // timing experiments (ZGPU_SWEEP_MODE): launch floor
   typedef __attribute__((address_space(1))) uint8_t zg_gu8;
   typedef __attribute__((address_space(1))) uint32_t zg_gu32;
   zg_gu8* out = (zg_gu8*)sd.out;                               // global, not flat, accesses
   const zg_gu32* og = (const zg_gu32*)sd.og;
   const uint32_t n4 = size >> 2;
-  const uint32_t nb_all = (n4 + BG - 1) / BG;                 // batches of the unit
+  const uint32_t nb_all = part == 2u ? sd.head : (n4 + BG - 1) / BG;   // batches of the unit (part 2: of its head)
   const uint32_t nb = b0 + nbatch <= nb_all ? nbatch : (nb_all > b0 ? nb_all - b0 : 0u);
   // sources lie at most 2^31 bytes before the unit's first byte (offsets < 2^30 + a unit): a resource that starts there
   const uint32_t lowb = (uint32_t)sd.out & 3u;
@@ -1531,7 +1548,7 @@ __global__ void __launch_bounds__(ZG_SW_T) __attribute__((amdgpu_waves_per_eu(2,
     for (int k = 0; k < ZG_SW_B; k++) o[k] = onx[k];
   }
   // tail bytes of the unit (size not a multiple of four): by the workgroup that would hold their group
-  if ((size & 3u) && n4 >= b0 * BG && n4 < (b0 + nbatch) * BG && t < (size & 3u)) {
+  if (part != 2u && (size & 3u) && n4 >= b0 * BG && n4 < (b0 + nbatch) * BG && t < (size & 3u)) {
     const uint32_t x = (n4 << 2) + t;
     const uint32_t e = og[x];
     if (e) out[x] = out[(int64_t)x - (int64_t)e];
@@ -1740,15 +1757,50 @@ void zg_launch_flat(const ZgBatchDev& d, hipStream_t s) {
   else if (shape == 2) hipLaunchKernelGGL((zg_k_flat<1024, 8192, 1>), dim3(d.nunits), dim3(1024), 0, s, d);
   else hipLaunchKernelGGL((zg_k_flat<1024, 16384, 2>), dim3(d.nunits), dim3(1024), 0, s, d);
 }
-void zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* steps, uint32_t nsteps) {
+bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* steps, uint32_t nsteps, hipStream_t s2, hipEvent_t* evs, uint32_t nev,
+                     uint32_t unit_bytes, uint32_t window_max) {
   const uint32_t dbgmode = getenv("ZGPU_SWEEP_MODE") ? (uint32_t)atoi(getenv("ZGPU_SWEEP_MODE")) : 0u;   // timing experiments only
-  const uint32_t nbatch = getenv("ZGPU_SWEEP_NB") && atoi(getenv("ZGPU_SWEEP_NB")) > 0 ? (uint32_t)atoi(getenv("ZGPU_SWEEP_NB")) : 1u;   // 4 KiB batches per workgroup (more than one did not pay: the step is bound by its total traffic, not by a latency chain)
+  const uint32_t nbatch = getenv("ZGPU_SWEEP_NB") && atoi(getenv("ZGPU_SWEEP_NB")) > 0 ? (uint32_t)atoi(getenv("ZGPU_SWEEP_NB")) : 1u;   // 4 KiB batches per workgroup (more than one did not pay)
+  constexpr uint32_t BB = 4u * ZG_SW_T * ZG_SW_B;             // bytes per batch
   uint32_t n = 0;
-  for (uint32_t i = 0; i < nsteps; i++) n += steps[i].nunits;
+  bool contiguous = true;
+  for (uint32_t i = 0; i < nsteps; i++) { if (steps[i].list_off != steps[0].list_off + n) contiguous = false; n += steps[i].nunits; }
   if (n) hipLaunchKernelGGL(zg_k_swprep, dim3((n + 255) / 256), dim3(256), 0, s, d, n);
-  for (uint32_t i = 0; i < nsteps; i++)
-    hipLaunchKernelGGL(zg_k_sweep, dim3((steps[i].slices + nbatch - 1) / nbatch, steps[i].nunits), dim3(ZG_SW_T), 0, s, d, steps[i].list_off, nbatch, dbgmode);
+  // The tails are worth a chain of their own when they are clearly shorter than the units (else: the plain chain).
+  const uint32_t tail_batches = window_max / BB + 2u;
+  const bool split = nev >= 3 && contiguous && nsteps > 1 && (uint64_t)tail_batches * BB + 65536u < unit_bytes;
+  if (!split) {
+    for (uint32_t i = 0; i < nsteps; i++)
+      hipLaunchKernelGGL(zg_k_sweep, dim3((steps[i].slices + nbatch - 1) / nbatch, steps[i].nunits), dim3(ZG_SW_T), 0, s, d, steps[i].list_off, nbatch, dbgmode, 0u);
+  } else {
+    // stream s: tail of step 0, 1, 2, ...; stream s2: the heads of steps [g0, g1) in one launch as soon as the tails of step g1 - 2
+    // are done (the heads of step i copy from the tails of steps < i).
+    const uint32_t gs = (nsteps + (nev - 2) - 1) / (nev - 2) > 16u ? (nsteps + (nev - 2) - 1) / (nev - 2) : 16u;
+    uint32_t g0 = 0, e = 0;
+    const uint32_t head_lds = getenv("ZGPU_SWEEP_HEAD_LDS") ? (uint32_t)atoi(getenv("ZGPU_SWEEP_HEAD_LDS")) : 52u * 1024u;
+    auto heads = [&]() {
+      const uint32_t g1 = g0 + gs < nsteps ? g0 + gs : nsteps;
+      uint32_t units = 0, slices = 0;
+      for (uint32_t i = g0; i < g1; i++) { units += steps[i].nunits; slices = steps[i].slices > slices ? steps[i].slices : slices; }
+      (void)hipEventRecord(evs[e], s);
+      (void)hipStreamWaitEvent(s2, evs[e], 0);
+      e++;
+      // (the heads are bulk work beside a chain of short launches: an unused LDS allocation keeps them to a few workgroups per
+      //  CU, so that a tail step always finds free wave slots instead of waiting for head workgroups to retire)
+      hipLaunchKernelGGL(zg_k_sweep, dim3((slices + nbatch - 1) / nbatch, units), dim3(ZG_SW_T), head_lds, s2, d, steps[g0].list_off, nbatch, dbgmode, 2u);
+      g0 = g1;
+    };
+    auto need = [&]() { return (int64_t)(g0 + gs < nsteps ? g0 + gs : nsteps) - 2; };   // the last tail step the next group of heads waits for
+    while (g0 < nsteps && need() < 0) heads();
+    for (uint32_t i = 0; i < nsteps; i++) {
+      hipLaunchKernelGGL(zg_k_sweep, dim3((tail_batches + nbatch - 1) / nbatch + 1u, steps[i].nunits), dim3(ZG_SW_T), 0, s, d, steps[i].list_off, nbatch, dbgmode, 1u);
+      while (g0 < nsteps && need() <= (int64_t)i) heads();
+    }
+    (void)hipEventRecord(evs[e], s2);
+    (void)hipStreamWaitEvent(s, evs[e], 0);
+  }
   if (d.nframes) hipLaunchKernelGGL(zg_k_fin, dim3((d.nframes + 255) / 256), dim3(256), 0, s, d);
+  return split;
 }
 void zg_launch_lz(const ZgBatchDev& d, hipStream_t s) {
   hipLaunchKernelGGL(zg_k_lz, dim3(d.nframes), dim3(ZG_LZ_T), 0, s, d);

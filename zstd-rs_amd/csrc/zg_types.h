@@ -180,7 +180,9 @@ struct ZgUnit { uint32_t frame, first_block, nblocks, pad; };
 struct ZgUnitInfo { uint32_t size; uint32_t pad; };   // written by zg_k_flat: bytes of the unit
 
 // what a sweep workgroup needs to know about its unit
-struct ZgSweepDesc { uint64_t out; uint64_t og; uint32_t size; uint32_t live; uint32_t pad[2]; };
+// head: 4 KiB batches at the front of the unit that nothing later depends on when no match reaches further back than the
+// frame's window (the bytes a later unit may copy from are the last `window` bytes in front of it)
+struct ZgSweepDesc { uint64_t out; uint64_t og; uint32_t size; uint32_t live; uint32_t head; uint32_t pad; };
 
 // Huffman work: one group = streams that decode with the same table.
 struct ZgHufGroup { int32_t slot; uint32_t first_item; uint32_t nitems; uint32_t pad; };
