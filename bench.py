@@ -142,7 +142,7 @@ def e2e_rate(ctx, z, plain_len):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=150)
+    ap.add_argument("--steps", type=int, default=250)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="enwik9like", choices=["enwik9like", "silesia12", "blocks", "blocks4b", "iso"])
     ap.add_argument("--size", type=int, default=int(os.environ.get("ZGPU_BENCH_SIZE", 1000000000)), help="plaintext bytes per GPU (enwik9like)")

@@ -143,8 +143,8 @@ uint32_t zgpu_batch_num_frames(const zgpu_batch*);
 uint32_t zgpu_batch_num_blocks(const zgpu_batch*);
 uint64_t zgpu_batch_compressed_size(const zgpu_batch*);
 int zgpu_batch_frame_info(const zgpu_batch*, uint32_t frame, zgpu_frame_info* out);
-int zgpu_batch_read(zgpu_batch*, uint64_t offset, uint8_t* dst, uint64_t n);   /* D2H of plaintext bytes */
-const void* zgpu_batch_output_device(const zgpu_batch*);            /* device pointer of the plaintext (no copy) */
+int zgpu_batch_read(zgpu_batch*, uint64_t offset, uint8_t* dst, uint64_t n);   /* D2H of plaintext bytes (waits for the run like zgpu_batch_sync) */
+const void* zgpu_batch_output_device(const zgpu_batch*);            /* device pointer of the plaintext (no copy); valid after zgpu_batch_sync */
 /* kernel times of the last run in ms, measured with HIP events on the ctx stream:
  * [0] tables [1] huffman [2] sequence chains [3] sequence post-processing [4] scan [5] literals/raw/rle [6] flatten
  * [7] sweep [8] in-order fallback [9] whole pipeline. Returns how many were written. */

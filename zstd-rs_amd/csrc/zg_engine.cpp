@@ -458,7 +458,7 @@ int Batch::run() {
   ZG_HIP(hipEventRecord(ev[6], s));
   zg_launch_flat(d, s);
   ZG_HIP(hipEventRecord(ev[7], s));
-  sweep_mode = 0;
+  sweep_mode = 0; synced = false;
   if (!getenv("ZGPU_DEBUG_NO_SWEEP")) launch_sweep(true);
   ZG_HIP(hipEventRecord(ev[8], s));
   zg_launch_lz(d, s);   // only frames that left the flatten path (a block regenerating > 128 KiB)
@@ -509,6 +509,7 @@ int Batch::sync() {
   float m = 0;
   if (hipEventElapsedTime(&m, sc->ev_huf[0], sc->ev_huf[1]) == hipSuccess) ms[ZG_T_HUF] = m;   // beside seq + seqpost, not in line
   if (hipEventElapsedTime(&m, ev[0], ev[ZG_T_TOTAL]) == hipSuccess) ms[ZG_T_TOTAL] = m;
+  synced = true;
   return ZG_OK;
 }
 
@@ -542,6 +543,7 @@ int Batch::commit(FrameState* st) {
 }
 
 int Batch::read_output(uint64_t off, uint8_t* dst, uint64_t n) {
+  if (ran && !synced) { const int st = sync(); if (st) return st; }   // (sync() may still have to repeat the sweep)
   if (off + n > dev.dst_cap) return ZG_BAD_ARG;
   if (n) ZG_HIP(hipMemcpy(dst, dev.dst + off, n, hipMemcpyDeviceToHost));
   return ZG_OK;

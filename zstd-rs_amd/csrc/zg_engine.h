@@ -99,6 +99,7 @@ class Batch {
   int sync();                            // wait, download per-frame results, compute timings
   void launch_sweep(bool split);
   bool split_sweep = false;              // the last run used the split sweep: sync() checks that it was entitled to
+  bool synced = false;                   // sync() ran after the last run(): outputs may be read
   uint32_t sweep_mode = 0;               // of the last run: 0 plain chain of steps, 1 split, 2 split and then repeated as a plain chain (tests)
   int read_output(uint64_t off, uint8_t* dst, uint64_t n);   // D2H
   int read_output_async(uint64_t off, uint8_t* dst, uint64_t n, hipStream_t s);

@@ -203,7 +203,7 @@ int zgpu_pool_read(zgpu_pool* p, uint32_t i, uint8_t* dst, size_t cap, size_t* w
 }
 
 // FrameDecoder::decode_all (frame_decoder.rs:541-577) over all GPUs of the pool: the buffer is cut into frames on the host
-// (frame + block headers only), runs of consecutive frames become jobs of >= 64 MiB of input (or a single larger frame), the
+// (frame + block headers only), runs of consecutive frames become jobs of >= 64 MiB of input (see below; or a single larger frame), the
 // jobs are queued largest first and pulled by one worker per GPU; the plaintext is written back to back in input order.
 int zgpu_pool_decode_all(zgpu_pool* p, const uint8_t* src, size_t len, uint8_t* dst, size_t cap, size_t* written) {
   if (!p || !written || (!src && len) || (!dst && cap)) return ZGPU_E_BAD_ARG;
@@ -212,7 +212,12 @@ int zgpu_pool_decode_all(zgpu_pool* p, const uint8_t* src, size_t len, uint8_t* 
   const int walk = split_frames(src, len, &spans);     // frames in front of a malformed one are still decoded; the error wins below
   struct Job { uint64_t begin, end; Batch* batch = nullptr; int status = 0; uint32_t gpu = 0; uint64_t out_off = 0, out_size = 0; };
   std::vector<Job> jobs;
-  const uint64_t kJob = 64ull << 20;
+  // A submit costs ~2 ms whatever its size (the length of one block's sequence chain), so jobs are as large as balance allows:
+  // about four per GPU when there are several GPUs, one otherwise; at most 1 GiB of input (~25 GB of device memory while it runs).
+  const uint64_t nw_ = p->eng.size();
+  uint64_t kJob = nw_ > 1 ? (uint64_t)len / (4 * nw_) : (uint64_t)len;
+  if (kJob < (64ull << 20)) kJob = 64ull << 20;
+  if (kJob > (1ull << 30)) kJob = 1ull << 30;
   for (const FrameSpan& s : spans) {
     if (!jobs.empty() && jobs.back().end - jobs.back().begin < kJob && s.end - s.begin < kJob) jobs.back().end = s.end;
     else { Job j; j.begin = s.begin; j.end = s.end; jobs.push_back(j); }
