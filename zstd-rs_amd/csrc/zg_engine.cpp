@@ -481,7 +481,7 @@ void Batch::launch_sweep(bool split) {
   }
   if (dev.sweep_window) wmax = dev.sweep_window;
   if (wmax > 0x7FFFFFFFull) wmax = 0x7FFFFFFFull;
-  split_sweep = zg_launch_sweep(dev, eng->stream_, sweep_steps.data(), (uint32_t)sweep_steps.size(), eng->stream2_, sc->ev_sw, split ? 20u : 0u,
+  split_sweep = zg_launch_sweep(dev, eng->stream_, sweep_steps.data(), (uint32_t)sweep_steps.size(), eng->stream2_, sc->ev_sw, split ? 80u : 0u,
                                 bb.unit_blocks_used * kMaxBlockSize, (uint32_t)wmax);
   sweep_mode = split_sweep ? 1u : sweep_mode;
 }

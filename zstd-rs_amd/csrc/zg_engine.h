@@ -68,7 +68,7 @@ struct Scratch {
       d_dst, d_seqblocks, d_hufitems, d_hufgroups, d_totals, d_og, d_units, d_unitinfo, d_stepunits, d_swdesc, d_dbg, d_raw;
   hipEvent_t ev[ZG_T_COUNT + 1] = {};
   hipEvent_t ev_huf[2] = {}, ev_fork = nullptr;   // zg_k_huf runs on the engine's second stream beside zg_k_seq
-  hipEvent_t ev_sw[20] = {};                      // split sweep: heads on the second stream (zg_launch_sweep)
+  hipEvent_t ev_sw[80] = {};                      // split sweep: heads on the second stream (zg_launch_sweep)
   bool have_events = false;
   int init_events();
   void release();

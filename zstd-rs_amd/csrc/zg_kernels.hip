@@ -1775,7 +1775,8 @@ bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* step
   } else {
     // stream s: tail of step 0, 1, 2, ...; stream s2: the heads of steps [g0, g1) in one launch as soon as the tails of step g1 - 2
     // are done (the heads of step i copy from the tails of steps < i).
-    const uint32_t gs = (nsteps + (nev - 2) - 1) / (nev - 2) > 16u ? (nsteps + (nev - 2) - 1) / (nev - 2) : 16u;
+    const uint32_t gmin = getenv("ZGPU_SWEEP_GROUP") && atoi(getenv("ZGPU_SWEEP_GROUP")) > 0 ? (uint32_t)atoi(getenv("ZGPU_SWEEP_GROUP")) : 16u;   // steps whose heads share a launch
+    const uint32_t gs = (nsteps + (nev - 2) - 1) / (nev - 2) > gmin ? (nsteps + (nev - 2) - 1) / (nev - 2) : gmin;
     uint32_t g0 = 0, e = 0;
     const uint32_t head_lds = getenv("ZGPU_SWEEP_HEAD_LDS") ? (uint32_t)atoi(getenv("ZGPU_SWEEP_HEAD_LDS")) : 52u * 1024u;
     auto heads = [&]() {
