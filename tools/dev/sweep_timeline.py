@@ -8,14 +8,15 @@ last = max(i for i, r in enumerate(rows) if "zg_k_flat" in r["Kernel_Name"])
 rows = rows[last:]
 t0 = int(rows[0]["End_Timestamp"])
 gx = lambda r: int(r.get("Grid_Size_X", r.get("Grid_Size", "0")))
-big = max(gx(r) for r in rows if "sweep" in r["Kernel_Name"])
-heads = [r for r in rows if "sweep" in r["Kernel_Name"] and gx(r) * 4 > big]
-tails = [r for r in rows if "sweep" in r["Kernel_Name"] and gx(r) * 4 <= big]
+small = min(gx(r) for r in rows if "sweep" in r["Kernel_Name"])
+heads = [r for r in rows if "sweep" in r["Kernel_Name"] and gx(r) > small]
+tails = [r for r in rows if "sweep" in r["Kernel_Name"] and gx(r) == small]
 print("tails %d  heads %d  queues %s" % (len(tails), len(heads), sorted(set(r.get("Queue_Id", "?") for r in rows))))
 for r in heads:
     s, e = (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3
     inside = [x for x in tails if int(x["Start_Timestamp"]) >= int(r["Start_Timestamp"]) and int(x["End_Timestamp"]) <= int(r["End_Timestamp"])]
-    print("head  start %8.1f us  end %8.1f us  dur %7.1f us  grid %9d  tails running inside: %d" % (s, e, e - s, gx(r), len(inside)))
+    di = [(int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e3 for x in inside]
+    print("head  start %8.1f us  end %8.1f us  dur %7.1f us  tails inside: %d (avg %.1f us each)" % (s, e, e - s, len(inside), sum(di) / max(len(di), 1)))
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tails]
 g = [(int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3 for a, b in zip(tails, tails[1:])]
 print("tails: avg dur %.2f us, avg gap %.2f us, first start %.1f us, last end %.1f us" % (sum(d) / len(d), sum(g) / max(len(g), 1), (int(tails[0]["Start_Timestamp"]) - t0) / 1e3, (int(tails[-1]["End_Timestamp"]) - t0) / 1e3))
