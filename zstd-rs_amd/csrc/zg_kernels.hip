@@ -53,52 +53,173 @@ __device__ __forceinline__ void zg_set_lit_status(uint32_t* status, uint32_t b, 
   if (st) atomicMax(&status[b], ((255u - rank) << 8) | (uint32_t)st);
 }
 
+// What one lane of a wave wrote to LDS inside a divergent branch is read by the other lanes afterwards: the compiler
+// reasons per thread and may otherwise move those reads ahead of a branch the reading lanes do not take.
+__device__ __forceinline__ void zg_wave_publish() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ------------------------------------------------------------------------------------------------------------
-// zg_k_tables: Huffman tree descriptions (literals chain; the FSE tables of the sequences chain are zg_k_ftab's).
+// zg_k_tables: Huffman tree descriptions of the literals sections (HuffmanTable::build_decoder, huff0_decoder.rs:117-124
+// with :232-403; the FSE tables of the sequences chain are zg_k_ftab's). One WAVE per block:
+//   weights     lane 0 reads them (direct nibbles, or FSE-compressed: read_probabilities, a 64-entry table and two
+//               interleaved state chains, all bit-serial) with everything it touches in LDS: on gfx950 a load behind a
+//               global store waits for that store, so nothing is written out before the table is complete;
+//   build       all 64 lanes, four symbols each: weight sum and checks (:283-325), symbols per code length, a symbol's
+//               rank among the symbols of its length (ballots, symbol order), and the table itself: a symbol with code
+//               length b owns 2^(max_bits - b) consecutive entries (:327-403). Long runs are written by the whole wave,
+//               short ones by their lane, into LDS; the finished table leaves with 16-byte stores.
 // ------------------------------------------------------------------------------------------------------------
-#define ZG_TAB_L 64   // blocks (lanes) per workgroup, one full wave: 1.7 KiB of LDS each
+#define ZG_HT_W 4      // blocks (waves) per workgroup
 #define ZG_TAB_HDR 160 // bytes of a literals section staged for parsing (a tree description is at most 129 bytes)
-__global__ void __launch_bounds__(ZG_TAB_L) zg_k_tables(ZgBatchDev d) {
-  // Huffman tree descriptions of the literals sections (HuffmanTable::build_decoder, huff0_decoder.rs:117-124 with
-  // :232-403). One lane per block. A table is built where it can be read back without touching global memory: the
-  // weights are FSE-decoded through a small table that was just built, and on gfx950 a load behind a global store waits
-  // for that store (one in-order counter). So the description being parsed, the probabilities, the per-symbol counters,
-  // the weights' FSE table and the weights live in LDS, one private slice per lane; the finished Huffman table leaves
-  // with plain stores.
-  __shared__ int16_t s_probs[ZG_TAB_L][256];
-  __shared__ uint16_t s_counter[ZG_TAB_L][256];
-  __shared__ uint32_t s_fsew[ZG_TAB_L][64];
-  __shared__ uint8_t s_weights[ZG_TAB_L][264];
-  __shared__ __attribute__((aligned(16))) uint8_t s_hdr[ZG_TAB_L][ZG_TAB_HDR + 32];
-  const uint32_t ln = threadIdx.x;
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+struct ZgHufTabLds {
+  int16_t probs[256];
+  uint16_t counter[256];
+  uint32_t fsew[64];
+  uint8_t weights[264];
+  uint32_t cls[16];                                       // symbols per code length
+  int32_t res[4];                                         // lane 0 -> wave: status, number of weights, description bytes
+  __attribute__((aligned(16))) uint8_t hdr[ZG_TAB_HDR + 32];
+  __attribute__((aligned(16))) uint16_t table[ZG_HUF_SLOT_U16];
+};
+__global__ void __launch_bounds__(64 * ZG_HT_W) zg_k_tables(ZgBatchDev d) {
+  __shared__ ZgHufTabLds s_l[ZG_HT_W];
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const uint32_t b = blockIdx.x * ZG_HT_W + wv;
   if (b >= d.nblocks) return;
   const ZgBlock blk = d.blocks[b];
   if (blk.host_status || blk.btype != ZG_BT_COMPRESSED) return;
-  const uint8_t* body = d.src + blk.src_off;
+  ZgHufTabLds& L = s_l[wv];
   uint32_t desc_bytes = 0;
   int st = ZG_OK;
   if (blk.lit_type == ZG_LT_COMPRESSED) {
-    // copy the description (+8 bytes for the bit windows) into the lane's LDS slice: dword-aligned 16-byte loads, 8 in flight
+    // the description (+8 bytes for the bit windows): dword-aligned 16-byte loads, one per lane
     const uint32_t hl = blk.lit_comp_size < 136u ? blk.lit_comp_size : 136u;   // a tree description is at most 129 bytes
-    const uint8_t* g = body + blk.lit_off;
+    const uint8_t* g = d.src + blk.src_off + blk.lit_off;
     const uint64_t ga = (uint64_t)g & ~3ull;
     const uint32_t sh = (uint32_t)((uint64_t)g & 3u), nv = (hl + 8 + sh + 15) / 16;
-    for (uint32_t v0 = 0; v0 < nv; v0 += 8) {
-      zg_v4u r[8];
-#pragma unroll
-      for (int k = 0; k < 8; k++) r[k] = v0 + k < nv ? *(const zg_gv4u*)(ga + 16ull * (v0 + k)) : zg_v4u{0, 0, 0, 0};
-#pragma unroll
-      for (int k = 0; k < 8; k++) if (v0 + k < nv) *(zg_v4u*)(s_hdr[ln] + 16 * (v0 + k)) = r[k];
+    if (lane < nv) { const zg_v4u r = *(const zg_gv4u*)(ga + 16ull * lane); *(zg_v4u*)(L.hdr + 16 * lane) = r; }
+    if (lane < 16) L.cls[lane] = 0;
+    zg_wave_publish();
+    if (lane == 0) {
+      int nw = 0;
+      uint32_t used = 0;
+      L.res[0] = zg_huf_read_weights(L.hdr + sh, hl, L.weights, &nw, &used, L.fsew, L.probs, L.counter);
+      L.res[1] = nw; L.res[2] = (int32_t)used;
     }
-    int nw = 0, mb = 0;
-    uint32_t used = 0;
-    st = zg_huf_read_weights(s_hdr[ln] + sh, hl, s_weights[ln], &nw, &used, s_fsew[ln], s_probs[ln], s_counter[ln]);
-    if (!st) st = zg_huf_build(s_weights[ln], nw, d.huf_arena + (uint64_t)blk.huf_slot * ZG_HUF_SLOT_U16, &mb);
-    if (!st) { d.huf_maxbits[blk.huf_slot] = (uint8_t)mb; desc_bytes = used; }
+    zg_wave_publish();
+    st = L.res[0];
+    const int nw = L.res[1];
+    if (!st && nw > 255) {
+      // 256 weights (the two-decoder loop may end with one more than it checks for, :207-234): the implied symbol is "256",
+      // stored as byte 0. Too rare for a wave version: lane 0 builds the table the serial way.
+      if (lane == 0) {
+        int mb = 0;
+        L.res[0] = zg_huf_build(L.weights, nw, d.huf_arena + (uint64_t)blk.huf_slot * ZG_HUF_SLOT_U16, &mb);
+        if (!L.res[0]) d.huf_maxbits[blk.huf_slot] = (uint8_t)mb;
+      }
+      zg_wave_publish();
+      st = L.res[0];
+      if (!st) desc_bytes = (uint32_t)L.res[2];
+    } else if (!st) {
+      // ---- weight sum, max_bits, the implicit last weight (:283-325)
+      uint32_t w[4], sum = 0;
+      bool bad = false;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int sy = (int)lane + 64 * k;
+        w[k] = sy < nw ? L.weights[sy] : 0u;
+        bad = bad || w[k] > 11u;
+        sum += w[k] ? 1u << (w[k] - 1) : 0u;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      const bool anybad = __any(bad);
+      uint32_t max_bits = 0, last_weight = 0;
+      if (anybad || sum == 0) st = ZG_HUF_TABLE;
+      else {
+        max_bits = zg_hbit(sum);
+        const uint32_t left = (1u << max_bits) - sum;
+        if (left & (left - 1)) st = ZG_HUF_TABLE;             // LeftoverIsNotAPowerOf2 (left >= 1 always)
+        else if (max_bits > 11) st = ZG_HUF_TABLE;            // MaxBitsTooHigh
+        else last_weight = zg_hbit(left);
+      }
+      if (!st) {
+        // ---- code lengths; symbols per length
+        uint32_t bl[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int sy = (int)lane + 64 * k;
+          if (sy == nw) w[k] = last_weight;                   // the last symbol's weight is implied (:309-316)
+          bl[k] = w[k] ? max_bits + 1 - w[k] : 0u;
+          if (bl[k]) atomicAdd(&L.cls[bl[k]], 1u);
+        }
+        zg_wave_publish();
+        // first entry of every length: lengths in descending order from entry 0 (:339-351)
+        uint32_t first[12];
+        {
+          uint32_t acc = 0;
+#pragma unroll
+          for (int q = 11; q >= 1; q--) {
+            first[q] = acc;
+            if ((uint32_t)q <= max_bits) acc += L.cls[q] << (max_bits - (uint32_t)q);
+          }
+          if (acc != (1u << max_bits)) st = ZG_INTERNAL;      // assert :353-358
+        }
+        if (!st) {
+          // ---- a symbol's rank among the symbols of its length, in symbol order (symbol = lane + 64 k)
+          const uint64_t lt = (1ull << lane) - 1ull;
+          uint32_t rank[4] = {0, 0, 0, 0};
+          for (uint32_t q = 1; q <= max_bits; q++) {          // (uniform trip count)
+            uint32_t before = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              const uint64_t m = __ballot(bl[k] == q);
+              if (bl[k] == q) rank[k] = before + (uint32_t)__popcll(m & lt);
+              before += (uint32_t)__popcll(m);
+            }
+          }
+          // ---- the table: symbol (lane, k) owns entries [base, base + n)
+          uint32_t base[4], n[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            n[k] = bl[k] ? 1u << (max_bits - bl[k]) : 0u;
+            uint32_t f = 0;
+#pragma unroll
+            for (int q = 1; q <= 11; q++) f = bl[k] == (uint32_t)q ? first[q] : f;   // (selects: a dynamic index would put first[] into scratch memory)
+            base[k] = f + rank[k] * n[k];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const uint32_t e = ZG_HUF_PACK((lane + 64u * (uint32_t)k) & 255u, bl[k]);
+            // runs of 64 entries and more: the whole wave writes them, one after the other
+            uint64_t m = __ballot(n[k] >= 64u);
+            while (m) {
+              const int j = __builtin_ctzll(m);
+              m &= m - 1;
+              const uint32_t bj = __shfl(base[k], j, 64), nj = __shfl(n[k], j, 64), ej = __shfl(e, j, 64);
+              for (uint32_t i = lane; i < nj; i += 64) L.table[bj + i] = (uint16_t)ej;
+            }
+            if (n[k] < 64u) for (uint32_t i = 0; i < n[k]; i++) L.table[base[k] + i] = (uint16_t)e;
+          }
+          zg_wave_publish();
+          uint16_t* out = d.huf_arena + (uint64_t)blk.huf_slot * ZG_HUF_SLOT_U16;
+          for (uint32_t i = lane * 8; i < (1u << max_bits); i += 64 * 8) {
+            if (i + 8 <= (1u << max_bits)) *(zg_gv4u*)(out + i) = *(const zg_v4u*)(L.table + i);
+            else for (uint32_t j = i; j < (1u << max_bits); j++) out[j] = L.table[j];
+          }
+          if (lane == 0) { d.huf_maxbits[blk.huf_slot] = (uint8_t)max_bits; }
+          desc_bytes = (uint32_t)L.res[2];
+        }
+      }
+    }
   }
-  d.aux[b].huf_desc_bytes = desc_bytes;
-  d.tab_status[b] = (uint32_t)st;              // a bad tree description: zg_k_huf leaves the block alone, zg_k_merge reports it
+  if (lane == 0) {
+    d.aux[b].huf_desc_bytes = desc_bytes;
+    d.tab_status[b] = (uint32_t)st;              // a bad tree description: zg_k_huf leaves the block alone, zg_k_merge reports it
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -114,13 +235,6 @@ __global__ void __launch_bounds__(ZG_TAB_L) zg_k_tables(ZgBatchDev d) {
 //   entries     num_bits / base_line from (prob, k) as in the serial version (zg_fse_build, zg_dev.h), written coalesced.
 // ------------------------------------------------------------------------------------------------------------
 #define ZG_FT_W 4         // blocks (waves) per workgroup
-// What one lane of a wave wrote to LDS inside a divergent branch is read by the other lanes afterwards: the compiler
-// reasons per thread and may otherwise move those reads ahead of a branch the reading lanes do not take.
-__device__ __forceinline__ void zg_wave_publish() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 struct ZgFtabLds {
   int16_t probs[64];
   uint16_t cum[64];
@@ -1719,7 +1833,7 @@ void zg_launch_calib(const void* src, void* dst, uint64_t bytes, hipStream_t s) 
 // ------------------------------------------------------------------------------------------------------------
 void zg_launch_tables(const ZgBatchDev& d, hipStream_t s, int part) {
   uint32_t n = d.nblocks + 1;
-  if (part == 0) hipLaunchKernelGGL(zg_k_tables, dim3((n + ZG_TAB_L - 1) / ZG_TAB_L), dim3(ZG_TAB_L), 0, s, d);
+  if (part == 0) hipLaunchKernelGGL(zg_k_tables, dim3((n + ZG_HT_W - 1) / ZG_HT_W), dim3(64 * ZG_HT_W), 0, s, d);
   else hipLaunchKernelGGL(zg_k_ftab, dim3((n + ZG_FT_W - 1) / ZG_FT_W), dim3(64 * ZG_FT_W), 0, s, d);
 }
 void zg_launch_huf(const ZgBatchDev& d, hipStream_t s) {
