@@ -1286,6 +1286,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t zg_make_rsrc(const void* p, ui
   return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 #define ZG_OOB 0xFFFFFFFFu   // an offset no buffer resource covers
+// the same value, but new to the compiler: what is computed from it is computed again here instead of being kept in a register
+#define ZG_FRESH(v) ({ uint32_t v_ = (v); asm volatile("" : "+v"(v_)); v_; })
 
 // zg_k_flat<T, TS, SPT>: T threads resolve TS-byte tiles; a thread owns the tile bytes t, t + T, t + 2T ... through all phases
 // (consecutive lanes = consecutive bytes: LDS accesses are conflict-free and, above all, the scratch gathers of adjacent
@@ -1302,7 +1304,7 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
   __shared__ uint32_t s_word[TS];               // a root's effective offset; a literal: tag + index of its value in the block's literals
   __shared__ uint32_t s_bits[NW];               // marks: the first tile byte of every sequence
   __shared__ uint16_t s_cnt[NW];                // marks before each word of s_bits
-  __shared__ __attribute__((aligned(16))) zg_v4u s_rec[SOFF];   // per sequence of the tile: {offset, first tile byte | first match byte << 16, literal index at its first tile byte, -}
+  __shared__ __attribute__((aligned(16))) zg_v4u s_rec[SOFF];   // per sequence of the tile, as S1c wants it: {offset, first match byte, 2^31 + literal index of tile byte 0, 4 * offset}
   __shared__ uint32_t s_wtot[NW / 64];
   __shared__ uint32_t s_next, s_cut, s_err;
   __shared__ unsigned long long s_bad;          // first failing sequence of the block: index << 32 | match position << 8 | provisional status
@@ -1401,7 +1403,9 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
         if (a >= t1o) continue;
         const uint32_t st = (a > t0 ? a : t0) - t0;
         const uint32_t mr = (m0 > t0 ? (m0 < t1o ? m0 : t1o) : t0) - t0;
-        s_rec[j] = zg_v4u{off, st | (mr << 16), lstart + (a > t0 ? 0u : t0 - a), 0u};
+        // (z: the literal a tile byte x of this sequence stands for is z + x - 2^31; it only has to be right for x >= st)
+        // (w: unit positions are below 2^25, so an offset of 2^29 or more always leads in front of the unit: any large value says so)
+        s_rec[j] = zg_v4u{off, mr, 0x80000000u + lstart + (a > t0 ? 0u : t0 - a) - st, off < (1u << 29) ? 4u * off : 0x7FFFFFFCu};
         atomicOr(&s_bits[st >> 5], 1u << (st & 31u));
         // the last sequence the tile has room for, and more follow: the tile ends with this one
         if (j == SOFF - 1 && i < nseq && m1 <= t1o) s_cut = m1;
@@ -1409,19 +1413,22 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
       zg_lds_barrier();
       // ---- S1b: marks before every word (prefix sum over the words)
       {
+        const uint32_t tb = ZG_FRESH(t);   // (every phase derives its LDS addresses from its own copy of the thread index: held
+                                           //  across the tile loop they do not fit the register budget, and a spilled one comes back
+                                           //  through a scratch load whose wait also covers the records requested for the next tile)
         uint32_t c = 0, sc = 0;
-        if (t < NW) {
-          c = (uint32_t)__popc(s_bits[t]);
+        if (tb < NW) {
+          c = (uint32_t)__popc(s_bits[tb]);
           sc = c;
 #pragma unroll
-          for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(sc, o, 64); if ((int)(t & 63) >= o) sc += v; }
-          if ((t & 63) == 63) s_wtot[t >> 6] = sc;
+          for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(sc, o, 64); if ((int)(tb & 63) >= o) sc += v; }
+          if ((tb & 63) == 63) s_wtot[tb >> 6] = sc;
         }
         zg_lds_barrier();
-        if (t < NW) {
+        if (tb < NW) {
           uint32_t before = sc - c;
-          for (uint32_t w = 0; w < (t >> 6); w++) before += s_wtot[w];
-          s_cnt[t] = (uint16_t)before;
+          for (uint32_t w = 0; w < (tb >> 6); w++) before += s_wtot[w];
+          s_cnt[tb] = (uint16_t)before;
         }
       }
       // every wave's scratch stores of the previous tile have reached memory before any wave gathers from them. (The builtin,
@@ -1442,33 +1449,34 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
       // offset is its sequence's offset if the parent lies before the unit, else offset + e[parent]: the parent's scratch
       // word is requested here and added after the pointer jumping (the round trip hides behind it).
       uint32_t wadd[PER], unresolved = 0;
+      const uint32_t tc = ZG_FRESH(t);
       constexpr int G = 2;                       // bytes worked on together: their LDS round trips overlap
 #pragma unroll
       for (int k0 = 0; k0 < PER; k0 += G) {
         uint32_t word[G], cnt[G];
         zg_v4u rec[G];
 #pragma unroll
-        for (int g = 0; g < G; g++) { const uint32_t xw = (t + (k0 + g) * T) >> 5; word[g] = s_bits[xw]; cnt[g] = s_cnt[xw]; }
+        for (int g = 0; g < G; g++) { const uint32_t xw = (tc + (k0 + g) * T) >> 5; word[g] = s_bits[xw]; cnt[g] = s_cnt[xw]; }
 #pragma unroll
         for (int g = 0; g < G; g++) {
-          const uint32_t x = t + (k0 + g) * T;
+          const uint32_t x = tc + (k0 + g) * T;
           // marks up to and including x, minus one (the tile's first byte carries a mark); bytes behind the tile's end get the last sequence
           rec[g] = s_rec[cnt[g] + (uint32_t)__popc(word[g] & (0xFFFFFFFFu >> (31u - (x & 31u)))) - 1u];
         }
 #pragma unroll
         for (int g = 0; g < G; g++) {
           const int k = k0 + g;
-          const uint32_t x = t + k * T;
+          const uint32_t x = tc + k * T;
           const bool live = x < n;
-          const uint32_t off = rec[g].x, st = rec[g].y & 0xFFFFu, m0 = rec[g].y >> 16;
+          const uint32_t off = rec[g].x, m0 = rec[g].y;
           const bool is_lit = x < m0;
           const bool inner = !is_lit && off <= x;                           // parent inside the tile
           const bool exits = !is_lit && !inner;
-          const int32_t y = (int32_t)(tu0 + x) - (int32_t)off;              // unit position of the parent
-          wadd[k] = __builtin_amdgcn_raw_buffer_load_b32(og_rs, (live && exits && y >= 0) ? 4u * (uint32_t)y : ZG_OOB, 0, 0);
+          const int32_t y4 = (int32_t)(4u * (tu0 + x)) - (int32_t)rec[g].w; // 4 * unit position of the parent (units are far below 2^29 bytes)
+          wadd[k] = __builtin_amdgcn_raw_buffer_load_b32(og_rs, (live && exits && y4 >= 0) ? (uint32_t)y4 : ZG_OOB, 0, 0);
           // (bytes behind the tile's end write too: their slots are not used by anything)
           s_par[x] = (uint16_t)(is_lit ? ZG_PAR_LIT : inner ? x - off : ZG_PAR_EXIT);
-          s_word[x] = exits ? off : is_lit ? 0x80000000u | (rec[g].z + (x - st)) : 0u;
+          s_word[x] = exits ? off : is_lit ? rec[g].z + x : 0u;
           unresolved |= (live && inner) ? 1u << k : 0u;
         }
       }
@@ -1478,19 +1486,20 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
       // are harmless and no barrier is needed between rounds; a byte is done when its pointer's pointer is a root marker.
       // Each thread visits just its still-unresolved bytes (few: most parents are before the tile), four per step.
       {
+        const uint32_t t2 = ZG_FRESH(t);
         for (uint32_t guard = 0; unresolved && guard < (1u << 16); guard++) {
           uint32_t m = unresolved, kk[4], pp[4];
 #pragma unroll
           for (int j = 0; j < 4; j++) { kk[j] = m ? (uint32_t)__builtin_ctz(m) : 32u; m &= m - 1; }
 #pragma unroll
-          for (int j = 0; j < 4; j++) pp[j] = kk[j] < 32u ? s_par[t + kk[j] * T] : 0u;
+          for (int j = 0; j < 4; j++) pp[j] = kk[j] < 32u ? s_par[t2 + kk[j] * T] : 0u;
 #pragma unroll
           for (int j = 0; j < 4; j++) pp[j] = s_par[pp[j]];
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             if (kk[j] < 32u) {
               if (pp[j] >= ZG_PAR_EXIT) unresolved &= ~(1u << kk[j]);     // its pointer is the root
-              else s_par[t + kk[j] * T] = (uint16_t)pp[j];               // u16 stores are atomic
+              else s_par[t2 + kk[j] * T] = (uint16_t)pp[j];               // u16 stores are atomic
             }
           }
         }
@@ -1498,8 +1507,9 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
       }
       ZG_TICK(3)
       // ---- S3a: the scratch words requested in S1c have arrived: the roots' effective offsets are completed in LDS
+      const uint32_t t3 = ZG_FRESH(t);
 #pragma unroll
-      for (int k = 0; k < PER; k++) __hip_atomic_fetch_add(&s_word[t + k * T], wadd[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_u32; 0 where nothing was requested
+      for (int k = 0; k < PER; k++) __hip_atomic_fetch_add(&s_word[t3 + k * T], wadd[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_u32; 0 where nothing was requested
       zg_lds_barrier();
       ZG_TICK(4)
       if (s_err) break;
@@ -1511,12 +1521,12 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
         uint32_t lb[H], islm = 0, pr[H], w[H];
         // (three passes over the batch, so that its LDS reads go out together: one round trip for the pointers, one for the words)
 #pragma unroll
-        for (int h = 0; h < H; h++) pr[h] = s_par[t + (k0 + h) * T];
+        for (int h = 0; h < H; h++) pr[h] = s_par[t3 + (k0 + h) * T];
 #pragma unroll
-        for (int h = 0; h < H; h++) { const uint32_t x = t + (k0 + h) * T; w[h] = s_word[pr[h] >= ZG_PAR_EXIT ? x : pr[h]]; }
+        for (int h = 0; h < H; h++) { const uint32_t x = t3 + (k0 + h) * T; w[h] = s_word[pr[h] >= ZG_PAR_EXIT ? x : pr[h]]; }
 #pragma unroll
         for (int h = 0; h < H; h++) {
-          const uint32_t x = t + (k0 + h) * T;
+          const uint32_t x = t3 + (k0 + h) * T;
           const bool live = x < n;
           const uint32_t r = pr[h] >= ZG_PAR_EXIT ? x : pr[h];
           const uint32_t e = ((w[h] >> 31) ? 0u : w[h]) + (x - r);
@@ -1527,7 +1537,7 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
         }
 #pragma unroll
         for (int h = 0; h < H; h++)
-          __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(lb[h] | lit_fill), out_rs, ((islm >> h) & 1u) ? tu0 + t + (k0 + h) * T : ZG_OOB, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(lb[h] | lit_fill), out_rs, ((islm >> h) & 1u) ? tu0 + t3 + (k0 + h) * T : ZG_OOB, 0, 0);
       }
       zg_lds_barrier();  // s_par / s_word / the records are reused by the next tile
       ZG_TICK(5)
