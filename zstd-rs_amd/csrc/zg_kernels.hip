@@ -907,12 +907,13 @@ __device__ __forceinline__ ZgHistMap zg_map_compose(const ZgHistMap& A, const Zg
   return r;
 }
 
-__global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
+__global__ void __launch_bounds__(ZG_SP_T, 4) zg_k_seqpost(ZgBatchDev d) {
   __shared__ ZgHistMap s_wm[ZG_SP_T / 64];
   __shared__ uint32_t s_wl[ZG_SP_T / 64], s_wo[ZG_SP_T / 64], s_wx[ZG_SP_T / 64];
   __shared__ uint32_t s_err;
   __shared__ uint32_t s_llb[36], s_mlb[53];     // base | extra bits << 24 (a constant-memory lookup is a global load here)
   __shared__ uint16_t s_t[ZG_FSE_SLOT_U32];      // per state: symbol << 4 | state bits
+  __shared__ uint32_t s_tr[ZG_SP_T / 64][64 * 25]; // a wave's records on their way out (see below)
   const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const uint32_t b = d.seq_blocks[blockIdx.x];
   if (d.status[b]) return;                       // the bitstream (or a table) failed: nothing to post-process
@@ -1049,7 +1050,12 @@ __global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
     }
     pre = zg_map_compose(pre, ex);                 // history before this thread's first sequence, relative to the block start
     uint32_t lit_pos = pl + sl - tl, out_pos = po + so - to;
-    if (n) {
+    {
+      // The wave's 512 records are 6 KiB in a row; written thread by thread they would be dword stores 96 bytes apart (24
+      // store instructions, each touching 48 cache lines). A full wave passes them through LDS instead (25-dword rows: no
+      // bank conflicts) and stores 16 bytes per lane; the last, partial pass of a block stores record by record.
+      const bool full = __all(n == ZG_SP_S);
+      uint32_t* row = &s_tr[wv][lane * 25u];
       uint32_t bad = 0xFFFFFFFFu;
 #pragma unroll
       for (int j = 0; j < ZG_SP_S; j++) {
@@ -1062,13 +1068,28 @@ __global__ void __launch_bounds__(ZG_SP_T) zg_k_seqpost(ZgBatchDev d) {
           if (actual == 0) e = ZG_EXE_ZERO_OFFSET;                                  // :28-30
           if (e && bad == 0xFFFFFFFFu) bad = ((t * ZG_SP_S + (uint32_t)j) << 8) | e;
           const uint32_t mdst = out_pos + ll[j];
-          // (a three-element vector type would be stored as four dwords and clobber the next record's first field)
-          __attribute__((address_space(1))) uint32_t* qo = (__attribute__((address_space(1))) uint32_t*)(out + ib + j);
-          qo[0] = actual; qo[1] = ZG_SEQ_W1(mdst, ml[j]); qo[2] = ZG_SEQ_W2(lit_pos, ml[j]);
+          const uint32_t w1 = ZG_SEQ_W1(mdst, ml[j]), w2 = ZG_SEQ_W2(lit_pos, ml[j]);
+          if (full) { row[3 * j] = actual; row[3 * j + 1] = w1; row[3 * j + 2] = w2; }
+          else {
+            // (a three-element vector type would be stored as four dwords and clobber the next record's first field)
+            __attribute__((address_space(1))) uint32_t* qo = (__attribute__((address_space(1))) uint32_t*)(out + ib + j);
+            qo[0] = actual; qo[1] = w1; qo[2] = w2;
+          }
           lit_pos += ll[j]; out_pos += ll[j] + ml[j];
         }
       }
       if (bad != 0xFFFFFFFFu) atomicMin(&s_err, bad);                               // the first failing sequence decides
+      if (full) {
+        zg_wave_publish();
+        __attribute__((address_space(1))) uint32_t* wo = (__attribute__((address_space(1))) uint32_t*)(out + (ib - lane * ZG_SP_S));   // the wave's first record
+#pragma unroll
+        for (int q0 = 0; q0 < ZG_SP_S * 3 * 64 / 4; q0 += 64) {                    // 4 dwords per lane and step: they never straddle two rows (24 % 4 == 0)
+          const uint32_t m = 4u * ((uint32_t)q0 + lane);
+          const uint32_t* src4 = &s_tr[wv][(m / 24u) * 25u + m % 24u];
+          const zg_v4u v = {src4[0], src4[1], src4[2], src4[3]};
+          *(__attribute__((address_space(1))) zg_v4u*)(wo + m) = v;
+        }
+      }
     }
     // a new offset beyond the frame's window: legal here, but no encoder emits one and the split sweep relies on their absence
     // (repeat codes only repeat what a new offset set, or the frame's initial history, which the host checks)
