@@ -78,7 +78,7 @@ int Engine::create(int device, Engine** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->cus_ = prop.multiProcessorCount;
     const char* v = getenv("ZGPU_FLAT_T");
-    if (v) e->flat_shape_ = atoi(v) == 512 ? 1 : atoi(v) == 1024 ? 0 : 2;   // "512": 512 threads x 16 bytes; "1024": 1024 x 16; else 1024 x 8
+    if (v) e->flat_shape_ = atoi(v) == 512 ? 1 : 0;   // "512": 512 threads x 8 KiB tiles, two workgroups per CU; else the default
   }
   // two streams: the sequences chain is the critical one (its kernels last as long as one block's serial chain), so its
   // workgroups are dispatched first; the literals chain fills what is left

@@ -1899,7 +1899,6 @@ void zg_launch_flat(const ZgBatchDev& d, hipStream_t s) {
   if (!d.nunits) return;
   const uint32_t shape = (d.flags >> 2) & 3u;
   if (shape == 1) hipLaunchKernelGGL((zg_k_flat<512, 8192, 2>), dim3(d.nunits), dim3(512), 0, s, d);
-  else if (shape == 2) hipLaunchKernelGGL((zg_k_flat<1024, 8192, 1>), dim3(d.nunits), dim3(1024), 0, s, d);
   else hipLaunchKernelGGL((zg_k_flat<1024, 16384, 2>), dim3(d.nunits), dim3(1024), 0, s, d);
 }
 bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* steps, uint32_t nsteps, hipStream_t s2, hipEvent_t* evs, uint32_t nev,
