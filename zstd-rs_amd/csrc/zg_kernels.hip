@@ -407,7 +407,9 @@ __global__ void __launch_bounds__(64 * ZG_FT_W) zg_k_ftab(ZgBatchDev d) {
 // One workgroup = up to ZG_HUF_GROUP streams that share a table, the table staged once per workgroup.
 // ------------------------------------------------------------------------------------------------------------
 #define ZG_HUF_T (64 * ZG_HUF_GROUP)
-#define ZG_HP_CB 128                        // bits per lane and window
+#define ZG_HP_CB 128                        // bits per lane and window ...
+#define ZG_HP_CB_DENSE 32                   // ... or this many, once a chunk held more than ZG_HP_ROWS symbols
+#define ZG_HP_ROWS 48                       // symbols a lane can record per chunk (LDS, and with it the number of streams a CU decodes at once)
 #define ZG_HP_WARM 32                       // bits a lane starts above its chunk, to be on a code boundary when it enters it
 #define ZG_HP_WBYTES (64 * ZG_HP_CB / 8)    // stream bytes covered by a window
 #define ZG_HP_STAGE (ZG_HP_WBYTES + 64)     // staged: the window, 2 bytes below it (an 11-bit peek), alignment slack, 16+ bytes above
@@ -415,7 +417,11 @@ __global__ void __launch_bounds__(64 * ZG_FT_W) zg_k_ftab(ZgBatchDev d) {
 __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
   __shared__ uint16_t s_tab[ZG_HUF_SLOT_U16];
   __shared__ __attribute__((aligned(16))) uint8_t s_win[ZG_HUF_GROUP][ZG_HP_STAGE];
-  __shared__ uint8_t s_sym[ZG_HUF_GROUP][ZG_HP_CB][64];      // [symbol index][lane]: a chunk of CB bits holds at most CB symbols
+  // [symbol index][lane]. A chunk of cb bits holds at most cb symbols, but 128 rows per wave would be most of the kernel's LDS
+  // for a case that needs codes of < 3 bits on average: a window in which a chunk overflows ZG_HP_ROWS is decoded again,
+  // and the rest of the stream with it, in chunks of ZG_HP_CB_DENSE bits (which cannot overflow).
+  __shared__ uint8_t s_sym[ZG_HUF_GROUP][ZG_HP_ROWS][64];
+  static_assert(ZG_HP_CB_DENSE <= ZG_HP_ROWS && ZG_HP_CB_DENSE <= ZG_HP_CB, "the dense chunk size must fit the rows");
   const ZgHufGroup grp = d.huf_groups[blockIdx.x];
   const uint32_t t = threadIdx.x, wv = t >> 6, lane = t & 63;
   unsigned max_bits = grp.slot >= 0 ? d.huf_maxbits[grp.slot] : 0;
@@ -476,6 +482,7 @@ __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
   int32_t top = T;                                            // true entry position of the window
   uint32_t ndone = 0;
   bool overflow = false;
+  int32_t cb = ZG_HP_CB;                                      // bits per lane in this window
   while (top > 0) {
     // ---- stage the bytes that hold bits [top - 4096 - 16, top + 8): 16-byte pieces, zeros below the stream start
     const int64_t lowbit = (int64_t)top - 64 * ZG_HP_CB - 16;   // staged up to top + 128 bits at least (warm-up + a two-dword read)
@@ -498,7 +505,8 @@ __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
     const int32_t wq0 = (int32_t)((wb0 - A) * 8);             // stream bit index of staged bit 0 (LDS of one wave is in order: no barrier)
     const uint32_t* win32 = (const uint32_t*)win;
     // one pass over the lane's chunk from position `from`: symbols to s_sym, returns the exit position
-    const int32_t U = top - (int32_t)lane * ZG_HP_CB, L = U - ZG_HP_CB > 0 ? U - ZG_HP_CB : 0;
+    const int32_t U = top - (int32_t)lane * cb, L = U - cb > 0 ? U - cb : 0;
+    bool spill = false;                                         // more symbols in the chunk than rows
     uint32_t n = 0;
     int32_t entry = U;                                          // where the lane's recorded symbols start
     auto pass = [&](int32_t from) -> int32_t {
@@ -515,9 +523,10 @@ __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
         const uint32_t rb = (uint32_t)(q - wq0);
         const uint32_t d0 = win32[rb >> 5], d1 = win32[(rb >> 5) + 1];
         const uint32_t e = s_tab[__builtin_amdgcn_alignbit(d1, d0, rb & 31u) & pmask];
+        if (n >= ZG_HP_ROWS) { spill = true; break; }
         sym[64 * n++] = (uint8_t)e;
-        P -= (int32_t)(e >> 8);
-        if (n >= ZG_HP_CB) break;                              // cannot happen with a valid table (every code has >= 1 bit)
+        const int32_t nb = (int32_t)(e >> 8);
+        P -= nb > 1 ? nb : 1;                                  // (every code has >= 1 bit; the max keeps a corrupted entry from stalling the loop)
       }
       return P;
     };
@@ -529,6 +538,10 @@ __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
       const bool need = active && lane > 0 && pe != entry;
       if (!__any(need)) break;
       if (need) E = pass(pe);
+    }
+    if (__any(spill)) {                                          // only possible with cb == ZG_HP_CB
+      cb = ZG_HP_CB_DENSE;
+      continue;                                                 // the same window again (the staged bytes cover the smaller one)
     }
     // ---- all lanes are on the true path: count, place, write
     uint32_t incl = active ? n : 0u;
@@ -544,7 +557,7 @@ __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
     if (ndone + wtot > cap) overflow = true;                   // more symbols than the section holds
     ndone += wtot;
     // the last active lane's exit is the next entry; it is <= 0 when that lane's chunk reaches the stream start
-    const uint32_t nact = (uint32_t)((top + ZG_HP_CB - 1) / ZG_HP_CB);
+    const uint32_t nact = (uint32_t)((top + cb - 1) / cb);
     top = __shfl(E, (int)(nact < 64u ? nact - 1u : 63u), 64);
     if (overflow) break;
   }
