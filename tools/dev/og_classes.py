@@ -15,7 +15,9 @@ ctx = zgpu.Context(0)
 b = ctx.prepare(z)
 b.run(); b.sync()
 tot = lit = inside = before = runs = full64 = n64 = 0
-for fb, nb, base, usz in b.units()[:48]:
+for fb, nb, base, usz, noseq in b.units()[:48]:
+    if noseq:
+        continue
     e = b.scratch_words(base, usz).astype(np.int64)
     x = np.arange(usz, dtype=np.int64)
     tot += usz; lit += int((e == 0).sum()); inside += int(((e > 0) & (e <= x)).sum()); before += int((e > x).sum())

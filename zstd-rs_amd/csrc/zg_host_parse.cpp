@@ -251,24 +251,30 @@ void BatchBuilder::finish() {
     for (uint32_t i = 0; i < fr.nblocks; i += ub) {
       ZgUnit u;
       u.frame = f; u.first_block = fr.first_block + i;
-      u.nblocks = fr.nblocks - i < ub ? fr.nblocks - i : ub; u.pad = 0;
+      u.nblocks = fr.nblocks - i < ub ? fr.nblocks - i : ub; u.noseq = 1;
+      for (uint32_t k = 0; k < u.nblocks; k++) {
+        const ZgBlock& bk = blocks[u.first_block + k];
+        if (bk.btype == ZG_BT_COMPRESSED && bk.nseq) u.noseq = 0;
+      }
       units.push_back(u);
     }
     fr.nunits = (uint32_t)units.size() - fr.first_unit;
     if (fr.nunits > max_units) max_units = fr.nunits;
   }
-  // sweep steps: step s takes unit s of every frame that has one (frames are independent; units of a frame go in order)
+  // sweep steps: step s takes unit s of every frame that has one (frames are independent; units of a frame go in order).
+  // Units without sequences need no step, and a step nobody needs is not launched (literal-heavy frames: most of them).
   for (uint32_t s = 0; s < max_units; s++) {
     ZgStepRange r;
     r.list_off = (uint32_t)step_units.size(); r.nunits = 0; r.max_blocks = 0;
     for (uint32_t f = 0; f < frames.size(); f++) {
       if (frames[f].nunits <= s) continue;
       const uint32_t u = frames[f].first_unit + s;
+      if (units[u].noseq) continue;
       step_units.push_back(u);
       r.nunits++;
       if (units[u].nblocks > r.max_blocks) r.max_blocks = units[u].nblocks;
     }
-    steps.push_back(r);
+    if (r.nunits) steps.push_back(r);
   }
   for (uint32_t i = 0; i < nb; i++) {
     ZgBlock& b = blocks[i];

@@ -1344,7 +1344,7 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
   __shared__ unsigned long long s_bad;          // first failing sequence of the block: index << 32 | match position << 8 | provisional status
   const uint32_t t = threadIdx.x;
   const ZgUnit un = d.units[blockIdx.x];
-  if (t == 0) { ZgUnitInfo ui; ui.size = 0; ui.pad = 0; d.unit_info[blockIdx.x] = ui; }
+  if (t == 0) { ZgUnitInfo ui; ui.size = 0; ui.noseq = 0; d.unit_info[blockIdx.x] = ui; }
   if (d.totals[2]) return;
   const ZgFrameOut fo = d.frame_out[un.frame];
   if (!fo.fast) return;
@@ -1369,7 +1369,7 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
     const uint32_t bu0 = (uint32_t)(p.out_base - unit_abs0);      // unit-relative position of the block
     if (blk.btype != ZG_BT_COMPRESSED || blk.nseq == 0) {        // all of it is final already (zg_k_lit): effective offset 0
       const uint32_t n = blk.regen_size;
-      for (uint32_t i = t; i < n; i += T) og[bu0 + i] = 0u;
+      if (!un.noseq) for (uint32_t i = t; i < n; i += T) og[bu0 + i] = 0u;   // (a unit without sequences has no sweep step: nobody reads its scratch)
       unit_size = bu0 + n;
       continue;
     }
@@ -1594,7 +1594,7 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
     }
   }
   __syncthreads();
-  if (t == 0) { ZgUnitInfo ui; ui.size = unit_size; ui.pad = 0; d.unit_info[blockIdx.x] = ui; }
+  if (t == 0) { ZgUnitInfo ui; ui.size = unit_size; ui.noseq = un.noseq; d.unit_info[blockIdx.x] = ui; }
 #ifdef ZG_PROFILE_FLAT
   if (t == 0 && d.dbg) { for (int i = 0; i < 8; i++) atomicAdd(&d.dbg[i], tc[i]); }
 #endif

@@ -176,8 +176,9 @@ struct ZgFrameOut {
 };
 
 // LZ77 execution works on units: runs of consecutive blocks of one frame that zg_k_flat resolves together.
-struct ZgUnit { uint32_t frame, first_block, nblocks, pad; };
-struct ZgUnitInfo { uint32_t size; uint32_t pad; };   // written by zg_k_flat: bytes of the unit
+// noseq: none of the unit's blocks has sequences: all of it is literal bytes, final after zg_k_lit; no scratch, no sweep step
+struct ZgUnit { uint32_t frame, first_block, nblocks, noseq; };
+struct ZgUnitInfo { uint32_t size; uint32_t noseq; };   // written by zg_k_flat: bytes of the unit
 
 // what a sweep workgroup needs to know about its unit
 // head: 4 KiB batches at the front of the unit that nothing later depends on when no match reaches further back than the
