@@ -469,7 +469,7 @@ int Batch::run() {
 }
 
 // The sweep. split: tails on the main stream, heads beside them on the second one, which is right as long as no match
-// reaches further back than its frame's window (zg_k_flat reports one that does: sync() then repeats the sweep the plain way).
+// reaches further back than its frame's window (zg_k_seqpost reports one that does: sync() then repeats the sweep the plain way).
 void Batch::launch_sweep(bool split) {
   const char* e = getenv("ZGPU_SWEEP_SPLIT");
   if (e && e[0] == '0') split = false;

@@ -37,7 +37,7 @@ struct ZgBatchDev {
   const uint32_t* huf_items;   // (block << 2) | stream
   const ZgHufGroup* huf_groups;
   uint32_t nhuf_groups;
-  uint32_t* totals;            // [4]: [0..1] total output bytes (u64), [2] overflow flag, [3] a match reaches further back than its frame's window (zg_k_flat)
+  uint32_t* totals;            // [4]: [0..1] total output bytes (u64), [2] overflow flag, [3] a match reaches further back than its frame's window (zg_k_seqpost)
   uint32_t sweep_window;       // 0: a frame's window size bounds its matches (checked); else this many bytes instead (tests)
   uint32_t flags;              // bit 0: force the in-order fallback for every frame (tests); bits 2-3: shape of zg_k_flat (0: 1024 threads x 16 KiB tiles, 1: 512 x 8 KiB)
   uint64_t og_words;           // size of the flatten scratch in u32

@@ -1,20 +1,24 @@
 // zg_kernels.hip — gfx950 (MI355X, CDNA4, wave64) kernels of the zstd block-decode engine.
 //
-// Pipeline of one submit (two HIP streams, no host round trip in between):
+// Pipeline of one submit (two HIP streams; the host reads the frame sizes once, between zg_k_scanf and zg_k_lit):
 //   sequences chain (high-priority stream)
 //     zg_k_ftab     one wave per block         FSE table descriptions -> FSE arena (+ the predefined tables)
-//     zg_k_seq      four lanes per block       the three FSE state chains of a block -> raw records (8 B per sequence)
-//     zg_k_seqpost  one workgroup per block    extra bits, values, positions, offset history (scans) -> ZgSeq[]
+//     zg_k_seq      decoder + mover wave per 16 blocks, four lanes per block
+//                                              the three FSE state chains of a block -> the states of every sequence (8 B)
+//     zg_k_seqpost  one workgroup per block    symbols, extra bits, values, positions, offset history (scans) -> ZgSeq[] (12 B)
 //   literals chain (low-priority stream, beside zg_k_seq)
-//     zg_k_tables   one lane per block         Huffman tree descriptions -> Huffman arena
+//     zg_k_tables   one wave per block         Huffman tree descriptions -> Huffman arena
 //     zg_k_huf      one wave per stream        Huffman literal streams, self-synchronising -> literals arena
 //   then, on the first stream
 //     zg_k_merge    one thread per block       literals errors into the block status
 //     zg_k_scan     one workgroup per frame    block output positions + offset-history resolution (function-composition scan)
-//     zg_k_scanf    one workgroup              frame output positions
+//     zg_k_scanf    one workgroup              frame output positions and scratch bases
 //     zg_k_lit      one workgroup per block    raw and RLE blocks, blocks without sequences -> output
-//     zg_k_flat     one workgroup per unit     every match byte of a run of blocks -> its offset to a byte that is final before the unit is swept; literals -> output
-//     zg_k_sweep    one launch per unit index  unit after unit: match bytes gathered from finished output
+//     zg_k_flat     one workgroup per unit     every byte of a run of blocks -> its effective offset (to a literal byte, or to a byte in
+//                                              front of the unit); literals -> output
+//     zg_k_swprep   one thread per unit        sweep descriptors
+//     zg_k_sweep    one launch per unit index  the units' tails, unit after unit: match bytes gathered from finished output;
+//                   + one per 16 indices       their heads beside the chain on the second stream (split sweep)
 //     zg_k_fin      one thread per frame       execution errors -> frame status
 //     zg_k_lz       one workgroup per frame    in-order fallback (blocks regenerating > 128 KiB)
 //
@@ -23,7 +27,7 @@
 #include "zg_kernels.h"
 #include "zg_dev.h"
 
-#define ZG_SEQ_G 16       // blocks per workgroup (one wave, four lanes per block) in zg_k_seq: 16 x (2.5 KiB tables + 1.25 KiB side tables + ring + out) in LDS -> 2 workgroups per CU
+#define ZG_SEQ_G 16       // blocks per workgroup (four lanes per block in either wave) in zg_k_seq: 16 x (2.5 KiB + 1.25 KiB tables + ring + records) in LDS -> 2 workgroups per CU
 #define ZG_LZ_T 256       // threads per frame in zg_k_lz
 #define ZG_FLAT_MAX 131072u  // largest block output the flatten path handles (Block_Maximum_Size)
 
@@ -45,7 +49,7 @@ __device__ __forceinline__ void zg_set_status(uint32_t* status, uint32_t b, int 
 }
 // The streams of a block's literals run in different waves: which error is reported must not depend on who is first.
 // rank 0 is the most significant; the word keeps (255 - rank) << 8 | status, the largest wins (zg_k_merge strips the rank).
-// how far back a match of the frame may reach as far as the split sweep is concerned (zg_k_flat reports a longer one)
+// how far back a match of the frame may reach as far as the split sweep is concerned (zg_k_seqpost reports a longer one)
 __device__ __forceinline__ uint32_t zg_sweep_window(const ZgBatchDev& d, const ZgFrame& fr) {
   return d.sweep_window ? d.sweep_window : (fr.window_size > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)fr.window_size);
 }
