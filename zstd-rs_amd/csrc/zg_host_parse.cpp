@@ -234,8 +234,10 @@ void BatchBuilder::finish() {
     if (final_.huf == kCarryHuf) final_.huf = frames[lf].carry_huf_slot;
   }
   seq_blocks.clear(); huf_items.clear(); huf_groups.clear(); units.clear(); step_units.clear(); steps.clear();
-  // blocks per unit: zg_k_flat runs flat_slots workgroups at once, one per unit, so aim at ~flat_slots units over the
-  // whole submit (more blocks per unit = fewer sweep steps, but less parallelism in the flatten pass)
+  // blocks per unit: zg_k_flat runs flat_slots workgroups at once, one per unit, so aim at ~flat_slots units over the whole
+  // submit (more blocks per unit = fewer sweep steps, but less parallelism in the flatten pass). What costs there are the
+  // blocks that have sequences: a literal-heavy frame gets smaller units in proportion, so that few literal-only blocks share a
+  // unit — scratch words, a sweep step — with a block that needs them.
   uint32_t ub = unit_blocks;
   if (ub == 0) {
     const uint32_t slots = flat_slots ? flat_slots : 1;
@@ -248,10 +250,17 @@ void BatchBuilder::finish() {
   for (uint32_t f = 0; f < frames.size(); f++) {
     ZgFrame& fr = frames[f];
     fr.first_unit = (uint32_t)units.size();
-    for (uint32_t i = 0; i < fr.nblocks; i += ub) {
+    uint32_t ubf = ub;
+    if (unit_blocks == 0 && fr.nblocks) {
+      uint32_t nbs = 0;
+      for (uint32_t i = 0; i < fr.nblocks; i++) { const ZgBlock& bk = blocks[fr.first_block + i]; nbs += bk.btype == ZG_BT_COMPRESSED && bk.nseq ? 1u : 0u; }
+      ubf = (uint32_t)(((uint64_t)ub * nbs + fr.nblocks - 1) / fr.nblocks);
+      if (ubf < 4) ubf = 4;
+    }
+    for (uint32_t i = 0; i < fr.nblocks; i += ubf) {
       ZgUnit u;
       u.frame = f; u.first_block = fr.first_block + i;
-      u.nblocks = fr.nblocks - i < ub ? fr.nblocks - i : ub; u.noseq = 1;
+      u.nblocks = fr.nblocks - i < ubf ? fr.nblocks - i : ubf; u.noseq = 1;
       for (uint32_t k = 0; k < u.nblocks; k++) {
         const ZgBlock& bk = blocks[u.first_block + k];
         if (bk.btype == ZG_BT_COMPRESSED && bk.nseq) u.noseq = 0;
