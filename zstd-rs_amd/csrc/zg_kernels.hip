@@ -1505,17 +1505,28 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
         for (int g = 0; g < G; g++) {
           const int k = k0 + g;
           const uint32_t x = tc + k * T;
-          const bool live = x < n;
+          // (selects nested one condition at a time: combined conditions cost a scalar instruction each, and this kernel is bound by
+          //  the number of instructions of any kind it issues)
           const uint32_t off = rec[g].x, m0 = rec[g].y;
-          const bool is_lit = x < m0;
-          const bool inner = !is_lit && off <= x;                           // parent inside the tile
-          const bool exits = !is_lit && !inner;
+          const bool c_live = x < n, c_lit = x < m0, c_in = off <= x;      // c_in (when not a literal): parent inside the tile
           const int32_t y4 = (int32_t)(4u * (tu0 + x)) - (int32_t)rec[g].w; // 4 * unit position of the parent (units are far below 2^29 bytes)
-          wadd[k] = __builtin_amdgcn_raw_buffer_load_b32(og_rs, (live && exits && y4 >= 0) ? (uint32_t)y4 : ZG_OOB, 0, 0);
+          // the parent's scratch word is wanted for a live root whose parent lies in the unit; any other offset is made negative, i.e.
+          // out of the resource's range: no fetch
+          int32_t go = c_in ? -1 : y4;
+          go = c_lit ? -1 : go;
+          go = c_live ? go : -1;
+          wadd[k] = __builtin_amdgcn_raw_buffer_load_b32(og_rs, (uint32_t)go, 0, 0);
           // (bytes behind the tile's end write too: their slots are not used by anything)
-          s_par[x] = (uint16_t)(is_lit ? ZG_PAR_LIT : inner ? x - off : ZG_PAR_EXIT);
-          s_word[x] = exits ? off : is_lit ? rec[g].z + x : 0u;
-          unresolved |= (live && inner) ? 1u << k : 0u;
+          uint32_t par = c_in ? x - off : (uint32_t)ZG_PAR_EXIT;
+          par = c_lit ? (uint32_t)ZG_PAR_LIT : par;
+          s_par[x] = (uint16_t)par;
+          uint32_t wrd = c_in ? 0u : off;
+          wrd = c_lit ? rec[g].z + x : wrd;
+          s_word[x] = wrd;
+          uint32_t ub = c_in ? 1u << k : 0u;
+          ub = c_lit ? 0u : ub;
+          ub = c_live ? ub : 0u;
+          unresolved |= ub;
         }
       }
       zg_lds_barrier();
