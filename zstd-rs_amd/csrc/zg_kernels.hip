@@ -1571,10 +1571,12 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
         // (three passes over the batch, so that its LDS reads go out together: one round trip for the pointers, one for the words)
 #pragma unroll
         for (int h = 0; h < H; h++) pr[h] = s_par[t3 + (k0 + h) * T];
+        // (each of these loops takes its inputs last first: the one wait in front of the first use then covers the whole batch,
+        //  where first-to-last order costs a wait instruction per element; the kernel is bound by instructions issued)
 #pragma unroll
-        for (int h = 0; h < H; h++) { const uint32_t x = t3 + (k0 + h) * T; w[h] = s_word[pr[h] >= ZG_PAR_EXIT ? x : pr[h]]; }
+        for (int h = H - 1; h >= 0; h--) { const uint32_t x = t3 + (k0 + h) * T; w[h] = s_word[pr[h] >= ZG_PAR_EXIT ? x : pr[h]]; }
 #pragma unroll
-        for (int h = 0; h < H; h++) {
+        for (int h = H - 1; h >= 0; h--) {
           const uint32_t x = t3 + (k0 + h) * T;
           const bool live = x < n;
           const uint32_t r = pr[h] >= ZG_PAR_EXIT ? x : pr[h];
@@ -1585,7 +1587,7 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
           __builtin_amdgcn_raw_buffer_store_b32(e, og_rs, live ? 4u * (tu0 + x) : ZG_OOB, 0, 0);
         }
 #pragma unroll
-        for (int h = 0; h < H; h++)
+        for (int h = 0; h < H; h++)   // (lb[0] was requested last)
           __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(lb[h] | lit_fill), out_rs, ((islm >> h) & 1u) ? tu0 + t3 + (k0 + h) * T : ZG_OOB, 0, 0);
       }
       zg_lds_barrier();  // s_par / s_word / the records are reused by the next tile
