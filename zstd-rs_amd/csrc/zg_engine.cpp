@@ -304,6 +304,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   // a frame-layer error after some good frames: the good frames are still uploaded (callers such as the
   // FrameDecoder mirror may want them); decode_all reports parse_status.
   { const char* e = getenv("ZGPU_UNIT_BLOCKS"); if (e && atoi(e) > 0) b->bb.unit_blocks = (uint32_t)atoi(e); }
+  { const char* e = getenv("ZGPU_SPARSE_MAX"); if (e) b->bb.sparse_max = (uint32_t)atoi(e); }   // sequences per frame up to which zg_k_sparse replaces the sweep (0: never)
   b->bb.flat_slots = (uint32_t)cus_ * (flat_shape_ == 0 ? 1u : 2u);   // zg_k_flat: workgroups the device holds at once
   b->bb.finish();
   BatchBuilder& bb = b->bb;
@@ -457,6 +458,7 @@ int Batch::run() {
   zg_launch_lit(d, s);
   ZG_HIP(hipEventRecord(ev[6], s));
   zg_launch_flat(d, s);
+  { bool any = false; for (const ZgFrame& fr : bb.frames) any = any || fr.sparse; if (any) zg_launch_sparse(d, s); }
   ZG_HIP(hipEventRecord(ev[7], s));
   sweep_mode = 0; synced = false;
   if (!getenv("ZGPU_DEBUG_NO_SWEEP")) launch_sweep(true);

@@ -250,10 +250,16 @@ void BatchBuilder::finish() {
   for (uint32_t f = 0; f < frames.size(); f++) {
     ZgFrame& fr = frames[f];
     fr.first_unit = (uint32_t)units.size();
-    uint32_t ubf = ub;
+    uint32_t ubf = ub, nbs = 0;
+    uint64_t nsq = 0;
+    for (uint32_t i = 0; i < fr.nblocks; i++) {
+      const ZgBlock& bk = blocks[fr.first_block + i];
+      if (bk.btype == ZG_BT_COMPRESSED && bk.nseq) { nbs++; nsq += bk.nseq; }
+    }
+    // few sequences in a frame of many blocks: one wave copies its matches in order faster than a chain of sweep launches runs
+    fr.sparse = (sparse_max && nsq <= sparse_max && (uint64_t)fr.nblocks * 4 >= nsq) ? 1u : 0u;
+    fr.seq_first = fr.seq_count = 0; fr.pad2 = 0;
     if (unit_blocks == 0 && fr.nblocks) {
-      uint32_t nbs = 0;
-      for (uint32_t i = 0; i < fr.nblocks; i++) { const ZgBlock& bk = blocks[fr.first_block + i]; nbs += bk.btype == ZG_BT_COMPRESSED && bk.nseq ? 1u : 0u; }
       ubf = (uint32_t)(((uint64_t)ub * nbs + fr.nblocks - 1) / fr.nblocks);
       if (ubf < 4) ubf = 4;
     }
@@ -278,7 +284,7 @@ void BatchBuilder::finish() {
     for (uint32_t f = 0; f < frames.size(); f++) {
       if (frames[f].nunits <= s) continue;
       const uint32_t u = frames[f].first_unit + s;
-      if (units[u].noseq) continue;
+      if (units[u].noseq || frames[f].sparse) continue;
       step_units.push_back(u);
       r.nunits++;
       if (units[u].nblocks > r.max_blocks) r.max_blocks = units[u].nblocks;
@@ -294,7 +300,12 @@ void BatchBuilder::finish() {
       else if (*sl[k] == kCarry) *sl[k] = (int32_t)frames[b.frame].carry_slot;
     }
     if (b.huf_slot == kCarryHuf) b.huf_slot = frames[b.frame].carry_huf_slot;
-    if (b.nseq) { b.seq_idx = (uint32_t)seq_blocks.size(); seq_blocks.push_back(i); }
+    if (b.nseq) {
+      ZgFrame& fr = frames[b.frame];
+      if (!fr.seq_count) fr.seq_first = (uint32_t)seq_blocks.size();
+      fr.seq_count++;
+      b.seq_idx = (uint32_t)seq_blocks.size(); seq_blocks.push_back(i);
+    }
     if (b.lit_type >= ZG_LT_COMPRESSED) {
       for (uint32_t k = 0; k < b.nstreams; k++) {
         if (huf_groups.empty() || huf_groups.back().slot != b.huf_slot || huf_groups.back().nitems >= ZG_HUF_GROUP) {

@@ -60,6 +60,7 @@ void zg_launch_merge(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_scan(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_lit(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_flat(const ZgBatchDev& d, hipStream_t s);
+void zg_launch_sparse(const ZgBatchDev& d, hipStream_t s);   // the matches of frames marked sparse, in order (after zg_launch_flat)
 bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* steps, uint32_t nsteps, hipStream_t s2, hipEvent_t* evs, uint32_t nev,
                      uint32_t unit_bytes, uint32_t window_max);   // s2 / evs: the side stream of the split sweep (nev == 0: one stream, step by step); returns whether it split
 void zg_launch_lz(const ZgBatchDev& d, hipStream_t s);

@@ -1821,7 +1821,8 @@ __global__ void __launch_bounds__(ZG_LZ_T) zg_k_lz(ZgBatchDev d) {
       carry_out = to; carry_lit = tl;
       __syncthreads();
       if (s_err) break;
-      for (;;) {
+      for (uint32_t guard = 0;; guard++) {                       // (every round retires the first pending match at least: <= ZG_LZ_T rounds)
+        if (guard > ZG_LZ_T) { if (t == 0) s_err = ZG_INTERNAL; __syncthreads(); break; }
         // high-water mark = smallest destination among pending matches of this batch
         uint32_t m = pending ? mdst : 0xFFFFFFFFu;
         for (int sh = 32; sh >= 1; sh >>= 1) { uint32_t o = __shfl_xor(m, sh, 64); m = o < m ? o : m; }
@@ -1832,7 +1833,8 @@ __global__ void __launch_bounds__(ZG_LZ_T) zg_k_lz(ZgBatchDev d) {
         if (hwm == 0xFFFFFFFFu) break;
         if (pending) {
           // source bytes that must already exist: [dpos - off, min(dpos - off + ml, dpos))
-          uint64_t need_end = ml < off ? dpos - off + ml : dpos;
+          const int64_t src_end = (int64_t)dpos - (int64_t)off + (int64_t)ml;   // (<= 0: all of the source lies in front of the frame)
+          const uint64_t need_end = ml < off ? (src_end > 0 ? (uint64_t)src_end : 0ull) : dpos;
           if (need_end <= p.out_base + hwm) {
             zg_lane_match_copy(frame_out + dpos, off, ml);
             pending = false;
@@ -1924,6 +1926,59 @@ void zg_launch_scan(const ZgBatchDev& d, hipStream_t s) {
 }
 void zg_launch_lit(const ZgBatchDev& d, hipStream_t s) {
   if (d.nblocks) hipLaunchKernelGGL(zg_k_lit, dim3(d.nblocks), dim3(256), 0, s, d);
+}
+// ------------------------------------------------------------------------------------------------------------
+// zg_k_sparse: the matches of a frame that has hardly any (literal-heavy data: a sequence or two in one block out of twenty).
+// zg_k_flat has placed the literals and checked the offsets; what is left is a few hundred short copies per frame, which one
+// wave does in order (a match may copy from an earlier one) in the time of a few sweep launches — of which the frame would
+// need one per unit. One wave per frame, 64 sequences at a time, the same "copy what no pending match can still write"
+// rule as zg_k_lz.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) zg_k_sparse(ZgBatchDev d) {
+  if (d.totals[2]) return;
+  const uint32_t f = blockIdx.x, lane = threadIdx.x;
+  const ZgFrame fr = d.frames[f];
+  if (!fr.sparse) return;
+  const ZgFrameOut fo = d.frame_out[f];
+  if (!fo.fast || fo.err_packed != 0xFFFFFFFFu) return;        // the in-order path has it / zg_k_flat found a sequence that cannot be executed
+  uint8_t* frame_out = d.dst + fo.out_base;
+  for (uint32_t e = 0; e < fr.seq_count; e++) {
+    const uint32_t b = d.seq_blocks[fr.seq_first + e];
+    const ZgBlockPos p = d.pos[b];
+    if (!p.active) break;
+    const ZgBlock* blk = &d.blocks[b];
+    const uint32_t nseq = blk->nseq;
+    const ZgSeq* sq = d.seq_arena + blk->seq_base;
+    for (uint32_t s0 = 0; s0 < nseq; s0 += 64) {
+      const uint32_t i = s0 + lane;
+      bool pending = false;
+      uint32_t off = 0, ml = 0, mdst = 0xFFFFFFFFu;
+      uint64_t dpos = 0;
+      if (i < nseq) {
+        const ZgSeq q = sq[i];
+        ml = ZG_SEQ_ML(q); mdst = ZG_SEQ_MDST(q);
+        off = zg_sym_resolve(q.of, p.hist_init);
+        dpos = p.out_base + mdst;
+        pending = ml > 0;
+      }
+      for (uint32_t guard = 0;; guard++) {                       // (every round retires the first pending match at least: <= 64 rounds)
+        if (guard > 64u) { if (lane == 0) d.frame_out[f].status = ZG_INTERNAL; return; }
+        uint32_t hwm = pending ? mdst : 0xFFFFFFFFu;            // the lowest destination a pending match of the batch still has to write
+        for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t o = __shfl_xor(hwm, sh, 64); hwm = o < hwm ? o : hwm; }
+        if (hwm == 0xFFFFFFFFu) break;
+        if (pending) {
+          // source bytes that must exist: [dpos - off, need_end). What lies in front of the frame (dictionary, earlier submits) exists.
+          const int64_t src_end = (int64_t)dpos - (int64_t)off + (int64_t)ml;
+          const uint64_t need_end = ml < off ? (src_end > 0 ? (uint64_t)src_end : 0ull) : dpos;
+          if (need_end <= p.out_base + hwm) { zg_lane_match_copy(frame_out + dpos, off, ml); pending = false; }
+        }
+        __threadfence_block();                                   // the copies are visible to the lanes that copy from them next
+      }
+    }
+  }
+}
+void zg_launch_sparse(const ZgBatchDev& d, hipStream_t s) {
+  if (d.nframes) hipLaunchKernelGGL(zg_k_sparse, dim3(d.nframes), dim3(64), 0, s, d);
 }
 void zg_launch_flat(const ZgBatchDev& d, hipStream_t s) {
   if (!d.nunits) return;

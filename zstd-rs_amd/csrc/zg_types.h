@@ -124,6 +124,9 @@ struct ZgFrame {
   uint64_t prior_out;              // bytes of this frame already decoded by earlier submits (streaming)
   uint64_t dict_len;               // dictionary content length reachable before the frame start
   uint64_t prior_reach;            // of prior_out, the most recent bytes a match may still reach: what the caller has not drained (DecodeBuffer holds nothing older)
+  uint32_t seq_first, seq_count;   // the frame's blocks that have sequences: a range of the batch's seq_blocks list
+  uint32_t sparse;                 // so few sequences (literal-heavy data) that its matches are copied in order by one wave (zg_k_sparse)
+  uint32_t pad2;                   //   instead of going through the sweep: a chain of launches per unit would cost more than the copies
 };
 
 // What the table kernel records per block.
