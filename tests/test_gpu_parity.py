@@ -684,3 +684,19 @@ def test_split_sweep_is_repeated_when_a_match_exceeds_the_window():
     assert bad == 0 and mode == 2 and out == data
     out, mode, bad = _run_batch(z, {"ZGPU_UNIT_BLOCKS": "8"})
     assert bad == 0 and mode == 0 and out == data      # units shorter than the window: nothing to split
+
+
+def test_sparse_frames_copy_their_matches_in_order():
+    """a frame with hardly any sequences (literal-heavy data) skips the flatten scratch and the sweep: one wave copies its
+    matches in order (zg_k_sparse). Same bytes as with the sweep, as the generator's, and — forced onto a frame full of
+    sequences, where matches copy from matches — still the same."""
+    import zgdata
+    iso = zgdata.iso_like(6 << 20, seed=0x151)
+    z = zgdata.zstd_compress(iso)
+    for env in ({}, {"ZGPU_SPARSE_MAX": "0"}):
+        out, mode, bad = _run_batch(z, env)
+        assert bad == 0 and out == iso, env
+    text = zgdata.text_like(3 << 20, seed=0x152)
+    zt = zgdata.zstd_compress(text)
+    out, mode, bad = _run_batch(zt + z, {"ZGPU_SPARSE_MAX": "100000000"})     # both frames through zg_k_sparse
+    assert bad == 0 and out == text + iso

@@ -304,7 +304,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   // a frame-layer error after some good frames: the good frames are still uploaded (callers such as the
   // FrameDecoder mirror may want them); decode_all reports parse_status.
   { const char* e = getenv("ZGPU_UNIT_BLOCKS"); if (e && atoi(e) > 0) b->bb.unit_blocks = (uint32_t)atoi(e); }
-  { const char* e = getenv("ZGPU_SPARSE_MAX"); if (e) b->bb.sparse_max = (uint32_t)atoi(e); }   // sequences per frame up to which zg_k_sparse replaces the sweep (0: never)
+  { const char* e = getenv("ZGPU_SPARSE_MAX"); if (e) { b->bb.sparse_max = (uint32_t)atoi(e); b->bb.sparse_per_block = 1u << 20; } }   // (tests) sequences per frame up to which zg_k_sparse replaces the sweep, whatever their density; 0: never
   b->bb.flat_slots = (uint32_t)cus_ * (flat_shape_ == 0 ? 1u : 2u);   // zg_k_flat: workgroups the device holds at once
   b->bb.finish();
   BatchBuilder& bb = b->bb;

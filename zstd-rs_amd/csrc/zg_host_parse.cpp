@@ -257,7 +257,7 @@ void BatchBuilder::finish() {
       if (bk.btype == ZG_BT_COMPRESSED && bk.nseq) { nbs++; nsq += bk.nseq; }
     }
     // few sequences in a frame of many blocks: one wave copies its matches in order faster than a chain of sweep launches runs
-    fr.sparse = (sparse_max && nsq <= sparse_max && (uint64_t)fr.nblocks * 4 >= nsq) ? 1u : 0u;
+    fr.sparse = (sparse_max && nsq <= sparse_max && (uint64_t)fr.nblocks * sparse_per_block >= nsq) ? 1u : 0u;
     fr.seq_first = fr.seq_count = 0; fr.pad2 = 0;
     if (unit_blocks == 0 && fr.nblocks) {
       ubf = (uint32_t)(((uint64_t)ub * nbs + fr.nblocks - 1) / fr.nblocks);
