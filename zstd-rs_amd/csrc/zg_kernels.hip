@@ -19,6 +19,7 @@
 //     zg_k_swprep   one thread per unit        sweep descriptors
 //     zg_k_sweep    one launch per unit index  the units' tails, unit after unit: match bytes gathered from finished output;
 //                   + one per 16 indices       their heads beside the chain on the second stream (split sweep)
+//     zg_k_sparse   one wave per frame         frames with hardly any sequences: their matches in order, instead of sweep steps
 //     zg_k_fin      one thread per frame       execution errors -> frame status
 //     zg_k_lz       one workgroup per frame    in-order fallback (blocks regenerating > 128 KiB)
 //
