@@ -125,6 +125,31 @@ def cpu_baseline(zs, plain_len, cores):
             "note": "nt = one frame per thread on nt_cores threads; ruzstd itself is not buildable here (no rustc/cargo)"}
 
 
+def other_workload(name, local_rank, steps=20):
+    import zgdata
+    import zgpu
+    desc, plains, _, _ = build_workload(name, 0, 1, 0)
+    zs = [zgdata.zstd_compress(p, level=3) for p in plains]
+    pool = zgpu.Pool(devices=[local_rank])
+    pool.stage(zs)
+    for _ in range(2):
+        pool.run()
+    for k, p in enumerate(plains):
+        gpu, size, st = pool.frame(k)
+        assert st == 0 and size == len(p), (name, k, st, size)
+        assert hashlib.sha256(pool.read(k, size)).digest() == hashlib.sha256(p).digest(), "GPU output differs (%s frame %d)" % (name, k)
+    t0 = time.perf_counter()
+    busy = 0.0
+    for _ in range(steps):
+        gms, _ = pool.run()
+        busy += gms[0]
+    dt = time.perf_counter() - t0
+    pool.close()
+    D = sum(len(p) for p in plains)
+    return {"workload": desc, "plaintext_bytes": D, "compressed_bytes": sum(len(z) for z in zs), "frames": len(zs), "steps": steps,
+            "GBps": round(D * steps / dt / 1e9, 3), "ms_per_step": round(dt / steps * 1e3, 3), "kernel_ms_per_step": round(busy / steps, 3)}
+
+
 def e2e_rate(ctx, z, plain_len):
     """C ABI zgpu_decode_all: host buffer in, host buffer out (H2D + host block walk + kernels + D2H), pinned host buffers"""
     import torch
@@ -148,6 +173,7 @@ def main():
     ap.add_argument("--size", type=int, default=int(os.environ.get("ZGPU_BENCH_SIZE", 1000000000)), help="plaintext bytes per GPU (enwik9like)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-other", action="store_true", help="skip the short runs of the other BASELINE.json configurations")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -276,8 +302,14 @@ def main():
             n = min(len(plains[i0]), 64 << 20)
             zc = zs[i0] if n == len(plains[i0]) else zgdata.zstd_compress(plains[i0][:n], level=3)
             out["cpu_baseline"] = cpu_baseline(zc, n, max(1, min(os.cpu_count() or 1, 64)))
+        if not args.no_other and world == 1 and args.workload == "enwik9like":
+            # the other BASELINE.json configurations on this GPU, 20 passes each (parity gate on every frame first): context for the
+            # headline, not part of `value`
+            pool.close(); pool = None
+            out["other_workloads"] = {w: other_workload(w, local_rank) for w in ("silesia12", "blocks", "iso")}
         print(json.dumps(out), flush=True)
-    pool.close()
+    if pool is not None:
+        pool.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
