@@ -41,8 +41,54 @@ def lib():
         L.zgemu_fse_slot.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint8 * 4)]
         L.zgemu_huf_slot.restype = C.POINTER(C.c_uint16)
         L.zgemu_huf_slot.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int)]
+        L.zgemu_plan.restype = C.c_void_p
+        L.zgemu_plan.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint32]
+        for f in ("zgemu_num_units", "zgemu_num_steps", "zgemu_num_step_units"):
+            getattr(L, f).argtypes = [C.c_void_p]
+            getattr(L, f).restype = C.c_uint32
+        L.zgemu_unit.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32 * 4)]
+        L.zgemu_step.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32 * 3)]
+        L.zgemu_step_unit.argtypes = [C.c_void_p, C.c_uint32]
+        L.zgemu_step_unit.restype = C.c_uint32
+        L.zgemu_frame_plan.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32 * 7)]
+        L.zgemu_seq_block.argtypes = [C.c_void_p, C.c_uint32]
+        L.zgemu_seq_block.restype = C.c_uint32
         _LIB = L
     return _LIB
+
+
+class Plan:
+    """The host's plan for the LZ77 stages of a submit (BatchBuilder::finish): units, sweep steps, per-frame sequence ranges."""
+
+    def __init__(self, src, flat_slots=256, unit_blocks=0):
+        L = lib()
+        h = L.zgemu_plan(src, len(src), flat_slots, unit_blocks)
+        try:
+            assert L.zgemu_parse_status(h) == 0
+            self.nblocks = L.zgemu_num_blocks(h)
+            self.nseq = []
+            info = (C.c_uint32 * 12)()
+            for b in range(self.nblocks):
+                L.zgemu_block(h, b, C.byref(info))
+                self.nseq.append(info[5] if info[0] == 2 else 0)          # compressed blocks only (ZG_BT_COMPRESSED == 2)
+            u4, s3, f7 = (C.c_uint32 * 4)(), (C.c_uint32 * 3)(), (C.c_uint32 * 7)()
+            self.units = []
+            for u in range(L.zgemu_num_units(h)):
+                L.zgemu_unit(h, u, C.byref(u4))
+                self.units.append(tuple(u4))                               # (frame, first_block, nblocks, noseq)
+            self.steps = []
+            for i in range(L.zgemu_num_steps(h)):
+                L.zgemu_step(h, i, C.byref(s3))
+                self.steps.append(tuple(s3))                               # (list_off, nunits, max_blocks)
+            self.step_units = [L.zgemu_step_unit(h, i) for i in range(L.zgemu_num_step_units(h))]
+            self.frames = []
+            for f in range(L.zgemu_num_frames(h)):
+                L.zgemu_frame_plan(h, f, C.byref(f7))
+                self.frames.append(tuple(f7))                              # (first_block, nblocks, first_unit, nunits, seq_first, seq_count, sparse)
+            nsb = sum(fr[5] for fr in self.frames)
+            self.seq_blocks = [L.zgemu_seq_block(h, i) for i in range(nsb)]
+        finally:
+            L.zgemu_free(h)
 
 
 class EmuBatch:

@@ -305,6 +305,30 @@ void zgemu_block_hist(void* h, uint32_t b, uint32_t* out3) { EmuBatch* e = (EmuB
 const uint32_t* zgemu_fse_slot(void* h, uint32_t slot, uint8_t* logs) {
   EmuBatch* e = (EmuBatch*)h; memcpy(logs, e->slot_log.data() + (size_t)slot * 4, 4); return e->fse.data() + (size_t)slot * ZG_FSE_SLOT_U32;
 }
+// the host's plan for the LZ77 stages (zg_host_parse.cpp, finish()): units, sweep steps, per-frame sequence ranges. No decode:
+// only the block walk. flat_slots as the engine would pass it (workgroups zg_k_flat can hold at once).
+void* zgemu_plan(const uint8_t* src, size_t len, uint32_t flat_slots, uint32_t unit_blocks) {
+  EmuBatch* e = new EmuBatch();
+  e->src_store.assign(len + 128, 0);
+  memcpy(e->src_store.data() + 64, src, len);
+  e->src = e->src_store.data() + 64;
+  e->parse_status = walk(e->src, len, 1ull << 31, &e->bb);
+  e->bb.flat_slots = flat_slots; e->bb.unit_blocks = unit_blocks;
+  e->bb.finish();
+  e->pos.resize(e->bb.blocks.size() + 1);       // (zgemu_block reports a block's "active" flag from here)
+  return e;
+}
+uint32_t zgemu_num_units(void* h) { return (uint32_t)((EmuBatch*)h)->bb.units.size(); }
+void zgemu_unit(void* h, uint32_t u, uint32_t* out4) { const ZgUnit& x = ((EmuBatch*)h)->bb.units[u]; out4[0] = x.frame; out4[1] = x.first_block; out4[2] = x.nblocks; out4[3] = x.noseq; }
+uint32_t zgemu_num_steps(void* h) { return (uint32_t)((EmuBatch*)h)->bb.steps.size(); }
+void zgemu_step(void* h, uint32_t i, uint32_t* out3) { const ZgStepRange& r = ((EmuBatch*)h)->bb.steps[i]; out3[0] = r.list_off; out3[1] = r.nunits; out3[2] = r.max_blocks; }
+uint32_t zgemu_step_unit(void* h, uint32_t i) { return ((EmuBatch*)h)->bb.step_units[i]; }
+uint32_t zgemu_num_step_units(void* h) { return (uint32_t)((EmuBatch*)h)->bb.step_units.size(); }
+void zgemu_frame_plan(void* h, uint32_t f, uint32_t* out7) {
+  const ZgFrame& fr = ((EmuBatch*)h)->bb.frames[f];
+  out7[0] = fr.first_block; out7[1] = fr.nblocks; out7[2] = fr.first_unit; out7[3] = fr.nunits; out7[4] = fr.seq_first; out7[5] = fr.seq_count; out7[6] = fr.sparse;
+}
+uint32_t zgemu_seq_block(void* h, uint32_t i) { return ((EmuBatch*)h)->bb.seq_blocks[i]; }
 const uint16_t* zgemu_huf_slot(void* h, uint32_t slot, int* max_bits) {
   EmuBatch* e = (EmuBatch*)h; *max_bits = e->hufmax[slot]; return e->huf.data() + (size_t)slot * ZG_HUF_SLOT_U16;
 }
