@@ -364,7 +364,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   b->sweep_steps.clear();
   for (const ZgStepRange& r : bb.steps) {
     ZgSweepStep ss;
-    ss.list_off = r.list_off; ss.nunits = r.nunits; ss.slices = r.max_blocks * (kMaxBlockSize / 4096u); ss.pad = 0;   // zg_k_sweep: 4 KiB of output per workgroup
+    ss.list_off = r.list_off; ss.nunits = r.nunits; ss.slices = r.max_blocks * (kMaxBlockSize / ZG_SW_BATCH); ss.pad = 0;   // zg_k_sweep: ZG_SW_BATCH bytes of output per workgroup
     b->sweep_steps.push_back(ss);
   }
   d.dbg = getenv("ZGPU_DEBUG_TIMERS") ? sc->d_dbg.as<unsigned long long>() : nullptr;
@@ -475,16 +475,18 @@ int Batch::run() {
 void Batch::launch_sweep(bool split) {
   const char* e = getenv("ZGPU_SWEEP_SPLIT");
   if (e && e[0] == '0') split = false;
-  uint64_t wmax = 0;
+  uint64_t wmax = 0, wmin = ~0ull;
   for (const ZgFrame& fr : bb.frames) {
     wmax = fr.window_size > wmax ? fr.window_size : wmax;
+    wmin = fr.window_size < wmin ? fr.window_size : wmin;
     // an initial history other than the format's (dictionary, continued frame) may hold offsets nobody checked against the window
     if (fr.hist_init[0] != 1 || fr.hist_init[1] != 4 || fr.hist_init[2] != 8 || fr.dict_len || fr.prior_out) split = false;
   }
-  if (dev.sweep_window) wmax = dev.sweep_window;
+  if (dev.sweep_window) wmax = wmin = dev.sweep_window;
   if (wmax > 0x7FFFFFFFull) wmax = 0x7FFFFFFFull;
+  if (wmin > wmax) wmin = wmax;
   split_sweep = zg_launch_sweep(dev, eng->stream_, sweep_steps.data(), (uint32_t)sweep_steps.size(), eng->stream2_, sc->ev_sw, split ? 80u : 0u,
-                                bb.unit_blocks_used * kMaxBlockSize, (uint32_t)wmax);
+                                bb.unit_blocks_used * kMaxBlockSize, (uint32_t)wmax, (uint32_t)wmin);
   sweep_mode = split_sweep ? 1u : sweep_mode;
 }
 

@@ -50,6 +50,16 @@ struct ZgBatchDev {
   unsigned long long* dbg;     // phase cycle counters (profiling builds), diagnostics only
 };
 // one launch of zg_k_sweep
+// zg_k_sweep: threads per workgroup, groups of 4 output bytes a thread has in flight; a workgroup takes ZG_SW_BATCH bytes of a unit.
+// (128 or 256 threads with 2 or 4 groups each measure the same; one group per thread, or several batches per workgroup, are
+// slower. What matters more is that a launch has no workgroups that only come and go: see zg_launch_sweep.)
+#ifndef ZG_SW_T
+#define ZG_SW_T 256
+#endif
+#ifndef ZG_SW_B
+#define ZG_SW_B 2
+#endif
+#define ZG_SW_BATCH (4u * ZG_SW_T * ZG_SW_B)
 struct ZgSweepStep { uint32_t list_off, nunits, slices, pad; };
 
 void zg_launch_tables(const ZgBatchDev& d, hipStream_t s, int part);   // part 0: Huffman trees, part 1: FSE tables
@@ -62,6 +72,6 @@ void zg_launch_lit(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_flat(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_sparse(const ZgBatchDev& d, hipStream_t s);   // the matches of frames marked sparse, in order (after zg_launch_flat)
 bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* steps, uint32_t nsteps, hipStream_t s2, hipEvent_t* evs, uint32_t nev,
-                     uint32_t unit_bytes, uint32_t window_max);   // s2 / evs: the side stream of the split sweep (nev == 0: one stream, step by step); returns whether it split
+                     uint32_t unit_bytes, uint32_t window_max, uint32_t window_min);   // s2 / evs: the side stream of the split sweep (nev == 0: one stream, step by step); returns whether it split
 void zg_launch_lz(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_calib(const void* src, void* dst, uint64_t bytes, hipStream_t s);

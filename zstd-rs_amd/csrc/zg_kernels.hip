@@ -1619,8 +1619,6 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
 #undef ZG_TICK
 }
 
-#define ZG_SW_T 256
-#define ZG_SW_B 4       // groups of 4 output bytes a sweep thread has in flight
 // zg_k_swprep: one thread per (step, unit) entry: everything a sweep workgroup needs about its unit in one 32-byte
 // descriptor, so that a sweep launch starts with ONE dependent scalar load instead of a chain of five.
 __global__ void __launch_bounds__(256) zg_k_swprep(ZgBatchDev d, uint32_t n) {
@@ -1642,7 +1640,7 @@ __global__ void __launch_bounds__(256) zg_k_swprep(ZgBatchDev d, uint32_t n) {
 }
 
 // zg_k_sweep: one launch per step; step s fills unit s of every frame that has one (blockIdx.y picks the unit from the
-// step's list, blockIdx.x a 4 KiB slice of it). A group of four output bytes at w: byte i comes from (w + i) - e_i =
+// step's list, blockIdx.x a ZG_SW_BATCH-byte slice of it). A group of four output bytes at w: byte i comes from (w + i) - e_i =
 // byte i of the dword at w - e_i, so one load per DISTINCT offset of the group serves it (usually one or two: a match
 // boundary); literal bytes (e = 0) are already in place and come from the dword at w itself. The loads go through a
 // buffer resource: a load that is not needed gets an out-of-range offset (no traffic, no branch), so all loads of a
@@ -1654,7 +1652,7 @@ __global__ void __launch_bounds__(256) zg_k_swprep(ZgBatchDev d, uint32_t n) {
 __global__ void __launch_bounds__(ZG_SW_T) __attribute__((amdgpu_waves_per_eu(2, 3))) zg_k_sweep(ZgBatchDev d, uint32_t list_off, uint32_t nbatch, uint32_t dbgmode, uint32_t part) {
   const ZgSweepDesc sd = d.sweep_desc[list_off + blockIdx.y];
   const uint32_t t = threadIdx.x, size = sd.size;
-  constexpr uint32_t BG = ZG_SW_T * ZG_SW_B;                  // groups per batch (4 KiB of output)
+  constexpr uint32_t BG = ZG_SW_T * ZG_SW_B;                  // groups per batch (ZG_SW_BATCH bytes of output)
   const uint32_t b0 = blockIdx.x * nbatch + (part == 1u ? sd.head : 0u);   // the workgroup's batches: b0 .. b0 + nbatch - 1, one after the other
   if (!sd.live || 4ull * b0 * BG >= size) return;
   if (part == 2u && b0 >= sd.head) return;
@@ -1988,9 +1986,9 @@ void zg_launch_flat(const ZgBatchDev& d, hipStream_t s) {
   else hipLaunchKernelGGL((zg_k_flat<1024, 16384, 2>), dim3(d.nunits), dim3(1024), 0, s, d);
 }
 bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* steps, uint32_t nsteps, hipStream_t s2, hipEvent_t* evs, uint32_t nev,
-                     uint32_t unit_bytes, uint32_t window_max) {
+                     uint32_t unit_bytes, uint32_t window_max, uint32_t window_min) {
   const uint32_t dbgmode = getenv("ZGPU_SWEEP_MODE") ? (uint32_t)atoi(getenv("ZGPU_SWEEP_MODE")) : 0u;   // timing experiments only
-  const uint32_t nbatch = getenv("ZGPU_SWEEP_NB") && atoi(getenv("ZGPU_SWEEP_NB")) > 0 ? (uint32_t)atoi(getenv("ZGPU_SWEEP_NB")) : 1u;   // 4 KiB batches per workgroup (more than one did not pay)
+  const uint32_t nbatch = getenv("ZGPU_SWEEP_NB") && atoi(getenv("ZGPU_SWEEP_NB")) > 0 ? (uint32_t)atoi(getenv("ZGPU_SWEEP_NB")) : 1u;   // batches per workgroup (more than one did not pay)
   constexpr uint32_t BB = 4u * ZG_SW_T * ZG_SW_B;             // bytes per batch
   uint32_t n = 0;
   bool contiguous = true;
@@ -2013,6 +2011,7 @@ bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* step
       const uint32_t g1 = g0 + gs < nsteps ? g0 + gs : nsteps;
       uint32_t units = 0, slices = 0;
       for (uint32_t i = g0; i < g1; i++) { units += steps[i].nunits; slices = steps[i].slices > slices ? steps[i].slices : slices; }
+      slices = slices > window_min / BB ? slices - window_min / BB : 1u;   // a head is its unit without the last window (workgroups beyond it would only come and go)
       (void)hipEventRecord(evs[e], s);
       (void)hipStreamWaitEvent(s2, evs[e], 0);
       e++;
