@@ -7,10 +7,12 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 last = max(i for i, r in enumerate(rows) if "zg_k_flat" in r["Kernel_Name"])
 rows = rows[last:]
 t0 = int(rows[0]["End_Timestamp"])
-gx = lambda r: int(r.get("Grid_Size_X", r.get("Grid_Size", "0")))
-small = min(gx(r) for r in rows if "sweep" in r["Kernel_Name"])
-heads = [r for r in rows if "sweep" in r["Kernel_Name"] and gx(r) > small]
-tails = [r for r in rows if "sweep" in r["Kernel_Name"] and gx(r) == small]
+import collections
+sig = lambda r: (r.get("Grid_Size_X", r.get("Grid_Size", "0")), r.get("Grid_Size_Y", "1"))
+sw = [r for r in rows if "sweep" in r["Kernel_Name"]]
+tail_sig = collections.Counter(sig(r) for r in sw).most_common(1)[0][0]    # the chain: one launch per step, all of one shape
+tails = [r for r in sw if sig(r) == tail_sig]
+heads = [r for r in sw if sig(r) != tail_sig]
 print("tails %d  heads %d  queues %s" % (len(tails), len(heads), sorted(set(r.get("Queue_Id", "?") for r in rows))))
 for r in heads:
     s, e = (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3
