@@ -7,10 +7,10 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS=${*:-"--steps 10 --warmup 2 --no-cpu --no-e2e"}
+ARGS=${*:-"--steps 10 --warmup 2 --no-cpu --no-e2e --no-other"}
 timeout 600 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o trace -- python $ROOT/bench.py $ARGS > $OUT/stats.log 2>&1
-timeout 600 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/fetch -o pmc -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-e2e > $OUT/fetch.log 2>&1
-timeout 600 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/write -o pmc -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-e2e > $OUT/write.log 2>&1
+timeout 600 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/fetch -o pmc -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-e2e --no-other > $OUT/fetch.log 2>&1
+timeout 600 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/write -o pmc -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-e2e --no-other > $OUT/write.log 2>&1
 cat > /tmp/calib.py <<PY
 import sys
 sys.path.insert(0, "$ROOT/zstd-rs_amd")
