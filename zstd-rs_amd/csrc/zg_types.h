@@ -184,7 +184,7 @@ struct ZgUnit { uint32_t frame, first_block, nblocks, noseq; };
 struct ZgUnitInfo { uint32_t size; uint32_t noseq; };   // written by zg_k_flat: bytes of the unit
 
 // what a sweep workgroup needs to know about its unit
-// head: 4 KiB batches at the front of the unit that nothing later depends on when no match reaches further back than the
+// head: batches (ZG_SW_BATCH bytes) at the front of the unit that nothing later depends on when no match reaches further back than the
 // frame's window (the bytes a later unit may copy from are the last `window` bytes in front of it)
 struct ZgSweepDesc { uint64_t out; uint64_t og; uint32_t size; uint32_t live; uint32_t head; uint32_t pad; };
 
