@@ -16,25 +16,7 @@ namespace zg {
 int parse_frames(const uint8_t* src, size_t len, uint64_t max_window, BatchBuilder* bb, std::vector<struct FrameInfoLite>* info);
 }
 
-struct EmuBatch {
-  BatchBuilder bb;
-  std::vector<uint8_t> src_store;   // 64 bytes of padding in front and behind, as the engine allocates it
-  uint8_t* src = nullptr;
-  int use_fast = 1;
-  std::vector<ZgBlockAux> aux;
-  std::vector<uint8_t> slot_log;
-  std::vector<uint32_t> fse;
-  std::vector<uint16_t> huf;
-  std::vector<uint8_t> hufmax;
-  std::vector<uint32_t> status;
-  std::vector<uint8_t> lit;
-  std::vector<EmuSeq> seq;
-  std::vector<ZgBlockSeqOut> seqout;
-  std::vector<ZgBlockPos> pos;
-  std::vector<ZgFrameOut> fout;
-  std::vector<uint8_t> dst;
-  int parse_status = 0;
-};
+#include "zg_emu_batch.h"
 
 static void set_status(EmuBatch& e, uint32_t b, int st) { if (st && !e.status[b]) e.status[b] = (uint32_t)st; }
 
@@ -257,9 +239,11 @@ static void k_exec(EmuBatch& e) {  // zg_k_lit + zg_k_lz, serial
 
 extern "C" {
 
-void* zgemu_decode2(const uint8_t* src, size_t len, uint64_t max_window, int use_fast) {
+void* zgemu_decode3(const uint8_t* src, size_t len, uint64_t max_window, int use_fast, uint32_t unit_blocks, uint32_t flat_slots) {
   EmuBatch* e = new EmuBatch();
   e->use_fast = use_fast;
+  e->bb.unit_blocks = unit_blocks;        // 0: as the engine chooses from the submit size and flat_slots
+  if (flat_slots) e->bb.flat_slots = flat_slots;
   e->src_store.assign(len + 128, 0);
   memcpy(e->src_store.data() + 64, src, len);
   e->src = e->src_store.data() + 64;
@@ -277,6 +261,7 @@ void* zgemu_decode2(const uint8_t* src, size_t len, uint64_t max_window, int use
   k_tables(*e); k_huf(*e); k_seq(*e); k_scan(*e); k_exec(*e);
   return e;
 }
+void* zgemu_decode2(const uint8_t* src, size_t len, uint64_t max_window, int use_fast) { return zgemu_decode3(src, len, max_window, use_fast, 0, 0); }
 void* zgemu_decode(const uint8_t* src, size_t len, uint64_t max_window) { return zgemu_decode2(src, len, max_window, 1); }
 void zgemu_free(void* h) { delete (EmuBatch*)h; }
 int zgemu_parse_status(void* h) { return ((EmuBatch*)h)->parse_status; }

@@ -351,7 +351,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   d.aux = sc->d_aux.as<ZgBlockAux>(); d.slot_log = sc->d_slot_log.as<uint8_t>();
   d.fse_arena = sc->d_fse.as<uint32_t>(); d.huf_arena = sc->d_huf.as<uint16_t>(); d.huf_maxbits = sc->d_hufmax.as<uint8_t>();
   d.status = sc->d_status.as<uint32_t>(); d.tab_status = d.status + nb + 4; d.lit_status = d.tab_status + nb + 4;
-  d.lit_arena = sc->d_lit.as<uint8_t>(); d.seq_arena = sc->d_seq.as<ZgSeq>(); d.raw_arena = sc->d_raw.as<uint2>();
+  d.lit_arena = sc->d_lit.as<uint8_t>(); d.seq_arena = sc->d_seq.as<ZgSeq>(); d.raw_arena = sc->d_raw.as<ZgRaw>();
   d.seq_out = sc->d_seqout.as<ZgBlockSeqOut>(); d.pos = sc->d_pos.as<ZgBlockPos>(); d.frame_out = sc->d_frameout.as<ZgFrameOut>();
   d.dst = nullptr; d.dst_cap = 0; d.og = nullptr;
   d.dict = nullptr;

@@ -1,0 +1,388 @@
+// zg_flat4.h — body of zg_k_flat4, the LZ77 flatten stage (execute_sequences, sequence_execution.rs:5-54;
+// DecodeBuffer::push / repeat, decode_buffer.rs:74-141), at DWORD granularity: a lane owns groups of four consecutive
+// output bytes through every phase of a tile, so the rank query, the record fetches, the gathers of what lies in
+// front of the tile and the stores are paid once per group instead of once per byte.
+//
+// Two modes per unit (a unit = a run of consecutive blocks of one frame, one workgroup each):
+//   pointer mode  every byte gets its EFFECTIVE OFFSET e (byte[p] = byte[p - e], p - e a literal byte or a byte in front
+//                 of the unit; 0 for a literal byte) in the flatten scratch; zg_k_sweep turns offsets into bytes, unit
+//                 after unit. No byte values travel through this mode.
+//   direct mode   the unit is the FIRST one of its frame (and the frame starts from nothing: no dictionary, no earlier
+//                 submit), so everything a match can reach lies in the unit itself and is final once its tile is done:
+//                 the same pointer machinery resolves byte VALUES, the plaintext is written right here, and the unit
+//                 needs neither scratch words nor a sweep step.
+//
+// The file is written against a small set of primitives (zx_*): zg_kernels.hip maps them onto gfx950 builtins,
+// tests/emu/zg_emu_flat.cpp onto a fiber-based SIMT emulator, so the very same source runs on the CPU in the
+// not-gpu tests (against the oracle's sequences) before it ever meets a GPU.
+//
+// Tile geometry: T threads, TS bytes, GPT = TS / (4 T) groups per thread; thread t owns groups t, t + T, ... (adjacent
+// lanes = adjacent groups: 16-byte scratch accesses coalesce, LDS accesses are conflict-free). A tile starts at a
+// position whose scratch index is a multiple of four: up to three DEAD bytes in front of its first live byte.
+#pragma once
+#include <stdint.h>
+#include "zg_types.h"
+#include "zg_dev.h"
+
+#define ZG_PAR_LIT 0xFFFFu   // tile byte is a literal (or dead)
+#define ZG_PAR_EXIT 0x8000u  // tile byte is a match byte whose parent lies before the tile
+#define ZG_FLAT_MAX 131072u  // largest block output the flatten path handles (Block_Maximum_Size)
+
+
+template <int T, int TS, int SPT, bool DIRECT>
+struct ZgFlat4Lds {
+  static constexpr int NW = TS / 32, SOFF = SPT * T;
+  ZxU4 rec[SOFF];                                        // per sequence of the tile: {offset, first match byte (tile-relative), 2^31 + literal index of tile byte 0, -}
+  __attribute__((aligned(16))) uint32_t word[DIRECT ? 4 : TS];   // pointer mode: a root's effective offset; bit 31: the root is a literal
+  __attribute__((aligned(16))) uint16_t par[TS];         // 0xFFFF literal, 0x8000 match byte with its parent before the tile, else tile-relative parent
+  __attribute__((aligned(16))) uint8_t val[DIRECT ? TS : 16];    // direct mode: a root's byte value
+  uint32_t bits[NW];                                     // marks: the first tile byte of every sequence
+  uint16_t cnt[NW];                                      // marks before each word of bits
+  uint32_t wtot[NW / 64];
+  uint32_t next, cut, err;
+  unsigned long long bad;                                // first failing sequence of the block: index << 32 | match position << 8 | provisional status
+};
+
+template <int T, int TS, int SPT, bool DIRECT>
+ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, TS, SPT, DIRECT>& L) {
+  constexpr int GPT = TS / (4 * T);            // groups per thread
+  constexpr int SOFF = SPT * T;                // sequences a tile takes; a denser tile is cut short
+  constexpr int NW = TS / 32;                  // words of the mark bitmap
+  static_assert(GPT * 4 * T == TS && GPT >= 1 && GPT <= 4 && NW <= T && (NW % 64) == 0 && SPT >= 1 && SPT <= 2 && TS <= 0x8000, "shape");
+  const uint32_t t = zx_tid();
+  const ZgUnit un = d.units[ui];
+  if (d.totals[2]) return;
+  const ZgFrameOut fo = d.frame_out[un.frame];
+  if (!fo.fast) return;
+  const uint64_t unit_abs0 = d.pos[un.first_block].out_base;     // frame-relative position of the unit's first byte
+  uint8_t* out_u = d.dst + fo.out_base + unit_abs0;
+  uint32_t* og = DIRECT ? nullptr : d.og + fo.og_base + unit_abs0;
+  // groups are aligned in the scratch (pointer mode) / in the output (direct mode; there the two agree: frames that are
+  // packed back to back have og_base == out_base, and only those have direct units)
+  const uint32_t ualign = (uint32_t)((DIRECT ? fo.out_base : fo.og_base) + unit_abs0) & 3u;
+  const uint32_t ucap = un.nblocks * ZG_FLAT_MAX;
+  // scratch word of unit byte u: offset 4 (u + 4) (four words of slack in front: a tile's dead bytes, a gather window that starts before the unit)
+  const ZxBuf og_rs = zx_buf(DIRECT ? nullptr : og - 4, DIRECT ? 0u : 4u * (ucap + 4u));
+  // output byte u: offset u + ualign + 4 (the base is dword-aligned; the engine keeps 256 bytes in front of every output)
+  const ZxBuf out_rs = zx_buf(out_u - ualign - 4, ucap + ualign + 4u);
+  if (t == 0) { L.err = 0; L.bad = ~0ull; }
+  uint32_t unit_size = 0;
+  zx_barrier_vm();
+  for (uint32_t bi = 0; bi < un.nblocks; bi++) {
+    const uint32_t b = un.first_block + bi;
+    const ZgBlockPos p = d.pos[b];
+    if (!p.active) break;
+    const ZgBlock blk = d.blocks[b];
+    const uint32_t bu0 = (uint32_t)(p.out_base - unit_abs0);      // unit-relative position of the block
+    if (blk.btype != ZG_BT_COMPRESSED || blk.nseq == 0) {        // all of it is final already (zg_k_lit): effective offset 0
+      const uint32_t n = blk.regen_size;
+      if (!DIRECT && !(un.noseq & 1u)) for (uint32_t i = t; i < n; i += T) og[bu0 + i] = 0u;   // (a unit without sequences has no sweep step: nobody reads its scratch)
+      unit_size = bu0 + n;
+      continue;
+    }
+    const ZgBlockSeqOut so = d.seq_out[b];
+    const uint32_t S = blk.regen_size + so.sum_ml;               // <= ZG_FLAT_MAX on this path
+    unit_size = bu0 + S;
+    const uint32_t nseq = blk.nseq;
+    const uint8_t* body = d.src + blk.src_off;
+    const bool lit_rle = blk.lit_type == ZG_LT_RLE;
+    const uint8_t* lit = blk.lit_type <= ZG_LT_RLE ? body + blk.lit_off : d.lit_arena + blk.lit_base;
+    const uint32_t fill4 = lit_rle ? 0x01010101u * lit[0] : 0u;
+    // literal k of the block: offset k + lit_lo + 4 of a dword-aligned resource that starts 4 bytes in front of the literals'
+    // dword (a group's window may start up to 3 bytes before its first literal); RLE literals: nothing is fetched, fill4 is the value
+    const uint32_t lit_lo = (uint32_t)((uint64_t)lit & 3u);
+    const ZxBuf lit_rs = zx_buf(lit - lit_lo - 4, lit_rle ? 0u : ((blk.regen_size + lit_lo + 4u + 7u) & ~3u));
+    const ZxBuf seq_rs = zx_buf(d.seq_arena + blk.seq_base, nseq * 12u);
+    // bytes of the frame (and dictionary) that exist before this block: the farthest a match may reach. Offsets are < 2^30
+    // and positions in the block < 2^17: once 2^31 bytes exist every offset is in reach, else 32-bit arithmetic decides.
+    const uint64_t reach = p.out_base + d.frames[un.frame].prior_reach + d.frames[un.frame].dict_len;
+    const bool reach_all = reach >= 0x80000000ull;
+    const uint32_t reach32 = (uint32_t)reach;
+    // the sequences a thread places per tile travel in registers: they are requested one tile ahead
+    ZxU3 q[SPT];
+    uint32_t qn[SPT];                               // third word of the record behind q (its literal index)
+#define ZG_F4_FETCH(i0)                                                                        \
+    _Pragma("unroll") for (int s = 0; s < SPT; s++) {                                            \
+      const uint32_t i_ = (i0) + t + s * T;                                                      \
+      q[s] = zx_ld96(seq_rs, i_ < nseq ? 12u * i_ : ZX_OOB);                                     \
+      qn[s] = zx_ld32(seq_rs, i_ + 1 < nseq ? 12u * i_ + 20u : ZX_OOB);                          \
+    }
+    ZG_F4_FETCH(0)
+    uint32_t i_start = 0;
+    for (uint32_t t0 = 0; t0 < S;) {
+      // the tile: block positions [t0a, t0a + TS), the first `lead` of them dead (they belong to the previous tile or block)
+      const uint32_t lead = (ualign + bu0 + t0) & 3u;
+      const uint32_t t0a = t0 - lead;                              // (wraps below zero for the first tile of an unaligned block: all arithmetic on it is modular)
+      const uint32_t t1o = t0a + TS < S ? t0a + TS : S;            // where the tile ends unless it holds too many sequences (t0a + TS > 0: no wrap)
+      if (t == 0) { L.next = 0xFFFFFFFFu; L.cut = 0xFFFFFFFFu; }
+      if (t < NW) L.bits[t] = 0;
+      zx_barrier();
+      // ---- S1a: one thread per sequence i (index nseq stands for the trailing literals). It covers [a, m0) with literals
+      // and [m0, m1) with its match; the part inside the tile is described by one record and one mark at its first tile byte.
+#pragma unroll
+      for (int s = 0; s < SPT; s++) {
+        const uint32_t j = t + s * T, i = i_start + j;
+        const uint32_t qx = q[s].x, qy = q[s].y, qz = q[s].z, next = i + 1 < nseq ? qn[s] & 0x1FFFFu : so.sum_ll;
+        const bool valid = i <= nseq;
+        uint32_t a = 0, m0 = 0, m1 = 0, lstart = 0, off = 0;
+        if (i < nseq) {
+          lstart = qz & 0x1FFFFu; m0 = qy & 0x1FFFFu; m1 = m0 + ((qy >> 17) | (((qz >> 17) & 7u) << 15));
+          a = m0 - ((next - lstart) & 0x1FFFFu);
+          off = zg_sym_resolve(qx, p.hist_init);
+          // the first failing sequence (in order) decides, like the reference's in-order execution; which of the two
+          // "too far" errors it is (repeat_from_dict, decode_buffer.rs:144-179) is worked out off the hot path
+          if (off == 0) zx_min_lds64(&L.bad, ((unsigned long long)i << 32) | (m0 << 8) | (uint32_t)ZG_EXE_ZERO_OFFSET);              // sequence_execution.rs:28-30
+          else if (!reach_all && off > reach32 + m0) zx_min_lds64(&L.bad, ((unsigned long long)i << 32) | (m0 << 8) | (uint32_t)ZG_EXE_OFFSET_TOO_BIG);
+        } else if (i == nseq) {
+          lstart = so.sum_ll; a = so.sum_ll + so.sum_ml; m0 = m1 = S;
+        }
+        // first sequence that reaches beyond this tile starts the next one: sequences are in order along the lanes, so the
+        // lowest lane of a wave that sees one speaks for the wave (one LDS atomic per wave, not one per sequence)
+        const bool beyond = valid && (m1 > t1o || a >= t1o);
+        const unsigned long long bm = zx_ballot(beyond);
+        if (beyond && (t & 63u) == (uint32_t)__builtin_ctzll(bm)) zx_min_lds(&L.next, i);
+        if (valid && a < t1o) {
+          // (the tile's first sequence owns the dead bytes too: a mark at tile byte 0 keeps every rank query in range)
+          const uint32_t st = j == 0 ? 0u : (a > t0 ? a : t0) - t0a;
+          const uint32_t mr = (m0 > t0 ? (m0 < t1o ? m0 : t1o) : t0) - t0a;
+          // (z: the literal a tile byte x of this sequence stands for is z + x - 2^31)
+          ZxU4 r; r.x = off; r.y = mr; r.z = 0x80000000u + lstart + t0a - a; r.w = 0;
+          L.rec[j] = r;
+          zx_or_lds(&L.bits[st >> 5], 1u << (st & 31u));
+          // the last sequence the tile has room for, and more follow: the tile ends with this one
+          if (j == SOFF - 1 && i < nseq && m1 <= t1o) L.cut = m1;
+        }
+      }
+      zx_barrier();
+      // ---- S1b: marks before every word (prefix sum over the words)
+      {
+        const uint32_t tb = ZX_FRESH(t);
+        uint32_t c = 0, sc = 0;
+        if (tb < NW) {
+          c = (uint32_t)__builtin_popcount(L.bits[tb]);
+          sc = c;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) { const uint32_t v = zx_shfl_up(sc, o); if ((int)(tb & 63) >= o) sc += v; }
+          if ((tb & 63) == 63) L.wtot[tb >> 6] = sc;
+        }
+        zx_barrier();
+        if (tb < NW) {
+          uint32_t before = sc - c;
+          for (uint32_t w = 0; w < (tb >> 6); w++) before += L.wtot[w];
+          L.cnt[tb] = (uint16_t)before;
+        }
+      }
+      // every wave's stores of the previous tile (scratch words / output bytes) have reached memory before any wave gathers from them
+      zx_barrier_vm();
+      const uint32_t cut = L.cut;
+      const uint32_t t1 = cut != 0xFFFFFFFFu ? cut : t1o;
+      const uint32_t i_next = cut != 0xFFFFFFFFu ? i_start + SOFF : (L.next == 0xFFFFFFFFu ? nseq + 1 : L.next);
+      if (L.bad != ~0ull) break;
+      const uint32_t n = t1 - t0a;                                 // tile bytes [lead, n) are live
+      const uint32_t tu0a = bu0 + t0a;                             // unit-relative position of tile byte 0 (modular)
+      if (t1 < S) { ZG_F4_FETCH(i_next) }                          // next tile's sequences: in flight behind this tile's work
+      // ---- S1c: every group finds its (at most two: matches are >= 3 bytes long) sequences by rank of the marks; every byte
+      // becomes a literal, a match byte with its parent inside the tile (pointer), or a root: a match byte whose parent lies
+      // before the tile. What the roots of a group need from before the tile — the parents' scratch words (pointer mode) or
+      // byte values (direct mode) — is consecutive in memory per sequence: one window load per sequence of the group,
+      // requested here and consumed after the pointer jumping (the round trip hides behind it).
+      uint32_t wrd[GPT][4];
+      ZxU4 LA[GPT], LB[GPT];
+      ZxU2 VA[GPT], VB[GPT], LW[GPT];
+      uint32_t fbv[GPT], meta[GPT];      // meta: [3:0] literal bytes, [12:8] / [20:16] / [28:24] funnel shifts of the literal / A / B windows
+      uint32_t unresolved = 0;
+      {
+        const uint32_t tc = ZX_FRESH(t);
+        uint32_t wordv[GPT], cntv[GPT];
+#pragma unroll
+        for (int k = 0; k < GPT; k++) { const uint32_t xw = (tc + k * T) >> 3; wordv[k] = L.bits[xw]; cntv[k] = L.cnt[xw]; }
+        ZxU4 rA[GPT], rB[GPT];
+#pragma unroll
+        for (int k = 0; k < GPT; k++) {
+          const uint32_t x0 = 4u * (tc + k * T), sh = x0 & 31u;
+          const uint32_t ra = cntv[k] + (uint32_t)__builtin_popcount(wordv[k] & (0xFFFFFFFFu >> (31u - sh))) - 1u;   // marks up to and including x0, minus one
+          const uint32_t mk = (wordv[k] >> sh) & 0xEu;                 // a second sequence starts at byte 1, 2 or 3 of the group
+          fbv[k] = mk ? (uint32_t)__builtin_ctz(mk) : 4u;
+          rA[k] = L.rec[ra]; rB[k] = L.rec[ra + (mk ? 1u : 0u)];
+        }
+#pragma unroll
+        for (int k = 0; k < GPT; k++) {
+          const uint32_t x0 = 4u * (tc + k * T), fb = fbv[k];
+          uint32_t litm = 0, needA = 0, needB = 0, ilit = 4;
+          uint32_t parp[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const uint32_t x = x0 + i;
+            const bool useB = (uint32_t)i >= fb;
+            const uint32_t off = useB ? rB[k].x : rA[k].x, m0 = useB ? rB[k].y : rA[k].y;
+            const bool live = x - lead < n - lead;                  // lead <= x < n
+            const bool c_lit = x < m0, c_in = off + lead <= x;               // c_in: the parent is a live byte of this tile (the dead bytes belong to the tile before)
+            const bool is_lit = live && c_lit, is_in = live && !c_lit && c_in, is_exit = live && !c_lit && !c_in;
+            const int32_t u = (int32_t)(tu0a + x - off);             // unit-relative position of the parent
+            const bool ok = is_exit && u >= 0;                      // the parent lies in the unit: its word / value is wanted
+            parp[i] = is_in ? x - off : (is_exit ? (uint32_t)ZG_PAR_EXIT : (uint32_t)ZG_PAR_LIT);
+            wrd[k][i] = is_exit ? off : 0u;
+            litm |= is_lit ? 1u << i : 0u;
+            if (is_lit && ilit == 4) ilit = (uint32_t)i;
+            if (useB) needB |= ok ? 1u : 0u; else needA |= ok ? 1u : 0u;
+            unresolved |= is_in ? 1u << (4 * k + i) : 0u;
+          }
+          ZxU2 pp; pp.x = parp[0] | (parp[1] << 16); pp.y = parp[2] | (parp[3] << 16);
+          *(ZxU2*)&L.par[x0] = pp;
+          // the literal bytes of a group belong to one sequence (a second literal run would need a whole match between them):
+          // one 8-byte window that starts at the first of them
+          const uint32_t zl = ilit < fb ? rA[k].z : rB[k].z;
+          const uint32_t ol = ((zl + x0 + ilit) & 0x7FFFFFFFu) + lit_lo + 4u - ilit;   // offset of the byte group byte 0 would stand for
+          LW[k] = zx_ld64(lit_rs, litm ? ol & ~3u : ZX_OOB);
+          uint32_t m = litm | ((ol & 3u) << 11);
+          const int32_t uA = (int32_t)(tu0a + x0 - rA[k].x), uB = (int32_t)(tu0a + x0 - rB[k].x);   // where the parents' windows start
+          if (DIRECT) {
+            const uint32_t oA = (uint32_t)uA + ualign + 4u, oB = (uint32_t)uB + ualign + 4u;
+            VA[k] = zx_ld64(out_rs, needA ? oA & ~3u : ZX_OOB);
+            VB[k] = zx_ld64(out_rs, needB ? oB & ~3u : ZX_OOB);
+            m |= ((oA & 3u) << 19) | ((oB & 3u) << 27);
+          } else {
+            // a window that starts before the unit (its first words belong to whatever lies in front of the scratch): word by
+            // word, so that what is not wanted reads as zero. Once per unit and offset at most.
+            const bool strA = needA && uA < 0, strB = needB && uB < 0;
+            if (strA || strB) {
+              uint32_t la[4], lb[4];
+#pragma unroll
+              for (int i = 0; i < 4; i++) {
+                const bool useB = (uint32_t)i >= fb;
+                la[i] = zx_ld32(og_rs, (needA && !useB && uA + i >= 0) ? 4u * (uint32_t)(uA + i + 4) : ZX_OOB);
+                lb[i] = zx_ld32(og_rs, (needB && useB && uB + i >= 0) ? 4u * (uint32_t)(uB + i + 4) : ZX_OOB);
+              }
+              LA[k].x = la[0]; LA[k].y = la[1]; LA[k].z = la[2]; LA[k].w = la[3];
+              LB[k].x = lb[0]; LB[k].y = lb[1]; LB[k].z = lb[2]; LB[k].w = lb[3];
+            } else {
+              LA[k] = zx_ld128(og_rs, needA ? 4u * (uint32_t)(uA + 4) : ZX_OOB);
+              LB[k] = zx_ld128(og_rs, needB ? 4u * (uint32_t)(uB + 4) : ZX_OOB);
+            }
+          }
+          meta[k] = m;
+        }
+      }
+      zx_barrier();
+      // ---- S2: asynchronous pointer jumping. A byte's pointer only ever moves to another of its ancestors, so stale reads
+      // are harmless and no barrier is needed between rounds; a byte is done when its pointer's pointer is a root marker.
+      // Each thread visits just its still-unresolved bytes (few: most parents are before the tile), four per step.
+      {
+        const uint32_t t2 = ZX_FRESH(t);
+        for (uint32_t guard = 0; unresolved && guard < (1u << 16); guard++) {
+          uint32_t m = unresolved, kk[4], ad[4], pp[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) { kk[j] = m ? (uint32_t)__builtin_ctz(m) : 32u; m &= m - 1; ad[j] = 4u * (t2 + (kk[j] >> 2) * T) + (kk[j] & 3u); }
+#pragma unroll
+          for (int j = 0; j < 4; j++) pp[j] = kk[j] < 32u ? L.par[ad[j]] : 0u;
+#pragma unroll
+          for (int j = 0; j < 4; j++) pp[j] = L.par[pp[j]];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (kk[j] < 32u) {
+              if (pp[j] >= ZG_PAR_EXIT) unresolved &= ~(1u << kk[j]);     // its pointer is the root
+              else L.par[ad[j]] = (uint16_t)pp[j];                        // u16 stores are atomic
+            }
+          }
+        }
+        if (unresolved) L.err = ZG_INTERNAL;   // cannot happen: every step moves a pointer up its chain (seen by everybody behind the next barrier)
+      }
+      // ---- S3a: the windows requested in S1c have arrived: every root's word (value) is completed and published
+      {
+        const uint32_t t3 = ZX_FRESH(t);
+#pragma unroll
+        for (int k = 0; k < GPT; k++) {
+          const uint32_t x0 = 4u * (t3 + k * T), fb = fbv[k], m = meta[k];
+          if (DIRECT) {
+            const uint32_t vA = zx_alignbit(VA[k].y, VA[k].x, (m >> 16) & 31u), vB = zx_alignbit(VB[k].y, VB[k].x, (m >> 24) & 31u);
+            const uint32_t l4 = zx_alignbit(LW[k].y, LW[k].x, (m >> 8) & 31u) | fill4;
+            const uint32_t mB = fb >= 4u ? 0u : 0xFFFFFFFFu << (8u * fb);                       // bytes of the second sequence
+            const uint32_t mL = ((((m & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu);           // literal bytes
+            uint32_t v = (vA & ~mB) | (vB & mB);
+            v = (v & ~mL) | (l4 & mL);
+            *(uint32_t*)&L.val[x0] = v;
+          } else {
+            const uint32_t ga[4] = {LA[k].x, LA[k].y, LA[k].z, LA[k].w}, gb[4] = {LB[k].x, LB[k].y, LB[k].z, LB[k].w};
+            uint32_t w[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              // (a byte with its parent in the tile takes whatever its window slot holds: nobody reads the word of a byte that is not a root)
+              const uint32_t g = (uint32_t)i >= fb ? gb[i] : ga[i];
+              w[i] = ((m >> i) & 1u) ? 0x80000000u : wrd[k][i] + g;
+            }
+            ZxU4 wv; wv.x = w[0]; wv.y = w[1]; wv.z = w[2]; wv.w = w[3];
+            *(ZxU4*)&L.word[x0] = wv;
+          }
+        }
+      }
+      zx_barrier();
+      if (L.err) break;
+      // ---- S3b: every byte takes what its root holds. Pointer mode: effective offset = the root's + the distance to the root
+      // (a literal root counts 0) -> scratch, 16 bytes per group; the tile's literal bytes go to the output. Direct mode: the
+      // root's value -> output, 4 bytes per group.
+      {
+        const uint32_t t4 = ZX_FRESH(t);
+#pragma unroll
+        for (int k = 0; k < GPT; k++) {
+          const uint32_t x0 = 4u * (t4 + k * T), m = meta[k];
+          const ZxU2 pp = *(const ZxU2*)&L.par[x0];
+          const uint32_t pr[4] = {pp.x & 0xFFFFu, pp.x >> 16, pp.y & 0xFFFFu, pp.y >> 16};
+          const bool full = x0 >= lead && x0 + 4u <= n;
+          if (DIRECT) {
+            uint32_t vb[4];
+#pragma unroll
+            for (int i = 3; i >= 0; i--) vb[i] = L.val[pr[i] >= ZG_PAR_EXIT ? x0 + i : pr[i]];
+            const uint32_t v = vb[0] | (vb[1] << 8) | (vb[2] << 16) | (vb[3] << 24);
+            const uint32_t o = tu0a + x0 + ualign + 4u;
+            zx_st32(out_rs, full ? o : ZX_OOB, v);
+            if (!full) {
+#pragma unroll
+              for (int i = 0; i < 4; i++) zx_st8(out_rs, (x0 + i - lead < n - lead) ? o + i : ZX_OOB, vb[i]);
+            }
+          } else {
+            uint32_t w[4], e[4];
+#pragma unroll
+            for (int i = 3; i >= 0; i--) w[i] = L.word[pr[i] >= ZG_PAR_EXIT ? x0 + i : pr[i]];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              const uint32_t r = pr[i] >= ZG_PAR_EXIT ? x0 + i : pr[i];
+              e[i] = ((w[i] >> 31) ? 0u : w[i]) + (x0 + i - r);
+            }
+            const uint32_t o = 4u * (tu0a + x0 + 4u);
+            ZxU4 ev; ev.x = e[0]; ev.y = e[1]; ev.z = e[2]; ev.w = e[3];
+            zx_st128(og_rs, full ? o : ZX_OOB, ev);
+            if (!full) {
+#pragma unroll
+              for (int i = 0; i < 4; i++) zx_st32(og_rs, (x0 + i - lead < n - lead) ? o + 4u * i : ZX_OOB, e[i]);
+            }
+            // literal bytes -> output (meta holds which of the group's bytes are live literals)
+            const uint32_t l4 = zx_alignbit(LW[k].y, LW[k].x, (m >> 8) & 31u) | fill4;
+            const uint32_t ob = tu0a + x0 + ualign + 4u;
+#pragma unroll
+            for (int i = 0; i < 4; i++) zx_st8(out_rs, ((m >> i) & 1u) ? ob + i : ZX_OOB, (l4 >> (8 * i)) & 0xFFu);
+          }
+        }
+      }
+      zx_barrier();  // par / word / val / the records are reused by the next tile
+      t0 = t1;
+      i_start = i_next;
+    }
+#undef ZG_F4_FETCH
+    if (L.err || L.bad != ~0ull) {
+      if (t == 0) {
+        const ZgFrame fr = d.frames[un.frame];
+        uint32_t st = L.err;
+        if (!st) {
+          const unsigned long long bad = L.bad;
+          const uint32_t m0 = ((uint32_t)bad >> 8) & 0x1FFFFu;
+          st = (uint32_t)bad & 0xFFu;
+          if (st == (uint32_t)ZG_EXE_OFFSET_TOO_BIG && p.out_base + fr.prior_out + m0 <= fr.window_size) st = ZG_EXE_DICT_TOO_SMALL;
+        }
+        zx_min_glb(&d.frame_out[un.frame].err_packed, ((b - fr.first_block) << 8) | st);
+      }
+      break;
+    }
+  }
+  zx_barrier_vm();
+  if (t == 0) { ZgUnitInfo ui2; ui2.size = unit_size; ui2.noseq = un.noseq; d.unit_info[ui] = ui2; }
+}

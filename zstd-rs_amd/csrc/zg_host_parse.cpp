@@ -271,6 +271,9 @@ void BatchBuilder::finish() {
         const ZgBlock& bk = blocks[u.first_block + k];
         if (bk.btype == ZG_BT_COMPRESSED && bk.nseq) u.noseq = 0;
       }
+      // the first unit of a frame that starts from nothing (no dictionary, no earlier submit: the engine marks those frames
+      // fixed_base before finish()) copies from nothing outside itself: zg_k_flat4 resolves it to bytes right away (direct mode)
+      if (i == 0 && !u.noseq && direct_units && !fr.fixed_base && !fr.sparse) u.noseq = ZG_UNIT_DIRECT;
       units.push_back(u);
     }
     fr.nunits = (uint32_t)units.size() - fr.first_unit;

@@ -948,7 +948,7 @@ __global__ void __launch_bounds__(ZG_SP_T, 4) zg_k_seqpost(ZgBatchDev d) {
   const uint32_t nseq = blk.nseq, regen = blk.regen_size;
   const uint32_t wlim = zg_sweep_window(d, d.frames[blk.frame]);
   const uint8_t* bs = d.src + blk.src_off + d.aux[b].seq_bits_off;
-  const uint2* raw = d.raw_arena + blk.seq_base;
+  const uint2* raw = (const uint2*)(d.raw_arena + blk.seq_base);
   ZgSeq* out = d.seq_arena + blk.seq_base;
   if (t == 0) s_err = 0xFFFFFFFFu;
   if (t < 36) s_llb[t] = ZG_LL_BASE[t] | ((uint32_t)ZG_LL_BITS[t] << 24);
