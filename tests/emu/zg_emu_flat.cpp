@@ -93,6 +93,8 @@ int zgemu_flat4(void* h, int shape, int force_pointer, uint8_t* dst_out, uint32_
       const uint32_t size = uinfo[fr.first_unit + k].size;
       uint8_t* o = dst.data() + 256 + at;
       const uint32_t* g = og.data() + 16 + at;
+      // zg_k_lit places the literal bytes of pointer-mode units (scratch word 0): here they come from the serial model's output
+      for (uint32_t i = 0; i < size; i++) if (!g[i]) o[i] = e->dst[at + i];
       for (uint32_t i = 0; i < size; i++) if (g[i]) o[i] = o[(int64_t)i - (int64_t)g[i]];
     }
   }

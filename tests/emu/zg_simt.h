@@ -129,3 +129,6 @@ static inline void zx_st128(const ZxBuf& b, uint32_t off, const ZxU4& v) {
   else { zx_st32(b, off, v.x); if (off != ZX_OOB) { zx_st32(b, off + 4, v.y); zx_st32(b, off + 8, v.z); zx_st32(b, off + 12, v.w); } }
 }
 static inline uint32_t zx_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sh & 31u)); }
+// packed 16-bit lanes: a - b per lane; 0xFFFF per lane whose signed value is negative
+static inline uint32_t zx_pksub16(uint32_t a, uint32_t b) { return ((a - b) & 0xFFFFu) | (((a >> 16) - (b >> 16)) << 16); }
+static inline uint32_t zx_pksign16(uint32_t a) { return ((a & 0x8000u) ? 0xFFFFu : 0u) | ((a & 0x80000000u) ? 0xFFFF0000u : 0u); }

@@ -479,9 +479,10 @@ def test_corpus_other_shapes(env):
 
 
 def test_flat_scratch_matches_model(monkeypatch):
-    """zg_k_flat alone (the sweep is not launched): the flatten scratch of every unit — one effective offset per output byte,
-    0 for literal bytes — must equal the numpy model built from the oracle's sequences (tests/lz_model.py), for all three
-    tile shapes, tiny units included"""
+    """zg_k_flat4 alone (the sweep is not launched): the flatten scratch of every pointer-mode unit — one effective offset per
+    output byte, 0 for literal bytes — must equal the numpy model built from the oracle's sequences (tests/lz_model.py), for
+    both tile shapes, tiny units included; the bytes of direct units (a frame's first unit, resolved by the flatten itself)
+    must be the oracle's plaintext right after the flatten. With ZGPU_DIRECT=0 the first units go through the scratch too."""
     import numpy as np
     import zgdata
     import zgpu
@@ -489,11 +490,15 @@ def test_flat_scratch_matches_model(monkeypatch):
     pack = read_pack("decodecorpus.pack")
     cases = [pack[n] for n in ("z000000.zst", "z000033.zst", "z000059.zst", "z000068.zst", "z000088.zst")]
     cases.append(zgdata.zstd_compress(zgdata.text_like(5 << 20, seed=0xF1)))
+    plains = [oracle.decode_frame_all(z)[0] for z in cases]
     monkeypatch.setenv("ZGPU_DEBUG_NO_SWEEP", "1")
-    for shape, ub in (("1024", None), ("512", "2"), ("8", "1")):
+    for shape, ub, direct in (("1024", None, "1"), ("1024", None, "0"), ("512", "2", "1"), ("512", "1", "0"), ("1024", "1", "1")):
         monkeypatch.setenv("ZGPU_FLAT_T", shape)
+        monkeypatch.setenv("ZGPU_DIRECT", direct)
         if ub:
             monkeypatch.setenv("ZGPU_UNIT_BLOCKS", ub)
+        else:
+            monkeypatch.delenv("ZGPU_UNIT_BLOCKS", raising=False)
         c = zgpu.Context(0)
         for ci, z in enumerate(cases):
             b = c.prepare(z)
@@ -501,15 +506,27 @@ def test_flat_scratch_matches_model(monkeypatch):
             b.sync()
             units = b.units()
             e, bounds = lz_model.expected_scratch(z, [u[0] for u in units])
+            ndirect = 0
             for ui, (fb, nb, base, size, noseq) in enumerate(units):
                 want = e[bounds[ui]:bounds[ui + 1]]
                 assert size == len(want), (shape, ci, ui)
-                if noseq:                       # only literal bytes: no scratch words are written, no sweep step reads them
+                if noseq & 1:                   # only literal bytes: no scratch words are written, no sweep step reads them
                     assert not want.any(), (shape, ci, ui)
+                    continue
+                if noseq & 2:                   # direct unit: final bytes, no scratch
+                    ndirect += 1
+                    assert ui == 0 and direct == "1"
+                    assert b.read(bounds[ui], size) == plains[ci][bounds[ui]:bounds[ui + 1]], (shape, ci, ui)
                     continue
                 got = b.scratch_words(base, size)
                 bad = np.flatnonzero(got != want)
                 assert len(bad) == 0, (shape, ci, ui, int(bad[0]), got[bad[0]:bad[0] + 4], want[bad[0]:bad[0] + 4])
+                # the literal bytes of a pointer-mode unit are in place already (zg_k_lit)
+                lit = np.flatnonzero(want == 0)
+                have = np.frombuffer(b.read(bounds[ui], size), dtype=np.uint8)
+                ref = np.frombuffer(plains[ci][bounds[ui]:bounds[ui + 1]], dtype=np.uint8)
+                assert np.array_equal(have[lit], ref[lit]), (shape, ci, ui)
+            assert ndirect <= 1 and (direct == "1" or ndirect == 0)
             b.close()
         c.close()
 

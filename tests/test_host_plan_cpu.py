@@ -32,7 +32,9 @@ def test_units_steps_and_sparse_frames(slots, unit_blocks):
         for u in range(fu, fu + nu):
             frame, first, n, noseq = p.units[u]
             assert frame == f and first == at and n >= 1
-            assert bool(noseq) == (not any(p.nseq[first:first + n]))
+            assert bool(noseq & 1) == (not any(p.nseq[first:first + n]))
+            # direct mode: the first unit of a frame that has sequences and is not sparse, and nothing else
+            assert bool(noseq & 2) == (u == fu and not (noseq & 1) and not sparse)
             if unit_blocks:
                 assert n == unit_blocks or u == fu + nu - 1
             at += n
@@ -44,7 +46,7 @@ def test_units_steps_and_sparse_frames(slots, unit_blocks):
         nsq = sum(p.nseq[fb:fb + nb])
         assert bool(sparse) == (nsq <= 2048 and nsq <= 4 * nb)
     assert covered == p.nblocks
-    # sweep steps: every unit that has sequences and belongs to a frame that is not sparse appears exactly once; a frame's units in
+    # sweep steps: every pointer-mode unit (it has sequences and is not its frame's first one) of a frame that is not sparse appears exactly once; a frame's units in
     # step order; no empty step; the lists back to back
     want_units = [u for u, (f, _, _, noseq) in enumerate(p.units) if not noseq and not p.frames[f][6]]
     assert sorted(p.step_units) == want_units

@@ -304,6 +304,8 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   // a frame-layer error after some good frames: the good frames are still uploaded (callers such as the
   // FrameDecoder mirror may want them); decode_all reports parse_status.
   { const char* e = getenv("ZGPU_UNIT_BLOCKS"); if (e && atoi(e) > 0) b->bb.unit_blocks = (uint32_t)atoi(e); }
+  { const char* e = getenv("ZGPU_DIRECT"); if (e && e[0] == '0') b->bb.direct_units = false; }   // (tests) every unit through scratch + sweep
+  { const char* e = getenv("ZGPU_FLAT"); if (e && !strcmp(e, "old")) b->bb.direct_units = false; }
   { const char* e = getenv("ZGPU_SPARSE_MAX"); if (e) { b->bb.sparse_max = (uint32_t)atoi(e); b->bb.sparse_per_block = 1u << 20; } }   // (tests) sequences per frame up to which zg_k_sparse replaces the sweep, whatever their density; 0: never
   b->bb.flat_slots = (uint32_t)cus_ * (flat_shape_ == 0 ? 1u : 2u);   // zg_k_flat: workgroups the device holds at once
   b->bb.finish();
@@ -333,7 +335,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
       (st = sc->d_aux.reserve((size_t)nb * sizeof(ZgBlockAux) + 16)) || (st = sc->d_slot_log.reserve((size_t)nslots * 4)) ||
       (st = sc->d_fse.reserve((size_t)nslots * ZG_FSE_SLOT_U32 * 4)) || (st = sc->d_huf.reserve((size_t)(bb.nhuf_slots + 1) * ZG_HUF_SLOT_U16 * 2)) ||
       (st = sc->d_hufmax.reserve(bb.nhuf_slots + 16)) || (st = sc->d_status.reserve(3 * ((size_t)nb * 4 + 16))) ||
-      (st = sc->d_lit.reserve(bb.lit_bytes + 64)) || (st = sc->d_seq.reserve((bb.seq_count + 2) * sizeof(ZgSeq))) ||
+      (st = sc->d_lit.reserve(bb.lit_bytes + 128)) || (st = sc->d_seq.reserve((bb.seq_count + 2) * sizeof(ZgSeq))) ||
       (st = sc->d_raw.reserve((bb.seq_count + 2) * 8)) ||
       (st = sc->d_seqout.reserve((size_t)nb * sizeof(ZgBlockSeqOut) + 16)) || (st = sc->d_pos.reserve((size_t)nb * sizeof(ZgBlockPos) + 16)) ||
       (st = sc->d_frameout.reserve((size_t)nf * sizeof(ZgFrameOut) + 16)) || (st = sc->d_totals.reserve(64)) ||
@@ -351,7 +353,8 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   d.aux = sc->d_aux.as<ZgBlockAux>(); d.slot_log = sc->d_slot_log.as<uint8_t>();
   d.fse_arena = sc->d_fse.as<uint32_t>(); d.huf_arena = sc->d_huf.as<uint16_t>(); d.huf_maxbits = sc->d_hufmax.as<uint8_t>();
   d.status = sc->d_status.as<uint32_t>(); d.tab_status = d.status + nb + 4; d.lit_status = d.tab_status + nb + 4;
-  d.lit_arena = sc->d_lit.as<uint8_t>(); d.seq_arena = sc->d_seq.as<ZgSeq>(); d.raw_arena = sc->d_raw.as<ZgRaw>();
+  d.lit_arena = sc->d_lit.as<uint8_t>() + 64;   // (zg_k_flat4 reads literal windows that start up to 7 bytes in front of a block's literals)
+  d.seq_arena = sc->d_seq.as<ZgSeq>(); d.raw_arena = sc->d_raw.as<ZgRaw>();
   d.seq_out = sc->d_seqout.as<ZgBlockSeqOut>(); d.pos = sc->d_pos.as<ZgBlockPos>(); d.frame_out = sc->d_frameout.as<ZgFrameOut>();
   d.dst = nullptr; d.dst_cap = 0; d.og = nullptr;
   d.dict = nullptr;
@@ -370,6 +373,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   d.dbg = getenv("ZGPU_DEBUG_TIMERS") ? sc->d_dbg.as<unsigned long long>() : nullptr;
   { const char* e = getenv("ZGPU_FORCE_INORDER"); d.flags = (e && e[0] == '1') ? 1u : 0u; }
   d.flags |= (uint32_t)flat_shape_ << 2;
+  { const char* e = getenv("ZGPU_FLAT"); if (e && !strcmp(e, "old")) d.flags |= 16u; }   // (measurement only) round 2's byte-granular zg_k_flat
   { const char* e = getenv("ZGPU_SWEEP_W"); d.sweep_window = (e && atoi(e) > 0) ? (uint32_t)atoi(e) : 0u; }
   if (hipStreamSynchronize(stream_) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
   *out = b;
@@ -451,8 +455,8 @@ int Batch::run() {
     d.dst = sc->d_dst.as<uint8_t>() + kOutFront; d.dst_cap = total_out;
     og_words = total_out;
   }
-  if (any_fast && (st = sc->d_og.reserve(og_words * 4 + 64))) return st;
-  d.og = sc->d_og.as<uint32_t>();
+  if (any_fast && (st = sc->d_og.reserve(og_words * 4 + 128))) return st;
+  d.og = sc->d_og.as<uint32_t>() + 16;   // (zg_k_flat4: a gather window may start up to four words in front of a unit's scratch)
   d.og_words = og_words;
   // ---- phase 2: LZ77 execution
   zg_launch_lit(d, s);

@@ -24,10 +24,13 @@
 #include "zg_types.h"
 #include "zg_dev.h"
 
-#define ZG_PAR_LIT 0xFFFFu   // tile byte is a literal (or dead)
-#define ZG_PAR_EXIT 0x8000u  // tile byte is a match byte whose parent lies before the tile
-#define ZG_FLAT_MAX 131072u  // largest block output the flatten path handles (Block_Maximum_Size)
 
+
+// four 16-bit lanes (a01 = lanes 0 and 1, a23 = lanes 2 and 3) -> one byte each: the lanes' low / high bytes
+ZX_DEV uint32_t zg_lanes_lo(uint32_t a23, uint32_t a01) { return (a01 & 0xFFu) | ((a01 >> 8) & 0xFF00u) | ((a23 << 16) & 0xFF0000u) | ((a23 << 8) & 0xFF000000u); }
+ZX_DEV uint32_t zg_lanes_hi(uint32_t a23, uint32_t a01) { return ((a01 >> 8) & 0xFFu) | ((a01 >> 16) & 0xFF00u) | ((a23 << 8) & 0xFF0000u) | (a23 & 0xFF000000u); }
+// (a & m) | (b & ~m)
+ZX_DEV uint32_t zx_bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
 
 template <int T, int TS, int SPT, bool DIRECT>
 struct ZgFlat4Lds {
@@ -48,7 +51,7 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
   constexpr int GPT = TS / (4 * T);            // groups per thread
   constexpr int SOFF = SPT * T;                // sequences a tile takes; a denser tile is cut short
   constexpr int NW = TS / 32;                  // words of the mark bitmap
-  static_assert(GPT * 4 * T == TS && GPT >= 1 && GPT <= 4 && NW <= T && (NW % 64) == 0 && SPT >= 1 && SPT <= 2 && TS <= 0x8000, "shape");
+  static_assert(GPT * 4 * T == TS && GPT >= 1 && GPT <= 4 && NW <= T && (NW % 64) == 0 && SPT >= 1 && SPT <= 2 && TS <= 0x4000, "shape");
   const uint32_t t = zx_tid();
   const ZgUnit un = d.units[ui];
   if (d.totals[2]) return;
@@ -135,6 +138,7 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
           else if (!reach_all && off > reach32 + m0) zx_min_lds64(&L.bad, ((unsigned long long)i << 32) | (m0 << 8) | (uint32_t)ZG_EXE_OFFSET_TOO_BIG);
         } else if (i == nseq) {
           lstart = so.sum_ll; a = so.sum_ll + so.sum_ml; m0 = m1 = S;
+          off = 0x3FFFFFFFu;          // (tile bytes behind the block's end are classified like any others: as roots, not as their own parents)
         }
         // first sequence that reaches beyond this tile starts the next one: sequences are in order along the lanes, so the
         // lowest lane of a wave that sees one speaks for the wave (one LDS atomic per wave, not one per sequence)
@@ -181,22 +185,25 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
       const uint32_t n = t1 - t0a;                                 // tile bytes [lead, n) are live
       const uint32_t tu0a = bu0 + t0a;                             // unit-relative position of tile byte 0 (modular)
       if (t1 < S) { ZG_F4_FETCH(i_next) }                          // next tile's sequences: in flight behind this tile's work
-      // ---- S1c: every group finds its (at most two: matches are >= 3 bytes long) sequences by rank of the marks; every byte
+      // ---- S1c: every group finds its (at most two: matches are >= 3 bytes long) sequences by rank of the marks, and every byte
       // becomes a literal, a match byte with its parent inside the tile (pointer), or a root: a match byte whose parent lies
-      // before the tile. What the roots of a group need from before the tile — the parents' scratch words (pointer mode) or
-      // byte values (direct mode) — is consecutive in memory per sequence: one window load per sequence of the group,
-      // requested here and consumed after the pointer jumping (the round trip hides behind it).
-      uint32_t wrd[GPT][4];
+      // before the tile. The four bytes are classified together, as two pairs of 16-bit lanes (packed arithmetic): the kernel is
+      // bound by the instructions it issues. What the roots of a group need from before the tile — the parents' scratch words
+      // (pointer mode) or byte values (direct mode) — is consecutive in memory per sequence: one window load per sequence of
+      // the group, requested here and consumed after the pointer jumping (the round trip hides behind it). A window is
+      // requested whether or not its bytes turn out to be roots: what a non-root byte receives is never looked at.
       ZxU4 LA[GPT], LB[GPT];
       ZxU2 VA[GPT], VB[GPT], LW[GPT];
-      uint32_t fbv[GPT], meta[GPT];      // meta: [3:0] literal bytes, [12:8] / [20:16] / [28:24] funnel shifts of the literal / A / B windows
-      uint32_t unresolved = 0;
+      uint32_t offA[GPT], offB[GPT], meta[GPT], litl[GPT];   // meta: [2:0] first byte of the second sequence, [12:8] / [20:16] / [28:24] funnel shifts of the literal / A / B windows; litl: literal bytes (byte mask)
+      uint32_t unresolved = 0;                               // bit 8 i + k: byte i of the thread's k-th group has its parent in the tile
       {
         const uint32_t tc = ZX_FRESH(t);
+        const uint32_t lead2 = lead * 0x10001u;
         uint32_t wordv[GPT], cntv[GPT];
 #pragma unroll
         for (int k = 0; k < GPT; k++) { const uint32_t xw = (tc + k * T) >> 3; wordv[k] = L.bits[xw]; cntv[k] = L.cnt[xw]; }
         ZxU4 rA[GPT], rB[GPT];
+        uint32_t fbv[GPT];
 #pragma unroll
         for (int k = 0; k < GPT; k++) {
           const uint32_t x0 = 4u * (tc + k * T), sh = x0 & 31u;
@@ -208,56 +215,56 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
 #pragma unroll
         for (int k = 0; k < GPT; k++) {
           const uint32_t x0 = 4u * (tc + k * T), fb = fbv[k];
-          uint32_t litm = 0, needA = 0, needB = 0, ilit = 4;
-          uint32_t parp[4];
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const uint32_t x = x0 + i;
-            const bool useB = (uint32_t)i >= fb;
-            const uint32_t off = useB ? rB[k].x : rA[k].x, m0 = useB ? rB[k].y : rA[k].y;
-            const bool live = x - lead < n - lead;                  // lead <= x < n
-            const bool c_lit = x < m0, c_in = off + lead <= x;               // c_in: the parent is a live byte of this tile (the dead bytes belong to the tile before)
-            const bool is_lit = live && c_lit, is_in = live && !c_lit && c_in, is_exit = live && !c_lit && !c_in;
-            const int32_t u = (int32_t)(tu0a + x - off);             // unit-relative position of the parent
-            const bool ok = is_exit && u >= 0;                      // the parent lies in the unit: its word / value is wanted
-            parp[i] = is_in ? x - off : (is_exit ? (uint32_t)ZG_PAR_EXIT : (uint32_t)ZG_PAR_LIT);
-            wrd[k][i] = is_exit ? off : 0u;
-            litm |= is_lit ? 1u << i : 0u;
-            if (is_lit && ilit == 4) ilit = (uint32_t)i;
-            if (useB) needB |= ok ? 1u : 0u; else needA |= ok ? 1u : 0u;
-            unresolved |= is_in ? 1u << (4 * k + i) : 0u;
-          }
-          ZxU2 pp; pp.x = parp[0] | (parp[1] << 16); pp.y = parp[2] | (parp[3] << 16);
+          // lanes: bytes (0, 1) and (2, 3) of the group; mB: the lanes of the second sequence
+          const uint32_t x01 = x0 * 0x10001u + 0x10000u, x23 = x01 + 0x20002u;
+          const uint32_t mB01 = fb == 1u ? 0xFFFF0000u : 0u, mB23 = fb <= 2u ? 0xFFFFFFFFu : (fb == 3u ? 0xFFFF0000u : 0u);
+          const uint32_t oa = rA[k].x < 0x7FF0u ? rA[k].x : 0x7FF0u, ob = rB[k].x < 0x7FF0u ? rB[k].x : 0x7FF0u;   // (a tile is at most 2^14 bytes: a larger offset leads in front of it all the same, and the lanes stay inside 16 signed bits)
+          const uint32_t oa2 = oa * 0x10001u, ob2 = ob * 0x10001u, ma2 = rA[k].y * 0x10001u, mb2 = rB[k].y * 0x10001u;
+          const uint32_t p01 = zx_pksub16(x01, zx_bfi(mB01, ob2, oa2)), p23 = zx_pksub16(x23, zx_bfi(mB23, ob2, oa2));   // tile-relative parents
+          const uint32_t e01 = zx_pksign16(zx_pksub16(p01, lead2)), e23 = zx_pksign16(zx_pksub16(p23, lead2));           // lanes whose parent lies before the tile's live bytes
+          const uint32_t l01 = zx_pksign16(zx_pksub16(x01, zx_bfi(mB01, mb2, ma2))), l23 = zx_pksign16(zx_pksub16(x23, zx_bfi(mB23, mb2, ma2)));   // literal lanes (x < first match byte)
+          ZxU2 pp;
+          pp.x = zx_bfi(e01, ZG_PAR_EXIT * 0x10001u, p01) | l01;        // literal: 0xFFFF, root: 0x8000, else the parent
+          pp.y = zx_bfi(e23, ZG_PAR_EXIT * 0x10001u, p23) | l23;
           *(ZxU2*)&L.par[x0] = pp;
-          // the literal bytes of a group belong to one sequence (a second literal run would need a whole match between them):
-          // one 8-byte window that starts at the first of them
-          const uint32_t zl = ilit < fb ? rA[k].z : rB[k].z;
-          const uint32_t ol = ((zl + x0 + ilit) & 0x7FFFFFFFu) + lit_lo + 4u - ilit;   // offset of the byte group byte 0 would stand for
-          LW[k] = zx_ld64(lit_rs, litm ? ol & ~3u : ZX_OOB);
-          uint32_t m = litm | ((ol & 3u) << 11);
-          const int32_t uA = (int32_t)(tu0a + x0 - rA[k].x), uB = (int32_t)(tu0a + x0 - rB[k].x);   // where the parents' windows start
+          // the high bytes of the four lanes: bit 7 clear = parent in the tile
+          const uint32_t hb = zg_lanes_hi(pp.y, pp.x);
+          unresolved |= ((~hb & 0x80808080u) >> 7) << k;
+          offA[k] = rA[k].x; offB[k] = rB[k].x;
+          uint32_t m = fb;
+          const int32_t uA = (int32_t)(tu0a + x0 - rA[k].x), uB = (int32_t)(tu0a + x0 - rB[k].x);   // unit-relative positions where the parents' windows start
           if (DIRECT) {
+            // the literal bytes of a group belong to one sequence (a second literal run would need a whole match between them):
+            // one 8-byte window that starts at the first of them
+            // literal bytes as a byte mask (the tile's dead bytes are literals by class: not these)
+            const uint32_t lb = zg_lanes_lo(l23, l01) & (x0 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8u * lead));
+            const uint32_t ilit = lb ? (uint32_t)__builtin_ctz(lb) >> 3 : 0u;
+            const uint32_t zl = ilit < fb ? rA[k].z : rB[k].z;
+            const uint32_t ol = ((zl + x0 + ilit) & 0x7FFFFFFFu) + lit_lo + 4u - ilit;   // offset of the byte group byte 0 would stand for
+            LW[k] = zx_ld64(lit_rs, lb ? ol & ~3u : ZX_OOB);
+            litl[k] = lb;
             const uint32_t oA = (uint32_t)uA + ualign + 4u, oB = (uint32_t)uB + ualign + 4u;
-            VA[k] = zx_ld64(out_rs, needA ? oA & ~3u : ZX_OOB);
-            VB[k] = zx_ld64(out_rs, needB ? oB & ~3u : ZX_OOB);
-            m |= ((oA & 3u) << 19) | ((oB & 3u) << 27);
+            // (a window may start up to three bytes before the frame: its first bytes are then literals or belong to the other sequence)
+            VA[k] = zx_ld64(out_rs, uA >= -3 ? oA & ~3u : ZX_OOB);
+            VB[k] = zx_ld64(out_rs, (uB >= -3 && fb < 4u) ? oB & ~3u : ZX_OOB);
+            m |= ((ol & 3u) << 11) | ((oA & 3u) << 19) | ((oB & 3u) << 27);
           } else {
-            // a window that starts before the unit (its first words belong to whatever lies in front of the scratch): word by
-            // word, so that what is not wanted reads as zero. Once per unit and offset at most.
-            const bool strA = needA && uA < 0, strB = needB && uB < 0;
+            litl[k] = zg_lanes_lo(l23, l01);
+            // a window that starts just before the unit (its first words belong to whatever lies in front of the scratch): word by
+            // word, so that what lies in front reads as zero. Once per unit and offset at most.
+            const bool strA = (uint32_t)(uA + 3) < 3u, strB = (uint32_t)(uB + 3) < 3u && fb < 4u;
             if (strA || strB) {
               uint32_t la[4], lb[4];
 #pragma unroll
               for (int i = 0; i < 4; i++) {
-                const bool useB = (uint32_t)i >= fb;
-                la[i] = zx_ld32(og_rs, (needA && !useB && uA + i >= 0) ? 4u * (uint32_t)(uA + i + 4) : ZX_OOB);
-                lb[i] = zx_ld32(og_rs, (needB && useB && uB + i >= 0) ? 4u * (uint32_t)(uB + i + 4) : ZX_OOB);
+                la[i] = zx_ld32(og_rs, uA + i >= 0 ? 4u * (uint32_t)(uA + i + 4) : ZX_OOB);
+                lb[i] = zx_ld32(og_rs, (uB + i >= 0 && fb < 4u) ? 4u * (uint32_t)(uB + i + 4) : ZX_OOB);
               }
               LA[k].x = la[0]; LA[k].y = la[1]; LA[k].z = la[2]; LA[k].w = la[3];
               LB[k].x = lb[0]; LB[k].y = lb[1]; LB[k].z = lb[2]; LB[k].w = lb[3];
             } else {
-              LA[k] = zx_ld128(og_rs, needA ? 4u * (uint32_t)(uA + 4) : ZX_OOB);
-              LB[k] = zx_ld128(og_rs, needB ? 4u * (uint32_t)(uB + 4) : ZX_OOB);
+              LA[k] = zx_ld128(og_rs, uA >= 0 ? 4u * (uint32_t)(uA + 4) : ZX_OOB);
+              LB[k] = zx_ld128(og_rs, (uB >= 0 && fb < 4u) ? 4u * (uint32_t)(uB + 4) : ZX_OOB);
             }
           }
           meta[k] = m;
@@ -272,7 +279,7 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
         for (uint32_t guard = 0; unresolved && guard < (1u << 16); guard++) {
           uint32_t m = unresolved, kk[4], ad[4], pp[4];
 #pragma unroll
-          for (int j = 0; j < 4; j++) { kk[j] = m ? (uint32_t)__builtin_ctz(m) : 32u; m &= m - 1; ad[j] = 4u * (t2 + (kk[j] >> 2) * T) + (kk[j] & 3u); }
+          for (int j = 0; j < 4; j++) { kk[j] = m ? (uint32_t)__builtin_ctz(m) : 32u; m &= m - 1; ad[j] = 4u * (t2 + (kk[j] & 7u) * T) + (kk[j] >> 3); }   // bit 8 i + k: byte i of group k
 #pragma unroll
           for (int j = 0; j < 4; j++) pp[j] = kk[j] < 32u ? L.par[ad[j]] : 0u;
 #pragma unroll
@@ -292,25 +299,26 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
         const uint32_t t3 = ZX_FRESH(t);
 #pragma unroll
         for (int k = 0; k < GPT; k++) {
-          const uint32_t x0 = 4u * (t3 + k * T), fb = fbv[k], m = meta[k];
+          const uint32_t x0 = 4u * (t3 + k * T), m = meta[k], fb = m & 7u;
           if (DIRECT) {
             const uint32_t vA = zx_alignbit(VA[k].y, VA[k].x, (m >> 16) & 31u), vB = zx_alignbit(VB[k].y, VB[k].x, (m >> 24) & 31u);
             const uint32_t l4 = zx_alignbit(LW[k].y, LW[k].x, (m >> 8) & 31u) | fill4;
             const uint32_t mB = fb >= 4u ? 0u : 0xFFFFFFFFu << (8u * fb);                       // bytes of the second sequence
-            const uint32_t mL = ((((m & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu);           // literal bytes
-            uint32_t v = (vA & ~mB) | (vB & mB);
-            v = (v & ~mL) | (l4 & mL);
-            *(uint32_t*)&L.val[x0] = v;
+            *(uint32_t*)&L.val[x0] = zx_bfi(litl[k], l4, zx_bfi(mB, vB, vA));
           } else {
-            const uint32_t ga[4] = {LA[k].x, LA[k].y, LA[k].z, LA[k].w}, gb[4] = {LB[k].x, LB[k].y, LB[k].z, LB[k].w};
-            uint32_t w[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-              // (a byte with its parent in the tile takes whatever its window slot holds: nobody reads the word of a byte that is not a root)
-              const uint32_t g = (uint32_t)i >= fb ? gb[i] : ga[i];
-              w[i] = ((m >> i) & 1u) ? 0x80000000u : wrd[k][i] + g;
-            }
-            ZxU4 wv; wv.x = w[0]; wv.y = w[1]; wv.z = w[2]; wv.w = w[3];
+            // a root's effective offset = its sequence's offset + the effective offset of its parent (0 when that lies before the
+            // unit); a literal root counts 0. (A byte with its parent in the tile takes whatever its window slot holds: nobody
+            // reads the word of a byte that is not a root.)
+            // (selects and masks only: a branch per byte would cost more than it skips)
+            const uint32_t lb = litl[k], oa = offA[k], ob = offB[k];
+            const uint32_t sa0 = oa + LA[k].x, sa1 = oa + LA[k].y, sa2 = oa + LA[k].z, sa3 = oa + LA[k].w;
+            const uint32_t sb1 = ob + LB[k].y, sb2 = ob + LB[k].z, sb3 = ob + LB[k].w;
+            const uint32_t w1 = fb <= 1u ? sb1 : sa1, w2 = fb <= 2u ? sb2 : sa2, w3 = fb <= 3u ? sb3 : sa3;
+            ZxU4 wv;
+            wv.x = sa0 & ~(uint32_t)(int32_t)(int8_t)lb;
+            wv.y = w1 & ~(uint32_t)(int32_t)(int8_t)(lb >> 8);
+            wv.z = w2 & ~(uint32_t)(int32_t)(int8_t)(lb >> 16);
+            wv.w = w3 & ~(uint32_t)(int32_t)(int8_t)(lb >> 24);
             *(ZxU4*)&L.word[x0] = wv;
           }
         }
@@ -318,20 +326,23 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
       zx_barrier();
       if (L.err) break;
       // ---- S3b: every byte takes what its root holds. Pointer mode: effective offset = the root's + the distance to the root
-      // (a literal root counts 0) -> scratch, 16 bytes per group; the tile's literal bytes go to the output. Direct mode: the
-      // root's value -> output, 4 bytes per group.
+      // -> scratch, 16 bytes per group (the literal bytes themselves are placed by zg_k_lit). Direct mode: the root's value ->
+      // output, 4 bytes per group.
       {
         const uint32_t t4 = ZX_FRESH(t);
 #pragma unroll
         for (int k = 0; k < GPT; k++) {
-          const uint32_t x0 = 4u * (t4 + k * T), m = meta[k];
+          const uint32_t x0 = 4u * (t4 + k * T);
           const ZxU2 pp = *(const ZxU2*)&L.par[x0];
           const uint32_t pr[4] = {pp.x & 0xFFFFu, pp.x >> 16, pp.y & 0xFFFFu, pp.y >> 16};
           const bool full = x0 >= lead && x0 + 4u <= n;
+          uint32_t r[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) r[i] = pr[i] >= ZG_PAR_EXIT ? x0 + i : pr[i];
           if (DIRECT) {
             uint32_t vb[4];
 #pragma unroll
-            for (int i = 3; i >= 0; i--) vb[i] = L.val[pr[i] >= ZG_PAR_EXIT ? x0 + i : pr[i]];
+            for (int i = 3; i >= 0; i--) vb[i] = L.val[r[i]];
             const uint32_t v = vb[0] | (vb[1] << 8) | (vb[2] << 16) | (vb[3] << 24);
             const uint32_t o = tu0a + x0 + ualign + 4u;
             zx_st32(out_rs, full ? o : ZX_OOB, v);
@@ -340,26 +351,18 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
               for (int i = 0; i < 4; i++) zx_st8(out_rs, (x0 + i - lead < n - lead) ? o + i : ZX_OOB, vb[i]);
             }
           } else {
-            uint32_t w[4], e[4];
+            uint32_t w[4];
 #pragma unroll
-            for (int i = 3; i >= 0; i--) w[i] = L.word[pr[i] >= ZG_PAR_EXIT ? x0 + i : pr[i]];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-              const uint32_t r = pr[i] >= ZG_PAR_EXIT ? x0 + i : pr[i];
-              e[i] = ((w[i] >> 31) ? 0u : w[i]) + (x0 + i - r);
-            }
+            for (int i = 3; i >= 0; i--) w[i] = L.word[r[i]];
+            ZxU4 ev;
+            ev.x = w[0] + (x0 - r[0]); ev.y = w[1] + (x0 + 1u - r[1]); ev.z = w[2] + (x0 + 2u - r[2]); ev.w = w[3] + (x0 + 3u - r[3]);
             const uint32_t o = 4u * (tu0a + x0 + 4u);
-            ZxU4 ev; ev.x = e[0]; ev.y = e[1]; ev.z = e[2]; ev.w = e[3];
             zx_st128(og_rs, full ? o : ZX_OOB, ev);
             if (!full) {
+              const uint32_t e[4] = {ev.x, ev.y, ev.z, ev.w};
 #pragma unroll
               for (int i = 0; i < 4; i++) zx_st32(og_rs, (x0 + i - lead < n - lead) ? o + 4u * i : ZX_OOB, e[i]);
             }
-            // literal bytes -> output (meta holds which of the group's bytes are live literals)
-            const uint32_t l4 = zx_alignbit(LW[k].y, LW[k].x, (m >> 8) & 31u) | fill4;
-            const uint32_t ob = tu0a + x0 + ualign + 4u;
-#pragma unroll
-            for (int i = 0; i < 4; i++) zx_st8(out_rs, ((m >> i) & 1u) ? ob + i : ZX_OOB, (l4 >> (8 * i)) & 0xFFu);
           }
         }
       }

@@ -30,7 +30,6 @@
 
 #define ZG_SEQ_G 16       // blocks per workgroup (four lanes per block in either wave) in zg_k_seq: 16 x (2.5 KiB + 1.25 KiB tables + ring + records) in LDS -> 2 workgroups per CU
 #define ZG_LZ_T 256       // threads per frame in zg_k_lz
-#define ZG_FLAT_MAX 131072u  // largest block output the flatten path handles (Block_Maximum_Size)
 
 typedef uint32_t zg_v4u __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) zg_v4u zg_gv4u;   // 16 bytes in global memory: global_load/store, not flat
@@ -1263,8 +1262,8 @@ __global__ void __launch_bounds__(1024) zg_k_scanf(ZgBatchDev d) {
 
 // ------------------------------------------------------------------------------------------------------------
 // zg_k_lit: blocks that do not depend on earlier output at all — raw blocks, RLE blocks (block_decoder.rs:55-82) and
-// compressed blocks without sequences (block_decoder.rs:184-194: the literals are the block). Literal runs of blocks
-// WITH sequences (DecodeBuffer::push, decode_buffer.rs:74-77) are placed by zg_k_flat (flatten path) or zg_k_lz.
+// compressed blocks without sequences (block_decoder.rs:184-194: the literals are the block) — and the literal runs of blocks
+// WITH sequences (DecodeBuffer::push, decode_buffer.rs:74-77) unless zg_k_flat4 (direct units) or zg_k_lz places them.
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void zg_wg_copy(uint8_t* dst, const uint8_t* src, uint64_t n, uint32_t t, uint32_t T) {
   uint64_t n8 = n >> 3;
@@ -1278,6 +1277,8 @@ __device__ __forceinline__ void zg_wg_fill(uint8_t* dst, uint8_t byte, uint64_t 
 }
 
 __global__ void __launch_bounds__(256) zg_k_lit(ZgBatchDev d) {
+  __shared__ uint32_t s_long[256 * 3];          // literal runs too long for one lane: {source index, destination, length}
+  __shared__ uint32_t s_nlong;
   if (d.totals[2]) return;
   const uint32_t b = blockIdx.x, t = threadIdx.x;
   const ZgBlockPos p = d.pos[b];
@@ -1287,9 +1288,49 @@ __global__ void __launch_bounds__(256) zg_k_lit(ZgBatchDev d) {
   const uint8_t* body = d.src + blk.src_off;
   if (blk.btype == ZG_BT_RAW) { zg_wg_copy(out, body, blk.regen_size, t, 256); return; }
   if (blk.btype == ZG_BT_RLE) { zg_wg_fill(out, body[0], blk.regen_size, t, 256); return; }
-  if (blk.nseq) return;
-  if (blk.lit_type == ZG_LT_RLE) zg_wg_fill(out, body[blk.lit_off], blk.regen_size, t, 256);
-  else zg_wg_copy(out, blk.lit_type == ZG_LT_RAW ? body + blk.lit_off : d.lit_arena + blk.lit_base, blk.regen_size, t, 256);
+  const bool lit_rle = blk.lit_type == ZG_LT_RLE;
+  const uint8_t* lit = blk.lit_type <= ZG_LT_RLE ? body + blk.lit_off : d.lit_arena + blk.lit_base;
+  if (!blk.nseq) {
+    if (lit_rle) zg_wg_fill(out, lit[0], blk.regen_size, t, 256);
+    else zg_wg_copy(out, lit, blk.regen_size, t, 256);
+    return;
+  }
+  // A block with sequences: its literal runs (DecodeBuffer::push, decode_buffer.rs:74-77; the trailing literals,
+  // sequence_execution.rs:40-44) are independent of everything else and go to their places here, one lane per sequence,
+  // unless the block's unit is resolved to bytes by zg_k_flat4 itself (direct unit) or the frame left the flatten path
+  // (zg_k_lz places its own). The effective offsets of pointer-mode units then only describe match bytes.
+  if ((blk.flags & ZG_BLK_DIRECT) || !d.frame_out[blk.frame].fast) return;
+  const ZgSeq* sq = d.seq_arena + blk.seq_base;
+  const ZgBlockSeqOut so = d.seq_out[b];
+  const uint32_t nseq = blk.nseq, fillv = lit_rle ? lit[0] : 0u;
+  constexpr uint32_t SHORT = 24;                 // a lane copies runs up to this long by itself
+  for (uint32_t i0 = 0; i0 <= nseq; i0 += 256) {
+    if (t == 0) s_nlong = 0;
+    __syncthreads();
+    const uint32_t i = i0 + t;
+    uint32_t lstart = 0, ll = 0, a = 0;
+    if (i < nseq) {
+      const ZgSeq q = sq[i];
+      const uint32_t next = i + 1 < nseq ? ZG_SEQ_LIT(sq[i + 1]) : so.sum_ll;
+      lstart = ZG_SEQ_LIT(q); ll = (next - lstart) & 0x1FFFFu; a = ZG_SEQ_MDST(q) - ll;
+    } else if (i == nseq) {
+      lstart = so.sum_ll; ll = blk.regen_size - so.sum_ll; a = so.sum_ll + so.sum_ml;
+    }
+    if (ll > SHORT) {
+      const uint32_t k = atomicAdd(&s_nlong, 1u);
+      s_long[3 * k] = lstart; s_long[3 * k + 1] = a; s_long[3 * k + 2] = ll;
+    } else {
+      for (uint32_t k = 0; k < ll; k++) out[a + k] = lit_rle ? (uint8_t)fillv : lit[lstart + k];
+    }
+    __syncthreads();
+    const uint32_t nl = s_nlong;
+    for (uint32_t j = 0; j < nl; j++) {
+      const uint32_t ls = s_long[3 * j], la = s_long[3 * j + 1], n = s_long[3 * j + 2];
+      if (lit_rle) zg_wg_fill(out + la, (uint8_t)fillv, n, t, 256);
+      else zg_wg_copy(out + la, lit + ls, n, t, 256);
+    }
+    __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1310,8 +1351,6 @@ __global__ void __launch_bounds__(256) zg_k_lit(ZgBatchDev d) {
 //              and needs no co-residency assumption): every match byte of the unit is one independent gather from
 //              bytes that are final by then.
 // ------------------------------------------------------------------------------------------------------------
-#define ZG_PAR_LIT 0xFFFFu   // tile byte is a literal
-#define ZG_PAR_EXIT 0x8000u  // tile byte is a match byte whose parent lies before the tile
 
 // workgroup barrier that orders LDS only: unlike __syncthreads() it does not wait for this wave's global loads/stores
 __device__ __forceinline__ void zg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -1617,6 +1656,50 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
   if (t == 0 && d.dbg) { for (int i = 0; i < 8; i++) atomicAdd(&d.dbg[i], tc[i]); }
 #endif
 #undef ZG_TICK
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// zg_k_flat4: the flatten stage at dword granularity, with direct (value) units — the body is zg_flat4.h, written against
+// the zx_* primitives below so that tests/emu runs the same source on the CPU. One workgroup per unit.
+// ------------------------------------------------------------------------------------------------------------
+#define ZX_DEV __device__ __forceinline__
+#define ZX_OOB ZG_OOB
+#define ZX_FRESH(v) ZG_FRESH(v)
+typedef __amdgpu_buffer_rsrc_t ZxBuf;
+ZX_DEV uint32_t zx_tid() { return threadIdx.x; }
+ZX_DEV void zx_barrier() { zg_lds_barrier(); }
+// every wave's global stores have reached memory, then the barrier (the builtin, not inline asm: the compiler then knows
+// that nothing is in flight here and does not protect registers of earlier loads with waits that also cover later ones)
+ZX_DEV void zx_barrier_vm() { __builtin_amdgcn_s_waitcnt(0x0F70); zg_lds_barrier(); }
+ZX_DEV unsigned long long zx_ballot(bool p) { return __ballot(p); }
+ZX_DEV uint32_t zx_shfl_up(uint32_t v, int o) { return __shfl_up(v, o, 64); }
+ZX_DEV void zx_or_lds(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+ZX_DEV void zx_min_lds(uint32_t* p, uint32_t v) { atomicMin(p, v); }
+ZX_DEV void zx_min_lds64(unsigned long long* p, unsigned long long v) { atomicMin(p, v); }
+ZX_DEV void zx_min_glb(uint32_t* p, uint32_t v) { atomicMin(p, v); }
+ZX_DEV ZxBuf zx_buf(const void* base, uint32_t bytes) { return zg_make_rsrc(base, bytes); }
+ZX_DEV uint32_t zx_ld8(ZxBuf b, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b8(b, off, 0, 0); }
+ZX_DEV uint32_t zx_ld32(ZxBuf b, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b32(b, off, 0, 0); }
+ZX_DEV ZxU2 zx_ld64(ZxBuf b, uint32_t off) { const zg_v2u v = __builtin_amdgcn_raw_buffer_load_b64(b, off, 0, 0); ZxU2 r; r.x = v.x; r.y = v.y; return r; }
+ZX_DEV ZxU3 zx_ld96(ZxBuf b, uint32_t off) { const zg_v3u v = __builtin_amdgcn_raw_buffer_load_b96(b, off, 0, 0); ZxU3 r; r.x = v.x; r.y = v.y; r.z = v.z; return r; }
+ZX_DEV ZxU4 zx_ld128(ZxBuf b, uint32_t off) { const zg_v4u v = __builtin_amdgcn_raw_buffer_load_b128(b, off, 0, 0); ZxU4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
+ZX_DEV void zx_st8(ZxBuf b, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v, b, off, 0, 0); }
+ZX_DEV void zx_st32(ZxBuf b, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, b, off, 0, 0); }
+ZX_DEV void zx_st128(ZxBuf b, uint32_t off, const ZxU4& v) { __builtin_amdgcn_raw_buffer_store_b128(zg_v4u{v.x, v.y, v.z, v.w}, b, off, 0, 0); }
+ZX_DEV uint32_t zx_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+typedef short zg_v2s __attribute__((ext_vector_type(2)));
+// packed 16-bit lanes (v_pk_sub_i16, v_pk_ashrrev_i16): a - b per lane; 0xFFFF per lane whose signed value is negative
+ZX_DEV uint32_t zx_pksub16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (zg_v2s)(__builtin_bit_cast(zg_v2s, a) - __builtin_bit_cast(zg_v2s, b))); }
+// (as an instruction: written as a shift the compiler turns what is done with the result — lane masks for v_bfi — into a compare and a select per lane)
+ZX_DEV uint32_t zx_pksign16(uint32_t a) { uint32_t r; asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a)); return r; }
+#include "zg_flat4.h"
+
+template <int T, int TS, int SPT>
+__global__ void __launch_bounds__(T, 4) zg_k_flat4(ZgBatchDev d) {
+  __shared__ union { ZgFlat4Lds<T, TS, SPT, false> p; ZgFlat4Lds<T, TS, SPT, true> v; } s_u;
+  if (threadIdx.x == 0) { ZgUnitInfo ui; ui.size = 0; ui.noseq = 0; d.unit_info[blockIdx.x] = ui; }
+  if (d.units[blockIdx.x].noseq & ZG_UNIT_DIRECT) zg_flat4_unit<T, TS, SPT, true>(d, blockIdx.x, s_u.v);
+  else zg_flat4_unit<T, TS, SPT, false>(d, blockIdx.x, s_u.p);
 }
 
 // zg_k_swprep: one thread per (step, unit) entry: everything a sweep workgroup needs about its unit in one 32-byte
@@ -1982,8 +2065,13 @@ void zg_launch_sparse(const ZgBatchDev& d, hipStream_t s) {
 void zg_launch_flat(const ZgBatchDev& d, hipStream_t s) {
   if (!d.nunits) return;
   const uint32_t shape = (d.flags >> 2) & 3u;
-  if (shape == 1) hipLaunchKernelGGL((zg_k_flat<512, 8192, 2>), dim3(d.nunits), dim3(512), 0, s, d);
-  else hipLaunchKernelGGL((zg_k_flat<1024, 16384, 2>), dim3(d.nunits), dim3(1024), 0, s, d);
+  if (d.flags & 16u) {   // (measurement only, ZGPU_FLAT=old) the byte-granular kernel of round 2
+    if (shape == 1) hipLaunchKernelGGL((zg_k_flat<512, 8192, 2>), dim3(d.nunits), dim3(512), 0, s, d);
+    else hipLaunchKernelGGL((zg_k_flat<1024, 16384, 2>), dim3(d.nunits), dim3(1024), 0, s, d);
+    return;
+  }
+  if (shape == 1) hipLaunchKernelGGL((zg_k_flat4<512, 8192, 2>), dim3(d.nunits), dim3(512), 0, s, d);
+  else hipLaunchKernelGGL((zg_k_flat4<1024, 16384, 2>), dim3(d.nunits), dim3(1024), 0, s, d);
 }
 bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* steps, uint32_t nsteps, hipStream_t s2, hipEvent_t* evs, uint32_t nev,
                      uint32_t unit_bytes, uint32_t window_max, uint32_t window_min) {

@@ -265,15 +265,16 @@ class Batch:
         return int(self.L.zgpu_batch_debug_sweep_mode(self.h))
 
     def units(self):
-        """[(first_block, nblocks, scratch_base, size, noseq)] — the units zg_k_flat worked on (size valid after sync); noseq: no block of
-        the unit has sequences, so it has no scratch words and no sweep step"""
+        """[(first_block, nblocks, scratch_base, size, noseq)] — the units zg_k_flat4 worked on (size valid after sync); noseq: bit 0: no
+        block of the unit has sequences, bit 1: direct unit (resolved to bytes by the flatten itself); either way it has no scratch
+        words and no sweep step"""
         out = []
         for u in range(self.L.zgpu_batch_num_units(self.h)):
             fb, nb, base = C.c_uint32(), C.c_uint32(), C.c_uint64()
             assert self.L.zgpu_batch_unit(self.h, u, C.byref(fb), C.byref(nb), C.byref(base)) == 0
             info = (C.c_uint32 * 2)()
             assert self.L.zgpu_batch_debug_scratch(self.h, 1, 8 * u, info, 8) == 0
-            out.append((fb.value, nb.value, base.value, info[0], bool(info[1])))
+            out.append((fb.value, nb.value, base.value, info[0], int(info[1])))
         return out
 
     def scratch_words(self, base, n):
