@@ -208,6 +208,42 @@ uint64_t zgpu_decoder_content_size(const zgpu_decoder*);             /* :246 */
 int zgpu_decoder_checksum_from_data(const zgpu_decoder*, uint32_t* out); /* :254 — returns 1 if present */
 uint32_t zgpu_decoder_calculated_checksum(const zgpu_decoder*);      /* :263-270 XXH64 seed 0, low 32 bits */
 
+/* ---- the thin boundary: host-parsed block tables -----------------------------------------------------------------------
+ * For a caller that keeps ruzstd's own header parse — read_frame_header (ruzstd/src/decoding/frame.rs:6-85) and
+ * read_block_header (block_decoder.rs:201-247) — and hands the Block_Content of whole runs of blocks to the device: exactly the
+ * seam of BlockDecoder::decode_block_content (block_decoder.rs:39-95) as FrameDecoder::decode_blocks calls it
+ * (frame_decoder.rs:319-375), batched. INTEGRATION.md section 2 shows the Rust side. One zgpu_frame = one frame in flight
+ * (DecoderScratch, scratch.rs:15-27, lives on the device behind it); several may exist per context. */
+typedef struct zgpu_frame zgpu_frame;
+typedef struct {
+  uint64_t src_off;        /* offset of Block_Content in the src of the submit */
+  uint32_t src_len;        /* Block_Content bytes: Block_Size for raw and compressed blocks, 1 for RLE blocks (block_decoder.rs:249-283) */
+  uint32_t raw_rle_size;   /* raw / RLE blocks: decompressed size (= Block_Size); compressed blocks: 0 */
+  uint8_t type;            /* 0 raw, 1 RLE, 2 compressed (blocks/block.rs:31-44) */
+  uint8_t last;            /* Last_Block flag */
+  uint8_t pad[6];
+} zgpu_block;
+/* FrameDecoderState::new/reset (frame_decoder.rs:103-134) from the header fields the caller parsed. dict_id_or_0 names a
+ * dictionary registered with zgpu_add_dict (init_from_dict, scratch.rs:70-78); ZGPU_E_DICT_NOT_PROVIDED / ZGPU_E_WINDOW_SIZE_TOO_BIG
+ * as the reference (:137-145, :212-219). content_size_or_0 is a hint only. */
+int zgpu_frame_begin(zgpu_ctx*, uint64_t window_size, uint64_t content_size_or_0, uint32_t dict_id_or_0, zgpu_frame** out);
+void zgpu_frame_end(zgpu_frame*);
+/* decode_block_content x nblocks. src is copied to the device before this returns; the kernels run on the context's
+ * streams. Blocks of a frame depend on each other: a second submit first waits for the one in flight. The run ends with the
+ * first block marked last. */
+int zgpu_blocks_submit(zgpu_frame*, const uint8_t* src, size_t src_len, const zgpu_block* blocks, size_t nblocks);
+/* wait for the submit in flight. *first_bad_block = frame-relative index (counted over all submits) of the first block that
+ * failed, SIZE_MAX if none; *its_status = its DecompressBlockError leaf (the zgpu_status values above). Blocks in front of
+ * it are decoded and readable, like the reference's. The return value only reports engine failures (HIP, memory). */
+int zgpu_sync(zgpu_frame*, size_t* first_bad_block, int32_t* its_status);
+/* can_collect / read (decode_buffer.rs:182-219, frame_decoder.rs:381-424): while the frame is unfinished the last window_size
+ * bytes stay back. frame_finished: the caller has submitted the last block (it reads the flag itself). */
+size_t zgpu_available(const zgpu_frame*, int frame_finished);
+int zgpu_read(zgpu_frame*, uint8_t* dst, size_t cap, int frame_finished, size_t* n);      /* D2H happened at zgpu_sync; this drains */
+int zgpu_device_output(zgpu_frame*, const void** dptr, size_t* len);   /* the frame's most recent bytes as they sit in HBM (no copy) */
+uint32_t zgpu_frame_checksum(const zgpu_frame*);         /* XXH64 (seed 0) of the bytes read so far, low 32 bits (frame_decoder.rs:263-270) */
+uint64_t zgpu_frame_blocks_decoded(const zgpu_frame*);   /* frame_decoder.rs:297 */
+
 /* ---- StreamingDecoder mirror (ruzstd/src/decoding/streaming_decoder.rs:40-156): io::Read over one frame ---------------- */
 typedef struct zgpu_streaming zgpu_streaming;
 typedef size_t (*zgpu_read_fn)(void* user, uint8_t* dst, size_t n);   /* io::Read::read of the source: 0 = end of input */

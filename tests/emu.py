@@ -17,7 +17,7 @@ def lib():
     if _LIB is None:
         d = os.path.join(HERE, "emu")
         subprocess.check_call(["make", "-C", d, "-s"])
-        L = C.CDLL(os.path.join(d, "libzg_emu.so"))
+        L = C.CDLL(os.environ.get("ZG_EMU_LIB") or os.path.join(d, "libzg_emu.so"))   # (ZG_EMU_LIB: e.g. the address-sanitizer build, `make -C tests/emu asan`)
         L.zgemu_decode.restype = C.c_void_p
         L.zgemu_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64]
         L.zgemu_decode2.restype = C.c_void_p

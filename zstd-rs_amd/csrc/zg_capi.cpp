@@ -624,6 +624,144 @@ uint32_t zgpu_decoder_calculated_checksum(const zgpu_decoder* d) { return (uint3
 
 }  // extern "C"
 
+// ---- the thin boundary: the caller keeps the frame / block header parse (ruzstd: frame.rs:6-85, block_decoder.rs:201-247) and
+// hands over host-parsed block tables; this is the seam BlockDecoder::decode_block_content (block_decoder.rs:39-95) sits at,
+// called from FrameDecoder::decode_blocks (frame_decoder.rs:319-375). Built on the same FrameState as the FrameDecoder mirror.
+struct zgpu_frame {
+  zgpu_decoder dec;              // device window + carried tables + the host buffer read() drains (no frame header of its own)
+  Batch* pending = nullptr;      // the submit in flight
+  uint64_t submitted = 0;        // blocks handed over since zgpu_frame_begin
+  uint64_t pending_first = 0;    // frame-relative index of the pending submit's first block
+  uint64_t content_size = 0;
+  bool saw_last = false;
+  int sticky = 0;                // first error of the frame
+  uint64_t bad_block = ~0ull;
+};
+
+static int frame_finish_pending(zgpu_frame* f) {
+  Batch* b = f->pending;
+  if (!b) return ZGPU_OK;
+  f->pending = nullptr;
+  zgpu_decoder* d = &f->dec;
+  int st = b->sync();
+  if (st) { delete b; return st; }
+  if (b->frame_out.empty()) { delete b; return ZGPU_E_INTERNAL; }
+  const ZgFrameOut fo = b->frame_out[0];
+  if ((st = b->commit(&d->fs))) { delete b; return st; }
+  const size_t old = d->buf.size();
+  d->buf.resize(old + fo.out_size);
+  if (fo.out_size && hipMemcpy(d->buf.data() + old, (const uint8_t*)d->fs.out_ptr() + fo.out_base, fo.out_size, hipMemcpyDeviceToHost) != hipSuccess) {
+    delete b;
+    return ZGPU_E_HIP;
+  }
+  const size_t nb = b->bb.blocks.size();
+  const uint32_t good = fo.status ? fo.good_blocks : (uint32_t)nb - ((nb && b->bb.blocks.back().host_status) ? 1u : 0u);
+  d->block_counter += good;
+  const int result = fo.status ? (int)fo.status : b->parse_status;
+  if (result && !f->sticky) { f->sticky = result; f->bad_block = f->pending_first + good; }
+  if (!result && b->saw_last_block) { d->frame_finished = true; f->saw_last = true; }
+  delete b;
+  return ZGPU_OK;
+}
+
+extern "C" {
+
+int zgpu_frame_begin(zgpu_ctx* c, uint64_t window_size, uint64_t content_size_or_0, uint32_t dict_id_or_0, zgpu_frame** out) {
+  // FrameDecoderState::new / reset (frame_decoder.rs:103-134) with the header fields the caller parsed; DecoderScratch::reset
+  // (scratch.rs:48-68), then init_from_dict (:70-78) when the header names a dictionary (frame_decoder.rs:212-219)
+  if (!c || !out) return ZGPU_E_BAD_ARG;
+  if (window_size > c->eng->max_window) return ZGPU_E_WINDOW_SIZE_TOO_BIG;           // frame_decoder.rs:137-145
+  zgpu_frame* f = new (std::nothrow) zgpu_frame();
+  if (!f) return ZGPU_E_NOMEM;
+  zgpu_decoder* d = &f->dec;
+  d->ctx = c; d->has_state = true; d->window_size = window_size; d->hash.reset(0);
+  d->fs.reset();
+  d->fs.window_size = window_size;
+  f->content_size = content_size_or_0;
+  if (dict_id_or_0) {
+    auto it = c->dicts.find(dict_id_or_0);
+    if (it == c->dicts.end()) { delete f; return ZGPU_E_DICT_NOT_PROVIDED; }
+    const int st = apply_dict(d, it->second);
+    if (st) { d->fs.release(); delete f; return st; }
+  }
+  *out = f;
+  return ZGPU_OK;
+}
+
+void zgpu_frame_end(zgpu_frame* f) {
+  if (!f) return;
+  delete f->pending;
+  f->dec.fs.release();
+  delete f;
+}
+
+int zgpu_blocks_submit(zgpu_frame* f, const uint8_t* src, size_t src_len, const zgpu_block* blocks, size_t nblocks) {
+  // decode_block_content x nblocks (block_decoder.rs:39-95), as one batched submit. src is copied to the device before
+  // this returns; the kernels run on the context's streams (zgpu_sync waits for them).
+  if (!f || (!src && src_len) || (!blocks && nblocks)) return ZGPU_E_BAD_ARG;
+  int st = frame_finish_pending(f);            // blocks of one frame depend on each other: one submit in flight
+  if (st) return st;
+  if (f->sticky || nblocks == 0) return ZGPU_OK;   // the frame failed already: zgpu_sync reports where
+  if (f->saw_last) return ZGPU_E_BAD_ARG;          // blocks behind the frame's last block
+  zgpu_decoder* d = &f->dec;
+  std::vector<Engine::HostBlock> hb(nblocks);
+  for (size_t i = 0; i < nblocks; i++) {
+    hb[i].src_off = blocks[i].src_off; hb[i].src_len = blocks[i].src_len; hb[i].raw_rle_size = blocks[i].raw_rle_size;
+    hb[i].type = blocks[i].type; hb[i].last = blocks[i].last;
+  }
+  Batch* b = nullptr;
+  st = d->ctx->eng->prepare_blocks(src, src_len, hb.data(), nblocks, &d->fs, d->held(), &b);
+  if (st) return st;
+  if (b->bb.blocks.empty()) { delete b; return ZGPU_E_INTERNAL; }
+  if ((st = b->run())) { delete b; return st; }
+  f->pending = b;
+  f->pending_first = f->submitted;
+  f->submitted += b->bb.blocks.size();
+  return ZGPU_OK;
+}
+
+int zgpu_sync(zgpu_frame* f, size_t* first_bad_block, int32_t* its_status) {
+  if (!f) return ZGPU_E_BAD_ARG;
+  const int st = frame_finish_pending(f);
+  if (first_bad_block) *first_bad_block = f->sticky ? (size_t)f->bad_block : (size_t)-1;
+  if (its_status) *its_status = f->sticky;
+  return st;
+}
+
+size_t zgpu_available(const zgpu_frame* f, int frame_finished) {
+  // DecodeBuffer::can_drain_to_window_size / can_drain (decode_buffer.rs:182-219): while the frame is unfinished the last
+  // window_size bytes stay back (a later match may still copy from them)
+  if (!f || f->pending) return 0;
+  const zgpu_decoder* d = &f->dec;
+  if (frame_finished) return d->held();
+  return d->held() > d->window_size ? d->held() - (size_t)d->window_size : 0;
+}
+
+int zgpu_read(zgpu_frame* f, uint8_t* dst, size_t cap, int frame_finished, size_t* n) {
+  if (!f || !n || (!dst && cap)) return ZGPU_E_BAD_ARG;
+  const int st = frame_finish_pending(f);
+  if (st) return st;
+  size_t k = zgpu_available(f, frame_finished);
+  if (k > cap) k = cap;
+  *n = dec_drain(&f->dec, k, dst);
+  return ZGPU_OK;
+}
+
+int zgpu_device_output(zgpu_frame* f, const void** dptr, size_t* len) {
+  if (!f || !dptr || !len) return ZGPU_E_BAD_ARG;
+  const int st = frame_finish_pending(f);
+  if (st) return st;
+  const FrameState& fs = f->dec.fs;
+  *dptr = fs.d_out.p ? (const void*)(fs.out_ptr() + fs.base) : nullptr;   // the most recent fs.have bytes of the frame, in HBM
+  *len = (size_t)fs.have;
+  return ZGPU_OK;
+}
+
+uint32_t zgpu_frame_checksum(const zgpu_frame* f) { return f ? (uint32_t)f->dec.hash.digest() : 0u; }   // XXH64 (seed 0) of the bytes read so far, low 32 bits
+uint64_t zgpu_frame_blocks_decoded(const zgpu_frame* f) { return f ? f->dec.block_counter : 0; }
+
+}  // extern "C"
+
 // ---- collect_to_writer (frame_decoder.rs:395-407) and StreamingDecoder (streaming_decoder.rs:40-156) -------------------------
 struct zgpu_streaming {
   zgpu_decoder* dec = nullptr;

@@ -43,6 +43,7 @@ int Scratch::init_events() {
   for (auto& e : ev_huf)
     if (hipEventCreate(&e) != hipSuccess) return ZG_HIP_ERROR;
   if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return ZG_HIP_ERROR;
+  if (hipEventCreateWithFlags(&ev_lit, hipEventDisableTiming) != hipSuccess) return ZG_HIP_ERROR;
   for (auto& e : ev_sw)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return ZG_HIP_ERROR;
   have_events = true;
@@ -58,6 +59,7 @@ void Scratch::release() {
   for (auto& e : ev_huf)
     if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
+  if (ev_lit) { (void)hipEventDestroy(ev_lit); ev_lit = nullptr; }
   for (auto& e : ev_sw)
     if (e) { (void)hipEventDestroy(e); e = nullptr; }
   have_events = false;
@@ -298,6 +300,40 @@ int Engine::prepare_run(const uint8_t* src, size_t len, FrameState* fs, bool has
   return upload(b, src, *consumed, out);
 }
 
+int Engine::prepare_blocks(const uint8_t* src, size_t len, const HostBlock* hb, size_t n, FrameState* fs, uint64_t keep, Batch** out) {
+  // the block loop of FrameDecoder::decode_blocks (frame_decoder.rs:319-375) with the headers already read by the caller
+  Batch* b = new Batch();
+  b->eng = this;
+  b->fs = fs;
+  b->keep_bytes = keep;
+  b->src_len = len;
+  FrameInfo fi;
+  fi.window_size = fs->window_size;
+  b->bb.begin_frame(fs->window_size, fs->hist, fs->carry_mask);
+  int st = ZG_OK;
+  for (size_t i = 0; i < n && !st; i++) {
+    const HostBlock& h = hb[i];
+    BlockHeader bh;
+    bh.last = h.last != 0; bh.type = h.type;
+    if (h.type > ZG_BT_COMPRESSED) { st = ZG_RESERVED_BLOCK; b->bb.fail_frame(st); break; }                 // block_decoder.rs:226-228
+    if ((h.type == ZG_BT_COMPRESSED ? h.src_len : h.raw_rle_size) > kMaxBlockSize) { st = ZG_BLOCK_SIZE_TOO_LARGE; b->bb.fail_frame(st); break; }   // :259-266
+    if (h.src_off > len || h.src_len > len - h.src_off) { st = ZG_FAILED_READ_BLOCK_BODY; b->bb.fail_frame(st); break; }
+    bh.decompressed_size = h.type == ZG_BT_COMPRESSED ? 0 : h.raw_rle_size;
+    bh.content_size = h.type == ZG_BT_RLE ? 1 : h.src_len;
+    if (h.type == ZG_BT_RAW && h.src_len != h.raw_rle_size) { st = ZG_FAILED_READ_BLOCK_BODY; b->bb.fail_frame(st); break; }
+    if (h.type == ZG_BT_RLE && h.src_len < 1) { st = ZG_FAILED_READ_BLOCK_BODY; b->bb.fail_frame(st); break; }
+    st = b->bb.add_block(bh, src + h.src_off, h.src_off);
+    fi.nblocks++;
+    if (bh.last) { b->saw_last_block = true; break; }
+  }
+  fi.host_status = st;
+  b->info.push_back(fi);
+  b->parse_status = st;
+  b->bb.frames[0].fixed_base = 1;
+  if ((st = fs->d_fse.reserve(ZG_FSE_SLOT_U32 * 4)) || (st = fs->d_huf.reserve(ZG_HUF_SLOT_U16 * 2))) { delete b; return st; }
+  return upload(b, src, len, out);
+}
+
 int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   Engine* eng = this;
   ZG_HIP(hipSetDevice(device_));
@@ -459,9 +495,15 @@ int Batch::run() {
   d.og = sc->d_og.as<uint32_t>() + 16;   // (zg_k_flat4: a gather window may start up to four words in front of a unit's scratch)
   d.og_words = og_words;
   // ---- phase 2: LZ77 execution
-  zg_launch_lit(d, s);
+  zg_launch_lit(d, s, 0);
   ZG_HIP(hipEventRecord(ev[6], s));
+  // the literal runs of blocks with sequences depend on nothing but the entropy stages: they are placed beside the flatten
+  // (which is bound by the instructions it issues; this is a stream of short loads and stores) and joined in front of the sweep
+  ZG_HIP(hipStreamWaitEvent(s2, ev[6], 0));
+  zg_launch_lit(d, s2, 1);
+  ZG_HIP(hipEventRecord(sc->ev_lit, s2));
   zg_launch_flat(d, s);
+  ZG_HIP(hipStreamWaitEvent(s, sc->ev_lit, 0));
   { bool any = false; for (const ZgFrame& fr : bb.frames) any = any || fr.sparse; if (any) zg_launch_sparse(d, s); }
   ZG_HIP(hipEventRecord(ev[7], s));
   sweep_mode = 0; synced = false;

@@ -67,7 +67,7 @@ struct Scratch {
   DevBuf d_src, d_blocks, d_frames, d_aux, d_slot_log, d_fse, d_huf, d_hufmax, d_status, d_lit, d_seq, d_seqout, d_pos, d_frameout,
       d_dst, d_seqblocks, d_hufitems, d_hufgroups, d_totals, d_og, d_units, d_unitinfo, d_stepunits, d_swdesc, d_dbg, d_raw;
   hipEvent_t ev[ZG_T_COUNT + 1] = {};
-  hipEvent_t ev_huf[2] = {}, ev_fork = nullptr;   // zg_k_huf runs on the engine's second stream beside zg_k_seq
+  hipEvent_t ev_huf[2] = {}, ev_fork = nullptr, ev_lit = nullptr;   // zg_k_huf runs on the engine's second stream beside zg_k_seq
   hipEvent_t ev_sw[80] = {};                      // split sweep: heads on the second stream (zg_launch_sweep)
   bool have_events = false;
   int init_events();
@@ -137,6 +137,10 @@ class Engine {
   // max_blocks: 0 = up to the last block of the frame. fs carries the frame's state across calls; keep = frame bytes
   // that must stay reachable (FrameState::make_room).
   int prepare_run(const uint8_t* src, size_t len, FrameState* fs, bool has_checksum, uint32_t max_blocks, uint64_t keep, Batch** out, size_t* consumed);
+  // Same for blocks whose 3-byte headers the CALLER parsed (the thin boundary: ruzstd keeps read_block_header,
+  // block_decoder.rs:201-247): hb[i] describes Block_Content i inside src. The run ends with the first block marked last.
+  struct HostBlock { uint64_t src_off; uint32_t src_len; uint32_t raw_rle_size; uint8_t type; uint8_t last; };
+  int prepare_blocks(const uint8_t* src, size_t len, const HostBlock* hb, size_t n, FrameState* fs, uint64_t keep, Batch** out);
   hipStream_t stream() const { return stream_; }
   hipStream_t copy_stream() const { return stream2_; }
   int device() const { return device_; }

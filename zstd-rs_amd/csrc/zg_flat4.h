@@ -63,7 +63,10 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
   // groups are aligned in the scratch (pointer mode) / in the output (direct mode; there the two agree: frames that are
   // packed back to back have og_base == out_base, and only those have direct units)
   const uint32_t ualign = (uint32_t)((DIRECT ? fo.out_base : fo.og_base) + unit_abs0) & 3u;
-  const uint32_t ucap = un.nblocks * ZG_FLAT_MAX;
+  // what the unit can hold at most — and never more than what is left of the frame: tile bytes behind a block's end are
+  // classified (and their windows requested) like live ones, and the output / scratch allocations end with the last frame
+  const uint64_t fleft = fo.out_size - unit_abs0;
+  const uint32_t ucap = (uint64_t)un.nblocks * ZG_FLAT_MAX < fleft ? un.nblocks * ZG_FLAT_MAX : (uint32_t)fleft;
   // scratch word of unit byte u: offset 4 (u + 4) (four words of slack in front: a tile's dead bytes, a gather window that starts before the unit)
   const ZxBuf og_rs = zx_buf(DIRECT ? nullptr : og - 4, DIRECT ? 0u : 4u * (ucap + 4u));
   // output byte u: offset u + ualign + 4 (the base is dword-aligned; the engine keeps 256 bytes in front of every output)

@@ -1276,7 +1276,7 @@ __device__ __forceinline__ void zg_wg_fill(uint8_t* dst, uint8_t byte, uint64_t 
   for (uint64_t i = (n8 << 3) + t; i < n; i += T) dst[i] = byte;
 }
 
-__global__ void __launch_bounds__(256) zg_k_lit(ZgBatchDev d) {
+__global__ void __launch_bounds__(256) zg_k_lit(ZgBatchDev d, uint32_t part) {   // part 0: whole blocks; part 1: the literal runs of blocks with sequences
   __shared__ uint32_t s_long[256 * 3];          // literal runs too long for one lane: {source index, destination, length}
   __shared__ uint32_t s_nlong;
   if (d.totals[2]) return;
@@ -1286,15 +1286,17 @@ __global__ void __launch_bounds__(256) zg_k_lit(ZgBatchDev d) {
   const ZgBlock blk = d.blocks[b];
   uint8_t* out = d.dst + d.frame_out[blk.frame].out_base + p.out_base;
   const uint8_t* body = d.src + blk.src_off;
-  if (blk.btype == ZG_BT_RAW) { zg_wg_copy(out, body, blk.regen_size, t, 256); return; }
-  if (blk.btype == ZG_BT_RLE) { zg_wg_fill(out, body[0], blk.regen_size, t, 256); return; }
+  if (blk.btype == ZG_BT_RAW) { if (part == 0) zg_wg_copy(out, body, blk.regen_size, t, 256); return; }
+  if (blk.btype == ZG_BT_RLE) { if (part == 0) zg_wg_fill(out, body[0], blk.regen_size, t, 256); return; }
   const bool lit_rle = blk.lit_type == ZG_LT_RLE;
   const uint8_t* lit = blk.lit_type <= ZG_LT_RLE ? body + blk.lit_off : d.lit_arena + blk.lit_base;
   if (!blk.nseq) {
+    if (part != 0) return;
     if (lit_rle) zg_wg_fill(out, lit[0], blk.regen_size, t, 256);
     else zg_wg_copy(out, lit, blk.regen_size, t, 256);
     return;
   }
+  if (part != 1) return;
   // A block with sequences: its literal runs (DecodeBuffer::push, decode_buffer.rs:74-77; the trailing literals,
   // sequence_execution.rs:40-44) are independent of everything else and go to their places here, one lane per sequence,
   // unless the block's unit is resolved to bytes by zg_k_flat4 itself (direct unit) or the frame left the flatten path
@@ -2006,8 +2008,8 @@ void zg_launch_scan(const ZgBatchDev& d, hipStream_t s) {
   hipLaunchKernelGGL(zg_k_scan, dim3(d.nframes), dim3(ZG_SCAN_T), 0, s, d);
   hipLaunchKernelGGL(zg_k_scanf, dim3(1), dim3(1024), 0, s, d);
 }
-void zg_launch_lit(const ZgBatchDev& d, hipStream_t s) {
-  if (d.nblocks) hipLaunchKernelGGL(zg_k_lit, dim3(d.nblocks), dim3(256), 0, s, d);
+void zg_launch_lit(const ZgBatchDev& d, hipStream_t s, uint32_t part) {
+  if (d.nblocks) hipLaunchKernelGGL(zg_k_lit, dim3(d.nblocks), dim3(256), 0, s, d, part);
 }
 // ------------------------------------------------------------------------------------------------------------
 // zg_k_sparse: the matches of a frame that has hardly any (literal-heavy data: a sequence or two in one block out of twenty).

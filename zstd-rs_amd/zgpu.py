@@ -39,6 +39,12 @@ class Seq(C.Structure):
     _fields_ = [("of", C.c_uint32), ("ml", C.c_uint32), ("mdst", C.c_uint32), ("lit_start", C.c_uint32)]
 
 
+class Block(C.Structure):
+    """zgpu_block: one host-parsed Block_Header (include/zgpu.h, the thin boundary)"""
+    _fields_ = [("src_off", C.c_uint64), ("src_len", C.c_uint32), ("raw_rle_size", C.c_uint32), ("type", C.c_uint8), ("last", C.c_uint8),
+                ("pad", C.c_uint8 * 6)]
+
+
 EXPORTS = [
     "zgpu_ctx_create", "zgpu_ctx_destroy", "zgpu_set_max_window_size", "zgpu_max_window_size", "zgpu_last_error", "zgpu_status_name",
     "zgpu_decode_all", "zgpu_batch_prepare", "zgpu_batch_run", "zgpu_batch_sync", "zgpu_batch_num_frames", "zgpu_batch_num_blocks",
@@ -51,6 +57,8 @@ EXPORTS = [
     "zgpu_decoder_calculated_checksum", "zgpu_decode_all_alloc", "zgpu_free", "zgpu_decoder_collect_to_writer", "zgpu_streaming_create",
     "zgpu_streaming_destroy", "zgpu_streaming_decoder", "zgpu_streaming_read", "zgpu_pool_create", "zgpu_pool_create_on", "zgpu_pool_destroy",
     "zgpu_pool_num_gpus", "zgpu_pool_decode_all", "zgpu_pool_plan", "zgpu_pool_stage", "zgpu_pool_run", "zgpu_pool_frame", "zgpu_pool_read",
+    "zgpu_frame_begin", "zgpu_frame_end", "zgpu_blocks_submit", "zgpu_sync", "zgpu_available", "zgpu_read", "zgpu_device_output",
+    "zgpu_frame_checksum", "zgpu_frame_blocks_decoded",
 ]
 WRITE_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
 READ_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
@@ -104,6 +112,18 @@ def load_library():
     L.zgpu_batch_unit.argtypes = [vp, C.c_uint32, P(C.c_uint32), P(C.c_uint32), P(C.c_uint64)]
     L.zgpu_batch_debug_scratch.argtypes = [vp, C.c_int, C.c_uint64, vp, C.c_uint64]
     L.zgpu_debug_calibrate.argtypes = [vp, C.c_uint64]
+    L.zgpu_frame_begin.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, P(vp)]
+    L.zgpu_frame_end.argtypes = [vp]
+    L.zgpu_blocks_submit.argtypes = [vp, u8p, sz, P(Block), sz]
+    L.zgpu_sync.argtypes = [vp, P(sz), P(C.c_int32)]
+    L.zgpu_available.argtypes = [vp, C.c_int]
+    L.zgpu_available.restype = sz
+    L.zgpu_read.argtypes = [vp, vp, sz, C.c_int, P(sz)]
+    L.zgpu_device_output.argtypes = [vp, P(vp), P(sz)]
+    L.zgpu_frame_checksum.argtypes = [vp]
+    L.zgpu_frame_checksum.restype = C.c_uint32
+    L.zgpu_frame_blocks_decoded.argtypes = [vp]
+    L.zgpu_frame_blocks_decoded.restype = C.c_uint64
     L.zgpu_decoder_create.argtypes = [vp, P(vp)]
     L.zgpu_add_dict.argtypes = [vp, u8p, sz, P(C.c_uint32)]
     L.zgpu_decoder_force_dict.argtypes = [vp, C.c_uint32]
@@ -624,3 +644,66 @@ class StreamingDecoder:
 
     def into_frame_decoder(self):
         return self.decoder
+
+
+class BlockFrame:
+    """The thin boundary (include/zgpu.h: zgpu_frame_begin / zgpu_blocks_submit / zgpu_sync / zgpu_read): the caller parses the
+    frame header and the 3-byte block headers itself (as ruzstd's FrameDecoder does before it calls decode_block_content,
+    frame_decoder.rs:319-375) and submits block tables."""
+
+    def __init__(self, ctx, window_size, content_size=0, dict_id=0):
+        self.L = ctx.L
+        self.h = C.c_void_p()
+        st = self.L.zgpu_frame_begin(ctx.h, window_size, content_size, dict_id, C.byref(self.h))
+        if st:
+            self.h = None
+            raise ZgpuError(st)
+
+    def close(self):
+        if self.h:
+            self.L.zgpu_frame_end(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def submit(self, src, blocks):
+        """blocks: [(src_off, src_len, type, last, raw_rle_size)] offsets into src"""
+        arr = (Block * max(len(blocks), 1))()
+        for i, (off, ln, ty, last, sz) in enumerate(blocks):
+            arr[i].src_off, arr[i].src_len, arr[i].type, arr[i].last, arr[i].raw_rle_size = off, ln, ty, last, sz
+        st = self.L.zgpu_blocks_submit(self.h, src, len(src), arr, len(blocks))
+        if st:
+            raise ZgpuError(st)
+
+    def sync(self):
+        """returns (first_bad_block or None, its status)"""
+        bad, st = C.c_size_t(), C.c_int32()
+        r = self.L.zgpu_sync(self.h, C.byref(bad), C.byref(st))
+        if r:
+            raise ZgpuError(r)
+        return (None if bad.value == C.c_size_t(-1).value else bad.value), st.value
+
+    def available(self, finished):
+        return self.L.zgpu_available(self.h, 1 if finished else 0)
+
+    def read(self, cap, finished):
+        buf = C.create_string_buffer(max(cap, 1))
+        n = C.c_size_t()
+        st = self.L.zgpu_read(self.h, buf, cap, 1 if finished else 0, C.byref(n))
+        if st:
+            raise ZgpuError(st)
+        return buf.raw[:n.value]
+
+    def device_output(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        st = self.L.zgpu_device_output(self.h, C.byref(p), C.byref(n))
+        if st:
+            raise ZgpuError(st)
+        return p.value, n.value
+
+    def checksum(self):
+        return self.L.zgpu_frame_checksum(self.h)
+
+    def blocks_decoded(self):
+        return self.L.zgpu_frame_blocks_decoded(self.h)
