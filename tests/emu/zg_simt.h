@@ -82,7 +82,7 @@ inline void run(uint32_t T, const std::function<void()>& body) {
 
 // ---- the zx_* primitives on the emulator -----------------------------------------------------------------------------
 #define ZX_DEV static inline
-#define ZX_OOB 0xFFFFFFFFu
+#define ZX_OOB 0x80000000u   // as on the GPU (zg_kernels.hip): far outside every resource, and adding a few bytes to it does not wrap into one
 #define ZX_FRESH(v) (v)
 struct ZxBuf { uint8_t* base; uint32_t bytes; };
 static inline uint32_t zx_tid() { return simt::M()->cur; }
@@ -114,7 +114,8 @@ static inline void zx_min_glb(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
 template <typename P> static inline ZxBuf zx_buf(P* base, uint32_t bytes) { ZxBuf b; b.base = (uint8_t*)base; b.bytes = bytes; return b; }
 static inline ZxBuf zx_buf(decltype(nullptr), uint32_t) { ZxBuf b; b.base = nullptr; b.bytes = 0; return b; }
 // raw buffer semantics: every dword (byte) of an access is range-checked by itself; out of range reads 0, writes nothing
-static inline uint32_t zx__dw(const ZxBuf& b, uint64_t off) { uint32_t v = 0; if (off + 4 <= b.bytes) memcpy(&v, b.base + off, 4); return v; }
+// (offsets are 32-bit on the hardware: an offset near 2^32 wraps around for the later dwords of a wide access)
+static inline uint32_t zx__dw(const ZxBuf& b, uint64_t off64) { const uint32_t off = (uint32_t)off64; uint32_t v = 0; if ((uint64_t)off + 4 <= b.bytes) memcpy(&v, b.base + off, 4); return v; }
 static inline uint32_t zx_ld8(const ZxBuf& b, uint32_t off) { return off < b.bytes ? b.base[off] : 0u; }
 static inline uint32_t zx_ld32(const ZxBuf& b, uint32_t off) { return zx__dw(b, off); }
 #define ZX_ALIGNED(off, a) do { if ((off) != ZX_OOB && (off) < b.bytes && (((uintptr_t)b.base + (off)) % (a))) { fprintf(stderr, "simt: misaligned buffer access %u %% %d at %s:%d\n", (unsigned)(off), (int)(a), __FILE__, __LINE__); abort(); } } while (0)

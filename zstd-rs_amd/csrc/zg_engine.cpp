@@ -500,7 +500,7 @@ int Batch::run() {
   // the literal runs of blocks with sequences depend on nothing but the entropy stages: they are placed beside the flatten
   // (which is bound by the instructions it issues; this is a stream of short loads and stores) and joined in front of the sweep
   ZG_HIP(hipStreamWaitEvent(s2, ev[6], 0));
-  zg_launch_lit(d, s2, 1);
+  if (!getenv("ZGPU_DEBUG_NO_LITRUN")) zg_launch_lit(d, s2, 1);   // (bisecting aid: the sweep then works on missing literal bytes)
   ZG_HIP(hipEventRecord(sc->ev_lit, s2));
   zg_launch_flat(d, s);
   ZG_HIP(hipStreamWaitEvent(s, sc->ev_lit, 0));

@@ -1665,7 +1665,9 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
 // the zx_* primitives below so that tests/emu runs the same source on the CPU. One workgroup per unit.
 // ------------------------------------------------------------------------------------------------------------
 #define ZX_DEV __device__ __forceinline__
-#define ZX_OOB ZG_OOB
+// "not needed": an offset no resource of the flatten covers (they are all far below 2^31 bytes). Not 0xFFFFFFFF: the compiler narrows
+// a wide load whose first dwords are unused by ADDING to the offset, and 0xFFFFFFFF + 4 is 3 — inside every resource.
+#define ZX_OOB 0x80000000u
 #define ZX_FRESH(v) ZG_FRESH(v)
 typedef __amdgpu_buffer_rsrc_t ZxBuf;
 ZX_DEV uint32_t zx_tid() { return threadIdx.x; }
