@@ -107,6 +107,16 @@ static inline uint32_t zx_shfl_up(uint32_t v, int o) {
   simt::yield(simt::WAVE_WAIT);
   return r;
 }
+static inline uint32_t zx_shfl(uint32_t v, int src) {
+  simt::Machine* m = simt::M();
+  const uint32_t me = m->cur, w0 = me & ~63u;
+  m->slot[me] = v;
+  simt::yield(simt::WAVE_WAIT);
+  const uint32_t r = (uint32_t)m->slot[w0 + (uint32_t)src];
+  simt::yield(simt::WAVE_WAIT);
+  return r;
+}
+static inline uint32_t zx_add_lds(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
 static inline void zx_or_lds(uint32_t* p, uint32_t v) { *p |= v; }
 static inline void zx_min_lds(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
 static inline void zx_min_lds64(unsigned long long* p, unsigned long long v) { if (v < *p) *p = v; }

@@ -37,7 +37,7 @@ struct ZgFlat4Lds {
   static constexpr int NW = TS / 32, SOFF = SPT * T;
   ZxU4 rec[SOFF];                                        // per sequence of the tile: {offset, first match byte (tile-relative), 2^31 + literal index of tile byte 0, -}
   __attribute__((aligned(16))) uint32_t word[DIRECT ? 4 : TS];   // pointer mode: a root's effective offset; bit 31: the root is a literal
-  __attribute__((aligned(16))) uint16_t par[TS];         // 0xFFFF literal, 0x8000 match byte with its parent before the tile, else tile-relative parent
+  __attribute__((aligned(16))) uint16_t par[TS + 8];     // 0xFFFF literal, 0x8000 match byte with its parent before the tile, else tile-relative parent; [TS]: a dummy byte that is always a root
   __attribute__((aligned(16))) uint8_t val[DIRECT ? TS : 16];    // direct mode: a root's byte value
   uint32_t bits[NW];                                     // marks: the first tile byte of every sequence
   uint16_t cnt[NW];                                      // marks before each word of bits
@@ -71,7 +71,7 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
   const ZxBuf og_rs = zx_buf(DIRECT ? nullptr : og - 4, DIRECT ? 0u : 4u * (ucap + 4u));
   // output byte u: offset u + ualign + 4 (the base is dword-aligned; the engine keeps 256 bytes in front of every output)
   const ZxBuf out_rs = zx_buf(out_u - ualign - 4, ucap + ualign + 4u);
-  if (t == 0) { L.err = 0; L.bad = ~0ull; }
+  if (t == 0) { L.err = 0; L.bad = ~0ull; L.par[TS] = (uint16_t)ZG_PAR_LIT; }
   uint32_t unit_size = 0;
   zx_barrier_vm();
   for (uint32_t bi = 0; bi < un.nblocks; bi++) {
@@ -275,27 +275,32 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
       }
       zx_barrier();
       // ---- S2: asynchronous pointer jumping. A byte's pointer only ever moves to another of its ancestors, so stale reads
-      // are harmless and no barrier is needed between rounds; a byte is done when its pointer's pointer is a root marker.
-      // Each thread visits just its still-unresolved bytes (few: most parents are before the tile), four per step.
+      // are harmless and no barrier is needed between visits; a byte is done when its pointer's pointer is a root marker.
+      // Chains are deep on text (a word copied from a copy of a copy ...: half of these bytes are more than one hop from their
+      // root, the deepest of a tile ~20), and a wave lasts as long as its busiest lane, so a visit follows TWO hops (measured on
+      // the CPU model: 112 -> 70 wave iterations per tile) and everything is branch-free: each thread visits up to four of its
+      // still-unresolved bytes per iteration, an empty slot visits a dummy byte (index TS, always a root) and writes to it.
       {
         const uint32_t t2 = ZX_FRESH(t);
-        for (uint32_t guard = 0; unresolved && guard < (1u << 16); guard++) {
-          uint32_t m = unresolved, kk[4], ad[4], pp[4];
+        for (uint32_t guard = 0; zx_ballot(unresolved != 0u) && guard < (1u << 16); guard++) {
+          uint32_t m = unresolved, kk[4], ad[4], p1[4], p2[4], p3[4];
 #pragma unroll
-          for (int j = 0; j < 4; j++) { kk[j] = m ? (uint32_t)__builtin_ctz(m) : 32u; m &= m - 1; ad[j] = 4u * (t2 + (kk[j] & 7u) * T) + (kk[j] >> 3); }   // bit 8 i + k: byte i of group k
+          for (int j = 0; j < 4; j++) { kk[j] = m ? (uint32_t)__builtin_ctz(m) : 32u; m &= m - 1; ad[j] = kk[j] < 32u ? 4u * (t2 + (kk[j] & 7u) * T) + (kk[j] >> 3) : (uint32_t)TS; }   // bit 8 i + k: byte i of group k
 #pragma unroll
-          for (int j = 0; j < 4; j++) pp[j] = kk[j] < 32u ? L.par[ad[j]] : 0u;
+          for (int j = 0; j < 4; j++) p1[j] = L.par[ad[j]];
 #pragma unroll
-          for (int j = 0; j < 4; j++) pp[j] = L.par[pp[j]];
+          for (int j = 0; j < 4; j++) p2[j] = L.par[p1[j] < ZG_PAR_EXIT ? p1[j] : (uint32_t)TS];
+#pragma unroll
+          for (int j = 0; j < 4; j++) p3[j] = L.par[p2[j] < ZG_PAR_EXIT ? p2[j] : (uint32_t)TS];
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            if (kk[j] < 32u) {
-              if (pp[j] >= ZG_PAR_EXIT) unresolved &= ~(1u << kk[j]);     // its pointer is the root
-              else L.par[ad[j]] = (uint16_t)pp[j];                        // u16 stores are atomic
-            }
+            const bool r2 = p2[j] >= ZG_PAR_EXIT, r3 = p3[j] >= ZG_PAR_EXIT;   // p1 is the root / p2 is the root
+            const uint32_t np = r3 ? p2[j] : p3[j];
+            L.par[r2 ? (uint32_t)TS : ad[j]] = (uint16_t)(r2 ? (uint32_t)ZG_PAR_LIT : np);   // (u16 stores are atomic; the dummy only ever receives a root marker)
+            unresolved &= ((r2 || r3) && kk[j] < 32u) ? ~(1u << (kk[j] & 31u)) : 0xFFFFFFFFu;
           }
+          if (guard == (1u << 16) - 1u) L.err = ZG_INTERNAL;   // cannot happen: every visit moves a pointer up its chain (seen by everybody behind the next barrier)
         }
-        if (unresolved) L.err = ZG_INTERNAL;   // cannot happen: every step moves a pointer up its chain (seen by everybody behind the next barrier)
       }
       // ---- S3a: the windows requested in S1c have arrived: every root's word (value) is completed and published
       {

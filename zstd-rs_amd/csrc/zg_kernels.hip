@@ -1677,6 +1677,8 @@ ZX_DEV void zx_barrier() { zg_lds_barrier(); }
 ZX_DEV void zx_barrier_vm() { __builtin_amdgcn_s_waitcnt(0x0F70); zg_lds_barrier(); }
 ZX_DEV unsigned long long zx_ballot(bool p) { return __ballot(p); }
 ZX_DEV uint32_t zx_shfl_up(uint32_t v, int o) { return __shfl_up(v, o, 64); }
+ZX_DEV uint32_t zx_shfl(uint32_t v, int src) { return __shfl(v, src, 64); }
+ZX_DEV uint32_t zx_add_lds(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 ZX_DEV void zx_or_lds(uint32_t* p, uint32_t v) { atomicOr(p, v); }
 ZX_DEV void zx_min_lds(uint32_t* p, uint32_t v) { atomicMin(p, v); }
 ZX_DEV void zx_min_lds64(unsigned long long* p, unsigned long long v) { atomicMin(p, v); }
