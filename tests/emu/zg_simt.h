@@ -107,16 +107,6 @@ static inline uint32_t zx_shfl_up(uint32_t v, int o) {
   simt::yield(simt::WAVE_WAIT);
   return r;
 }
-static inline uint32_t zx_shfl(uint32_t v, int src) {
-  simt::Machine* m = simt::M();
-  const uint32_t me = m->cur, w0 = me & ~63u;
-  m->slot[me] = v;
-  simt::yield(simt::WAVE_WAIT);
-  const uint32_t r = (uint32_t)m->slot[w0 + (uint32_t)src];
-  simt::yield(simt::WAVE_WAIT);
-  return r;
-}
-static inline uint32_t zx_add_lds(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
 static inline void zx_or_lds(uint32_t* p, uint32_t v) { *p |= v; }
 static inline void zx_min_lds(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
 static inline void zx_min_lds64(unsigned long long* p, unsigned long long v) { if (v < *p) *p = v; }
@@ -126,19 +116,12 @@ static inline ZxBuf zx_buf(decltype(nullptr), uint32_t) { ZxBuf b; b.base = null
 // raw buffer semantics: every dword (byte) of an access is range-checked by itself; out of range reads 0, writes nothing
 // (offsets are 32-bit on the hardware: an offset near 2^32 wraps around for the later dwords of a wide access)
 static inline uint32_t zx__dw(const ZxBuf& b, uint64_t off64) { const uint32_t off = (uint32_t)off64; uint32_t v = 0; if ((uint64_t)off + 4 <= b.bytes) memcpy(&v, b.base + off, 4); return v; }
-static inline uint32_t zx_ld8(const ZxBuf& b, uint32_t off) { return off < b.bytes ? b.base[off] : 0u; }
 static inline uint32_t zx_ld32(const ZxBuf& b, uint32_t off) { return zx__dw(b, off); }
 #define ZX_ALIGNED(off, a) do { if ((off) != ZX_OOB && (off) < b.bytes && (((uintptr_t)b.base + (off)) % (a))) { fprintf(stderr, "simt: misaligned buffer access %u %% %d at %s:%d\n", (unsigned)(off), (int)(a), __FILE__, __LINE__); abort(); } } while (0)
 static inline ZxU2 zx_ld64(const ZxBuf& b, uint32_t off) { ZX_ALIGNED(off, 4); ZxU2 r; r.x = zx__dw(b, off); r.y = zx__dw(b, (uint64_t)off + 4); return r; }
 static inline ZxU3 zx_ld96(const ZxBuf& b, uint32_t off) { ZX_ALIGNED(off, 4); ZxU3 r; r.x = zx__dw(b, off); r.y = zx__dw(b, (uint64_t)off + 4); r.z = zx__dw(b, (uint64_t)off + 8); return r; }
-static inline ZxU4 zx_ld128(const ZxBuf& b, uint32_t off) { ZX_ALIGNED(off, 4); ZxU4 r; r.x = zx__dw(b, off); r.y = zx__dw(b, (uint64_t)off + 4); r.z = zx__dw(b, (uint64_t)off + 8); r.w = zx__dw(b, (uint64_t)off + 12); return r; }
 static inline void zx_st8(const ZxBuf& b, uint32_t off, uint32_t v) { if (off < b.bytes) b.base[off] = (uint8_t)v; }
 static inline void zx_st32(const ZxBuf& b, uint32_t off, uint32_t v) { ZX_ALIGNED(off, 4); if ((uint64_t)off + 4 <= b.bytes) memcpy(b.base + off, &v, 4); }
-static inline void zx_st128(const ZxBuf& b, uint32_t off, const ZxU4& v) {
-  ZX_ALIGNED(off, 16);
-  if ((uint64_t)off + 16 <= b.bytes) memcpy(b.base + off, &v, 16);
-  else { zx_st32(b, off, v.x); if (off != ZX_OOB) { zx_st32(b, off + 4, v.y); zx_st32(b, off + 8, v.z); zx_st32(b, off + 12, v.w); } }
-}
 static inline uint32_t zx_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sh & 31u)); }
 // packed 16-bit lanes: a - b per lane; 0xFFFF per lane whose signed value is negative
 static inline uint32_t zx_pksub16(uint32_t a, uint32_t b) { return ((a - b) & 0xFFFFu) | (((a >> 16) - (b >> 16)) << 16); }

@@ -479,10 +479,11 @@ def test_corpus_other_shapes(env):
 
 
 def test_flat_scratch_matches_model(monkeypatch):
-    """zg_k_flat4 alone (the sweep is not launched): the flatten scratch of every pointer-mode unit — one effective offset per
+    """zg_k_flatten alone (the sweep is not launched): the flatten scratch of every pointer-mode unit — one effective offset per
     output byte, 0 for literal bytes — must equal the numpy model built from the oracle's sequences (tests/lz_model.py), for
-    both tile shapes, tiny units included; the bytes of direct units (a frame's first unit, resolved by the flatten itself)
-    must be the oracle's plaintext right after the flatten. With ZGPU_DIRECT=0 the first units go through the scratch too."""
+    both tile shapes, tiny units included; the bytes of direct units (a frame's first unit, resolved to bytes by the flatten
+    itself, zg_flat4.h) must be the oracle's plaintext right after the flatten. With ZGPU_DIRECT=0 the first units go through
+    the scratch too."""
     import numpy as np
     import zgdata
     import zgpu
@@ -521,7 +522,7 @@ def test_flat_scratch_matches_model(monkeypatch):
                 got = b.scratch_words(base, size)
                 bad = np.flatnonzero(got != want)
                 assert len(bad) == 0, (shape, ci, ui, int(bad[0]), got[bad[0]:bad[0] + 4], want[bad[0]:bad[0] + 4])
-                # the literal bytes of a pointer-mode unit are in place already (zg_k_lit)
+                # the literal bytes of a pointer-mode unit are in place already
                 lit = np.flatnonzero(want == 0)
                 have = np.frombuffer(b.read(bounds[ui], size), dtype=np.uint8)
                 ref = np.frombuffer(plains[ci][bounds[ui]:bounds[ui + 1]], dtype=np.uint8)

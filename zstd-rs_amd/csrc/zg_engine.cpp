@@ -43,7 +43,6 @@ int Scratch::init_events() {
   for (auto& e : ev_huf)
     if (hipEventCreate(&e) != hipSuccess) return ZG_HIP_ERROR;
   if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return ZG_HIP_ERROR;
-  if (hipEventCreateWithFlags(&ev_lit, hipEventDisableTiming) != hipSuccess) return ZG_HIP_ERROR;
   for (auto& e : ev_sw)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return ZG_HIP_ERROR;
   have_events = true;
@@ -59,7 +58,6 @@ void Scratch::release() {
   for (auto& e : ev_huf)
     if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
-  if (ev_lit) { (void)hipEventDestroy(ev_lit); ev_lit = nullptr; }
   for (auto& e : ev_sw)
     if (e) { (void)hipEventDestroy(e); e = nullptr; }
   have_events = false;
@@ -341,7 +339,6 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   // FrameDecoder mirror may want them); decode_all reports parse_status.
   { const char* e = getenv("ZGPU_UNIT_BLOCKS"); if (e && atoi(e) > 0) b->bb.unit_blocks = (uint32_t)atoi(e); }
   { const char* e = getenv("ZGPU_DIRECT"); if (e && e[0] == '0') b->bb.direct_units = false; }   // (tests) every unit through scratch + sweep
-  { const char* e = getenv("ZGPU_FLAT"); if (e && !strcmp(e, "old")) b->bb.direct_units = false; }
   { const char* e = getenv("ZGPU_SPARSE_MAX"); if (e) { b->bb.sparse_max = (uint32_t)atoi(e); b->bb.sparse_per_block = 1u << 20; } }   // (tests) sequences per frame up to which zg_k_sparse replaces the sweep, whatever their density; 0: never
   b->bb.flat_slots = (uint32_t)cus_ * (flat_shape_ == 0 ? 1u : 2u);   // zg_k_flat: workgroups the device holds at once
   b->bb.finish();
@@ -409,7 +406,6 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   d.dbg = getenv("ZGPU_DEBUG_TIMERS") ? sc->d_dbg.as<unsigned long long>() : nullptr;
   { const char* e = getenv("ZGPU_FORCE_INORDER"); d.flags = (e && e[0] == '1') ? 1u : 0u; }
   d.flags |= (uint32_t)flat_shape_ << 2;
-  { const char* e = getenv("ZGPU_FLAT"); if (e && !strcmp(e, "old")) d.flags |= 16u; }   // (measurement only) round 2's byte-granular zg_k_flat
   { const char* e = getenv("ZGPU_SWEEP_W"); d.sweep_window = (e && atoi(e) > 0) ? (uint32_t)atoi(e) : 0u; }
   if (hipStreamSynchronize(stream_) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
   *out = b;
@@ -491,19 +487,13 @@ int Batch::run() {
     d.dst = sc->d_dst.as<uint8_t>() + kOutFront; d.dst_cap = total_out;
     og_words = total_out;
   }
-  if (any_fast && (st = sc->d_og.reserve(og_words * 4 + 128))) return st;
-  d.og = sc->d_og.as<uint32_t>() + 16;   // (zg_k_flat4: a gather window may start up to four words in front of a unit's scratch)
+  if (any_fast && (st = sc->d_og.reserve(og_words * 4 + 64))) return st;
+  d.og = sc->d_og.as<uint32_t>();
   d.og_words = og_words;
   // ---- phase 2: LZ77 execution
-  zg_launch_lit(d, s, 0);
+  zg_launch_lit(d, s);
   ZG_HIP(hipEventRecord(ev[6], s));
-  // the literal runs of blocks with sequences depend on nothing but the entropy stages: they are placed beside the flatten
-  // (which is bound by the instructions it issues; this is a stream of short loads and stores) and joined in front of the sweep
-  ZG_HIP(hipStreamWaitEvent(s2, ev[6], 0));
-  if (!getenv("ZGPU_DEBUG_NO_LITRUN")) zg_launch_lit(d, s2, 1);   // (bisecting aid: the sweep then works on missing literal bytes)
-  ZG_HIP(hipEventRecord(sc->ev_lit, s2));
   zg_launch_flat(d, s);
-  ZG_HIP(hipStreamWaitEvent(s, sc->ev_lit, 0));
   { bool any = false; for (const ZgFrame& fr : bb.frames) any = any || fr.sparse; if (any) zg_launch_sparse(d, s); }
   ZG_HIP(hipEventRecord(ev[7], s));
   sweep_mode = 0; synced = false;

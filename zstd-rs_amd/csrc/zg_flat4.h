@@ -1,24 +1,23 @@
-// zg_flat4.h — body of zg_k_flat4, the LZ77 flatten stage (execute_sequences, sequence_execution.rs:5-54;
-// DecodeBuffer::push / repeat, decode_buffer.rs:74-141), at DWORD granularity: a lane owns groups of four consecutive
-// output bytes through every phase of a tile, so the rank query, the record fetches, the gathers of what lies in
-// front of the tile and the stores are paid once per group instead of once per byte.
+// zg_flat4.h — body of the DIRECT units of zg_k_flatten: LZ77 execution (execute_sequences, sequence_execution.rs:5-54;
+// DecodeBuffer::push / repeat, decode_buffer.rs:74-141) of a frame's FIRST unit (a unit = a run of consecutive blocks of one
+// frame, one workgroup each), at DWORD granularity: a lane owns groups of four consecutive output bytes through every phase of
+// a tile, so the rank query, the record fetches, the gathers of what lies in front of the tile and the stores are paid once per
+// group instead of once per byte.
 //
-// Two modes per unit (a unit = a run of consecutive blocks of one frame, one workgroup each):
-//   pointer mode  every byte gets its EFFECTIVE OFFSET e (byte[p] = byte[p - e], p - e a literal byte or a byte in front
-//                 of the unit; 0 for a literal byte) in the flatten scratch; zg_k_sweep turns offsets into bytes, unit
-//                 after unit. No byte values travel through this mode.
-//   direct mode   the unit is the FIRST one of its frame (and the frame starts from nothing: no dictionary, no earlier
-//                 submit), so everything a match can reach lies in the unit itself and is final once its tile is done:
-//                 the same pointer machinery resolves byte VALUES, the plaintext is written right here, and the unit
-//                 needs neither scratch words nor a sweep step.
+// The first unit of a frame that starts from nothing (no dictionary, no earlier submit) copies from nothing outside itself:
+// everything a match can reach is final once its tile is done. So the pointer machinery of the flatten (tile bytes point to
+// their parents, pointer jumping finds every byte's root: a literal byte, or a match byte whose parent lies before the tile)
+// resolves byte VALUES here, the plaintext is written right away, and the unit needs neither scratch words nor a sweep
+// step. Units further back in a frame go through zg_flat1_unit (zg_kernels.hip): effective offsets + zg_k_sweep. (A
+// pointer-mode variant of this body existed during round 3 and measured 18 % slower than zg_flat1_unit; see DESIGN.md.)
 //
 // The file is written against a small set of primitives (zx_*): zg_kernels.hip maps them onto gfx950 builtins,
 // tests/emu/zg_emu_flat.cpp onto a fiber-based SIMT emulator, so the very same source runs on the CPU in the
-// not-gpu tests (against the oracle's sequences) before it ever meets a GPU.
+// not-gpu tests (against the oracle's plaintext) before it ever meets a GPU.
 //
 // Tile geometry: T threads, TS bytes, GPT = TS / (4 T) groups per thread; thread t owns groups t, t + T, ... (adjacent
-// lanes = adjacent groups: 16-byte scratch accesses coalesce, LDS accesses are conflict-free). A tile starts at a
-// position whose scratch index is a multiple of four: up to three DEAD bytes in front of its first live byte.
+// lanes = adjacent groups: output stores coalesce, LDS accesses are conflict-free). A tile starts at a position whose
+// output address is a multiple of four: up to three DEAD bytes in front of its first live byte.
 #pragma once
 #include <stdint.h>
 #include "zg_types.h"
@@ -32,13 +31,12 @@ ZX_DEV uint32_t zg_lanes_hi(uint32_t a23, uint32_t a01) { return ((a01 >> 8) & 0
 // (a & m) | (b & ~m)
 ZX_DEV uint32_t zx_bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
 
-template <int T, int TS, int SPT, bool DIRECT>
+template <int T, int TS, int SPT>
 struct ZgFlat4Lds {
   static constexpr int NW = TS / 32, SOFF = SPT * T;
   ZxU4 rec[SOFF];                                        // per sequence of the tile: {offset, first match byte (tile-relative), 2^31 + literal index of tile byte 0, -}
-  __attribute__((aligned(16))) uint32_t word[DIRECT ? 4 : TS];   // pointer mode: a root's effective offset; bit 31: the root is a literal
   __attribute__((aligned(16))) uint16_t par[TS + 8];     // 0xFFFF literal, 0x8000 match byte with its parent before the tile, else tile-relative parent; [TS]: a dummy byte that is always a root
-  __attribute__((aligned(16))) uint8_t val[DIRECT ? TS : 16];    // direct mode: a root's byte value
+  __attribute__((aligned(16))) uint8_t val[TS];          // a root's byte value
   uint32_t bits[NW];                                     // marks: the first tile byte of every sequence
   uint16_t cnt[NW];                                      // marks before each word of bits
   uint32_t wtot[NW / 64];
@@ -46,8 +44,8 @@ struct ZgFlat4Lds {
   unsigned long long bad;                                // first failing sequence of the block: index << 32 | match position << 8 | provisional status
 };
 
-template <int T, int TS, int SPT, bool DIRECT>
-ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, TS, SPT, DIRECT>& L) {
+template <int T, int TS, int SPT>
+ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, TS, SPT>& L) {
   constexpr int GPT = TS / (4 * T);            // groups per thread
   constexpr int SOFF = SPT * T;                // sequences a tile takes; a denser tile is cut short
   constexpr int NW = TS / 32;                  // words of the mark bitmap
@@ -59,16 +57,11 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
   if (!fo.fast) return;
   const uint64_t unit_abs0 = d.pos[un.first_block].out_base;     // frame-relative position of the unit's first byte
   uint8_t* out_u = d.dst + fo.out_base + unit_abs0;
-  uint32_t* og = DIRECT ? nullptr : d.og + fo.og_base + unit_abs0;
-  // groups are aligned in the scratch (pointer mode) / in the output (direct mode; there the two agree: frames that are
-  // packed back to back have og_base == out_base, and only those have direct units)
-  const uint32_t ualign = (uint32_t)((DIRECT ? fo.out_base : fo.og_base) + unit_abs0) & 3u;
+  const uint32_t ualign = (uint32_t)(fo.out_base + unit_abs0) & 3u;   // groups are aligned in the output
   // what the unit can hold at most — and never more than what is left of the frame: tile bytes behind a block's end are
-  // classified (and their windows requested) like live ones, and the output / scratch allocations end with the last frame
+  // classified (and their windows requested) like live ones, and the output allocation ends with the last frame
   const uint64_t fleft = fo.out_size - unit_abs0;
   const uint32_t ucap = (uint64_t)un.nblocks * ZG_FLAT_MAX < fleft ? un.nblocks * ZG_FLAT_MAX : (uint32_t)fleft;
-  // scratch word of unit byte u: offset 4 (u + 4) (four words of slack in front: a tile's dead bytes, a gather window that starts before the unit)
-  const ZxBuf og_rs = zx_buf(DIRECT ? nullptr : og - 4, DIRECT ? 0u : 4u * (ucap + 4u));
   // output byte u: offset u + ualign + 4 (the base is dword-aligned; the engine keeps 256 bytes in front of every output)
   const ZxBuf out_rs = zx_buf(out_u - ualign - 4, ucap + ualign + 4u);
   if (t == 0) { L.err = 0; L.bad = ~0ull; L.par[TS] = (uint16_t)ZG_PAR_LIT; }
@@ -80,10 +73,8 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
     if (!p.active) break;
     const ZgBlock blk = d.blocks[b];
     const uint32_t bu0 = (uint32_t)(p.out_base - unit_abs0);      // unit-relative position of the block
-    if (blk.btype != ZG_BT_COMPRESSED || blk.nseq == 0) {        // all of it is final already (zg_k_lit): effective offset 0
-      const uint32_t n = blk.regen_size;
-      if (!DIRECT && !(un.noseq & 1u)) for (uint32_t i = t; i < n; i += T) og[bu0 + i] = 0u;   // (a unit without sequences has no sweep step: nobody reads its scratch)
-      unit_size = bu0 + n;
+    if (blk.btype != ZG_BT_COMPRESSED || blk.nseq == 0) {        // all of it is final already (zg_k_lit)
+      unit_size = bu0 + blk.regen_size;
       continue;
     }
     const ZgBlockSeqOut so = d.seq_out[b];
@@ -191,13 +182,12 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
       // ---- S1c: every group finds its (at most two: matches are >= 3 bytes long) sequences by rank of the marks, and every byte
       // becomes a literal, a match byte with its parent inside the tile (pointer), or a root: a match byte whose parent lies
       // before the tile. The four bytes are classified together, as two pairs of 16-bit lanes (packed arithmetic): the kernel is
-      // bound by the instructions it issues. What the roots of a group need from before the tile — the parents' scratch words
-      // (pointer mode) or byte values (direct mode) — is consecutive in memory per sequence: one window load per sequence of
-      // the group, requested here and consumed after the pointer jumping (the round trip hides behind it). A window is
-      // requested whether or not its bytes turn out to be roots: what a non-root byte receives is never looked at.
-      ZxU4 LA[GPT], LB[GPT];
+      // bound by the instructions it issues. What the roots of a group need from before the tile — the parents' byte values —
+      // is consecutive in memory per sequence: one window load per sequence of the group, requested here and consumed after
+      // the pointer jumping (the round trip hides behind it). A window is requested whether or not its bytes turn out to be
+      // roots: what a non-root byte receives is never looked at.
       ZxU2 VA[GPT], VB[GPT], LW[GPT];
-      uint32_t offA[GPT], offB[GPT], meta[GPT], litl[GPT];   // meta: [2:0] first byte of the second sequence, [12:8] / [20:16] / [28:24] funnel shifts of the literal / A / B windows; litl: literal bytes (byte mask)
+      uint32_t meta[GPT], litl[GPT];   // meta: [2:0] first byte of the second sequence, [12:8] / [20:16] / [28:24] funnel shifts of the literal / A / B windows; litl: literal bytes (byte mask)
       uint32_t unresolved = 0;                               // bit 8 i + k: byte i of the thread's k-th group has its parent in the tile
       {
         const uint32_t tc = ZX_FRESH(t);
@@ -233,43 +223,22 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
           // the high bytes of the four lanes: bit 7 clear = parent in the tile
           const uint32_t hb = zg_lanes_hi(pp.y, pp.x);
           unresolved |= ((~hb & 0x80808080u) >> 7) << k;
-          offA[k] = rA[k].x; offB[k] = rB[k].x;
           uint32_t m = fb;
           const int32_t uA = (int32_t)(tu0a + x0 - rA[k].x), uB = (int32_t)(tu0a + x0 - rB[k].x);   // unit-relative positions where the parents' windows start
-          if (DIRECT) {
-            // the literal bytes of a group belong to one sequence (a second literal run would need a whole match between them):
-            // one 8-byte window that starts at the first of them
-            // literal bytes as a byte mask (the tile's dead bytes are literals by class: not these)
-            const uint32_t lb = zg_lanes_lo(l23, l01) & (x0 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8u * lead));
-            const uint32_t ilit = lb ? (uint32_t)__builtin_ctz(lb) >> 3 : 0u;
-            const uint32_t zl = ilit < fb ? rA[k].z : rB[k].z;
-            const uint32_t ol = ((zl + x0 + ilit) & 0x7FFFFFFFu) + lit_lo + 4u - ilit;   // offset of the byte group byte 0 would stand for
-            LW[k] = zx_ld64(lit_rs, lb ? ol & ~3u : ZX_OOB);
-            litl[k] = lb;
-            const uint32_t oA = (uint32_t)uA + ualign + 4u, oB = (uint32_t)uB + ualign + 4u;
-            // (a window may start up to three bytes before the frame: its first bytes are then literals or belong to the other sequence)
-            VA[k] = zx_ld64(out_rs, uA >= -3 ? oA & ~3u : ZX_OOB);
-            VB[k] = zx_ld64(out_rs, (uB >= -3 && fb < 4u) ? oB & ~3u : ZX_OOB);
-            m |= ((ol & 3u) << 11) | ((oA & 3u) << 19) | ((oB & 3u) << 27);
-          } else {
-            litl[k] = zg_lanes_lo(l23, l01);
-            // a window that starts just before the unit (its first words belong to whatever lies in front of the scratch): word by
-            // word, so that what lies in front reads as zero. Once per unit and offset at most.
-            const bool strA = (uint32_t)(uA + 3) < 3u, strB = (uint32_t)(uB + 3) < 3u && fb < 4u;
-            if (strA || strB) {
-              uint32_t la[4], lb[4];
-#pragma unroll
-              for (int i = 0; i < 4; i++) {
-                la[i] = zx_ld32(og_rs, uA + i >= 0 ? 4u * (uint32_t)(uA + i + 4) : ZX_OOB);
-                lb[i] = zx_ld32(og_rs, (uB + i >= 0 && fb < 4u) ? 4u * (uint32_t)(uB + i + 4) : ZX_OOB);
-              }
-              LA[k].x = la[0]; LA[k].y = la[1]; LA[k].z = la[2]; LA[k].w = la[3];
-              LB[k].x = lb[0]; LB[k].y = lb[1]; LB[k].z = lb[2]; LB[k].w = lb[3];
-            } else {
-              LA[k] = zx_ld128(og_rs, uA >= 0 ? 4u * (uint32_t)(uA + 4) : ZX_OOB);
-              LB[k] = zx_ld128(og_rs, (uB >= 0 && fb < 4u) ? 4u * (uint32_t)(uB + 4) : ZX_OOB);
-            }
-          }
+          // the literal bytes of a group belong to one sequence (a second literal run would need a whole match between them):
+          // one 8-byte window that starts at the first of them
+          // literal bytes as a byte mask (the tile's dead bytes are literals by class: not these)
+          const uint32_t lb = zg_lanes_lo(l23, l01) & (x0 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8u * lead));
+          const uint32_t ilit = lb ? (uint32_t)__builtin_ctz(lb) >> 3 : 0u;
+          const uint32_t zl = ilit < fb ? rA[k].z : rB[k].z;
+          const uint32_t ol = ((zl + x0 + ilit) & 0x7FFFFFFFu) + lit_lo + 4u - ilit;   // offset of the byte group byte 0 would stand for
+          LW[k] = zx_ld64(lit_rs, lb ? ol & ~3u : ZX_OOB);
+          litl[k] = lb;
+          const uint32_t oA = (uint32_t)uA + ualign + 4u, oB = (uint32_t)uB + ualign + 4u;
+          // (a window may start up to three bytes before the frame: its first bytes are then literals or belong to the other sequence)
+          VA[k] = zx_ld64(out_rs, uA >= -3 ? oA & ~3u : ZX_OOB);
+          VB[k] = zx_ld64(out_rs, (uB >= -3 && fb < 4u) ? oB & ~3u : ZX_OOB);
+          m |= ((ol & 3u) << 11) | ((oA & 3u) << 19) | ((oB & 3u) << 27);
           meta[k] = m;
         }
       }
@@ -302,40 +271,21 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
           if (guard == (1u << 16) - 1u) L.err = ZG_INTERNAL;   // cannot happen: every visit moves a pointer up its chain (seen by everybody behind the next barrier)
         }
       }
-      // ---- S3a: the windows requested in S1c have arrived: every root's word (value) is completed and published
+      // ---- S3a: the windows requested in S1c have arrived: every root's value is published
       {
         const uint32_t t3 = ZX_FRESH(t);
 #pragma unroll
         for (int k = 0; k < GPT; k++) {
           const uint32_t x0 = 4u * (t3 + k * T), m = meta[k], fb = m & 7u;
-          if (DIRECT) {
-            const uint32_t vA = zx_alignbit(VA[k].y, VA[k].x, (m >> 16) & 31u), vB = zx_alignbit(VB[k].y, VB[k].x, (m >> 24) & 31u);
-            const uint32_t l4 = zx_alignbit(LW[k].y, LW[k].x, (m >> 8) & 31u) | fill4;
-            const uint32_t mB = fb >= 4u ? 0u : 0xFFFFFFFFu << (8u * fb);                       // bytes of the second sequence
-            *(uint32_t*)&L.val[x0] = zx_bfi(litl[k], l4, zx_bfi(mB, vB, vA));
-          } else {
-            // a root's effective offset = its sequence's offset + the effective offset of its parent (0 when that lies before the
-            // unit); a literal root counts 0. (A byte with its parent in the tile takes whatever its window slot holds: nobody
-            // reads the word of a byte that is not a root.)
-            // (selects and masks only: a branch per byte would cost more than it skips)
-            const uint32_t lb = litl[k], oa = offA[k], ob = offB[k];
-            const uint32_t sa0 = oa + LA[k].x, sa1 = oa + LA[k].y, sa2 = oa + LA[k].z, sa3 = oa + LA[k].w;
-            const uint32_t sb1 = ob + LB[k].y, sb2 = ob + LB[k].z, sb3 = ob + LB[k].w;
-            const uint32_t w1 = fb <= 1u ? sb1 : sa1, w2 = fb <= 2u ? sb2 : sa2, w3 = fb <= 3u ? sb3 : sa3;
-            ZxU4 wv;
-            wv.x = sa0 & ~(uint32_t)(int32_t)(int8_t)lb;
-            wv.y = w1 & ~(uint32_t)(int32_t)(int8_t)(lb >> 8);
-            wv.z = w2 & ~(uint32_t)(int32_t)(int8_t)(lb >> 16);
-            wv.w = w3 & ~(uint32_t)(int32_t)(int8_t)(lb >> 24);
-            *(ZxU4*)&L.word[x0] = wv;
-          }
+          const uint32_t vA = zx_alignbit(VA[k].y, VA[k].x, (m >> 16) & 31u), vB = zx_alignbit(VB[k].y, VB[k].x, (m >> 24) & 31u);
+          const uint32_t l4 = zx_alignbit(LW[k].y, LW[k].x, (m >> 8) & 31u) | fill4;
+          const uint32_t mB = fb >= 4u ? 0u : 0xFFFFFFFFu << (8u * fb);                       // bytes of the second sequence
+          *(uint32_t*)&L.val[x0] = zx_bfi(litl[k], l4, zx_bfi(mB, vB, vA));
         }
       }
       zx_barrier();
       if (L.err) break;
-      // ---- S3b: every byte takes what its root holds. Pointer mode: effective offset = the root's + the distance to the root
-      // -> scratch, 16 bytes per group (the literal bytes themselves are placed by zg_k_lit). Direct mode: the root's value ->
-      // output, 4 bytes per group.
+      // ---- S3b: every byte takes the value its root holds -> output, 4 bytes per group
       {
         const uint32_t t4 = ZX_FRESH(t);
 #pragma unroll
@@ -347,34 +297,19 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
           uint32_t r[4];
 #pragma unroll
           for (int i = 0; i < 4; i++) r[i] = pr[i] >= ZG_PAR_EXIT ? x0 + i : pr[i];
-          if (DIRECT) {
-            uint32_t vb[4];
+          uint32_t vb[4];
 #pragma unroll
-            for (int i = 3; i >= 0; i--) vb[i] = L.val[r[i]];
-            const uint32_t v = vb[0] | (vb[1] << 8) | (vb[2] << 16) | (vb[3] << 24);
-            const uint32_t o = tu0a + x0 + ualign + 4u;
-            zx_st32(out_rs, full ? o : ZX_OOB, v);
-            if (!full) {
+          for (int i = 3; i >= 0; i--) vb[i] = L.val[r[i]];
+          const uint32_t v = vb[0] | (vb[1] << 8) | (vb[2] << 16) | (vb[3] << 24);
+          const uint32_t o = tu0a + x0 + ualign + 4u;
+          zx_st32(out_rs, full ? o : ZX_OOB, v);
+          if (!full) {
 #pragma unroll
-              for (int i = 0; i < 4; i++) zx_st8(out_rs, (x0 + i - lead < n - lead) ? o + i : ZX_OOB, vb[i]);
-            }
-          } else {
-            uint32_t w[4];
-#pragma unroll
-            for (int i = 3; i >= 0; i--) w[i] = L.word[r[i]];
-            ZxU4 ev;
-            ev.x = w[0] + (x0 - r[0]); ev.y = w[1] + (x0 + 1u - r[1]); ev.z = w[2] + (x0 + 2u - r[2]); ev.w = w[3] + (x0 + 3u - r[3]);
-            const uint32_t o = 4u * (tu0a + x0 + 4u);
-            zx_st128(og_rs, full ? o : ZX_OOB, ev);
-            if (!full) {
-              const uint32_t e[4] = {ev.x, ev.y, ev.z, ev.w};
-#pragma unroll
-              for (int i = 0; i < 4; i++) zx_st32(og_rs, (x0 + i - lead < n - lead) ? o + 4u * i : ZX_OOB, e[i]);
-            }
+            for (int i = 0; i < 4; i++) zx_st8(out_rs, (x0 + i - lead < n - lead) ? o + i : ZX_OOB, vb[i]);
           }
         }
       }
-      zx_barrier();  // par / word / val / the records are reused by the next tile
+      zx_barrier();  // par / val / the records are reused by the next tile
       t0 = t1;
       i_start = i_next;
     }

@@ -272,9 +272,8 @@ void BatchBuilder::finish() {
         if (bk.btype == ZG_BT_COMPRESSED && bk.nseq) u.noseq = 0;
       }
       // the first unit of a frame that starts from nothing (no dictionary, no earlier submit: the engine marks those frames
-      // fixed_base before finish()) copies from nothing outside itself: zg_k_flat4 resolves it to bytes right away (direct mode)
+      // fixed_base before finish()) copies from nothing outside itself: the flatten resolves it to bytes right away (direct unit, zg_flat4.h)
       if (i == 0 && !u.noseq && direct_units && !fr.fixed_base && !fr.sparse) u.noseq = ZG_UNIT_DIRECT;
-      for (uint32_t k = 0; k < u.nblocks; k++) blocks[u.first_block + k].flags = (u.noseq & ZG_UNIT_DIRECT) ? ZG_BLK_DIRECT : 0u;
       units.push_back(u);
     }
     fr.nunits = (uint32_t)units.size() - fr.first_unit;

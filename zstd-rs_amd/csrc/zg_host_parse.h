@@ -66,7 +66,7 @@ class BatchBuilder {
   uint32_t unit_blocks_used = 0;   // what finish() chose
   uint32_t sparse_max = 2048;      // a frame with at most this many sequences (and <= sparse_per_block per block) skips the sweep: zg_k_sparse (0: never)
   uint32_t sparse_per_block = 4;
-  bool direct_units = true;    // first units of frames that start from nothing are resolved to bytes by zg_k_flat4 itself (no scratch, no sweep step)
+  bool direct_units = true;    // first units of frames that start from nothing are resolved to bytes by the flatten itself (no scratch, no sweep step)
   uint32_t flat_slots = 256;   // workgroups of zg_k_flat the device runs at once (engine: CUs x workgroups per CU)
   uint64_t lit_bytes = 0;      // literals arena size
   uint64_t seq_count = 0;      // sequence arena size

@@ -23,7 +23,7 @@ void zg_launch_seq(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_seqpost(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_merge(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_scan(const ZgBatchDev& d, hipStream_t s);
-void zg_launch_lit(const ZgBatchDev& d, hipStream_t s, uint32_t part);   // part 0: raw / RLE blocks and blocks without sequences; part 1: the literal runs of blocks with sequences
+void zg_launch_lit(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_flat(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_sparse(const ZgBatchDev& d, hipStream_t s);   // the matches of frames marked sparse, in order (after zg_launch_flat)
 bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* steps, uint32_t nsteps, hipStream_t s2, hipEvent_t* evs, uint32_t nev,

@@ -14,7 +14,7 @@
 //     zg_k_scan     one workgroup per frame    block output positions + offset-history resolution (function-composition scan)
 //     zg_k_scanf    one workgroup              frame output positions and scratch bases
 //     zg_k_lit      one workgroup per block    raw and RLE blocks, blocks without sequences -> output
-//     zg_k_flat     one workgroup per unit     every byte of a run of blocks -> its effective offset (to a literal byte, or to a byte in
+//     zg_k_flatten  one workgroup per unit     every byte of a run of blocks -> its effective offset (to a literal byte, or to a byte in
 //                                              front of the unit); literals -> output
 //     zg_k_swprep   one thread per unit        sweep descriptors
 //     zg_k_sweep    one launch per unit index  the units' tails, unit after unit: match bytes gathered from finished output;
@@ -1262,8 +1262,8 @@ __global__ void __launch_bounds__(1024) zg_k_scanf(ZgBatchDev d) {
 
 // ------------------------------------------------------------------------------------------------------------
 // zg_k_lit: blocks that do not depend on earlier output at all — raw blocks, RLE blocks (block_decoder.rs:55-82) and
-// compressed blocks without sequences (block_decoder.rs:184-194: the literals are the block) — and the literal runs of blocks
-// WITH sequences (DecodeBuffer::push, decode_buffer.rs:74-77) unless zg_k_flat4 (direct units) or zg_k_lz places them.
+// compressed blocks without sequences (block_decoder.rs:184-194: the literals are the block). Literal runs of blocks
+// WITH sequences (DecodeBuffer::push, decode_buffer.rs:74-77) are placed by zg_k_flatten (flatten path) or zg_k_lz.
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void zg_wg_copy(uint8_t* dst, const uint8_t* src, uint64_t n, uint32_t t, uint32_t T) {
   uint64_t n8 = n >> 3;
@@ -1276,9 +1276,7 @@ __device__ __forceinline__ void zg_wg_fill(uint8_t* dst, uint8_t byte, uint64_t 
   for (uint64_t i = (n8 << 3) + t; i < n; i += T) dst[i] = byte;
 }
 
-__global__ void __launch_bounds__(256) zg_k_lit(ZgBatchDev d, uint32_t part) {   // part 0: whole blocks; part 1: the literal runs of blocks with sequences
-  __shared__ uint32_t s_long[256 * 3];          // literal runs too long for one lane: {source index, destination, length}
-  __shared__ uint32_t s_nlong;
+__global__ void __launch_bounds__(256) zg_k_lit(ZgBatchDev d) {
   if (d.totals[2]) return;
   const uint32_t b = blockIdx.x, t = threadIdx.x;
   const ZgBlockPos p = d.pos[b];
@@ -1286,53 +1284,11 @@ __global__ void __launch_bounds__(256) zg_k_lit(ZgBatchDev d, uint32_t part) {  
   const ZgBlock blk = d.blocks[b];
   uint8_t* out = d.dst + d.frame_out[blk.frame].out_base + p.out_base;
   const uint8_t* body = d.src + blk.src_off;
-  if (blk.btype == ZG_BT_RAW) { if (part == 0) zg_wg_copy(out, body, blk.regen_size, t, 256); return; }
-  if (blk.btype == ZG_BT_RLE) { if (part == 0) zg_wg_fill(out, body[0], blk.regen_size, t, 256); return; }
-  const bool lit_rle = blk.lit_type == ZG_LT_RLE;
-  const uint8_t* lit = blk.lit_type <= ZG_LT_RLE ? body + blk.lit_off : d.lit_arena + blk.lit_base;
-  if (!blk.nseq) {
-    if (part != 0) return;
-    if (lit_rle) zg_wg_fill(out, lit[0], blk.regen_size, t, 256);
-    else zg_wg_copy(out, lit, blk.regen_size, t, 256);
-    return;
-  }
-  if (part != 1) return;
-  // A block with sequences: its literal runs (DecodeBuffer::push, decode_buffer.rs:74-77; the trailing literals,
-  // sequence_execution.rs:40-44) are independent of everything else and go to their places here, one lane per sequence,
-  // unless the block's unit is resolved to bytes by zg_k_flat4 itself (direct unit) or the frame left the flatten path
-  // (zg_k_lz places its own). The effective offsets of pointer-mode units then only describe match bytes.
-  if ((blk.flags & ZG_BLK_DIRECT) || !d.frame_out[blk.frame].fast) return;
-  const ZgSeq* sq = d.seq_arena + blk.seq_base;
-  const ZgBlockSeqOut so = d.seq_out[b];
-  const uint32_t nseq = blk.nseq, fillv = lit_rle ? lit[0] : 0u;
-  constexpr uint32_t SHORT = 24;                 // a lane copies runs up to this long by itself
-  for (uint32_t i0 = 0; i0 <= nseq; i0 += 256) {
-    if (t == 0) s_nlong = 0;
-    __syncthreads();
-    const uint32_t i = i0 + t;
-    uint32_t lstart = 0, ll = 0, a = 0;
-    if (i < nseq) {
-      const ZgSeq q = sq[i];
-      const uint32_t next = i + 1 < nseq ? ZG_SEQ_LIT(sq[i + 1]) : so.sum_ll;
-      lstart = ZG_SEQ_LIT(q); ll = (next - lstart) & 0x1FFFFu; a = ZG_SEQ_MDST(q) - ll;
-    } else if (i == nseq) {
-      lstart = so.sum_ll; ll = blk.regen_size - so.sum_ll; a = so.sum_ll + so.sum_ml;
-    }
-    if (ll > SHORT) {
-      const uint32_t k = atomicAdd(&s_nlong, 1u);
-      s_long[3 * k] = lstart; s_long[3 * k + 1] = a; s_long[3 * k + 2] = ll;
-    } else {
-      for (uint32_t k = 0; k < ll; k++) out[a + k] = lit_rle ? (uint8_t)fillv : lit[lstart + k];
-    }
-    __syncthreads();
-    const uint32_t nl = s_nlong;
-    for (uint32_t j = 0; j < nl; j++) {
-      const uint32_t ls = s_long[3 * j], la = s_long[3 * j + 1], n = s_long[3 * j + 2];
-      if (lit_rle) zg_wg_fill(out + la, (uint8_t)fillv, n, t, 256);
-      else zg_wg_copy(out + la, lit + ls, n, t, 256);
-    }
-    __syncthreads();
-  }
+  if (blk.btype == ZG_BT_RAW) { zg_wg_copy(out, body, blk.regen_size, t, 256); return; }
+  if (blk.btype == ZG_BT_RLE) { zg_wg_fill(out, body[0], blk.regen_size, t, 256); return; }
+  if (blk.nseq) return;
+  if (blk.lit_type == ZG_LT_RLE) zg_wg_fill(out, body[blk.lit_off], blk.regen_size, t, 256);
+  else zg_wg_copy(out, blk.lit_type == ZG_LT_RAW ? body + blk.lit_off : d.lit_arena + blk.lit_base, blk.regen_size, t, 256);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1375,22 +1331,25 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t zg_make_rsrc(const void* p, ui
 // tile; a tile that would hold more than SPT * T sequences is cut short. No phase has a data-dependent branch: loads and
 // stores that depend on the data go through buffer resources with an out-of-range offset for "not needed" (no traffic).
 template <int T, int TS, int SPT>
-__global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDev d) {
+struct ZgFlat1Lds {
+  static constexpr int NW = TS / 32, SOFF = SPT * T;
+  uint16_t par[TS];                // 0xFFFF literal, 0x8000 match byte with its parent before the tile, else tile-relative parent
+  uint32_t word[TS];               // a root's effective offset; a literal: tag + index of its value in the block's literals
+  uint32_t bits[NW];               // marks: the first tile byte of every sequence
+  uint16_t cnt[NW];                // marks before each word of bits
+  __attribute__((aligned(16))) zg_v4u rec[SOFF];   // per sequence of the tile, as S1c wants it: {offset, first match byte, 2^31 + literal index of tile byte 0, 4 * offset}
+  uint32_t wtot[NW / 64];
+  uint32_t next, cut, err;
+  unsigned long long bad;          // first failing sequence of the block: index << 32 | match position << 8 | provisional status
+};
+template <int T, int TS, int SPT>
+__device__ __forceinline__ void zg_flat1_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat1Lds<T, TS, SPT>& L) {
   constexpr int PER = TS / T;                   // tile bytes per thread
   constexpr int SOFF = SPT * T;                 // sequences a tile takes; a denser tile is cut short
   constexpr int NW = TS / 32;                   // words of the mark bitmap
   static_assert(PER * T == TS && PER <= 16 && NW <= T && (NW % 64) == 0 && SPT >= 1 && SPT <= 2, "shape");
-  __shared__ uint16_t s_par[TS];                // 0xFFFF literal, 0x8000 match byte with its parent before the tile, else tile-relative parent
-  __shared__ uint32_t s_word[TS];               // a root's effective offset; a literal: tag + index of its value in the block's literals
-  __shared__ uint32_t s_bits[NW];               // marks: the first tile byte of every sequence
-  __shared__ uint16_t s_cnt[NW];                // marks before each word of s_bits
-  __shared__ __attribute__((aligned(16))) zg_v4u s_rec[SOFF];   // per sequence of the tile, as S1c wants it: {offset, first match byte, 2^31 + literal index of tile byte 0, 4 * offset}
-  __shared__ uint32_t s_wtot[NW / 64];
-  __shared__ uint32_t s_next, s_cut, s_err;
-  __shared__ unsigned long long s_bad;          // first failing sequence of the block: index << 32 | match position << 8 | provisional status
   const uint32_t t = threadIdx.x;
-  const ZgUnit un = d.units[blockIdx.x];
-  if (t == 0) { ZgUnitInfo ui; ui.size = 0; ui.noseq = 0; d.unit_info[blockIdx.x] = ui; }
+  const ZgUnit un = d.units[ui];
   if (d.totals[2]) return;
   const ZgFrameOut fo = d.frame_out[un.frame];
   if (!fo.fast) return;
@@ -1398,7 +1357,7 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
   uint8_t* out_u = d.dst + fo.out_base + unit_abs0;
   uint32_t* og = d.og + fo.og_base + unit_abs0;
   const __amdgpu_buffer_rsrc_t og_rs = zg_make_rsrc(og, un.nblocks * (ZG_FLAT_MAX * 4u));
-  if (t == 0) { s_err = 0; s_bad = ~0ull; }
+  if (t == 0) { L.err = 0; L.bad = ~0ull; }
   uint32_t unit_size = 0;
 #ifdef ZG_PROFILE_FLAT   // per-phase cycle counters (tools/dev/flat_phases.py); costs registers, off in the product build
   unsigned long long tc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
@@ -1450,8 +1409,8 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
     uint32_t i_start = 0;
     for (uint32_t t0 = 0; t0 < S;) {
       const uint32_t t1o = t0 + TS < S ? t0 + TS : S;            // where the tile ends unless it holds too many sequences
-      if (t == 0) { s_next = 0xFFFFFFFFu; s_cut = 0xFFFFFFFFu; }
-      if (t < NW) s_bits[t] = 0;
+      if (t == 0) { L.next = 0xFFFFFFFFu; L.cut = 0xFFFFFFFFu; }
+      if (t < NW) L.bits[t] = 0;
       zg_lds_barrier();
       ZG_TICK(0)
       // ---- S1a: one thread per sequence i (index nseq stands for the trailing literals). It covers [a, m0) with literals
@@ -1470,8 +1429,8 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
           off = zg_sym_resolve(qx, p.hist_init);
           // the first failing sequence (in order) decides, like the reference's in-order execution; which of the two
           // "too far" errors it is (repeat_from_dict, decode_buffer.rs:144-179) is worked out off the hot path
-          if (off == 0) atomicMin(&s_bad, ((unsigned long long)i << 32) | (m0 << 8) | (uint32_t)ZG_EXE_ZERO_OFFSET);              // sequence_execution.rs:28-30
-          else if (!reach_all && off > reach32 + m0) atomicMin(&s_bad, ((unsigned long long)i << 32) | (m0 << 8) | (uint32_t)ZG_EXE_OFFSET_TOO_BIG);
+          if (off == 0) atomicMin(&L.bad, ((unsigned long long)i << 32) | (m0 << 8) | (uint32_t)ZG_EXE_ZERO_OFFSET);              // sequence_execution.rs:28-30
+          else if (!reach_all && off > reach32 + m0) atomicMin(&L.bad, ((unsigned long long)i << 32) | (m0 << 8) | (uint32_t)ZG_EXE_OFFSET_TOO_BIG);
         } else {
           lstart = so.sum_ll; a = so.sum_ll + so.sum_ml; m0 = m1 = S;
         }
@@ -1479,16 +1438,16 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
         // lowest lane of a wave that sees one speaks for the wave (one LDS atomic per wave, not one per sequence)
         const bool beyond = m1 > t1o || a >= t1o;
         const unsigned long long bm = __ballot(beyond);
-        if (beyond && (t & 63u) == (uint32_t)__builtin_ctzll(bm)) atomicMin(&s_next, i);
+        if (beyond && (t & 63u) == (uint32_t)__builtin_ctzll(bm)) atomicMin(&L.next, i);
         if (a >= t1o) continue;
         const uint32_t st = (a > t0 ? a : t0) - t0;
         const uint32_t mr = (m0 > t0 ? (m0 < t1o ? m0 : t1o) : t0) - t0;
         // (z: the literal a tile byte x of this sequence stands for is z + x - 2^31; it only has to be right for x >= st)
         // (w: unit positions are below 2^25, so an offset of 2^29 or more always leads in front of the unit: any large value says so)
-        s_rec[j] = zg_v4u{off, mr, 0x80000000u + lstart + (a > t0 ? 0u : t0 - a) - st, off < (1u << 29) ? 4u * off : 0x7FFFFFFCu};
-        atomicOr(&s_bits[st >> 5], 1u << (st & 31u));
+        L.rec[j] = zg_v4u{off, mr, 0x80000000u + lstart + (a > t0 ? 0u : t0 - a) - st, off < (1u << 29) ? 4u * off : 0x7FFFFFFCu};
+        atomicOr(&L.bits[st >> 5], 1u << (st & 31u));
         // the last sequence the tile has room for, and more follow: the tile ends with this one
-        if (j == SOFF - 1 && i < nseq && m1 <= t1o) s_cut = m1;
+        if (j == SOFF - 1 && i < nseq && m1 <= t1o) L.cut = m1;
       }
       zg_lds_barrier();
       // ---- S1b: marks before every word (prefix sum over the words)
@@ -1498,17 +1457,17 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
                                            //  through a scratch load whose wait also covers the records requested for the next tile)
         uint32_t c = 0, sc = 0;
         if (tb < NW) {
-          c = (uint32_t)__popc(s_bits[tb]);
+          c = (uint32_t)__popc(L.bits[tb]);
           sc = c;
 #pragma unroll
           for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(sc, o, 64); if ((int)(tb & 63) >= o) sc += v; }
-          if ((tb & 63) == 63) s_wtot[tb >> 6] = sc;
+          if ((tb & 63) == 63) L.wtot[tb >> 6] = sc;
         }
         zg_lds_barrier();
         if (tb < NW) {
           uint32_t before = sc - c;
-          for (uint32_t w = 0; w < (tb >> 6); w++) before += s_wtot[w];
-          s_cnt[tb] = (uint16_t)before;
+          for (uint32_t w = 0; w < (tb >> 6); w++) before += L.wtot[w];
+          L.cnt[tb] = (uint16_t)before;
         }
       }
       // every wave's scratch stores of the previous tile have reached memory before any wave gathers from them. (The builtin,
@@ -1517,10 +1476,10 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
       zg_lds_barrier();
       ZG_TICK(1)
-      const uint32_t cut = s_cut;
+      const uint32_t cut = L.cut;
       const uint32_t t1 = cut != 0xFFFFFFFFu ? cut : t1o;
-      const uint32_t i_next = cut != 0xFFFFFFFFu ? i_start + SOFF : (s_next == 0xFFFFFFFFu ? nseq + 1 : s_next);
-      if (s_bad != ~0ull) break;
+      const uint32_t i_next = cut != 0xFFFFFFFFu ? i_start + SOFF : (L.next == 0xFFFFFFFFu ? nseq + 1 : L.next);
+      if (L.bad != ~0ull) break;
       const uint32_t n = t1 - t0;
       const uint32_t tu0 = bu0 + t0;                             // unit-relative position of the tile
       if (t1 < S) fetch(i_next);                                  // next tile's sequences: in flight behind this tile's work
@@ -1536,12 +1495,12 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
         uint32_t word[G], cnt[G];
         zg_v4u rec[G];
 #pragma unroll
-        for (int g = 0; g < G; g++) { const uint32_t xw = (tc + (k0 + g) * T) >> 5; word[g] = s_bits[xw]; cnt[g] = s_cnt[xw]; }
+        for (int g = 0; g < G; g++) { const uint32_t xw = (tc + (k0 + g) * T) >> 5; word[g] = L.bits[xw]; cnt[g] = L.cnt[xw]; }
 #pragma unroll
         for (int g = 0; g < G; g++) {
           const uint32_t x = tc + (k0 + g) * T;
           // marks up to and including x, minus one (the tile's first byte carries a mark); bytes behind the tile's end get the last sequence
-          rec[g] = s_rec[cnt[g] + (uint32_t)__popc(word[g] & (0xFFFFFFFFu >> (31u - (x & 31u)))) - 1u];
+          rec[g] = L.rec[cnt[g] + (uint32_t)__popc(word[g] & (0xFFFFFFFFu >> (31u - (x & 31u)))) - 1u];
         }
 #pragma unroll
         for (int g = 0; g < G; g++) {
@@ -1561,10 +1520,10 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
           // (bytes behind the tile's end write too: their slots are not used by anything)
           uint32_t par = c_in ? x - off : (uint32_t)ZG_PAR_EXIT;
           par = c_lit ? (uint32_t)ZG_PAR_LIT : par;
-          s_par[x] = (uint16_t)par;
+          L.par[x] = (uint16_t)par;
           uint32_t wrd = c_in ? 0u : off;
           wrd = c_lit ? rec[g].z + x : wrd;
-          s_word[x] = wrd;
+          L.word[x] = wrd;
           uint32_t ub = c_in ? 1u << k : 0u;
           ub = c_lit ? 0u : ub;
           ub = c_live ? ub : 0u;
@@ -1583,27 +1542,27 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
 #pragma unroll
           for (int j = 0; j < 4; j++) { kk[j] = m ? (uint32_t)__builtin_ctz(m) : 32u; m &= m - 1; }
 #pragma unroll
-          for (int j = 0; j < 4; j++) pp[j] = kk[j] < 32u ? s_par[t2 + kk[j] * T] : 0u;
+          for (int j = 0; j < 4; j++) pp[j] = kk[j] < 32u ? L.par[t2 + kk[j] * T] : 0u;
 #pragma unroll
-          for (int j = 0; j < 4; j++) pp[j] = s_par[pp[j]];
+          for (int j = 0; j < 4; j++) pp[j] = L.par[pp[j]];
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             if (kk[j] < 32u) {
               if (pp[j] >= ZG_PAR_EXIT) unresolved &= ~(1u << kk[j]);     // its pointer is the root
-              else s_par[t2 + kk[j] * T] = (uint16_t)pp[j];               // u16 stores are atomic
+              else L.par[t2 + kk[j] * T] = (uint16_t)pp[j];               // u16 stores are atomic
             }
           }
         }
-        if (unresolved) s_err = ZG_INTERNAL;   // cannot happen: every step moves a pointer up its chain (seen by everybody behind the next barrier)
+        if (unresolved) L.err = ZG_INTERNAL;   // cannot happen: every step moves a pointer up its chain (seen by everybody behind the next barrier)
       }
       ZG_TICK(3)
       // ---- S3a: the scratch words requested in S1c have arrived: the roots' effective offsets are completed in LDS
       const uint32_t t3 = ZG_FRESH(t);
 #pragma unroll
-      for (int k = 0; k < PER; k++) __hip_atomic_fetch_add(&s_word[t3 + k * T], wadd[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_u32; 0 where nothing was requested
+      for (int k = 0; k < PER; k++) __hip_atomic_fetch_add(&L.word[t3 + k * T], wadd[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_u32; 0 where nothing was requested
       zg_lds_barrier();
       ZG_TICK(4)
-      if (s_err) break;
+      if (L.err) break;
       // ---- S3b: every byte's effective offset = its root's + the distance to the root (a literal root counts 0) -> scratch;
       // the tile's literal bytes are fetched and go to the output
       constexpr int H = PER < 8 ? PER : 8;                        // bytes per batch (their loads are in flight together)
@@ -1612,11 +1571,11 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
         uint32_t lb[H], islm = 0, pr[H], w[H];
         // (three passes over the batch, so that its LDS reads go out together: one round trip for the pointers, one for the words)
 #pragma unroll
-        for (int h = 0; h < H; h++) pr[h] = s_par[t3 + (k0 + h) * T];
+        for (int h = 0; h < H; h++) pr[h] = L.par[t3 + (k0 + h) * T];
         // (each of these loops takes its inputs last first: the one wait in front of the first use then covers the whole batch,
         //  where first-to-last order costs a wait instruction per element; the kernel is bound by instructions issued)
 #pragma unroll
-        for (int h = H - 1; h >= 0; h--) { const uint32_t x = t3 + (k0 + h) * T; w[h] = s_word[pr[h] >= ZG_PAR_EXIT ? x : pr[h]]; }
+        for (int h = H - 1; h >= 0; h--) { const uint32_t x = t3 + (k0 + h) * T; w[h] = L.word[pr[h] >= ZG_PAR_EXIT ? x : pr[h]]; }
 #pragma unroll
         for (int h = H - 1; h >= 0; h--) {
           const uint32_t x = t3 + (k0 + h) * T;
@@ -1632,17 +1591,17 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
         for (int h = 0; h < H; h++)   // (lb[0] was requested last)
           __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(lb[h] | lit_fill), out_rs, ((islm >> h) & 1u) ? tu0 + t3 + (k0 + h) * T : ZG_OOB, 0, 0);
       }
-      zg_lds_barrier();  // s_par / s_word / the records are reused by the next tile
+      zg_lds_barrier();  // L.par / L.word / the records are reused by the next tile
       ZG_TICK(5)
       t0 = t1;
       i_start = i_next;
     }
-    if (s_err || s_bad != ~0ull) {
+    if (L.err || L.bad != ~0ull) {
       if (t == 0) {
         const ZgFrame fr = d.frames[un.frame];
-        uint32_t st = s_err;
+        uint32_t st = L.err;
         if (!st) {
-          const unsigned long long bad = s_bad;
+          const unsigned long long bad = L.bad;
           const uint32_t m0 = ((uint32_t)bad >> 8) & 0x1FFFFu;
           st = (uint32_t)bad & 0xFFu;
           if (st == (uint32_t)ZG_EXE_OFFSET_TOO_BIG && p.out_base + fr.prior_out + m0 <= fr.window_size) st = ZG_EXE_DICT_TOO_SMALL;
@@ -1653,7 +1612,7 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
     }
   }
   __syncthreads();
-  if (t == 0) { ZgUnitInfo ui; ui.size = unit_size; ui.noseq = un.noseq; d.unit_info[blockIdx.x] = ui; }
+  if (t == 0) { ZgUnitInfo ui2; ui2.size = unit_size; ui2.noseq = un.noseq; d.unit_info[ui] = ui2; }
 #ifdef ZG_PROFILE_FLAT
   if (t == 0 && d.dbg) { for (int i = 0; i < 8; i++) atomicAdd(&d.dbg[i], tc[i]); }
 #endif
@@ -1661,8 +1620,8 @@ __global__ void __launch_bounds__(T, (TS / T == 16) ? 4 : 8) zg_k_flat(ZgBatchDe
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// zg_k_flat4: the flatten stage at dword granularity, with direct (value) units — the body is zg_flat4.h, written against
-// the zx_* primitives below so that tests/emu runs the same source on the CPU. One workgroup per unit.
+// zg_flat4_unit: the flatten of a frame's first unit at dword granularity, resolved to byte values (direct unit) — the body is
+// zg_flat4.h, written against the zx_* primitives below so that tests/emu runs the same source on the CPU.
 // ------------------------------------------------------------------------------------------------------------
 #define ZX_DEV __device__ __forceinline__
 // "not needed": an offset no resource of the flatten covers (they are all far below 2^31 bytes). Not 0xFFFFFFFF: the compiler narrows
@@ -1677,21 +1636,16 @@ ZX_DEV void zx_barrier() { zg_lds_barrier(); }
 ZX_DEV void zx_barrier_vm() { __builtin_amdgcn_s_waitcnt(0x0F70); zg_lds_barrier(); }
 ZX_DEV unsigned long long zx_ballot(bool p) { return __ballot(p); }
 ZX_DEV uint32_t zx_shfl_up(uint32_t v, int o) { return __shfl_up(v, o, 64); }
-ZX_DEV uint32_t zx_shfl(uint32_t v, int src) { return __shfl(v, src, 64); }
-ZX_DEV uint32_t zx_add_lds(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 ZX_DEV void zx_or_lds(uint32_t* p, uint32_t v) { atomicOr(p, v); }
 ZX_DEV void zx_min_lds(uint32_t* p, uint32_t v) { atomicMin(p, v); }
 ZX_DEV void zx_min_lds64(unsigned long long* p, unsigned long long v) { atomicMin(p, v); }
 ZX_DEV void zx_min_glb(uint32_t* p, uint32_t v) { atomicMin(p, v); }
 ZX_DEV ZxBuf zx_buf(const void* base, uint32_t bytes) { return zg_make_rsrc(base, bytes); }
-ZX_DEV uint32_t zx_ld8(ZxBuf b, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b8(b, off, 0, 0); }
 ZX_DEV uint32_t zx_ld32(ZxBuf b, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b32(b, off, 0, 0); }
 ZX_DEV ZxU2 zx_ld64(ZxBuf b, uint32_t off) { const zg_v2u v = __builtin_amdgcn_raw_buffer_load_b64(b, off, 0, 0); ZxU2 r; r.x = v.x; r.y = v.y; return r; }
 ZX_DEV ZxU3 zx_ld96(ZxBuf b, uint32_t off) { const zg_v3u v = __builtin_amdgcn_raw_buffer_load_b96(b, off, 0, 0); ZxU3 r; r.x = v.x; r.y = v.y; r.z = v.z; return r; }
-ZX_DEV ZxU4 zx_ld128(ZxBuf b, uint32_t off) { const zg_v4u v = __builtin_amdgcn_raw_buffer_load_b128(b, off, 0, 0); ZxU4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
 ZX_DEV void zx_st8(ZxBuf b, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v, b, off, 0, 0); }
 ZX_DEV void zx_st32(ZxBuf b, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, b, off, 0, 0); }
-ZX_DEV void zx_st128(ZxBuf b, uint32_t off, const ZxU4& v) { __builtin_amdgcn_raw_buffer_store_b128(zg_v4u{v.x, v.y, v.z, v.w}, b, off, 0, 0); }
 ZX_DEV uint32_t zx_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 typedef short zg_v2s __attribute__((ext_vector_type(2)));
 // packed 16-bit lanes (v_pk_sub_i16, v_pk_ashrrev_i16): a - b per lane; 0xFFFF per lane whose signed value is negative
@@ -1700,12 +1654,17 @@ ZX_DEV uint32_t zx_pksub16(uint32_t a, uint32_t b) { return __builtin_bit_cast(u
 ZX_DEV uint32_t zx_pksign16(uint32_t a) { uint32_t r; asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a)); return r; }
 #include "zg_flat4.h"
 
+// zg_k_flatten: one workgroup per unit. A frame's first unit (nothing in front of it to copy from) is resolved to bytes by the
+// dword-granular body (zg_flat4_unit: no scratch, no sweep step); every other unit gets its effective offsets from the
+// byte-granular body above (zg_flat1_unit) — measured on the 1e9-byte frame, the dword-granular body in pointer mode issued 23 %
+// more vector instructions than this one (its pointer jumping works on clumps of four bytes that share their fate, and a wave
+// lasts as long as its busiest lane), so it is used where it wins: where values can flow.
 template <int T, int TS, int SPT>
-__global__ void __launch_bounds__(T, 4) zg_k_flat4(ZgBatchDev d) {
-  __shared__ union { ZgFlat4Lds<T, TS, SPT, false> p; ZgFlat4Lds<T, TS, SPT, true> v; } s_u;
+__global__ void __launch_bounds__(T, 4) zg_k_flatten(ZgBatchDev d) {
+  __shared__ union { ZgFlat1Lds<T, TS, SPT> p; ZgFlat4Lds<T, TS, SPT> v; } s_u;
   if (threadIdx.x == 0) { ZgUnitInfo ui; ui.size = 0; ui.noseq = 0; d.unit_info[blockIdx.x] = ui; }
-  if (d.units[blockIdx.x].noseq & ZG_UNIT_DIRECT) zg_flat4_unit<T, TS, SPT, true>(d, blockIdx.x, s_u.v);
-  else zg_flat4_unit<T, TS, SPT, false>(d, blockIdx.x, s_u.p);
+  if (d.units[blockIdx.x].noseq & ZG_UNIT_DIRECT) zg_flat4_unit<T, TS, SPT>(d, blockIdx.x, s_u.v);
+  else zg_flat1_unit<T, TS, SPT>(d, blockIdx.x, s_u.p);
 }
 
 // zg_k_swprep: one thread per (step, unit) entry: everything a sweep workgroup needs about its unit in one 32-byte
@@ -2012,8 +1971,8 @@ void zg_launch_scan(const ZgBatchDev& d, hipStream_t s) {
   hipLaunchKernelGGL(zg_k_scan, dim3(d.nframes), dim3(ZG_SCAN_T), 0, s, d);
   hipLaunchKernelGGL(zg_k_scanf, dim3(1), dim3(1024), 0, s, d);
 }
-void zg_launch_lit(const ZgBatchDev& d, hipStream_t s, uint32_t part) {
-  if (d.nblocks) hipLaunchKernelGGL(zg_k_lit, dim3(d.nblocks), dim3(256), 0, s, d, part);
+void zg_launch_lit(const ZgBatchDev& d, hipStream_t s) {
+  if (d.nblocks) hipLaunchKernelGGL(zg_k_lit, dim3(d.nblocks), dim3(256), 0, s, d);
 }
 // ------------------------------------------------------------------------------------------------------------
 // zg_k_sparse: the matches of a frame that has hardly any (literal-heavy data: a sequence or two in one block out of twenty).
@@ -2071,13 +2030,8 @@ void zg_launch_sparse(const ZgBatchDev& d, hipStream_t s) {
 void zg_launch_flat(const ZgBatchDev& d, hipStream_t s) {
   if (!d.nunits) return;
   const uint32_t shape = (d.flags >> 2) & 3u;
-  if (d.flags & 16u) {   // (measurement only, ZGPU_FLAT=old) the byte-granular kernel of round 2
-    if (shape == 1) hipLaunchKernelGGL((zg_k_flat<512, 8192, 2>), dim3(d.nunits), dim3(512), 0, s, d);
-    else hipLaunchKernelGGL((zg_k_flat<1024, 16384, 2>), dim3(d.nunits), dim3(1024), 0, s, d);
-    return;
-  }
-  if (shape == 1) hipLaunchKernelGGL((zg_k_flat4<512, 8192, 2>), dim3(d.nunits), dim3(512), 0, s, d);
-  else hipLaunchKernelGGL((zg_k_flat4<1024, 16384, 2>), dim3(d.nunits), dim3(1024), 0, s, d);
+  if (shape == 1) hipLaunchKernelGGL((zg_k_flatten<512, 8192, 2>), dim3(d.nunits), dim3(512), 0, s, d);
+  else hipLaunchKernelGGL((zg_k_flatten<1024, 16384, 2>), dim3(d.nunits), dim3(1024), 0, s, d);
 }
 bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* steps, uint32_t nsteps, hipStream_t s2, hipEvent_t* evs, uint32_t nev,
                      uint32_t unit_bytes, uint32_t window_max, uint32_t window_min) {

@@ -89,7 +89,6 @@ enum { ZG_MODE_PREDEFINED = 0, ZG_MODE_RLE = 1, ZG_MODE_FSE = 2, ZG_MODE_REPEAT 
 #define ZG_HUF_PACK(sym, nb) ((uint16_t)((sym) | ((nb) << 8)))
 
 // One block as described by the host parser (block header + both section headers + table lineage).
-#define ZG_BLK_DIRECT 1u
 struct ZgBlock {
   uint64_t src_off;        // offset of the block body in the compressed buffer
   uint32_t src_len;        // body length (Block_Content: 1 for RLE blocks)
@@ -109,7 +108,7 @@ struct ZgBlock {
   uint64_t lit_base;       // offset of this block's regenerated literals in the literals arena
   uint64_t seq_base;       // index of this block's first sequence in the sequence arena
   uint32_t seq_idx;        // position of this block in the list of blocks that have sequences (flatten scratch slot)
-  uint32_t flags;          // ZG_BLK_DIRECT: the block belongs to a direct unit (zg_k_flat4 writes its bytes, literals included)
+  uint32_t pad1;
 };
 
 // One frame of the batch.
@@ -181,7 +180,7 @@ struct ZgFrameOut {
 
 // LZ77 execution works on units: runs of consecutive blocks of one frame that zg_k_flat resolves together.
 // noseq: bit 0: none of the unit's blocks has sequences: all of it is literal bytes, final after zg_k_lit; bit 1 (ZG_UNIT_DIRECT):
-// the frame's first unit, resolved to bytes by zg_k_flat4 itself. Either way: no scratch words, no sweep step.
+// the frame's first unit, resolved to bytes by the flatten itself (zg_flat4.h). Either way: no scratch words, no sweep step.
 // flatten stage (zg_flat4.h): parent markers of a tile byte, and the largest block output the flatten path handles
 #define ZG_PAR_LIT 0xFFFFu   // tile byte is a literal (or dead)
 #define ZG_PAR_EXIT 0x8000u  // tile byte is a match byte whose parent lies before the tile
