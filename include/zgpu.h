@@ -106,8 +106,10 @@ int zgpu_pool_create(int n_gpus /* <= 0: all visible */, zgpu_pool** out);
 int zgpu_pool_create_on(const int* devices, int n, zgpu_pool** out);   /* explicit device ids (e.g. {LOCAL_RANK} in a one-process-per-GPU job) */
 void zgpu_pool_destroy(zgpu_pool*);
 int zgpu_pool_num_gpus(const zgpu_pool*);
-/* decode_all over the pool: the buffer is cut into frames on the host, jobs (runs of frames, >= 64 MiB of input) are queued
- * largest first and pulled by the GPUs; plaintext back to back in input order, first error in input order wins. */
+/* decode_all over the pool: the buffer is cut into frames on the host, jobs (runs of frames, >= 32 MiB of input) are queued
+ * largest first and pulled by two engines per GPU, so that the upload of one job, the kernels of another and the download of a
+ * third overlap (pass pinned host memory for src and dst to get real DMA overlap); plaintext back to back in input order, first
+ * error in input order wins. Device memory is proportional to the jobs in flight when the frames declare their content size. */
 int zgpu_pool_decode_all(zgpu_pool*, const uint8_t* src, size_t len, uint8_t* dst, size_t cap, size_t* written);
 /* The plan of the queue, host only (no GPU touched): longest-processing-time-first order of n jobs by cost and the worker
  * each job goes to when n_workers workers pull in that order with time proportional to cost; load_out[w] = sum of w's costs. */
@@ -116,6 +118,8 @@ int zgpu_pool_plan(const uint64_t* cost, uint32_t n, uint32_t n_workers, uint32_
  * resident submit per GPU — then run passes over them; outputs stay in HBM. */
 int zgpu_pool_stage(zgpu_pool*, const uint8_t* const* frames, const size_t* lens, uint32_t n);
 int zgpu_pool_run(zgpu_pool*, float* gpu_ms /* [num_gpus] kernel pipeline ms per GPU */, float* wall_ms);
+/* per-kernel times of GPU g's last pass (ms, the order of zgpu_batch_timings) and what its resident submit holds */
+int zgpu_pool_timings(const zgpu_pool*, uint32_t g, float* ms, int n, uint64_t* plain_bytes, uint64_t* comp_bytes, uint32_t* nblocks);
 int zgpu_pool_frame(zgpu_pool*, uint32_t i, int* gpu, uint64_t* out_size, uint32_t* status);
 int zgpu_pool_read(zgpu_pool*, uint32_t i, uint8_t* dst, size_t cap, size_t* written);
 

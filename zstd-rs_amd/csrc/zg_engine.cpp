@@ -14,15 +14,15 @@ namespace zg {
 int DevBuf::reserve(size_t n, bool keep, hipStream_t s) {
   if (n <= cap && p) return 0;
   size_t ncap = n < 256 ? 256 : n;
-  if (p && ncap < cap + cap / 2) ncap = cap + cap / 2;   // a buffer that grows again: amortise
+  // a buffer that grows again: amortise, but by no more than 256 MiB (the large ones are sized exactly by their callers)
+  if (p) { const size_t slack = cap / 2 < (256u << 20) ? cap / 2 : (256u << 20); if (ncap < cap + slack) ncap = cap + slack; }
+  if (p && !(keep && cap)) { (void)hipFree(p); p = nullptr; cap = 0; }   // nothing to keep: free first (old + new need not fit together)
   void* np = nullptr;
   if (hipMalloc(&np, ncap) != hipSuccess) return ZG_NOMEM;
   if (p) {
-    if (keep && cap) {
-      if (hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-        (void)hipFree(np);
-        return ZG_HIP_ERROR;
-      }
+    if (hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+      (void)hipFree(np);
+      return ZG_HIP_ERROR;
     }
     (void)hipFree(p);
   }
@@ -47,6 +47,10 @@ int Scratch::init_events() {
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return ZG_HIP_ERROR;
   have_events = true;
   return 0;
+}
+void Scratch::release_but_output() {
+  DevBuf* all[] = {&d_src, &d_aux, &d_slot_log, &d_fse, &d_huf, &d_hufmax, &d_lit, &d_seq, &d_og, &d_raw};
+  for (DevBuf* b : all) b->release();
 }
 void Scratch::release() {
   DevBuf* all[] = {&d_src, &d_blocks, &d_frames, &d_aux, &d_slot_log, &d_fse, &d_huf, &d_hufmax, &d_status, &d_lit, &d_seq, &d_seqout, &d_pos,
@@ -526,6 +530,14 @@ void Batch::launch_sweep(bool split) {
   sweep_mode = split_sweep ? 1u : sweep_mode;
 }
 
+void Batch::release_scratch() {
+  if (!sc || !eng || !synced) return;
+  (void)hipSetDevice(eng->device_);
+  sc->release_but_output();
+  dev.og = nullptr; dev.src = nullptr; dev.lit_arena = nullptr; dev.seq_arena = nullptr; dev.raw_arena = nullptr;
+  ran = false;                     // (the submit cannot be run again; reading its output stays possible)
+}
+
 int Batch::sync() {
   ZG_HIP(hipSetDevice(eng->device_));
   ZG_HIP(hipStreamSynchronize(eng->stream_));
@@ -585,7 +597,10 @@ int Batch::commit(FrameState* st) {
 int Batch::read_output(uint64_t off, uint8_t* dst, uint64_t n) {
   if (ran && !synced) { const int st = sync(); if (st) return st; }   // (sync() may still have to repeat the sweep)
   if (off + n > dev.dst_cap) return ZG_BAD_ARG;
-  if (n) ZG_HIP(hipMemcpy(dst, dev.dst + off, n, hipMemcpyDeviceToHost));
+  if (n) {   // on the engine's second stream (idle once the run is synced): several engines' downloads and uploads overlap
+    ZG_HIP(hipMemcpyAsync(dst, dev.dst + off, n, hipMemcpyDeviceToHost, eng->stream2_));
+    ZG_HIP(hipStreamSynchronize(eng->stream2_));
+  }
   return ZG_OK;
 }
 int Batch::read_output_async(uint64_t off, uint8_t* dst, uint64_t n, hipStream_t s) {

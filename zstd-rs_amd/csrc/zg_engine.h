@@ -72,6 +72,7 @@ struct Scratch {
   bool have_events = false;
   int init_events();
   void release();
+  void release_but_output();
 };
 
 class Engine;
@@ -104,6 +105,8 @@ class Batch {
   int read_output(uint64_t off, uint8_t* dst, uint64_t n);   // D2H
   int read_output_async(uint64_t off, uint8_t* dst, uint64_t n, hipStream_t s);
   const uint8_t* device_output() const { return dev.dst; }
+  // after sync(): free everything but the plaintext (a finished submit that waits to be read: zgpu_pool_decode_all)
+  void release_scratch();
   // intermediates, for parity tests
   int read_block_status(std::vector<uint32_t>* out);
   int read_literals(uint32_t block, std::vector<uint8_t>* out);

@@ -1391,7 +1391,10 @@ __device__ __forceinline__ void zg_flat1_unit(const ZgBatchDev& d, const uint32_
     const __amdgpu_buffer_rsrc_t out_rs = zg_make_rsrc(out_u, un.nblocks * ZG_FLAT_MAX);
     // bytes of the frame (and dictionary) that exist before this block: the farthest a match may reach. Offsets are < 2^30
     // and positions in the block < 2^17: once 2^31 bytes exist every offset is in reach, else 32-bit arithmetic decides.
-    const uint64_t reach = p.out_base + d.frames[un.frame].prior_reach + d.frames[un.frame].dict_len;
+    // (once the caller has drained bytes the dictionary is out of reach: DecodeBuffer holds nothing older than what is undrained, and
+    //  total_output_counter has passed window_size by then — repeat_from_dict, decode_buffer.rs:144-179, answers OffsetTooBig)
+    const ZgFrame& frr = d.frames[un.frame];
+    const uint64_t reach = p.out_base + frr.prior_reach + (frr.prior_reach == frr.prior_out ? frr.dict_len : 0ull);
     const bool reach_all = reach >= 0x80000000ull;
     const uint32_t reach32 = (uint32_t)reach;
     // the sequences a thread places per tile travel in registers: they are requested one tile ahead
@@ -1862,7 +1865,7 @@ __global__ void __launch_bounds__(ZG_LZ_T) zg_k_lz(ZgBatchDev d) {
         if (lit_rle) { const uint8_t v = lit[0]; for (uint32_t k = 0; k < ll; k++) o[k] = v; }
         else { const uint8_t* s = lit + lit_start; for (uint32_t k = 0; k < ll; k++) o[k] = s[k]; }
         if (off == 0) { atomicCAS(&s_err, 0u, (uint32_t)ZG_EXE_ZERO_OFFSET); }
-        else if ((uint64_t)off > dpos + fr.prior_reach + fr.dict_len) { atomicCAS(&s_err, 0u, (uint32_t)(dpos + fr.prior_out <= fr.window_size ? ZG_EXE_DICT_TOO_SMALL : ZG_EXE_OFFSET_TOO_BIG)); }
+        else if ((uint64_t)off > dpos + fr.prior_reach + (fr.prior_reach == fr.prior_out ? fr.dict_len : 0ull)) { atomicCAS(&s_err, 0u, (uint32_t)(dpos + fr.prior_out <= fr.window_size ? ZG_EXE_DICT_TOO_SMALL : ZG_EXE_OFFSET_TOO_BIG)); }
         else pending = ml > 0;
       }
       carry_out = to; carry_lit = tl;

@@ -6,6 +6,9 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
@@ -43,58 +46,114 @@ struct Staged {            // one worker's resident submit: its frames concatena
 
 }  // namespace
 
+// the calling thread's current HIP device is left as it was found
+struct DeviceGuard {
+  int dev = -1;
+  DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+  ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
+
 struct zgpu_pool {
-  std::vector<Engine*> eng;
+  std::vector<Engine*> eng;        // one per GPU: the resident (staged) submits and zgpu_pool_run
+  std::vector<Engine*> eng2;       // a second engine per GPU for zgpu_pool_decode_all: the upload of one job, the kernels of another and the
+                                   // download of a third overlap on their own streams (same index as eng)
   std::vector<Staged> staged;
-  std::vector<uint32_t> frame_worker, frame_slot;   // staged frames: which worker, which frame of its batch
+  std::vector<uint32_t> frame_worker, frame_slot, frame_count;   // staged entries: which worker, first frame of its batch, number of frames (0: skippable only)
   uint32_t nframes = 0;
+  // persistent workers: one thread per engine, woken per pass (no thread is created inside a timed region)
+  std::vector<std::thread> threads;
+  std::mutex mu;
+  std::condition_variable cv_go, cv_done;
+  std::function<void(uint32_t)> task;   // task(worker index)
+  uint64_t gen = 0;
+  uint32_t pending = 0;
+  bool quit = false;
+  void start_workers(uint32_t n) {
+    for (uint32_t w = 0; w < n; w++)
+      threads.emplace_back([this, w]() {
+        uint64_t seen = 0;
+        for (;;) {
+          std::function<void(uint32_t)> fn;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_go.wait(lk, [&]() { return quit || gen != seen; });
+            if (quit) return;
+            seen = gen;
+            fn = task;
+          }
+          fn(w);
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            if (--pending == 0) cv_done.notify_all();
+          }
+        }
+      });
+  }
+  // run fn(w) on every worker thread, return when all are done
+  void run_on_workers(const std::function<void(uint32_t)>& fn) {
+    std::unique_lock<std::mutex> lk(mu);
+    task = fn;
+    pending = (uint32_t)threads.size();
+    gen++;
+    cv_go.notify_all();
+    cv_done.wait(lk, [&]() { return pending == 0; });
+  }
+  void stop_workers() {
+    { std::lock_guard<std::mutex> lk(mu); quit = true; }
+    cv_go.notify_all();
+    for (auto& t : threads) t.join();
+    threads.clear();
+  }
 };
 
 extern "C" {
+
+static int pool_build(const int* devices, int n, zgpu_pool** out) {
+  DeviceGuard guard;
+  zgpu_pool* p = new (std::nothrow) zgpu_pool();
+  if (!p) return ZGPU_E_NOMEM;
+  for (int i = 0; i < n; i++) {
+    Engine *e = nullptr, *e2 = nullptr;
+    int st = Engine::create(devices[i], &e);
+    if (!st) st = Engine::create(devices[i], &e2);
+    if (st) { delete e; for (Engine* x : p->eng) delete x; for (Engine* x : p->eng2) delete x; delete p; return st; }
+    p->eng.push_back(e);
+    p->eng2.push_back(e2);
+  }
+  p->staged.resize(p->eng.size());
+  p->start_workers(2u * (uint32_t)p->eng.size());   // workers [0, n): the GPUs' first engines; [n, 2n): their second ones (decode_all only)
+  *out = p;
+  return ZGPU_OK;
+}
 
 int zgpu_pool_create(int n_gpus, zgpu_pool** out) {
   if (!out) return ZGPU_E_BAD_ARG;
   int have = 0;
   if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) return ZGPU_E_HIP;   // no GPU: fail loudly, no CPU path
   if (n_gpus <= 0 || n_gpus > have) n_gpus = have;
-  zgpu_pool* p = new (std::nothrow) zgpu_pool();
-  if (!p) return ZGPU_E_NOMEM;
-  for (int i = 0; i < n_gpus; i++) {
-    Engine* e = nullptr;
-    int st = Engine::create(i, &e);
-    if (st) { zgpu_pool_destroy(p); return st; }
-    p->eng.push_back(e);
-  }
-  p->staged.resize(p->eng.size());
-  *out = p;
-  return ZGPU_OK;
+  std::vector<int> dev(n_gpus);
+  for (int i = 0; i < n_gpus; i++) dev[i] = i;
+  return pool_build(dev.data(), n_gpus, out);
 }
 
-// one engine on a given device (a process that owns one GPU of the node, e.g. one rank of a torch.distributed job)
+// one engine pair on each given device (a process that owns one GPU of the node, e.g. one rank of a torch.distributed job)
 int zgpu_pool_create_on(const int* devices, int n, zgpu_pool** out) {
   if (!out || !devices || n <= 0) return ZGPU_E_BAD_ARG;
-  zgpu_pool* p = new (std::nothrow) zgpu_pool();
-  if (!p) return ZGPU_E_NOMEM;
-  for (int i = 0; i < n; i++) {
-    Engine* e = nullptr;
-    int st = Engine::create(devices[i], &e);
-    if (st) { zgpu_pool_destroy(p); return st; }
-    p->eng.push_back(e);
-  }
-  p->staged.resize(p->eng.size());
-  *out = p;
-  return ZGPU_OK;
+  return pool_build(devices, n, out);
 }
 
 static void pool_unstage(zgpu_pool* p) {
   for (Staged& s : p->staged) { delete s.batch; s = Staged(); }
-  p->frame_worker.clear(); p->frame_slot.clear(); p->nframes = 0;
+  p->frame_worker.clear(); p->frame_slot.clear(); p->frame_count.clear(); p->nframes = 0;
 }
 
 void zgpu_pool_destroy(zgpu_pool* p) {
   if (!p) return;
+  DeviceGuard guard;
+  p->stop_workers();
   pool_unstage(p);
   for (Engine* e : p->eng) delete e;
+  for (Engine* e : p->eng2) delete e;
   delete p;
 }
 int zgpu_pool_num_gpus(const zgpu_pool* p) { return p ? (int)p->eng.size() : 0; }
@@ -113,6 +172,7 @@ int zgpu_pool_plan(const uint64_t* cost, uint32_t n, uint32_t n_workers, uint32_
 // outside any timed region). Each entry of `frames` is one zstd frame (or a run of concatenated frames).
 int zgpu_pool_stage(zgpu_pool* p, const uint8_t* const* frames, const size_t* lens, uint32_t n) {
   if (!p || (!frames && n) || (!lens && n)) return ZGPU_E_BAD_ARG;
+  DeviceGuard guard;
   pool_unstage(p);
   const uint32_t nw = (uint32_t)p->eng.size();
   std::vector<uint64_t> cost(n);
@@ -122,6 +182,7 @@ int zgpu_pool_stage(zgpu_pool* p, const uint8_t* const* frames, const size_t* le
   lpt_plan(cost.data(), n, nw, &order, &worker, &load);
   p->frame_worker = worker;
   p->frame_slot.assign(n, 0);
+  p->frame_count.assign(n, 0);
   p->nframes = n;
   for (uint32_t w = 0; w < nw; w++) p->staged[w].blob.reserve(load[w]);
   for (uint32_t i = 0; i < n; i++) {             // blob order = caller's order among a worker's frames
@@ -129,47 +190,50 @@ int zgpu_pool_stage(zgpu_pool* p, const uint8_t* const* frames, const size_t* le
     s.frames.push_back(i);
     s.blob.insert(s.blob.end(), frames[i], frames[i] + lens[i]);
   }
-  std::vector<std::thread> th;
-  for (uint32_t w = 0; w < nw; w++)
-    th.emplace_back([p, w]() {
-      Staged& s = p->staged[w];
-      if (s.frames.empty()) return;
-      s.status = p->eng[w]->prepare(s.blob.data(), s.blob.size(), &s.batch);
-      if (!s.status && s.batch) s.status = s.batch->parse_status;
-    });
-  for (auto& t : th) t.join();
-  // a caller's entry may hold several frames (skippable ones hold none): slot = index of its first frame in the worker's batch
-  for (uint32_t w = 0; w < nw; w++) {
+  p->run_on_workers([p, nw](uint32_t w) {
+    if (w >= nw) return;
     Staged& s = p->staged[w];
-    if (s.status) return s.status;
+    if (s.frames.empty()) return;
+    s.status = p->eng[w]->prepare(s.blob.data(), s.blob.size(), &s.batch);
+    if (!s.status && s.batch) s.status = s.batch->parse_status;
+  });
+  // a caller's entry may hold several frames (skippable ones hold none): slot = index of its first frame in the worker's batch
+  int st = 0;
+  for (uint32_t w = 0; w < nw && !st; w++) {
+    Staged& s = p->staged[w];
+    if (s.status) { st = s.status; break; }
     uint32_t slot = 0;
     for (uint32_t i : s.frames) {
       p->frame_slot[i] = slot;
       std::vector<FrameSpan> sp;
       (void)split_frames(frames[i], lens[i], &sp);
-      for (const FrameSpan& f : sp) slot += f.skippable ? 0 : 1;
+      uint32_t c = 0;
+      for (const FrameSpan& f : sp) c += f.skippable ? 0 : 1;
+      p->frame_count[i] = c;
+      slot += c;
     }
   }
-  return ZGPU_OK;
+  if (st) pool_unstage(p);      // nothing half-staged is left behind
+  return st;
 }
 
 // One pass over everything staged: every GPU decodes its submit, all at once. gpu_ms[g] = kernel pipeline time of GPU g
 // (HIP events); returns when all are done. *wall_ms = time from the first enqueue to the last completion.
 int zgpu_pool_run(zgpu_pool* p, float* gpu_ms, float* wall_ms) {
   if (!p) return ZGPU_E_BAD_ARG;
+  DeviceGuard guard;
   const uint32_t nw = (uint32_t)p->eng.size();
   auto t0 = std::chrono::steady_clock::now();
-  std::vector<std::thread> th;
-  for (uint32_t w = 0; w < nw; w++)
-    th.emplace_back([p, w]() {
-      Staged& s = p->staged[w];
-      if (!s.batch) return;
-      int st = s.batch->run();
-      if (!st) st = s.batch->sync();
-      s.status = st;
-      s.kernel_ms = s.batch->ms[ZG_T_TOTAL];
-    });
-  for (auto& t : th) t.join();
+  auto pass = [p](uint32_t w) {
+    Staged& s = p->staged[w];
+    if (!s.batch) return;
+    int st = s.batch->run();
+    if (!st) st = s.batch->sync();
+    s.status = st;
+    s.kernel_ms = s.batch->ms[ZG_T_TOTAL];
+  };
+  if (nw == 1) pass(0);                                     // one GPU: on the caller's thread
+  else p->run_on_workers([&](uint32_t w) { if (w < nw) pass(w); });
   if (wall_ms) *wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   int st = 0;
   for (uint32_t w = 0; w < nw; w++) {
@@ -179,13 +243,26 @@ int zgpu_pool_run(zgpu_pool* p, float* gpu_ms, float* wall_ms) {
   return st;
 }
 
+// per-kernel times (HIP events, ms; the order of zgpu_batch_timings) of GPU g's last pass, and what its submit holds
+int zgpu_pool_timings(const zgpu_pool* p, uint32_t g, float* ms, int n, uint64_t* plain_bytes, uint64_t* comp_bytes, uint32_t* nblocks) {
+  if (!p || g >= p->staged.size() || (!ms && n)) return ZGPU_E_BAD_ARG;
+  const Staged& s = p->staged[g];
+  int k = n < ZG_T_COUNT ? n : ZG_T_COUNT;
+  for (int i = 0; i < k; i++) ms[i] = s.batch ? s.batch->ms[i] : 0.f;
+  if (plain_bytes) *plain_bytes = s.batch ? s.batch->total_out : 0;
+  if (comp_bytes) *comp_bytes = s.batch ? s.batch->src_len : 0;
+  if (nblocks) *nblocks = s.batch ? (uint32_t)s.batch->bb.blocks.size() : 0;
+  return ZGPU_OK;
+}
+
 // result of staged entry i after a run: which GPU took it, size and status of its (first) frame
 int zgpu_pool_frame(zgpu_pool* p, uint32_t i, int* gpu, uint64_t* out_size, uint32_t* status) {
   if (!p || i >= p->nframes) return ZGPU_E_BAD_ARG;
   const Staged& s = p->staged[p->frame_worker[i]];
+  if (gpu) *gpu = p->eng[p->frame_worker[i]]->device();
+  if (p->frame_count[i] == 0) { if (out_size) *out_size = 0; if (status) *status = 0; return s.batch ? ZGPU_OK : ZGPU_E_BAD_ARG; }   // skippable frames only
   if (!s.batch || p->frame_slot[i] >= s.batch->frame_out.size()) return ZGPU_E_BAD_ARG;
   const ZgFrameOut& fo = s.batch->frame_out[p->frame_slot[i]];
-  if (gpu) *gpu = p->eng[p->frame_worker[i]]->device();
   if (out_size) *out_size = fo.out_size;
   if (status) *status = fo.status;
   return ZGPU_OK;
@@ -193,7 +270,9 @@ int zgpu_pool_frame(zgpu_pool* p, uint32_t i, int* gpu, uint64_t* out_size, uint
 int zgpu_pool_read(zgpu_pool* p, uint32_t i, uint8_t* dst, size_t cap, size_t* written) {
   if (!p || i >= p->nframes) return ZGPU_E_BAD_ARG;
   Staged& s = p->staged[p->frame_worker[i]];
+  if (p->frame_count[i] == 0) { if (written) *written = 0; return s.batch ? ZGPU_OK : ZGPU_E_BAD_ARG; }
   if (!s.batch || p->frame_slot[i] >= s.batch->frame_out.size()) return ZGPU_E_BAD_ARG;
+  DeviceGuard guard;
   const ZgFrameOut& fo = s.batch->frame_out[p->frame_slot[i]];
   if (fo.status) return (int)fo.status;
   if (fo.out_size > cap) return ZGPU_E_TARGET_TOO_SMALL;
@@ -203,68 +282,89 @@ int zgpu_pool_read(zgpu_pool* p, uint32_t i, uint8_t* dst, size_t cap, size_t* w
 }
 
 // FrameDecoder::decode_all (frame_decoder.rs:541-577) over all GPUs of the pool: the buffer is cut into frames on the host
-// (frame + block headers only), runs of consecutive frames become jobs of >= 64 MiB of input (see below; or a single larger frame), the
-// jobs are queued largest first and pulled by one worker per GPU; the plaintext is written back to back in input order.
+// (frame + block headers only), runs of consecutive frames become jobs, the jobs are queued largest first and pulled by two
+// workers per GPU, each with its own engine: while one job's kernels run, the other engine uploads the next job or downloads
+// the previous one (H2D, kernels and D2H overlap when src and dst are pinned host memory; pageable buffers work, but their copies
+// are staged by the runtime). The plaintext is written back to back in input order. When every frame declares its
+// Frame_Content_Size — what every libzstd frame does — a job's place in dst is known before it is decoded: it is copied out and
+// its device memory released as soon as it is done (device memory is proportional to the jobs in flight, not to the input).
+// Otherwise the outputs wait on the GPUs — without their scratch — until all sizes are known.
 int zgpu_pool_decode_all(zgpu_pool* p, const uint8_t* src, size_t len, uint8_t* dst, size_t cap, size_t* written) {
   if (!p || !written || (!src && len) || (!dst && cap)) return ZGPU_E_BAD_ARG;
   *written = 0;
+  DeviceGuard guard;
   std::vector<FrameSpan> spans;
   const int walk = split_frames(src, len, &spans);     // frames in front of a malformed one are still decoded; the error wins below
-  struct Job { uint64_t begin, end; Batch* batch = nullptr; int status = 0; uint32_t gpu = 0; uint64_t out_off = 0, out_size = 0; };
+  struct Job { uint64_t begin, end; Batch* batch = nullptr; int status = 0; uint32_t worker = 0; uint64_t out_off = 0, out_size = 0, want_size = 0; bool placed = false; };
   std::vector<Job> jobs;
-  // A submit costs ~2 ms whatever its size (the length of one block's sequence chain), so jobs are as large as balance allows:
-  // about four per GPU when there are several GPUs, one otherwise; at most 1 GiB of input (~25 GB of device memory while it runs).
-  const uint64_t nw_ = p->eng.size();
-  uint64_t kJob = nw_ > 1 ? (uint64_t)len / (4 * nw_) : (uint64_t)len;
-  if (kJob < (64ull << 20)) kJob = 64ull << 20;
-  if (kJob > (1ull << 30)) kJob = 1ull << 30;
+  const uint64_t nw = p->eng.size();
+  // jobs: about eight per GPU (four per engine) so that the copies of one overlap the kernels of another, but not below 32 MiB of
+  // input (a submit costs ~2 ms whatever its size: the length of one block's sequence chain) nor above 512 MiB
+  uint64_t kJob = (uint64_t)len / (8 * nw);
+  if (kJob < (32ull << 20)) kJob = 32ull << 20;
+  if (kJob > (512ull << 20)) kJob = 512ull << 20;
+  bool sizes_known = true;
   for (const FrameSpan& s : spans) {
+    if (!s.skippable && !s.has_content_size) sizes_known = false;
     if (!jobs.empty() && jobs.back().end - jobs.back().begin < kJob && s.end - s.begin < kJob) jobs.back().end = s.end;
     else { Job j; j.begin = s.begin; j.end = s.end; jobs.push_back(j); }
+    if (!s.skippable) jobs.back().want_size += s.content_size;
   }
+  uint64_t want_total = 0;
+  for (Job& j : jobs) { j.out_off = want_total; want_total += j.want_size; }
+  const bool direct_out = sizes_known && walk == 0 && want_total <= cap;
   std::vector<uint32_t> order(jobs.size());
   for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return jobs[a].end - jobs[a].begin > jobs[b].end - jobs[b].begin; });
   std::atomic<uint32_t> next(0);
-  const uint32_t nw = (uint32_t)p->eng.size();
-  std::vector<std::thread> th;
-  for (uint32_t w = 0; w < nw; w++)
-    th.emplace_back([&, w]() {
-      for (;;) {
-        const uint32_t k = next.fetch_add(1);
-        if (k >= order.size()) break;
-        Job& j = jobs[order[k]];
-        j.gpu = w;
-        j.status = p->eng[w]->prepare(src + j.begin, (size_t)(j.end - j.begin), &j.batch);
-        if (!j.status && j.batch->parse_status) j.status = j.batch->parse_status;
-        if (!j.status) j.status = j.batch->run();      // outputs stay on the GPU until every job's size is known
-        if (!j.status) j.status = j.batch->sync();
-        if (!j.status)
-          for (const ZgFrameOut& fo : j.batch->frame_out)
-            if (fo.status) { j.status = (int)fo.status; break; }
-        if (!j.status) j.out_size = j.batch->total_out;
+  p->run_on_workers([&](uint32_t w) {
+    Engine* eng = w < nw ? p->eng[w] : p->eng2[w - nw];
+    for (;;) {
+      const uint32_t k = next.fetch_add(1);
+      if (k >= order.size()) break;
+      Job& j = jobs[order[k]];
+      j.worker = w;
+      j.status = eng->prepare(src + j.begin, (size_t)(j.end - j.begin), &j.batch);
+      if (!j.status && j.batch->parse_status) j.status = j.batch->parse_status;
+      if (!j.status) j.status = j.batch->run();
+      if (!j.status) j.status = j.batch->sync();
+      if (!j.status)
+        for (const ZgFrameOut& fo : j.batch->frame_out)
+          if (fo.status) { j.status = (int)fo.status; break; }
+      if (!j.status) j.out_size = j.batch->total_out;
+      if (!j.status && direct_out && j.out_size == j.want_size) {
+        j.status = j.batch->read_output(0, dst + j.out_off, j.out_size);
+        j.placed = true;
+        delete j.batch; j.batch = nullptr;
+      } else if (j.batch) {
+        j.batch->release_scratch();        // only the plaintext stays on the device until its place is known
       }
-    });
-  for (auto& t : th) t.join();
+    }
+  });
   int st = 0;
   uint64_t total = 0;
+  bool all_placed = true;
   for (Job& j : jobs) {                                  // the first error in input order is the one the reference would return
     if (j.status) { st = j.status; break; }
-    j.out_off = total;
+    if (!j.placed || j.out_off != total) all_placed = false;
     total += j.out_size;
   }
   if (!st && walk) st = walk;
   if (!st && total > cap) st = ZGPU_E_TARGET_TOO_SMALL;
-  if (!st) {
-    th.clear();
-    std::vector<int> cst(nw, 0);
-    for (uint32_t w = 0; w < nw; w++)
-      th.emplace_back([&, w]() {
-        for (Job& j : jobs)
-          if (j.gpu == w && j.batch && !cst[w]) cst[w] = j.batch->read_output(0, dst + j.out_off, j.out_size);
-      });
-    for (auto& t : th) t.join();
-    for (int c : cst) if (c && !st) st = c;
+  if (!st && !all_placed) {
+    // sizes were not declared (or a frame lied about its size): place everything now. Jobs already copied out move inside dst
+    // (front to back is safe: a job never moves towards the end... unless sizes were understated, so go through a staging copy)
+    uint64_t off = 0;
+    std::vector<uint8_t> tmp;
+    for (Job& j : jobs) {
+      if (j.placed) {
+        if (j.out_off != off) { tmp.assign(dst + j.out_off, dst + j.out_off + j.out_size); memcpy(dst + off, tmp.data(), j.out_size); }
+      } else if (j.batch) {
+        const int c = j.batch->read_output(0, dst + off, j.out_size);
+        if (c && !st) st = c;
+      }
+      off += j.out_size;
+    }
   }
   for (Job& j : jobs) delete j.batch;
   if (!st) *written = (size_t)total;

@@ -56,7 +56,7 @@ EXPORTS = [
     "zgpu_decoder_bytes_read_from_source", "zgpu_decoder_content_size", "zgpu_decoder_checksum_from_data",
     "zgpu_decoder_calculated_checksum", "zgpu_decode_all_alloc", "zgpu_free", "zgpu_decoder_collect_to_writer", "zgpu_streaming_create",
     "zgpu_streaming_destroy", "zgpu_streaming_decoder", "zgpu_streaming_read", "zgpu_pool_create", "zgpu_pool_create_on", "zgpu_pool_destroy",
-    "zgpu_pool_num_gpus", "zgpu_pool_decode_all", "zgpu_pool_plan", "zgpu_pool_stage", "zgpu_pool_run", "zgpu_pool_frame", "zgpu_pool_read",
+    "zgpu_pool_num_gpus", "zgpu_pool_decode_all", "zgpu_pool_plan", "zgpu_pool_stage", "zgpu_pool_run", "zgpu_pool_frame", "zgpu_pool_read", "zgpu_pool_timings",
     "zgpu_frame_begin", "zgpu_frame_end", "zgpu_blocks_submit", "zgpu_sync", "zgpu_available", "zgpu_read", "zgpu_device_output",
     "zgpu_frame_checksum", "zgpu_frame_blocks_decoded",
 ]
@@ -162,6 +162,7 @@ def load_library():
     L.zgpu_pool_run.argtypes = [vp, P(C.c_float), P(C.c_float)]
     L.zgpu_pool_frame.argtypes = [vp, C.c_uint32, P(C.c_int), P(C.c_uint64), P(C.c_uint32)]
     L.zgpu_pool_read.argtypes = [vp, C.c_uint32, vp, sz, P(sz)]
+    L.zgpu_pool_timings.argtypes = [vp, C.c_uint32, P(C.c_float), C.c_int, P(C.c_uint64), P(C.c_uint64), P(C.c_uint32)]
     _LIB = L
     return L
 
@@ -523,6 +524,15 @@ class Pool:
         if st:
             raise ZgpuError(st)
         return list(g), w.value
+
+    def timings(self, g=0):
+        """per-kernel times (ms) of GPU g's last pass + (plaintext bytes, compressed bytes, blocks) of its resident submit"""
+        a = (C.c_float * 10)()
+        pb, cb, nb = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        st = self.L.zgpu_pool_timings(self.h, g, a, 10, C.byref(pb), C.byref(cb), C.byref(nb))
+        if st:
+            raise ZgpuError(st)
+        return dict(zip(["tables", "huf", "seq", "seqpost", "scan", "lit", "flat", "sweep", "lz", "total"], list(a))), pb.value, cb.value, nb.value
 
     def frame(self, i):
         gpu, size, st = C.c_int(), C.c_uint64(), C.c_uint32()
