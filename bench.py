@@ -2,28 +2,35 @@
 """bench.py — decompressed GB/s of the zstd block-decode path on MI355X.
 
 A "step" is one pass of the hot path (FSE tables -> Huffman literals || FSE sequence chains -> scan -> LZ77 flatten ->
-sweep) over everything staged on this rank's GPU: the compressed frames and the host-parsed block tables are already in
-HBM when the timed region starts, the plaintext stays in HBM. The PCIe-inclusive rate (C ABI zgpu_decode_all, host buffer
-in, host buffer out) is measured separately and reported as `e2e_GBps`; it is never `value`.
+sweep) over everything staged on the GPUs: the compressed frames and the host-parsed block tables are already in HBM when
+the timed region starts, the plaintext stays in HBM. The PCIe-inclusive rate (C ABI zgpu_pool_decode_all, pinned host buffer
+in, pinned host buffer out, uploads / kernels / downloads overlapped) is measured separately and reported as `e2e_GBps`; it is
+never `value`.
 
-Workloads (BASELINE.json configs):
+Workloads (BASELINE.json configs). Sizes are per GPU; frames beyond the distinct ones are repeats of them (host
+generation and compression stay in seconds), every frame's output is compared with its plaintext before anything is timed:
   enwik9like  configs[1]  enwik9.zst as ONE frame per GPU. $ZGPU_DATA/enwik9 (1e9 bytes) is compressed with libzstd -3 when
-              present; else the stand-in text_like(1e9 B, seed 0xE9 + rank, V=14000) | libzstd -3 (ratio 3.19, 7630 blocks).
-              N > 1: every rank decodes its own frame (a single frame does not shard: replicas, weak scaling).
+              present; else the stand-in text_like(1e9 B, seed 0xE9 + gpu, V=14000) | libzstd -3 (ratio 3.19, 7630 blocks).
+              N > 1: every GPU decodes its own frame (a single frame does not shard: replicas, weak scaling).
+  realtext    a real-text single frame per GPU: source code and documentation found in this image (tools/realtext.py, 475 MB,
+              sha256 in tools/realtext_manifest.json) | libzstd -3: what the stand-in is a stand-in for.
   silesia12   configs[2]  12 independent frames ($ZGPU_DATA/silesia/* when present, else 12 synthetic frames of the Silesia
-              sizes), sharded over the ranks in LPT order (strong scaling, bounded by the largest frame).
-  blocks      configs[3]  16 x 64 MiB text frames (1 GiB of 128 KiB blocks, ratio 3.19) per GPU (weak scaling).
-  blocks4b    variant 4b  the same plaintext as 2048 single-block frames per GPU.
-  iso         configs[4]  iso_like frames, ratio 1.18 (Huffman-literal dominated), 8 x 64 MiB per GPU (weak scaling).
+              sizes), sharded over the GPUs in LPT order (strong scaling, bounded by the largest frame).
+  blocks      configs[3]  128 x 64 MiB text frames = 8 GiB of 128 KiB blocks (ratio 3.19) per GPU: one GPU's share of the 64 GiB
+              run (16 distinct frames x 8). Weak scaling.
+  blocks4b    variant 4b  16384 single-block frames (128 KiB each, 2 GiB) per GPU.
+  iso         configs[4]  128 x 64 MiB iso_like frames, ratio 1.18 (Huffman-literal dominated), 8 GiB per GPU (8 distinct x 16).
 
-The frames go through the library's work queue (zgpu_pool: LPT order, one worker + engine per GPU); under
-torch.distributed.run there is one process per GPU and each rank's pool holds its own GPU (frames -> ranks by the same LPT rule,
-zgpu_dist.shard_frames). Prints ONE JSON line (rank 0).
+--gpus N: under torch.distributed.run (WORLD_SIZE set) there is one process per GPU and each rank's pool holds its own GPU
+(frames -> ranks by the LPT rule of the library's queue, zgpu_dist.shard_frames); without it ONE process drives N engines
+through the library's work queue (zgpu_pool_create(N): one worker thread + engine per GPU). Prints ONE JSON line (rank 0).
+The timed region lasts at least --min-seconds whatever --steps says: a step then consists of `passes_per_step` passes.
 """
 import argparse
 import ctypes as C
 import hashlib
 import json
+import math
 import os
 import sys
 import threading
@@ -36,39 +43,48 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 SILESIA_SIZES = [51220480, 41458703, 33553445, 21606400, 10192446, 10085684, 9970564, 8474240, 7251944, 6627202, 6152192, 5345280]
-SILESIA_NAMES = ["mozilla", "webster", "nci", "samba", "dickens", "osdb", "mr", "x-ray", "sao", "reymont", "ooffice", "xml"]
+KERNELS = ("tables", "huf", "seq", "seqpost", "scan", "lit", "flat", "sweep", "lz")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
 
 
-def build_workload(name, rank, world, size):
-    """returns (description, [(plaintext, zst)] of the WHOLE job's frames for sharded workloads / of this rank for replicated
-    ones, sharded?, data tag)"""
+def build_workload(name, gpu, size, small=False):
+    """returns (description, distinct plaintexts, repeat, sharded?, data tag). The job's frames are distinct x repeat for
+    per-GPU workloads (gpu = index of the GPU they are built for), the whole job's frames for sharded ones."""
     import zgdata
     data_dir = os.environ.get("ZGPU_DATA")
     if name == "enwik9like":
         path = os.path.join(data_dir, "enwik9") if data_dir else None
         if path and os.path.exists(path):
             plain = open(path, "rb").read()
-            return "enwik9 (%d B from $ZGPU_DATA) | libzstd %s -3, one frame per GPU" % (len(plain), zgdata.zstd_version()), [plain], False, "file"
-        plain = zgdata.text_like(size, seed=0xE9 + rank)
-        return ("enwik9-like single frame: text_like(%d B, seed 0xE9+rank, V=14000) | libzstd %s -3, one frame per GPU"
-                % (size, zgdata.zstd_version())), [plain], False, "synthetic"
+            return "enwik9 (%d B from $ZGPU_DATA) | libzstd %s -3, one frame per GPU" % (len(plain), zgdata.zstd_version()), [plain], 1, False, "file"
+        plain = zgdata.text_like(size, seed=0xE9 + gpu)
+        return ("enwik9-like single frame: text_like(%d B, seed 0xE9+gpu, V=14000) | libzstd %s -3, one frame per GPU"
+                % (size, zgdata.zstd_version())), [plain], 1, False, "synthetic"
+    if name == "realtext":
+        import realtext
+        plain, info = realtext.load()
+        return ("real text found in this image (%d files, %d B, sha256 %s.., manifest %s) | libzstd %s -3, one frame per GPU"
+                % (info["files"], info["bytes"], info["sha256"][:16], info["manifest"], zgdata.zstd_version())), [plain], 1, False, "file"
     if name == "silesia12":
         sdir = os.path.join(data_dir, "silesia") if data_dir else None
         if sdir and os.path.isdir(sdir) and len(os.listdir(sdir)) >= 12:
             plains = [open(os.path.join(sdir, f), "rb").read() for f in sorted(os.listdir(sdir))]
-            return "Silesia (%d files from $ZGPU_DATA) | libzstd -3, one frame per file" % len(plains), plains, True, "file"
+            return "Silesia (%d files from $ZGPU_DATA) | libzstd -3, one frame per file" % len(plains), plains, 1, True, "file"
         plains = [zgdata.text_like(s, seed=0x51 + i) if i % 3 else zgdata.iso_like(s, seed=0x51 + i) for i, s in enumerate(SILESIA_SIZES)]
-        return "Silesia-sized stand-in: 12 frames (text_like / iso_like, sizes of the 12 Silesia files) | libzstd -3", plains, True, "synthetic"
+        return "Silesia-sized stand-in: 12 frames (text_like / iso_like, sizes of the 12 Silesia files) | libzstd -3", plains, 1, True, "synthetic"
     if name == "blocks":
-        plains = [zgdata.text_like(64 << 20, seed=0xE9 + 16 * rank + i) for i in range(16)]
-        return "16 x 64 MiB text_like frames (1 GiB of 128 KiB blocks) per GPU | libzstd -3", plains, False, "synthetic"
+        rep = 1 if small else 8
+        plains = [zgdata.text_like(64 << 20, seed=0xE9 + 16 * gpu + i) for i in range(16)]
+        return "%d x 64 MiB text_like frames (%d GiB of 128 KiB blocks: 16 distinct x %d) per GPU | libzstd -3" % (16 * rep, rep, rep), plains, rep, False, "synthetic"
     if name == "blocks4b":
-        big = zgdata.text_like(256 << 20, seed=0xE9 + rank)
+        rep = 1 if small else 8
+        big = zgdata.text_like(256 << 20, seed=0xE9 + gpu)
         plains = [big[i:i + (128 << 10)] for i in range(0, len(big), 128 << 10)]
-        return "2048 single-block frames (128 KiB each) per GPU | libzstd -3", plains, False, "synthetic"
+        return "%d single-block frames (128 KiB each: 2048 distinct x %d) per GPU | libzstd -3" % (2048 * rep, rep), plains, rep, False, "synthetic"
     if name == "iso":
-        plains = [zgdata.iso_like(64 << 20, seed=0x150 + 8 * rank + i) for i in range(8)]
-        return "8 x 64 MiB iso_like frames (ratio 1.18) per GPU | libzstd -3", plains, False, "synthetic"
+        rep = 1 if small else 16
+        plains = [zgdata.iso_like(64 << 20, seed=0x150 + 8 * gpu + i) for i in range(8)]
+        return "%d x 64 MiB iso_like frames (ratio 1.18: 8 distinct x %d) per GPU | libzstd -3" % (8 * rep, rep), plains, rep, False, "synthetic"
     raise SystemExit("unknown workload " + name)
 
 
@@ -85,7 +101,7 @@ def _best_of(fn, n=3):
 def cpu_baseline(zs, plain_len, cores):
     """CPU decoders timed on this box's host cores, same run: the oracle (a C port of ruzstd's decode path; ruzstd itself cannot
     be built here: no Rust toolchain) and libzstd (the C library the reference's Readme compares itself with), one thread and
-    `cores` threads (one frame per thread), best of 3. zs: one compressed sample frame (bounded: this leg stays in seconds)."""
+    `cores` threads (one frame per thread), 3 runs each. zs: one compressed sample frame (bounded: this leg stays in seconds)."""
     import oracle
     import zgdata
     L = oracle.lib()
@@ -112,68 +128,135 @@ def cpu_baseline(zs, plain_len, cores):
                 t.join()
         return go
 
+    def runs(fn, n=3):
+        out = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            out.append(time.perf_counter() - t0)
+        return out
+
     one = C.create_string_buffer(plain_len)
-    t_o1 = _best_of(lambda: oracle_one(one))
-    t_z1 = _best_of(lambda: zstd_one(one))
-    t_on = _best_of(threaded(oracle_one, cores))
-    t_zn = _best_of(threaded(zstd_one, cores))
-    return {"value": round(plain_len / t_o1 / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+    t_o1, t_z1 = runs(lambda: oracle_one(one)), runs(lambda: zstd_one(one))
+    t_on, t_zn = runs(threaded(oracle_one, cores)), runs(threaded(zstd_one, cores))
+    gb = plain_len / 1e9
+    return {"value": round(gb / min(t_o1), 4), "unit": "GB/s", "cores": 1, "kind": "port",
             "sample": "%d-byte frame of the same workload through the oracle's decode_all (FrameDecoder::decode_all semantics), best of 3" % plain_len,
-            "oracle_nt_GBps": round(cores * plain_len / t_on / 1e9, 4), "nt_cores": cores,
-            "libzstd_1t_GBps": round(plain_len / t_z1 / 1e9, 4), "libzstd_nt_GBps": round(cores * plain_len / t_zn / 1e9, 4),
+            "oracle_nt_GBps": round(cores * gb / min(t_on), 4), "nt_cores": cores,
+            "libzstd_1t_GBps": round(gb / min(t_z1), 4), "libzstd_nt_GBps": round(cores * gb / min(t_zn), 4),
+            "libzstd_nt_GBps_runs": [round(cores * gb / t, 2) for t in t_zn], "oracle_nt_GBps_runs": [round(cores * gb / t, 2) for t in t_on],
             "libzstd_version": zgdata.zstd_version(), "host_cores_available": os.cpu_count(),
-            "note": "nt = one frame per thread on nt_cores threads; ruzstd itself is not buildable here (no rustc/cargo)"}
+            "note": "nt = one frame per thread on nt_cores threads (all three runs listed: the spread between runs and boxes is large); "
+                    "ruzstd itself is not buildable here (no rustc/cargo)"}
 
 
-def other_workload(name, local_rank, steps=20):
+def check_frames(pool, plains, repeat, first=0):
+    """every staged frame's output against the plaintext it was made from (byte for byte)"""
+    import numpy as np
+    refs = [np.frombuffer(p, dtype=np.uint8) for p in plains]
+    n = len(plains) * repeat
+    for k in range(n):
+        ref = refs[k % len(plains)]
+        gpu, size, st = pool.frame(first + k)
+        assert st == 0 and size == len(ref), ("frame", k, "status", st, "size", size)
+        got = np.frombuffer(pool.read(first + k, size), dtype=np.uint8)
+        assert np.array_equal(got, ref), "GPU output differs (frame %d)" % k
+
+
+def roofline(kern, A, workload):
+    """roofline block of one workload on one GPU. kern: per-kernel ms of a pass (HIP events on the engine's streams);
+    A: algorithmic bytes of the pass (every compressed byte read once + every plaintext byte written once)"""
+    dom = max(KERNELS, key=lambda k: kern[k])
+    pipe = A / (kern["total"] / 1e3) / 1e9 if kern["total"] > 0 else 0.0
+    ach_dom = A / (kern[dom] / 1e3) / 1e9 if kern[dom] > 0 else 0.0
+    traffic, traffic_src = None, None
+    try:   # HBM bytes from the committed rocprofv3 PMC passes; refused when the kernels changed since they were taken
+        pm = json.load(open(os.path.join(PROFILE_DIR, "%s_pmc.json" % workload)))
+        cur = hashlib.sha256(open(os.path.join(ROOT, "zstd-rs_amd", "csrc", "zg_kernels.hip"), "rb").read() +
+                             open(os.path.join(ROOT, "zstd-rs_amd", "csrc", "zg_flat4.h"), "rb").read()).hexdigest()
+        if pm.get("kernels_sha256") == cur:
+            traffic = pm["pipeline_hbm_bytes_per_pass"]
+            traffic_src = "profiles/r03/%s_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per-kernel calibration; all kernels of one pass)" % workload
+        else:
+            traffic_src = "profiles/r03/%s_pmc.json is stale for this build: not reported" % workload
+    except Exception:
+        pass
+    return {"bound": "hbm", "achieved": round(pipe, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pipe / HBM_PEAK_GBS, 6),
+            "scope": "whole pipeline of one pass on one GPU: (C + D) / t_kernels (SURVEY 8d)",
+            "kernel": "zg_k_" + ("flatten" if dom == "flat" else dom), "kernel_ms": round(kern[dom], 4), "achieved_dominant": round(ach_dom, 3),
+            "frac_dominant": round(ach_dom / HBM_PEAK_GBS, 6), "algorithmic_bytes": int(A), "traffic": traffic, "traffic_source": traffic_src}
+
+
+def timed_passes(pool, steps, min_seconds, barrier=None):
+    """the timed region: `steps` steps of `pps` passes each, pps chosen so that the region lasts >= min_seconds"""
+    t0 = time.perf_counter()
+    pool.run()
+    t1 = time.perf_counter() - t0
+    pps = max(1, int(math.ceil(min_seconds / max(steps * t1, 1e-9))))
+    if barrier:
+        barrier()
+    t0 = time.perf_counter()
+    busy = [0.0] * pool.n_gpus
+    for _ in range(steps * pps):
+        gms, _wall = pool.run()                        # blocks until every GPU of the pool has finished the pass
+        for g, v in enumerate(gms):
+            busy[g] += v
+    if barrier:
+        barrier()
+    return time.perf_counter() - t0, pps, [b / (steps * pps) for b in busy]
+
+
+def other_workload(name, device, min_seconds):
+    """one of the other BASELINE.json configurations on one GPU, at one GPU's share of its size"""
     import zgdata
     import zgpu
-    desc, plains, _, _ = build_workload(name, 0, 1, 0)
+    t_prep = time.perf_counter()
+    desc, plains, rep, _, _ = build_workload(name, 0, 0)
     zs = [zgdata.zstd_compress(p, level=3) for p in plains]
-    pool = zgpu.Pool(devices=[local_rank])
-    pool.stage(zs)
+    pool = zgpu.Pool(devices=[device])
+    pool.stage(zs * rep)
+    prep = time.perf_counter() - t_prep
     for _ in range(2):
         pool.run()
-    for k, p in enumerate(plains):
-        gpu, size, st = pool.frame(k)
-        assert st == 0 and size == len(p), (name, k, st, size)
-        assert hashlib.sha256(pool.read(k, size)).digest() == hashlib.sha256(p).digest(), "GPU output differs (%s frame %d)" % (name, k)
-    t0 = time.perf_counter()
-    busy = 0.0
-    for _ in range(steps):
-        gms, _ = pool.run()
-        busy += gms[0]
-    dt = time.perf_counter() - t0
+    check_frames(pool, plains, rep)
+    dt, pps, busy = timed_passes(pool, 1, min_seconds)
+    kern, D, Cb, nb = pool.timings(0)
     pool.close()
-    D = sum(len(p) for p in plains)
-    return {"workload": desc, "plaintext_bytes": D, "compressed_bytes": sum(len(z) for z in zs), "frames": len(zs), "steps": steps,
-            "GBps": round(D * steps / dt / 1e9, 3), "ms_per_step": round(dt / steps * 1e3, 3), "kernel_ms_per_step": round(busy / steps, 3)}
+    return {"workload": desc, "plaintext_bytes": D, "compressed_bytes": Cb, "frames": len(zs) * rep, "blocks": nb, "passes": pps,
+            "GBps": round(D * pps / dt / 1e9, 3), "ms_per_pass": round(dt / pps * 1e3, 3), "kernel_ms_per_pass": round(busy[0], 3),
+            "kernel_ms": {k: round(v, 4) for k, v in kern.items()}, "roofline": roofline(kern, Cb + D, name), "host_prepare_s": round(prep, 2)}
 
 
-def e2e_rate(ctx, z, plain_len):
-    """C ABI zgpu_decode_all: host buffer in, host buffer out (H2D + host block walk + kernels + D2H), pinned host buffers"""
+def e2e_rate(device, zs_list, plain_total):
+    """C ABI zgpu_pool_decode_all: pinned host buffer in, pinned host buffer out (host walk + H2D + kernels + D2H, jobs overlapped)"""
     import torch
-    src = torch.frombuffer(bytearray(z), dtype=torch.uint8).pin_memory()
-    dst = torch.empty(plain_len, dtype=torch.uint8).pin_memory()
+    import zgpu
+    blob = b"".join(zs_list)
+    src = torch.frombuffer(bytearray(blob), dtype=torch.uint8).pin_memory()
+    dst = torch.empty(plain_total, dtype=torch.uint8).pin_memory()
+    pool = zgpu.Pool(devices=[device])
     w = C.c_size_t()
 
     def go():
-        st = ctx.L.zgpu_decode_all(ctx.h, C.c_char_p(src.data_ptr()), len(z), C.c_void_p(dst.data_ptr()), plain_len, C.byref(w))
-        assert st == 0 and w.value == plain_len
+        st = pool.L.zgpu_pool_decode_all(pool.h, C.c_char_p(src.data_ptr()), len(blob), C.c_void_p(dst.data_ptr()), plain_total, C.byref(w))
+        assert st == 0 and w.value == plain_total, (st, w.value)
     go()
-    return plain_len / _best_of(go) / 1e9
+    t = _best_of(go)
+    pool.close()
+    return plain_total / t / 1e9, hashlib.sha256(dst.numpy().tobytes()).digest()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=250)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="enwik9like", choices=["enwik9like", "silesia12", "blocks", "blocks4b", "iso"])
+    ap.add_argument("--workload", default="enwik9like", choices=["enwik9like", "realtext", "silesia12", "blocks", "blocks4b", "iso"])
     ap.add_argument("--size", type=int, default=int(os.environ.get("ZGPU_BENCH_SIZE", 1000000000)), help="plaintext bytes per GPU (enwik9like)")
+    ap.add_argument("--min-seconds", type=float, default=2.0, help="lower bound of the timed region (passes per step are raised to reach it)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--no-other", action="store_true", help="skip the short runs of the other BASELINE.json configurations")
+    ap.add_argument("--no-other", action="store_true", help="skip the runs of the other BASELINE.json configurations")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -189,14 +272,33 @@ def main():
     import zgdata
     import zgpu
     import zgpu_dist
-    desc, plains, sharded, data_tag = build_workload(args.workload, rank, world, args.size)
-    zs = [zgdata.zstd_compress(p, level=3) for p in plains]
-    job_lens = [len(z) for z in zs]
-    mine = zgpu_dist.shard_frames(job_lens, world)[rank] if sharded else list(range(len(zs)))
-    order, _, loads = zgpu.plan(job_lens, world if sharded else 1)
-    pool = zgpu.Pool(devices=[local_rank])            # this rank's GPU behind the library's work queue
+    # one process per GPU (torch.distributed.run), or one process driving --gpus engines through the library's queue
+    in_process = world == 1 and args.gpus > 1
+    pool = zgpu.Pool(n_gpus=args.gpus) if in_process else zgpu.Pool(devices=[local_rank])
+    ngpu_here = pool.n_gpus                                   # (zgpu_pool_num_gpus: what the node really has)
+    n_gpus = world if world > 1 else ngpu_here
     t0 = time.perf_counter()
-    pool.stage([zs[i] for i in mine])                 # host block walk + H2D: the submission, outside the timed region
+    per_gpu = []                                             # (plains, repeat) per GPU of this process
+    sharded = False
+    for g in range(ngpu_here):
+        desc, plains, rep, sharded, data_tag = build_workload(args.workload, (rank if world > 1 else g), args.size)
+        per_gpu.append((plains, rep))
+        if sharded:
+            break
+    zs_gpu = [[zgdata.zstd_compress(p, level=3) for p in plains] for plains, _ in per_gpu]
+    if sharded:
+        job_lens = [len(z) for z in zs_gpu[0]]
+        mine = zgpu_dist.shard_frames(job_lens, world)[rank] if world > 1 else list(range(len(job_lens)))
+        staged_z = [zs_gpu[0][i] for i in mine]
+        staged_p = [per_gpu[0][0][i] for i in mine]
+        order, _, loads = zgpu.plan(job_lens, n_gpus)
+    else:
+        staged_z, staged_p = [], []
+        for (plains, rep), zs in zip(per_gpu, zs_gpu):
+            staged_z += zs * rep
+            staged_p += plains * rep
+        job_lens, loads = [len(z) for z in staged_z], None
+    pool.stage(staged_z)                                     # host block walk + H2D: the submission, outside the timed region
     prep_s = time.perf_counter() - t0
 
     def barrier():
@@ -207,106 +309,74 @@ def main():
     for _ in range(max(args.warmup, 1)):
         pool.run()
     # parity gate on a warm run: the full plaintext of every frame must match the generator's bytes
-    for k, i in enumerate(mine):
+    import numpy as np
+    used_gpus = set()
+    for k, p in enumerate(staged_p):
         gpu, size, st = pool.frame(k)
-        assert st == 0 and size == len(plains[i]), (i, st, size)
-        got = pool.read(k, size)
-        assert hashlib.sha256(got).digest() == hashlib.sha256(plains[i]).digest(), "GPU output differs (frame %d)" % i
-        del got
+        used_gpus.add(gpu)
+        assert st == 0 and size == len(p), (k, st, size)
+        assert np.array_equal(np.frombuffer(pool.read(k, size), dtype=np.uint8), np.frombuffer(p, dtype=np.uint8)), "GPU output differs (frame %d)" % k
 
-    kern = {}
-    barrier()
-    t0 = time.perf_counter()
-    busy = 0.0
-    for _ in range(args.steps):
-        gms, _wall = pool.run()                        # blocks until this rank's GPU has finished the pass
-        busy += gms[0]
-    barrier()
-    dt = time.perf_counter() - t0
+    dt, pps, busy = timed_passes(pool, args.steps, args.min_seconds, barrier)
     if world > 1:
         tmax = torch.tensor([dt], device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-
-    D_mine, C_mine = sum(len(plains[i]) for i in mine), sum(len(zs[i]) for i in mine)
+    D_mine, C_mine = sum(len(p) for p in staged_p), sum(len(z) for z in staged_z)
     if world > 1:
-        tot = torch.tensor([float(D_mine), float(C_mine), busy], device="cuda", dtype=torch.float64)
+        tot = torch.tensor([float(D_mine), float(C_mine), busy[0]], device="cuda", dtype=torch.float64)
         allt = [torch.zeros_like(tot) for _ in range(world)]
         dist.all_gather(allt, tot)
         D_job, C_job = sum(float(t[0]) for t in allt), sum(float(t[1]) for t in allt)
-        per_gpu_busy = [float(t[2]) / args.steps for t in allt]
+        per_gpu_busy = [float(t[2]) for t in allt]
     else:
-        D_job, C_job, per_gpu_busy = float(D_mine), float(C_mine), [busy / args.steps]
-    value = D_job * args.steps / dt / 1e9
+        D_job, C_job, per_gpu_busy = float(D_mine), float(C_mine), busy
+    value = D_job * args.steps * pps / dt / 1e9
 
-    out = None
     if rank == 0:
-        # kernel times of one more pass on this rank, per kernel (HIP events on the engine's own streams)
-        ctx = zgpu.Context(local_rank)
-        b = ctx.prepare(b"".join(zs[i] for i in mine))
-        for _ in range(2):
-            b.run(); b.sync()
-        acc = {}
-        reps = 5
-        for _ in range(reps):
-            b.run(); b.sync()
-            for k, v in b.timings().items():
-                acc[k] = acc.get(k, 0.0) + v / reps
-        kern = acc
-        nblocks = b.nblocks
-        b.close()
-        dom = max(("tables", "huf", "seq", "seqpost", "scan", "lit", "flat", "sweep", "lz"), key=lambda k: kern[k])
-        A = C_mine + D_mine            # algorithmic bytes of one pass: every compressed byte read once + every plaintext byte written once
-        pipe = A / (kern["total"] / 1e3) / 1e9 if kern["total"] > 0 else 0.0
-        ach_dom = A / (kern[dom] / 1e3) / 1e9 if kern[dom] > 0 else 0.0
-        traffic, traffic_src = None, None
-        try:   # HBM bytes from the committed rocprofv3 PMC passes; refused when the kernels changed since they were taken
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r02", "bench_pmc.json")))
-            cur = hashlib.sha256(open(os.path.join(ROOT, "zstd-rs_amd", "csrc", "zg_kernels.hip"), "rb").read()).hexdigest()
-            if pm.get("kernels_sha256") == cur and pm.get("workload") == args.workload and pm.get("plaintext_bytes") == D_mine:
-                traffic = pm["pipeline_hbm_bytes_per_pass"]
-                traffic_src = "profiles/r02/bench_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per-kernel calibration; all kernels of one pass)"
-            else:
-                traffic_src = "profiles/r02/bench_pmc.json is stale for this build/workload: not reported"
-        except Exception:
-            pass
+        kern, D0, C0, nblocks = pool.timings(0)               # GPU 0's last pass, per kernel (HIP events on the engine's own streams)
         out = {
-            "metric": "decompressed_GB_per_s", "value": round(value, 4), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
+            "metric": "decompressed_GB_per_s", "value": round(value, 4), "unit": "GB/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u8", "data": data_tag,
             "config": {"workload": desc, "name": args.workload, "plaintext_bytes_job": int(D_job), "compressed_bytes_job": int(C_job),
-                       "frames_job": len(zs) if sharded else len(zs) * world, "frames_this_gpu": len(mine), "blocks_this_gpu": nblocks,
-                       "timed_region": "kernels only, inputs + block tables resident in HBM, output left in HBM; one pool.run() per step",
-                       "queue": "zgpu_pool (LPT order, one worker + engine per GPU); ranks by zgpu_dist.shard_frames",
-                       "host_prepare_s": round(prep_s, 4)},
-            "roofline": {"bound": "hbm", "achieved": round(pipe, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pipe / HBM_PEAK_GBS, 6),
-                         "scope": "whole pipeline of one pass on one GPU: (C + D) / t_kernels (SURVEY 8d)",
-                         "kernel": "zg_k_" + dom, "kernel_ms": round(kern[dom], 4), "achieved_dominant": round(ach_dom, 3),
-                         "frac_dominant": round(ach_dom / HBM_PEAK_GBS, 6), "algorithmic_bytes": int(A), "traffic": traffic,
-                         "traffic_source": traffic_src},
-            "read_GBps": round(C_mine / (kern["total"] / 1e3) / 1e9, 3) if kern["total"] > 0 else 0.0,
+                       "passes_per_step": pps, "plaintext_bytes_per_step": int(D_job) * pps, "ms_per_pass": round(dt / (args.steps * pps) * 1e3, 3),
+                       "frames_job": len(staged_z) if world == 1 else None, "frames_gpu0_blocks": nblocks,
+                       "timed_region": "kernels only, inputs + block tables resident in HBM, output left in HBM; steps x passes_per_step "
+                                       "passes (one zgpu_pool_run each), >= %.1f s" % args.min_seconds,
+                       "queue": ("one process, zgpu_pool_create(%d): LPT order, one worker thread + engine per GPU; GPUs used: %s" % (args.gpus, sorted(used_gpus)))
+                                if world == 1 else "one process per GPU (torch.distributed.run); frames -> ranks by zgpu_dist.shard_frames (the queue's LPT rule)",
+                       "gpus_requested": args.gpus, "host_prepare_s": round(prep_s, 3)},
+            "roofline": roofline(kern, C0 + D0, args.workload),
+            "read_GBps": round(C0 / (kern["total"] / 1e3) / 1e9, 3) if kern["total"] > 0 else 0.0,
             "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
             "per_gpu_busy_ms": [round(x, 3) for x in per_gpu_busy],
-            "lpt": {"loads_compressed_bytes": loads, "bound_speedup": round(sum(job_lens) / max(loads), 3) if sharded and max(loads) else float(world)},
         }
+        if sharded:
+            out["lpt"] = {"loads_compressed_bytes": loads, "bound_speedup": round(sum(job_lens) / max(loads), 3) if max(loads) else float(n_gpus)}
+        pool.close(); pool = None
         if not args.no_e2e:
-            i0 = mine[0]
-            n = min(len(plains[i0]), 256 << 20) if args.workload == "enwik9like" else len(plains[i0])
-            ze = zs[i0] if n == len(plains[i0]) else zgdata.zstd_compress(plains[i0][:n], level=3)
-            out["e2e_GBps"] = round(e2e_rate(ctx, ze, n), 3)
-            out["e2e_note"] = "C ABI zgpu_decode_all on a %d-byte frame: pinned host buffer in, pinned host buffer out (H2D + host walk + kernels + D2H), best of 3" % n
-        ctx.close()
+            # the path a caller of the ABI sees: 1 GiB of 64 MiB frames (or the workload's own frames when they are many), host to host
+            if len(staged_z) >= 8:
+                ez, ep = staged_z[:16], staged_p[:16]
+            else:
+                ep = [zgdata.text_like(64 << 20, seed=0xE9 + i) for i in range(16)]
+                ez = [zgdata.zstd_compress(p, level=3) for p in ep]
+            rate, digest = e2e_rate(local_rank, ez, sum(len(p) for p in ep))
+            assert digest == hashlib.sha256(b"".join(ep)).digest()
+            out["e2e_GBps"] = round(rate, 3)
+            out["e2e_note"] = ("C ABI zgpu_pool_decode_all on %d frames (%d B of plaintext): pinned host buffer in, pinned host buffer out; host walk + H2D "
+                               "+ kernels + D2H with the jobs of two engines overlapped, best of 3; per GPU" % (len(ez), sum(len(p) for p in ep)))
         if not args.no_cpu:
             # bounded CPU sample of the same workload: one frame of at most 64 MiB of plaintext
-            i0 = mine[0]
-            n = min(len(plains[i0]), 64 << 20)
-            zc = zs[i0] if n == len(plains[i0]) else zgdata.zstd_compress(plains[i0][:n], level=3)
+            n = min(len(staged_p[0]), 64 << 20)
+            zc = staged_z[0] if n == len(staged_p[0]) else zgdata.zstd_compress(staged_p[0][:n], level=3)
             out["cpu_baseline"] = cpu_baseline(zc, n, max(1, min(os.cpu_count() or 1, 64)))
-        if not args.no_other and world == 1 and args.workload == "enwik9like":
-            # the other BASELINE.json configurations on this GPU, 20 passes each (parity gate on every frame first): context for the
-            # headline, not part of `value`
-            pool.close(); pool = None
-            out["other_workloads"] = {w: other_workload(w, local_rank) for w in ("silesia12", "blocks", "iso")}
+        if not args.no_other and n_gpus == 1 and args.workload == "enwik9like":
+            # the other BASELINE.json configurations on this GPU, at one GPU's share of their size (parity gate on every frame first):
+            # context for the headline, not part of `value`
+            del staged_p, staged_z, per_gpu, zs_gpu
+            out["other_workloads"] = {w: other_workload(w, local_rank, args.min_seconds) for w in ("silesia12", "blocks", "blocks4b", "iso", "realtext")}
         print(json.dumps(out), flush=True)
     if pool is not None:
         pool.close()

@@ -211,6 +211,7 @@ uint64_t zgpu_decoder_bytes_read_from_source(const zgpu_decoder*);   /* :273 */
 uint64_t zgpu_decoder_content_size(const zgpu_decoder*);             /* :246 */
 int zgpu_decoder_checksum_from_data(const zgpu_decoder*, uint32_t* out); /* :254 — returns 1 if present */
 uint32_t zgpu_decoder_calculated_checksum(const zgpu_decoder*);      /* :263-270 XXH64 seed 0, low 32 bits */
+uint64_t zgpu_decoder_device_bytes(const zgpu_decoder*);             /* device memory the frame holds now (window + carried tables): bounded by the window, not by the frame */
 
 /* ---- the thin boundary: host-parsed block tables -----------------------------------------------------------------------
  * For a caller that keeps ruzstd's own header parse — read_frame_header (ruzstd/src/decoding/frame.rs:6-85) and

@@ -626,7 +626,7 @@ def test_streaming_window_stays_bounded(ctx):
     z = zgdata.zstd_compress(plain)
     s = zgpu.CStreamingDecoder(ctx, io.BytesIO(z))
     h = hashlib.sha256()
-    marks, done = [], 0
+    marks, done, dev = [], 0, []
     t0 = time.perf_counter()
     while True:
         c = s.read(4 << 20)
@@ -634,9 +634,14 @@ def test_streaming_window_stays_bounded(ctx):
             break
         h.update(c)
         done += len(c)
+        dev.append(s.device_bytes())
         if done % (48 << 20) < (4 << 20):
             marks.append(time.perf_counter() - t0)
     assert done == len(plain) and h.digest() == hashlib.sha256(plain).digest()
+    # bounded: the device window never holds more than a few windows' worth (window 2 MiB, reads of 4 MiB), whatever the frame's
+    # length — and the second half of the frame needs no more than the first
+    assert max(dev) <= 48 << 20, max(dev)
+    assert max(dev[len(dev) // 2:]) <= max(dev[:len(dev) // 2]), (max(dev[:len(dev) // 2]), max(dev[len(dev) // 2:]))
     # linear: the last quarter does not take much longer than the second (a quadratic copy would take ~2.3x)
     assert len(marks) >= 4 and (marks[3] - marks[2]) < 1.7 * (marks[1] - marks[0]) + 0.05, marks
     s.close()

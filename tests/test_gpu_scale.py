@@ -174,3 +174,66 @@ def test_pool_queue_one_gpu(ctx):
     local = zgpu_dist.decode_sharded(zs, fn, 0, 1)
     assert [local[i] for i in range(len(zs))] == plains
     pool2.close()
+
+
+def test_config4_share_128_x_64mib_one_submit(ctx):
+    """one GPU's share of BASELINE config 4: 128 frames of 64 MiB (8 GiB of 128 KiB blocks) in ONE submit — 16 distinct frames x 8;
+    every frame's bytes against its plaintext. Each frame is two units: a direct one (resolved by the flatten itself) and one that
+    goes through scratch + sweep."""
+    import numpy as np
+    import zgdata
+    plains = [zgdata.text_like(64 << 20, seed=0xE9 + i) for i in range(16)]
+    zs = [zgdata.zstd_compress(p) for p in plains]
+    refs = [np.frombuffer(p, dtype=np.uint8) for p in plains]
+    b = ctx.prepare(b"".join(zs * 8))
+    assert b.parse_status == 0 and b.nframes == 128
+    b.run()
+    b.sync()
+    assert b.bad_status == 0, (b.bad_frame, b.bad_status)
+    assert b.total_out == 128 * (64 << 20)
+    modes = [u[4] for u in b.units()]
+    assert sum(1 for m in modes if m & 2) == 128 and sum(1 for m in modes if m == 0) >= 128
+    for f in range(128):
+        got = np.frombuffer(b.frame_bytes(f), dtype=np.uint8)
+        assert np.array_equal(got, refs[f % 16]), f
+    b.close()
+
+
+def test_pool_over_all_visible_gpus():
+    """zgpu_pool_create(0): every visible GPU gets an engine and a worker thread; frames are spread over them by the queue (LPT)
+    and come back in input order. With one GPU visible the placement assertion is skipped, the bytes are checked all the same."""
+    import zgdata
+    import zgpu
+    pool = zgpu.Pool(n_gpus=0)
+    n = pool.n_gpus
+    assert n >= 1
+    plains = [zgdata.text_like((1 << 20) + 4099 * i, seed=0x700 + i) for i in range(4 * n + 3)]
+    zs = [zgdata.zstd_compress(p) for p in plains]
+    pool.stage(zs)
+    gms, wall = pool.run()
+    assert len(gms) == n
+    gpus = set()
+    for k, p in enumerate(plains):
+        gpu, size, st = pool.frame(k)
+        gpus.add(gpu)
+        assert st == 0 and size == len(p)
+        assert pool.read(k, size) == p
+    if n > 1:
+        assert len(gpus) == n, gpus                      # 4n + 3 frames of similar size: LPT gives every GPU some
+    kern, D, Cb, nb = pool.timings(0)
+    assert kern["total"] > 0 and D > 0 and Cb > 0 and nb > 0
+    # decode_all over the same pool: more than two jobs per GPU (the output of a job leaves the device when the job is done)
+    big = [zgdata.text_like(110 << 20, seed=0x800 + i) for i in range(3 * n + 1)]
+    bz = [zgdata.zstd_compress(p) for p in big]
+    skip = b"\x50\x2a\x4d\x18" + (5).to_bytes(4, "little") + b"hello"          # a skippable frame in between (frame.rs:15-23)
+    nofcs = zgdata.zstd_compress(plains[0], content_size=False)                # and a frame that does not declare its size
+    blob = bz[0] + skip + b"".join(bz[1:])
+    want = b"".join(big)
+    out = pool.decode_all(blob, len(want))
+    assert _sha(out) == _sha(want)
+    out = pool.decode_all(blob + nofcs, len(want) + len(plains[0]))
+    assert _sha(out) == _sha(want + plains[0])
+    with pytest.raises(zgpu.ZgpuError) as e:
+        pool.decode_all(blob, len(want) - 1)
+    assert e.value.status == zgpu.E_TARGET_TOO_SMALL
+    pool.close()

@@ -58,7 +58,7 @@ EXPORTS = [
     "zgpu_streaming_destroy", "zgpu_streaming_decoder", "zgpu_streaming_read", "zgpu_pool_create", "zgpu_pool_create_on", "zgpu_pool_destroy",
     "zgpu_pool_num_gpus", "zgpu_pool_decode_all", "zgpu_pool_plan", "zgpu_pool_stage", "zgpu_pool_run", "zgpu_pool_frame", "zgpu_pool_read", "zgpu_pool_timings",
     "zgpu_frame_begin", "zgpu_frame_end", "zgpu_blocks_submit", "zgpu_sync", "zgpu_available", "zgpu_read", "zgpu_device_output",
-    "zgpu_frame_checksum", "zgpu_frame_blocks_decoded",
+    "zgpu_frame_checksum", "zgpu_frame_blocks_decoded", "zgpu_decoder_device_bytes",
 ]
 WRITE_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
 READ_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
@@ -124,6 +124,8 @@ def load_library():
     L.zgpu_frame_checksum.restype = C.c_uint32
     L.zgpu_frame_blocks_decoded.argtypes = [vp]
     L.zgpu_frame_blocks_decoded.restype = C.c_uint64
+    L.zgpu_decoder_device_bytes.argtypes = [vp]
+    L.zgpu_decoder_device_bytes.restype = C.c_uint64
     L.zgpu_decoder_create.argtypes = [vp, P(vp)]
     L.zgpu_add_dict.argtypes = [vp, u8p, sz, P(C.c_uint32)]
     L.zgpu_decoder_force_dict.argtypes = [vp, C.c_uint32]
@@ -575,6 +577,12 @@ class CStreamingDecoder:
         if st:
             raise ZgpuError(st)
         return buf.raw[:got.value]
+
+    def device_bytes(self):
+        """device memory the frame holds right now (zgpu_decoder_device_bytes of the decoder behind the stream)"""
+        self.L.zgpu_streaming_decoder.restype = C.c_void_p
+        self.L.zgpu_streaming_decoder.argtypes = [C.c_void_p]
+        return self.L.zgpu_decoder_device_bytes(self.L.zgpu_streaming_decoder(self.h))
 
     def close(self):
         if getattr(self, "h", None):
