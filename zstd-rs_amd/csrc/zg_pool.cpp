@@ -36,12 +36,12 @@ void lpt_plan(const uint64_t* cost, uint32_t n, uint32_t nw, std::vector<uint32_
   }
 }
 
-struct Staged {            // one worker's resident submit: its frames concatenated
+struct Staged {            // one resident submit: a job's frames concatenated
   std::vector<uint8_t> blob;
   std::vector<uint32_t> frames;   // caller's frame indices, in blob order
+  uint32_t gpu = 0, lane = 0;     // which GPU of the pool; which of its two engines
   Batch* batch = nullptr;
   int status = 0;
-  float kernel_ms = 0, wall_ms = 0;
 };
 
 }  // namespace
@@ -57,8 +57,9 @@ struct zgpu_pool {
   std::vector<Engine*> eng;        // one per GPU: the resident (staged) submits and zgpu_pool_run
   std::vector<Engine*> eng2;       // a second engine per GPU for zgpu_pool_decode_all: the upload of one job, the kernels of another and the
                                    // download of a third overlap on their own streams (same index as eng)
-  std::vector<Staged> staged;
-  std::vector<uint32_t> frame_worker, frame_slot, frame_count;   // staged entries: which worker, first frame of its batch, number of frames (0: skippable only)
+  std::vector<Staged> staged;      // the resident jobs (zgpu_pool_stage): a GPU's frames are cut into up to eight of them, alternating between its engines
+  std::vector<float> gpu_wall_ms;  // of the last pass, per GPU
+  std::vector<uint32_t> frame_worker, frame_slot, frame_count;   // staged entries: which job, first frame of its batch, number of frames (0: skippable only)
   uint32_t nframes = 0;
   // persistent workers: one thread per engine, woken per pass (no thread is created inside a timed region)
   std::vector<std::thread> threads;
@@ -120,7 +121,7 @@ static int pool_build(const int* devices, int n, zgpu_pool** out) {
     p->eng.push_back(e);
     p->eng2.push_back(e2);
   }
-  p->staged.resize(p->eng.size());
+  p->gpu_wall_ms.assign(p->eng.size(), 0.f);
   p->start_workers(2u * (uint32_t)p->eng.size());   // workers [0, n): the GPUs' first engines; [n, 2n): their second ones (decode_all only)
   *out = p;
   return ZGPU_OK;
@@ -143,7 +144,8 @@ int zgpu_pool_create_on(const int* devices, int n, zgpu_pool** out) {
 }
 
 static void pool_unstage(zgpu_pool* p) {
-  for (Staged& s : p->staged) { delete s.batch; s = Staged(); }
+  for (Staged& s : p->staged) delete s.batch;
+  p->staged.clear();
   p->frame_worker.clear(); p->frame_slot.clear(); p->frame_count.clear(); p->nframes = 0;
 }
 
@@ -180,27 +182,52 @@ int zgpu_pool_stage(zgpu_pool* p, const uint8_t* const* frames, const size_t* le
   std::vector<uint32_t> order, worker;
   std::vector<uint64_t> load;
   lpt_plan(cost.data(), n, nw, &order, &worker, &load);
-  p->frame_worker = worker;
+  p->frame_worker.assign(n, 0);
   p->frame_slot.assign(n, 0);
   p->frame_count.assign(n, 0);
   p->nframes = n;
-  for (uint32_t w = 0; w < nw; w++) p->staged[w].blob.reserve(load[w]);
-  for (uint32_t i = 0; i < n; i++) {             // blob order = caller's order among a worker's frames
-    Staged& s = p->staged[worker[i]];
-    s.frames.push_back(i);
-    s.blob.insert(s.blob.end(), frames[i], frames[i] + lens[i]);
+  // A GPU's frames become up to eight resident jobs, alternating between its two engines: the stages of a submit are bound by
+  // different things (the sequence chains by latency, the flatten by instruction issue, the sweep by memory traffic), and two
+  // submits in flight on their own streams fill each other's gaps. A job still costs the ~2 ms of one block's sequence chain
+  // whatever its size, so small inputs stay one job (>= 128 MiB of input and >= 4 frames per job).
+  const char* je = getenv("ZGPU_POOL_JOBS");
+  for (uint32_t w = 0; w < nw; w++) {
+    std::vector<uint32_t> mine;
+    for (uint32_t i = 0; i < n; i++) if (worker[i] == w) mine.push_back(i);
+    if (mine.empty()) continue;
+    uint32_t J = (uint32_t)((load[w] + (128ull << 20) - 1) / (128ull << 20));
+    if (J > mine.size() / 4) J = (uint32_t)mine.size() / 4;
+    if (J > 8) J = 8;
+    if (je && atoi(je) > 0) J = (uint32_t)atoi(je) < mine.size() ? (uint32_t)atoi(je) : (uint32_t)mine.size();
+    if (J < 2) J = 1;
+    const uint32_t first = (uint32_t)p->staged.size();
+    p->staged.resize(first + J);
+    for (uint32_t j = 0; j < J; j++) { p->staged[first + j].gpu = w; p->staged[first + j].lane = j & 1u; }
+    // consecutive runs of frames, balanced by bytes (blob order = caller's order among a job's frames)
+    uint64_t acc = 0;
+    uint32_t j = 0;
+    for (uint32_t i : mine) {
+      while (j + 1 < J && acc >= (load[w] * (j + 1)) / J) j++;
+      Staged& sj = p->staged[first + j];
+      sj.frames.push_back(i);
+      sj.blob.insert(sj.blob.end(), frames[i], frames[i] + lens[i]);
+      p->frame_worker[i] = first + j;
+      acc += lens[i];
+    }
   }
   p->run_on_workers([p, nw](uint32_t w) {
-    if (w >= nw) return;
-    Staged& s = p->staged[w];
-    if (s.frames.empty()) return;
-    s.status = p->eng[w]->prepare(s.blob.data(), s.blob.size(), &s.batch);
-    if (!s.status && s.batch) s.status = s.batch->parse_status;
+    const uint32_t g = w % nw, lane = w / nw;
+    for (Staged& s : p->staged) {
+      if (s.gpu != g || s.lane != lane || s.frames.empty()) continue;
+      Engine* eng = lane ? p->eng2[g] : p->eng[g];
+      s.status = eng->prepare(s.blob.data(), s.blob.size(), &s.batch);
+      if (!s.status && s.batch) s.status = s.batch->parse_status;
+      std::vector<uint8_t>().swap(s.blob);      // the compressed bytes live on the device now
+    }
   });
-  // a caller's entry may hold several frames (skippable ones hold none): slot = index of its first frame in the worker's batch
+  // a caller's entry may hold several frames (skippable ones hold none): slot = index of its first frame in its job's batch
   int st = 0;
-  for (uint32_t w = 0; w < nw && !st; w++) {
-    Staged& s = p->staged[w];
+  for (Staged& s : p->staged) {
     if (s.status) { st = s.status; break; }
     uint32_t slot = 0;
     for (uint32_t i : s.frames) {
@@ -224,34 +251,53 @@ int zgpu_pool_run(zgpu_pool* p, float* gpu_ms, float* wall_ms) {
   DeviceGuard guard;
   const uint32_t nw = (uint32_t)p->eng.size();
   auto t0 = std::chrono::steady_clock::now();
-  auto pass = [p](uint32_t w) {
-    Staged& s = p->staged[w];
-    if (!s.batch) return;
-    int st = s.batch->run();
-    if (!st) st = s.batch->sync();
-    s.status = st;
-    s.kernel_ms = s.batch->ms[ZG_T_TOTAL];
+  std::vector<float> lane_ms(2 * nw, 0.f);
+  auto pass = [&](uint32_t w) {
+    const uint32_t g = w % nw, lane = w / nw;
+    auto a = std::chrono::steady_clock::now();
+    bool any = false;
+    for (Staged& s : p->staged) {
+      if (s.gpu != g || s.lane != lane || !s.batch) continue;
+      int st = s.batch->run();
+      if (!st) st = s.batch->sync();
+      s.status = st;
+      any = true;
+    }
+    if (any) lane_ms[w] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - a).count();
   };
-  if (nw == 1) pass(0);                                     // one GPU: on the caller's thread
-  else p->run_on_workers([&](uint32_t w) { if (w < nw) pass(w); });
+  if (p->staged.size() == 1) pass(p->staged[0].lane * nw + p->staged[0].gpu);      // one job: on the caller's thread
+  else p->run_on_workers(pass);
   if (wall_ms) *wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   int st = 0;
-  for (uint32_t w = 0; w < nw; w++) {
-    if (gpu_ms) gpu_ms[w] = p->staged[w].kernel_ms;
-    if (!st && p->staged[w].status) st = p->staged[w].status;
+  for (uint32_t g = 0; g < nw; g++) {
+    // a GPU with one job: the kernel pipeline time of that job (HIP events); with several in flight: how long its engines were at it
+    uint32_t jobs = 0;
+    float km = 0;
+    for (const Staged& s : p->staged) if (s.gpu == g && s.batch) { jobs++; km = s.batch->ms[ZG_T_TOTAL]; }
+    p->gpu_wall_ms[g] = jobs == 1 ? km : (lane_ms[g] > lane_ms[nw + g] ? lane_ms[g] : lane_ms[nw + g]);
+    if (gpu_ms) gpu_ms[g] = p->gpu_wall_ms[g];
   }
+  for (const Staged& s : p->staged) if (!st && s.status) st = s.status;
   return st;
 }
 
-// per-kernel times (HIP events, ms; the order of zgpu_batch_timings) of GPU g's last pass, and what its submit holds
-int zgpu_pool_timings(const zgpu_pool* p, uint32_t g, float* ms, int n, uint64_t* plain_bytes, uint64_t* comp_bytes, uint32_t* nblocks) {
-  if (!p || g >= p->staged.size() || (!ms && n)) return ZGPU_E_BAD_ARG;
-  const Staged& s = p->staged[g];
+// per-kernel times (HIP events, ms; the order of zgpu_batch_timings) of GPU g's last pass, summed over its resident jobs (jobs that
+// ran side by side stretch each other: the sum then exceeds the pass), what those jobs hold, and how many they are
+int zgpu_pool_timings(const zgpu_pool* p, uint32_t g, float* ms, int n, uint64_t* plain_bytes, uint64_t* comp_bytes, uint32_t* nblocks, uint32_t* njobs) {
+  if (!p || g >= p->eng.size() || (!ms && n)) return ZGPU_E_BAD_ARG;
   int k = n < ZG_T_COUNT ? n : ZG_T_COUNT;
-  for (int i = 0; i < k; i++) ms[i] = s.batch ? s.batch->ms[i] : 0.f;
-  if (plain_bytes) *plain_bytes = s.batch ? s.batch->total_out : 0;
-  if (comp_bytes) *comp_bytes = s.batch ? s.batch->src_len : 0;
-  if (nblocks) *nblocks = s.batch ? (uint32_t)s.batch->bb.blocks.size() : 0;
+  for (int i = 0; i < k; i++) ms[i] = 0.f;
+  uint64_t pb = 0, cb = 0;
+  uint32_t nb = 0, nj = 0;
+  for (const Staged& s : p->staged) {
+    if (s.gpu != g || !s.batch) continue;
+    for (int i = 0; i < k; i++) ms[i] += s.batch->ms[i];
+    pb += s.batch->total_out; cb += s.batch->src_len; nb += (uint32_t)s.batch->bb.blocks.size(); nj++;
+  }
+  if (plain_bytes) *plain_bytes = pb;
+  if (comp_bytes) *comp_bytes = cb;
+  if (nblocks) *nblocks = nb;
+  if (njobs) *njobs = nj;
   return ZGPU_OK;
 }
 
@@ -259,7 +305,7 @@ int zgpu_pool_timings(const zgpu_pool* p, uint32_t g, float* ms, int n, uint64_t
 int zgpu_pool_frame(zgpu_pool* p, uint32_t i, int* gpu, uint64_t* out_size, uint32_t* status) {
   if (!p || i >= p->nframes) return ZGPU_E_BAD_ARG;
   const Staged& s = p->staged[p->frame_worker[i]];
-  if (gpu) *gpu = p->eng[p->frame_worker[i]]->device();
+  if (gpu) *gpu = p->eng[s.gpu]->device();
   if (p->frame_count[i] == 0) { if (out_size) *out_size = 0; if (status) *status = 0; return s.batch ? ZGPU_OK : ZGPU_E_BAD_ARG; }   // skippable frames only
   if (!s.batch || p->frame_slot[i] >= s.batch->frame_out.size()) return ZGPU_E_BAD_ARG;
   const ZgFrameOut& fo = s.batch->frame_out[p->frame_slot[i]];

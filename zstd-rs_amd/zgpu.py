@@ -164,7 +164,7 @@ def load_library():
     L.zgpu_pool_run.argtypes = [vp, P(C.c_float), P(C.c_float)]
     L.zgpu_pool_frame.argtypes = [vp, C.c_uint32, P(C.c_int), P(C.c_uint64), P(C.c_uint32)]
     L.zgpu_pool_read.argtypes = [vp, C.c_uint32, vp, sz, P(sz)]
-    L.zgpu_pool_timings.argtypes = [vp, C.c_uint32, P(C.c_float), C.c_int, P(C.c_uint64), P(C.c_uint64), P(C.c_uint32)]
+    L.zgpu_pool_timings.argtypes = [vp, C.c_uint32, P(C.c_float), C.c_int, P(C.c_uint64), P(C.c_uint64), P(C.c_uint32), P(C.c_uint32)]
     _LIB = L
     return L
 
@@ -530,10 +530,11 @@ class Pool:
     def timings(self, g=0):
         """per-kernel times (ms) of GPU g's last pass + (plaintext bytes, compressed bytes, blocks) of its resident submit"""
         a = (C.c_float * 10)()
-        pb, cb, nb = C.c_uint64(), C.c_uint64(), C.c_uint32()
-        st = self.L.zgpu_pool_timings(self.h, g, a, 10, C.byref(pb), C.byref(cb), C.byref(nb))
+        pb, cb, nb, nj = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint32()
+        st = self.L.zgpu_pool_timings(self.h, g, a, 10, C.byref(pb), C.byref(cb), C.byref(nb), C.byref(nj))
         if st:
             raise ZgpuError(st)
+        self.last_njobs = nj.value
         return dict(zip(["tables", "huf", "seq", "seqpost", "scan", "lit", "flat", "sweep", "lz", "total"], list(a))), pb.value, cb.value, nb.value
 
     def frame(self, i):
