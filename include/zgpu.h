@@ -114,9 +114,8 @@ int zgpu_pool_decode_all(zgpu_pool*, const uint8_t* src, size_t len, uint8_t* ds
 /* The plan of the queue, host only (no GPU touched): longest-processing-time-first order of n jobs by cost and the worker
  * each job goes to when n_workers workers pull in that order with time proportional to cost; load_out[w] = sum of w's costs. */
 int zgpu_pool_plan(const uint64_t* cost, uint32_t n, uint32_t n_workers, uint32_t* order_out, uint32_t* worker_out, uint64_t* load_out);
-/* device-resident form (bench / roofline): stage n entries (each one frame, or a run of frames) — LPT assignment over the GPUs;
- * a GPU's share becomes up to eight resident jobs that alternate between its two engines, so that the latency-bound, issue-bound
- * and bandwidth-bound stages of different jobs overlap — then run passes over them; outputs stay in HBM. */
+/* device-resident form (bench / roofline): stage n entries (each one frame, or a run of frames) — LPT assignment over the GPUs, one
+ * resident submit per GPU — then run passes over them; outputs stay in HBM. */
 int zgpu_pool_stage(zgpu_pool*, const uint8_t* const* frames, const size_t* lens, uint32_t n);
 int zgpu_pool_run(zgpu_pool*, float* gpu_ms /* [num_gpus] kernel pipeline ms per GPU */, float* wall_ms);
 /* per-kernel times of GPU g's last pass (ms, the order of zgpu_batch_timings), summed over its resident jobs, and what they hold */

@@ -186,20 +186,18 @@ int zgpu_pool_stage(zgpu_pool* p, const uint8_t* const* frames, const size_t* le
   p->frame_slot.assign(n, 0);
   p->frame_count.assign(n, 0);
   p->nframes = n;
-  // A GPU's frames become up to eight resident jobs, alternating between its two engines: the stages of a submit are bound by
-  // different things (the sequence chains by latency, the flatten by instruction issue, the sweep by memory traffic), and two
-  // submits in flight on their own streams fill each other's gaps. A job still costs the ~2 ms of one block's sequence chain
-  // whatever its size, so small inputs stay one job (>= 128 MiB of input and >= 4 frames per job).
+  // A GPU's frames are ONE resident job. ZGPU_POOL_JOBS=n (measurement) cuts them into n jobs that alternate between the GPU's two
+  // engines, so that stages of different jobs run side by side. Measured on one GPU's share of the BASELINE configs (round 3):
+  // text frames lose (8 GiB of 64 MiB frames: 141 -> 126 / 121 / 114 GB/s with 2 / 4 / 8 jobs: two flattens cannot share a CU's
+  // LDS, and a sweep beside anything else runs at a quarter of its speed), literal-heavy frames gain 8 % with two (the Huffman
+  // streams of one job beside the flatten of the other).
   const char* je = getenv("ZGPU_POOL_JOBS");
   for (uint32_t w = 0; w < nw; w++) {
     std::vector<uint32_t> mine;
     for (uint32_t i = 0; i < n; i++) if (worker[i] == w) mine.push_back(i);
     if (mine.empty()) continue;
-    uint32_t J = (uint32_t)((load[w] + (128ull << 20) - 1) / (128ull << 20));
-    if (J > mine.size() / 4) J = (uint32_t)mine.size() / 4;
-    if (J > 8) J = 8;
+    uint32_t J = 1;
     if (je && atoi(je) > 0) J = (uint32_t)atoi(je) < mine.size() ? (uint32_t)atoi(je) : (uint32_t)mine.size();
-    if (J < 2) J = 1;
     const uint32_t first = (uint32_t)p->staged.size();
     p->staged.resize(first + J);
     for (uint32_t j = 0; j < J; j++) { p->staged[first + j].gpu = w; p->staged[first + j].lane = j & 1u; }
