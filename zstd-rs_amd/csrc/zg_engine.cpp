@@ -43,6 +43,7 @@ int Scratch::init_events() {
   for (auto& e : ev_huf)
     if (hipEventCreate(&e) != hipSuccess) return ZG_HIP_ERROR;
   if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return ZG_HIP_ERROR;
+  if (hipEventCreateWithFlags(&ev_fork3, hipEventDisableTiming) != hipSuccess) return ZG_HIP_ERROR;
   for (auto& e : ev_sw)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return ZG_HIP_ERROR;
   have_events = true;
@@ -62,6 +63,7 @@ void Scratch::release() {
   for (auto& e : ev_huf)
     if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
+  if (ev_fork3) { (void)hipEventDestroy(ev_fork3); ev_fork3 = nullptr; }
   for (auto& e : ev_sw)
     if (e) { (void)hipEventDestroy(e); e = nullptr; }
   have_events = false;
@@ -90,6 +92,7 @@ int Engine::create(int device, Engine** out) {
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
   if (hipStreamCreateWithPriority(&e->stream_, hipStreamNonBlocking, prio_hi) != hipSuccess) { delete e; return ZG_HIP_ERROR; }
   if (hipStreamCreateWithPriority(&e->stream2_, hipStreamNonBlocking, prio_lo) != hipSuccess) { delete e; return ZG_HIP_ERROR; }
+  if (hipStreamCreateWithPriority(&e->stream3_, hipStreamNonBlocking, prio_hi) != hipSuccess) { delete e; return ZG_HIP_ERROR; }
   *out = e;
   return ZG_OK;
 }
@@ -98,6 +101,7 @@ Engine::~Engine() {
   for (Scratch* s : free_) { s->release(); delete s; }
   if (stream_) (void)hipStreamDestroy(stream_);
   if (stream2_) (void)hipStreamDestroy(stream2_);
+  if (stream3_) (void)hipStreamDestroy(stream3_);
 }
 Scratch* Engine::acquire() {
   if (!free_.empty()) { Scratch* s = free_.back(); free_.pop_back(); return s; }
@@ -342,7 +346,8 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   // a frame-layer error after some good frames: the good frames are still uploaded (callers such as the
   // FrameDecoder mirror may want them); decode_all reports parse_status.
   { const char* e = getenv("ZGPU_UNIT_BLOCKS"); if (e && atoi(e) > 0) b->bb.unit_blocks = (uint32_t)atoi(e); }
-  { const char* e = getenv("ZGPU_DIRECT"); if (e && e[0] == '0') b->bb.direct_units = false; }   // (tests) every unit through scratch + sweep
+  { const char* e = getenv("ZGPU_DIRECT"); if (e && e[0] == '0') b->bb.direct_units = false; }
+  { const char* e = getenv("ZGPU_RAMP"); if (e) b->bb.ramp_percent = (uint32_t)atoi(e); }   // (measurement) 0: equal units, the sweep after the flatten   // (tests) every unit through scratch + sweep
   { const char* e = getenv("ZGPU_SPARSE_MAX"); if (e) { b->bb.sparse_max = (uint32_t)atoi(e); b->bb.sparse_per_block = 1u << 20; } }   // (tests) sequences per frame up to which zg_k_sparse replaces the sweep, whatever their density; 0: never
   b->bb.flat_slots = (uint32_t)cus_ * (flat_shape_ == 0 ? 1u : 2u);   // zg_k_flat: workgroups the device holds at once
   b->bb.finish();
@@ -497,11 +502,27 @@ int Batch::run() {
   // ---- phase 2: LZ77 execution
   zg_launch_lit(d, s);
   ZG_HIP(hipEventRecord(ev[6], s));
-  zg_launch_flat(d, s);
-  { bool any = false; for (const ZgFrame& fr : bb.frames) any = any || fr.sparse; if (any) zg_launch_sparse(d, s); }
-  ZG_HIP(hipEventRecord(ev[7], s));
   sweep_mode = 0; synced = false;
-  if (!getenv("ZGPU_DEBUG_NO_SWEEP")) launch_sweep(true);
+  // One long frame in ramped units (BatchBuilder::finish): the flatten goes to its own stream and the sweep chain starts at once;
+  // a step waits for its unit's flag (zg_k_flatten sets it, zg_k_sweep polls it). ZGPU_OVERLAP=0: one after the other.
+  const char* ov = getenv("ZGPU_OVERLAP");
+  const bool overlap = bb.ramped && !(ov && ov[0] == '0') && !getenv("ZGPU_DEBUG_NO_SWEEP");
+  d.overlap_epoch = overlap ? ++epoch_ : 0u;
+  if (overlap) {
+    hipStream_t s3 = eng->stream3_;
+    ZG_HIP(hipMemsetAsync(d.unit_info, 0, (size_t)d.nunits * sizeof(ZgUnitInfo), s));   // the flags of earlier users of this memory
+    ZG_HIP(hipEventRecord(sc->ev_fork3, s));
+    ZG_HIP(hipStreamWaitEvent(s3, sc->ev_fork3, 0));
+    zg_launch_flat(d, s3);
+    ZG_HIP(hipEventRecord(ev[7], s3));
+    launch_sweep(true);
+    ZG_HIP(hipStreamWaitEvent(s, ev[7], 0));
+  } else {
+    zg_launch_flat(d, s);
+    { bool any = false; for (const ZgFrame& fr : bb.frames) any = any || fr.sparse; if (any) zg_launch_sparse(d, s); }
+    ZG_HIP(hipEventRecord(ev[7], s));
+    if (!getenv("ZGPU_DEBUG_NO_SWEEP")) launch_sweep(true);
+  }
   ZG_HIP(hipEventRecord(ev[8], s));
   zg_launch_lz(d, s);   // only frames that left the flatten path (a block regenerating > 128 KiB)
   ZG_HIP(hipEventRecord(ev[9], s));

@@ -67,7 +67,7 @@ struct Scratch {
   DevBuf d_src, d_blocks, d_frames, d_aux, d_slot_log, d_fse, d_huf, d_hufmax, d_status, d_lit, d_seq, d_seqout, d_pos, d_frameout,
       d_dst, d_seqblocks, d_hufitems, d_hufgroups, d_totals, d_og, d_units, d_unitinfo, d_stepunits, d_swdesc, d_dbg, d_raw;
   hipEvent_t ev[ZG_T_COUNT + 1] = {};
-  hipEvent_t ev_huf[2] = {}, ev_fork = nullptr;   // zg_k_huf runs on the engine's second stream beside zg_k_seq
+  hipEvent_t ev_huf[2] = {}, ev_fork = nullptr, ev_fork3 = nullptr;   // zg_k_huf runs on the engine's second stream beside zg_k_seq
   hipEvent_t ev_sw[80] = {};                      // split sweep: heads on the second stream (zg_launch_sweep)
   bool have_events = false;
   int init_events();
@@ -125,6 +125,7 @@ class Batch {
   std::vector<ZgSweepStep> sweep_steps;
   uint64_t og_words = 0;
   bool ran = false;
+  uint32_t epoch_ = 0;                   // runs of this batch so far (the flatten's per-unit flags carry it)
   FrameState* fs = nullptr;              // streaming submit: the frame state this run reads from / writes into
 };
 
@@ -155,7 +156,7 @@ class Engine {
   int device_ = 0;
   int cus_ = 256;                // compute units of the device (MI355X: 256)
   int flat_shape_ = 0;           // zg_k_flat shape: 0 = 1024 threads x 16 KiB tiles (one workgroup per CU), 1 = 512 x 8 KiB (two)
-  hipStream_t stream_ = nullptr, stream2_ = nullptr;
+  hipStream_t stream_ = nullptr, stream2_ = nullptr, stream3_ = nullptr;   // stream3_: the flatten, when the sweep chain runs beside it
   std::vector<Scratch*> free_;   // finished submits' buffers, for reuse
   Scratch* acquire();
   void recycle(Scratch* s);

@@ -234,6 +234,7 @@ void BatchBuilder::finish() {
     if (final_.huf == kCarryHuf) final_.huf = frames[lf].carry_huf_slot;
   }
   seq_blocks.clear(); huf_items.clear(); huf_groups.clear(); units.clear(); step_units.clear(); steps.clear();
+  ramped = false;
   // blocks per unit: zg_k_flat runs flat_slots workgroups at once, one per unit, so aim at ~flat_slots units over the whole
   // submit (more blocks per unit = fewer sweep steps, but less parallelism in the flatten pass). What costs there are the
   // blocks that have sequences: a literal-heavy frame gets smaller units in proportion, so that few literal-only blocks share a
@@ -263,10 +264,28 @@ void BatchBuilder::finish() {
       ubf = (uint32_t)(((uint64_t)ub * nbs + fr.nblocks - 1) / fr.nblocks);
       if (ubf < 4) ubf = 4;
     }
-    for (uint32_t i = 0; i < fr.nblocks; i += ubf) {
+    // One long frame alone in the submit: all its units are flattened side by side and swept one after the other. With units
+    // that grow along the frame the flatten finishes them in frame order, and the sweep of unit k (a chain of short launches
+    // that leaves most of the chip idle) runs while the flatten is still busy with the larger units behind it.
+    const bool ramp = ramp_percent && unit_blocks == 0 && frames.size() == 1 && fr.nblocks >= 64 * ubf && !fr.sparse;
+    const uint32_t nun = (fr.nblocks + ubf - 1) / ubf;
+    ramped = ramped || ramp;
+    uint32_t done_blocks = 0, ui = 0;
+    for (uint32_t i = 0; i < fr.nblocks; ui++) {
+      uint32_t take = ubf;
+      if (ramp) {
+        // cumulative target: blocks in front of unit ui + 1 = integral of the linear ramp
+        const double x = (double)(ui + 1) / nun, r = ramp_percent / 100.0;
+        const double cum = fr.nblocks * (x * (1.0 - r) + r * x * x);
+        uint32_t upto = ui + 1 == nun ? fr.nblocks : (uint32_t)(cum + 0.5);
+        if (upto <= done_blocks) upto = done_blocks + 1;
+        if (upto > fr.nblocks) upto = fr.nblocks;
+        take = upto - done_blocks;
+        if (take > 256) take = 256;
+      }
       ZgUnit u;
-      u.frame = f; u.first_block = fr.first_block + i;
-      u.nblocks = fr.nblocks - i < ubf ? fr.nblocks - i : ubf; u.noseq = 1;
+      u.frame = f; u.first_block = fr.first_block + i; u.desc = 0xFFFFFFFFu; u.pad = 0;
+      u.nblocks = fr.nblocks - i < take ? fr.nblocks - i : take; u.noseq = 1;
       for (uint32_t k = 0; k < u.nblocks; k++) {
         const ZgBlock& bk = blocks[u.first_block + k];
         if (bk.btype == ZG_BT_COMPRESSED && bk.nseq) u.noseq = 0;
@@ -277,6 +296,7 @@ void BatchBuilder::finish() {
       // pointer-mode one, and all units of a submit are flattened side by side (a frame of hundreds of units gains nothing)
       if (i == 0 && !u.noseq && direct_units && !fr.fixed_base && !fr.sparse && (fr.nblocks + ubf - 1) / ubf <= direct_max_units) u.noseq = ZG_UNIT_DIRECT;
       units.push_back(u);
+      i += u.nblocks; done_blocks += u.nblocks;
     }
     fr.nunits = (uint32_t)units.size() - fr.first_unit;
     if (fr.nunits > max_units) max_units = fr.nunits;
@@ -290,6 +310,7 @@ void BatchBuilder::finish() {
       if (frames[f].nunits <= s) continue;
       const uint32_t u = frames[f].first_unit + s;
       if (units[u].noseq || frames[f].sparse) continue;
+      units[u].desc = (uint32_t)step_units.size();
       step_units.push_back(u);
       r.nunits++;
       if (units[u].nblocks > r.max_blocks) r.max_blocks = units[u].nblocks;

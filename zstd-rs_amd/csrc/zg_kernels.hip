@@ -1615,7 +1615,7 @@ __device__ __forceinline__ void zg_flat1_unit(const ZgBatchDev& d, const uint32_
     }
   }
   __syncthreads();
-  if (t == 0) { ZgUnitInfo ui2; ui2.size = unit_size; ui2.noseq = un.noseq; d.unit_info[ui] = ui2; }
+  if (t == 0) { d.unit_info[ui].size = unit_size; d.unit_info[ui].noseq = un.noseq; }
 #ifdef ZG_PROFILE_FLAT
   if (t == 0 && d.dbg) { for (int i = 0; i < 8; i++) atomicAdd(&d.dbg[i], tc[i]); }
 #endif
@@ -1657,6 +1657,22 @@ ZX_DEV uint32_t zx_pksub16(uint32_t a, uint32_t b) { return __builtin_bit_cast(u
 ZX_DEV uint32_t zx_pksign16(uint32_t a) { uint32_t r; asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a)); return r; }
 #include "zg_flat4.h"
 
+// everything a sweep workgroup needs to know about its unit, in one 32-byte descriptor
+__device__ __forceinline__ ZgSweepDesc zg_sweep_desc(const ZgBatchDev& d, uint32_t u, uint32_t size) {
+  const ZgUnit un = d.units[u];
+  const ZgFrameOut fo = d.frame_out[un.frame];
+  ZgSweepDesc sd;
+  sd.out = (uint64_t)(d.dst + fo.out_base + d.pos[un.first_block].out_base);
+  sd.og = (uint64_t)(d.og + fo.og_base + d.pos[un.first_block].out_base);
+  sd.size = size;
+  const uint32_t w = zg_sweep_window(d, d.frames[un.frame]);
+  sd.head = sd.size > w ? (sd.size - w) / (4u * ZG_SW_T * ZG_SW_B) : 0u;
+  // a unit of the frame failed in the flatten: its scratch is incomplete; the frame is reported as failed
+  sd.live = (!d.totals[2] && fo.fast && fo.err_packed == 0xFFFFFFFFu) ? 1u : 0u;
+  sd.pad = 0;
+  return sd;
+}
+
 // zg_k_flatten: one workgroup per unit. A frame's first unit (nothing in front of it to copy from) is resolved to bytes by the
 // dword-granular body (zg_flat4_unit: no scratch, no sweep step); every other unit gets its effective offsets from the
 // byte-granular body above (zg_flat1_unit) — measured on the 1e9-byte frame, the dword-granular body in pointer mode issued 23 %
@@ -1665,9 +1681,23 @@ ZX_DEV uint32_t zx_pksign16(uint32_t a) { uint32_t r; asm("v_pk_ashrrev_i16 %0, 
 template <int T, int TS, int SPT>
 __global__ void __launch_bounds__(T, 4) zg_k_flatten(ZgBatchDev d) {
   __shared__ union { ZgFlat1Lds<T, TS, SPT> p; ZgFlat4Lds<T, TS, SPT> v; } s_u;
-  if (threadIdx.x == 0) { ZgUnitInfo ui; ui.size = 0; ui.noseq = 0; d.unit_info[blockIdx.x] = ui; }
+  if (threadIdx.x == 0) { d.unit_info[blockIdx.x].size = 0; d.unit_info[blockIdx.x].noseq = 0; }
   if (d.units[blockIdx.x].noseq & ZG_UNIT_DIRECT) zg_flat4_unit<T, TS, SPT>(d, blockIdx.x, s_u.v);
   else zg_flat1_unit<T, TS, SPT>(d, blockIdx.x, s_u.p);
+  // The sweep chain runs beside this kernel (one long frame in units that grow along it: see BatchBuilder::finish): the unit is
+  // handed to its sweep step here — descriptor, then everything this workgroup wrote made visible to the whole device (release),
+  // then the flag the step polls. (Producer recipe of the hardware guide: plain stores -> workgroup barrier -> one lane's
+  // agent-scope release -> vmcnt(0) -> relaxed agent-scope flag store.)
+  if (d.overlap_epoch) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t de = d.units[blockIdx.x].desc;
+      if (de != 0xFFFFFFFFu) d.sweep_desc[de] = zg_sweep_desc(d, blockIdx.x, d.unit_info[blockIdx.x].size);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&d.unit_info[blockIdx.x].done, d.overlap_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // zg_k_swprep: one thread per (step, unit) entry: everything a sweep workgroup needs about its unit in one 32-byte
@@ -1676,18 +1706,7 @@ __global__ void __launch_bounds__(256) zg_k_swprep(ZgBatchDev d, uint32_t n) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const uint32_t u = d.step_units[i];
-  const ZgUnit un = d.units[u];
-  const ZgFrameOut fo = d.frame_out[un.frame];
-  ZgSweepDesc sd;
-  sd.out = (uint64_t)(d.dst + fo.out_base + d.pos[un.first_block].out_base);
-  sd.og = (uint64_t)(d.og + fo.og_base + d.pos[un.first_block].out_base);
-  sd.size = d.unit_info[u].size;
-  const uint32_t w = zg_sweep_window(d, d.frames[un.frame]);
-  sd.head = sd.size > w ? (sd.size - w) / (4u * ZG_SW_T * ZG_SW_B) : 0u;
-  // a unit of the frame failed in zg_k_flat: its scratch is incomplete; the frame is reported as failed
-  sd.live = (!d.totals[2] && fo.fast && fo.err_packed == 0xFFFFFFFFu) ? 1u : 0u;
-  sd.pad = 0;
-  d.sweep_desc[i] = sd;
+  d.sweep_desc[i] = zg_sweep_desc(d, u, d.unit_info[u].size);
 }
 
 // zg_k_sweep: one launch per step; step s fills unit s of every frame that has one (blockIdx.y picks the unit from the
@@ -1701,6 +1720,24 @@ __global__ void __launch_bounds__(256) zg_k_swprep(ZgBatchDev d, uint32_t n) {
 // the TAIL of the units in front of it. Only the tails (part 1) form the chain of steps; the heads (part 2) are filled
 // beside it, many units per launch, on the engine's second stream. part 0 is the whole unit.
 __global__ void __launch_bounds__(ZG_SW_T) __attribute__((amdgpu_waves_per_eu(2, 3))) zg_k_sweep(ZgBatchDev d, uint32_t list_off, uint32_t nbatch, uint32_t dbgmode, uint32_t part) {
+  if (d.overlap_epoch) {
+    // the flatten may still be at this unit (it runs beside the chain): one lane polls the unit's flag. A step that finds it set
+    // — the usual case: units finish in frame order, ahead of the chain — reads data that was released before this launch began;
+    // one that had to wait acquires (consumer recipe of the hardware guide). The wait is bounded: the flatten does not depend
+    // on this kernel, but a hang must never be the way a mistake shows.
+    if (threadIdx.x == 0) {
+      const uint32_t u = d.step_units[list_off + blockIdx.y];
+      uint32_t spins = 0;
+      bool waited = false;
+      while (__hip_atomic_load(&d.unit_info[u].done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != d.overlap_epoch) {
+        __builtin_amdgcn_s_sleep(16);
+        waited = true;
+        if (++spins > (1u << 24)) { atomicCAS(&d.frame_out[d.units[u].frame].status, 0u, (uint32_t)ZG_INTERNAL); break; }
+      }
+      if (waited) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+  }
   const ZgSweepDesc sd = d.sweep_desc[list_off + blockIdx.y];
   const uint32_t t = threadIdx.x, size = sd.size;
   constexpr uint32_t BG = ZG_SW_T * ZG_SW_B;                  // groups per batch (ZG_SW_BATCH bytes of output)
@@ -2044,7 +2081,7 @@ bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* step
   uint32_t n = 0;
   bool contiguous = true;
   for (uint32_t i = 0; i < nsteps; i++) { if (steps[i].list_off != steps[0].list_off + n) contiguous = false; n += steps[i].nunits; }
-  if (n) hipLaunchKernelGGL(zg_k_swprep, dim3((n + 255) / 256), dim3(256), 0, s, d, n);
+  if (n && !d.overlap_epoch) hipLaunchKernelGGL(zg_k_swprep, dim3((n + 255) / 256), dim3(256), 0, s, d, n);   // (beside the flatten: every unit's flatten writes its own descriptor)
   // The tails are worth a chain of their own when they are clearly shorter than the units (else: the plain chain).
   const uint32_t tail_batches = window_max / BB + 2u;
   const bool split = nev >= 3 && contiguous && nsteps > 1 && (uint64_t)tail_batches * BB + 65536u < unit_bytes;

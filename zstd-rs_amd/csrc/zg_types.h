@@ -187,8 +187,8 @@ struct ZgFrameOut {
 #define ZG_FLAT_MAX 131072u  // largest block output the flatten path handles (Block_Maximum_Size)
 #define ZG_UNIT_NOSEQ 1u
 #define ZG_UNIT_DIRECT 2u
-struct ZgUnit { uint32_t frame, first_block, nblocks, noseq; };
-struct ZgUnitInfo { uint32_t size; uint32_t noseq; };   // written by zg_k_flat: bytes of the unit
+struct ZgUnit { uint32_t frame, first_block, nblocks, noseq; uint32_t desc, pad; };   // desc: the unit's entry in the sweep descriptors (0xFFFFFFFF: it has no sweep step)
+struct ZgUnitInfo { uint32_t size; uint32_t noseq; uint32_t done; uint32_t pad; };   // written by zg_k_flatten: bytes of the unit; done: the run (epoch) whose flatten has finished the unit
 
 // what a sweep workgroup needs to know about its unit
 // head: batches (ZG_SW_BATCH bytes) at the front of the unit that nothing later depends on when no match reaches further back than the
@@ -247,7 +247,9 @@ struct ZgBatchDev {
   const ZgUnit* units;
   uint32_t nunits;
   ZgUnitInfo* unit_info;       // [nunits]
-  ZgSweepDesc* sweep_desc;     // one per entry of step_units, written by zg_k_swprep after zg_k_flat
+  ZgSweepDesc* sweep_desc;     // one per entry of step_units, written by zg_k_swprep after zg_k_flatten (or by the flatten itself: overlap_epoch)
+  uint32_t overlap_epoch;      // != 0: the sweep chain runs beside the flatten; a unit's flatten publishes its descriptor and sets unit_info.done to this
+  uint32_t pad_ov;
   const uint32_t* step_units;  // sweep step s fills the units step_units[list_off(s) ...] (unit s of every frame that has one)
   unsigned long long* dbg;     // phase cycle counters (profiling builds), diagnostics only
 };

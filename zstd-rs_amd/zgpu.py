@@ -295,8 +295,8 @@ class Batch:
         for u in range(self.L.zgpu_batch_num_units(self.h)):
             fb, nb, base = C.c_uint32(), C.c_uint32(), C.c_uint64()
             assert self.L.zgpu_batch_unit(self.h, u, C.byref(fb), C.byref(nb), C.byref(base)) == 0
-            info = (C.c_uint32 * 2)()
-            assert self.L.zgpu_batch_debug_scratch(self.h, 1, 8 * u, info, 8) == 0
+            info = (C.c_uint32 * 4)()
+            assert self.L.zgpu_batch_debug_scratch(self.h, 1, 16 * u, info, 16) == 0
             out.append((fb.value, nb.value, base.value, info[0], int(info[1])))
         return out
 
