@@ -111,6 +111,19 @@ def test_1e9_frame_and_checksum(ctx, text1g):
     d.close()
 
 
+def test_ramped_units_chain_beside_flatten(ctx, monkeypatch):
+    """the measurement switch ZGPU_RAMP (off by default: it measured slower): one long frame in units that grow along it, the
+    flatten raising a flag per unit and the sweep chain polling it from a third stream — results must not change"""
+    import zgdata
+    plain = zgdata.text_like(200 << 20, seed=0x7A)
+    z = zgdata.zstd_compress(plain)
+    for ramp in ("50", "90"):
+        monkeypatch.setenv("ZGPU_RAMP", ramp)
+        _check_batch(ctx, [z], [plain])
+    monkeypatch.delenv("ZGPU_RAMP")
+    _check_batch(ctx, [z], [plain])
+
+
 def test_more_than_4gib_in_one_submit(ctx, text1g):
     """5 frames of 1e9 bytes in one submit: output positions beyond 2^32, flatten scratch beyond 16 GiB"""
     plain, z = text1g

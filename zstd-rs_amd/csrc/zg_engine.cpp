@@ -347,7 +347,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   // FrameDecoder mirror may want them); decode_all reports parse_status.
   { const char* e = getenv("ZGPU_UNIT_BLOCKS"); if (e && atoi(e) > 0) b->bb.unit_blocks = (uint32_t)atoi(e); }
   { const char* e = getenv("ZGPU_DIRECT"); if (e && e[0] == '0') b->bb.direct_units = false; }
-  { const char* e = getenv("ZGPU_RAMP"); if (e) b->bb.ramp_percent = (uint32_t)atoi(e); }   // (measurement) 0: equal units, the sweep after the flatten   // (tests) every unit through scratch + sweep
+  { const char* e = getenv("ZGPU_RAMP"); if (e) b->bb.ramp_percent = (uint32_t)atoi(e); }   // (measurement) N > 0: one long frame in units growing by +-N %, the sweep chain beside the flatten
   { const char* e = getenv("ZGPU_SPARSE_MAX"); if (e) { b->bb.sparse_max = (uint32_t)atoi(e); b->bb.sparse_per_block = 1u << 20; } }   // (tests) sequences per frame up to which zg_k_sparse replaces the sweep, whatever their density; 0: never
   b->bb.flat_slots = (uint32_t)cus_ * (flat_shape_ == 0 ? 1u : 2u);   // zg_k_flat: workgroups the device holds at once
   b->bb.finish();
@@ -509,14 +509,18 @@ int Batch::run() {
   const bool overlap = bb.ramped && !(ov && ov[0] == '0') && !getenv("ZGPU_DEBUG_NO_SWEEP");
   d.overlap_epoch = overlap ? ++epoch_ : 0u;
   if (overlap) {
+    // the flatten stays on the main stream and is enqueued FIRST; the chain goes to the third stream. (Should the two streams
+    // share a hardware queue, the chain then simply runs behind the flatten; the other way round its first step would sit in
+    // front of the kernel it waits for.)
     hipStream_t s3 = eng->stream3_;
     ZG_HIP(hipMemsetAsync(d.unit_info, 0, (size_t)d.nunits * sizeof(ZgUnitInfo), s));   // the flags of earlier users of this memory
     ZG_HIP(hipEventRecord(sc->ev_fork3, s));
+    zg_launch_flat(d, s);
+    ZG_HIP(hipEventRecord(ev[7], s));
     ZG_HIP(hipStreamWaitEvent(s3, sc->ev_fork3, 0));
-    zg_launch_flat(d, s3);
-    ZG_HIP(hipEventRecord(ev[7], s3));
-    launch_sweep(true);
-    ZG_HIP(hipStreamWaitEvent(s, ev[7], 0));
+    launch_sweep(true, s3);
+    ZG_HIP(hipEventRecord(sc->ev_fork3, s3));
+    ZG_HIP(hipStreamWaitEvent(s, sc->ev_fork3, 0));
   } else {
     zg_launch_flat(d, s);
     { bool any = false; for (const ZgFrame& fr : bb.frames) any = any || fr.sparse; if (any) zg_launch_sparse(d, s); }
@@ -533,7 +537,8 @@ int Batch::run() {
 
 // The sweep. split: tails on the main stream, heads beside them on the second one, which is right as long as no match
 // reaches further back than its frame's window (zg_k_seqpost reports one that does: sync() then repeats the sweep the plain way).
-void Batch::launch_sweep(bool split) {
+void Batch::launch_sweep(bool split, hipStream_t main) {
+  if (!main) main = eng->stream_;
   const char* e = getenv("ZGPU_SWEEP_SPLIT");
   if (e && e[0] == '0') split = false;
   uint64_t wmax = 0, wmin = ~0ull;
@@ -546,7 +551,7 @@ void Batch::launch_sweep(bool split) {
   if (dev.sweep_window) wmax = wmin = dev.sweep_window;
   if (wmax > 0x7FFFFFFFull) wmax = 0x7FFFFFFFull;
   if (wmin > wmax) wmin = wmax;
-  split_sweep = zg_launch_sweep(dev, eng->stream_, sweep_steps.data(), (uint32_t)sweep_steps.size(), eng->stream2_, sc->ev_sw, split ? 80u : 0u,
+  split_sweep = zg_launch_sweep(dev, main, sweep_steps.data(), (uint32_t)sweep_steps.size(), eng->stream2_, sc->ev_sw, split ? 80u : 0u,
                                 bb.unit_blocks_used * kMaxBlockSize, (uint32_t)wmax, (uint32_t)wmin);
   sweep_mode = split_sweep ? 1u : sweep_mode;
 }

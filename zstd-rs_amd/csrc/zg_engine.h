@@ -98,7 +98,7 @@ class Batch {
   int commit(FrameState* fs);
   bool saw_last_block = false;           // the run ended with the frame's last block
   int sync();                            // wait, download per-frame results, compute timings
-  void launch_sweep(bool split);
+  void launch_sweep(bool split, hipStream_t main = nullptr);   // main: the stream of the chain of steps (default: the engine's first)
   bool split_sweep = false;              // the last run used the split sweep: sync() checks that it was entitled to
   bool synced = false;                   // sync() ran after the last run(): outputs may be read
   uint32_t sweep_mode = 0;               // of the last run: 0 plain chain of steps, 1 split, 2 split and then repeated as a plain chain (tests)

@@ -67,8 +67,9 @@ class BatchBuilder {
   uint32_t sparse_max = 2048;      // a frame with at most this many sequences (and <= sparse_per_block per block) skips the sweep: zg_k_sparse (0: never)
   uint32_t sparse_per_block = 4;
   bool direct_units = true;    // first units of frames that start from nothing are resolved to bytes by the flatten itself (no scratch, no sweep step)
-  uint32_t ramp_percent = 50;  // a submit of ONE long frame: unit sizes grow from (100 - ramp)% to (100 + ramp)% of the mean along the frame, so
-                               // that the flatten finishes the units in frame order and the sweep chain can follow it (0: equal units)
+  uint32_t ramp_percent = 0;   // (measurement, ZGPU_RAMP) a submit of ONE long frame: unit sizes grow from (100 - ramp)% to (100 + ramp)% of the
+                               // mean along the frame, the flatten raises a flag per unit and the sweep chain runs beside it on a third stream.
+                               // Measured slower than flatten-then-sweep at every ramp (DESIGN.md "what did not work"), so 0 = off.
   bool ramped = false;         // finish() chose ramped units
   uint32_t direct_max_units = 32;   // ... in frames of at most this many units
   uint32_t flat_slots = 256;   // workgroups of zg_k_flat the device runs at once (engine: CUs x workgroups per CU)
