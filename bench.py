@@ -227,10 +227,11 @@ def other_workload(name, device, min_seconds):
     dt, pps, busy = timed_passes(pool, 1, min_seconds)
     kern, D, Cb, nb = pool.timings(0)
     pool_jobs = pool.last_njobs
+    plan = pool.plan_stats(0)
     pool.close()
     return {"workload": desc, "plaintext_bytes": D, "compressed_bytes": Cb, "frames": len(zs) * rep, "blocks": nb, "passes": pps,
             "GBps": round(D * pps / dt / 1e9, 3), "ms_per_pass": round(dt / pps * 1e3, 3), "kernel_ms_per_pass": round(busy[0], 3),
-            "kernel_ms": {k: round(v, 4) for k, v in kern.items()}, "roofline": roofline(kern, Cb + D, name, busy[0], pool_jobs), "host_prepare_s": round(prep, 2)}
+            "kernel_ms": {k: round(v, 4) for k, v in kern.items()}, "lz77_plan": plan, "roofline": roofline(kern, Cb + D, name, busy[0], pool_jobs), "host_prepare_s": round(prep, 2)}
 
 
 def e2e_rate(device, zs_list, plain_total):
@@ -356,6 +357,7 @@ def main():
             "roofline": roofline(kern, C0 + D0, args.workload, per_gpu_busy[0], pool.last_njobs),
             "read_GBps": round(C0 / (kern["total"] / 1e3) / 1e9, 3) if kern["total"] > 0 else 0.0,
             "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
+            "lz77_plan": pool.plan_stats(0),
             "per_gpu_busy_ms": [round(x, 3) for x in per_gpu_busy],
         }
         if sharded:

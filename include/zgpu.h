@@ -120,6 +120,9 @@ int zgpu_pool_stage(zgpu_pool*, const uint8_t* const* frames, const size_t* lens
 int zgpu_pool_run(zgpu_pool*, float* gpu_ms /* [num_gpus] kernel pipeline ms per GPU */, float* wall_ms);
 /* per-kernel times of GPU g's last pass (ms, the order of zgpu_batch_timings), summed over its resident jobs, and what they hold */
 int zgpu_pool_timings(const zgpu_pool*, uint32_t g, float* ms, int n, uint64_t* plain_bytes, uint64_t* comp_bytes, uint32_t* nblocks, uint32_t* njobs);
+/* the LZ77 plan of GPU g's resident jobs after a run: out[0..6] = units, direct units, units without sequences, pointer-mode units,
+ * sweep steps, plaintext bytes of the pointer-mode units, of the direct units (n >= 7) */
+int zgpu_pool_plan_stats(const zgpu_pool*, uint32_t g, uint64_t* out, int n);
 int zgpu_pool_frame(zgpu_pool*, uint32_t i, int* gpu, uint64_t* out_size, uint32_t* status);
 int zgpu_pool_read(zgpu_pool*, uint32_t i, uint8_t* dst, size_t cap, size_t* written);
 

@@ -1,17 +1,23 @@
 #!/usr/bin/env python3
-"""rocprofv3 outputs of tools/dev/profile.sh (gpurun_out/prof) -> the summaries kept under profiles/r02/.
+"""rocprofv3 outputs of tools/dev/profile.sh (gpurun_out/prof/<workload>/...) -> the summaries kept under profiles/r03/.
 
-  --reduce   (on the GPU box) condense the counter CSVs into gpurun_out/prof/pmc_reduced.json: per kernel the summed counter
-             and the number of launches. The raw CSVs (one row per launch: hundreds of sweep launches) stay behind.
-  (default)  (here) write profiles/r02/: kernel statistics, the bench line of the traced run, and bench_pmc.json: HBM bytes per
-             pass per kernel, raw and calibrated PER ACCESS PATTERN. On gfx950 FETCH_SIZE reports half of a wide (16 B/lane)
-             coalesced read (MI355X_MICROARCH.md, HBM section); what it reports for the engine's other patterns is measured by
-             the calibration kernels (zg_k_calib_*): the factor applied to a kernel is that of the pattern its reads are made of.
+  --reduce W..  (on the GPU box) condense the counter CSVs into gpurun_out/prof/pmc_reduced.json: per workload and kernel the summed
+                counter and the number of launches; the SQ-counter CSVs are cut down to the engine's kernels (one row per launch
+                and counter: the raw evidence kept under profiles/). The bulky traces stay behind.
+  (default)     (here) write profiles/r03/: per workload <w>_kernel_stats.csv, <w>_bench_under_rocprof.json and <w>_pmc.json: HBM bytes
+                per pass per kernel, raw and calibrated PER ACCESS PATTERN. On gfx950 FETCH_SIZE reports half of a wide coalesced
+                read (MI355X_MICROARCH.md, HBM section); what it reports for the engine's other patterns is measured by the
+                calibration kernels (zg_k_calib_*): the factor applied to a kernel is that of the pattern its reads are made of.
 """
-import collections, csv, hashlib, json, os, shutil, sys
+import collections, csv, glob, hashlib, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 P = os.path.join(ROOT, "gpurun_out", "prof")
-OUT = os.path.join(ROOT, "profiles", "r02")
+OUT = os.path.join(ROOT, "profiles", "r03")
+CSRC = os.path.join(ROOT, "zstd-rs_amd", "csrc")
+
+
+def kname(s):
+    return s.split("(")[0].replace("void ", "")
 
 
 def per_kernel(path, counter):
@@ -19,44 +25,56 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        k = kname(r["Kernel_Name"])
         acc[k][0] += float(r["Counter_Value"])
         acc[k][1].add(r["Dispatch_Id"])
     return {k: [v[0], len(v[1])] for k, v in acc.items()}
 
 
-def find(d):
+def find(d, suffix="counter_collection.csv"):
     for r, _, fs in os.walk(os.path.join(P, d)):
         for f in fs:
-            if f.endswith("counter_collection.csv"):
+            if f.endswith(suffix):
                 return os.path.join(r, f)
-    raise SystemExit("no counter csv under " + d)
+    return None
 
 
-def reduce():
-    red = {"fetch": per_kernel(find("fetch"), "FETCH_SIZE"), "write": per_kernel(find("write"), "WRITE_SIZE"),
-           "calib_fetch": per_kernel(find("calib_fetch"), "FETCH_SIZE"), "calib_write": per_kernel(find("calib_write"), "WRITE_SIZE")}
+def reduce(workloads):
+    red = {"calib_fetch": per_kernel(find("calib_fetch"), "FETCH_SIZE"), "calib_write": per_kernel(find("calib_write"), "WRITE_SIZE"), "workloads": {}}
+    for w in workloads:
+        f, wr = find(w + "/fetch"), find(w + "/write")
+        if not f or not wr:
+            print("no counters for", w)
+            continue
+        red["workloads"][w] = {"fetch": per_kernel(f, "FETCH_SIZE"), "write": per_kernel(wr, "WRITE_SIZE")}
+        ks = find(w + "/stats", "kernel_stats.csv")
+        if ks:
+            shutil.copy(ks, os.path.join(P, w + "_kernel_stats.csv"))
+        for k in (1, 2, 3):
+            sq = find("%s/sq%d" % (w, k))
+            if not sq:
+                continue
+            with open(os.path.join(P, "%s_sq%d.csv" % (w, k)), "w", newline="") as fo:
+                wtr = csv.writer(fo)
+                wtr.writerow(["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count", "Counter_Name", "Counter_Value"])
+                for r in csv.DictReader(open(sq)):
+                    k2 = kname(r["Kernel_Name"])
+                    if k2.startswith("zg_k_"):
+                        wtr.writerow([r["Dispatch_Id"], k2, r.get("Grid_Size", ""), r.get("Workgroup_Size", ""), r.get("LDS_Block_Size", ""),
+                                      r.get("VGPR_Count", ""), r.get("SGPR_Count", ""), r["Counter_Name"], r["Counter_Value"]])
     json.dump(red, open(os.path.join(P, "pmc_reduced.json"), "w"), indent=1)
-    for r, _, fs in os.walk(os.path.join(P, "stats")):
-        for f in fs:
-            if f.endswith("kernel_stats.csv"):
-                shutil.copy(os.path.join(r, f), os.path.join(P, "kernel_stats.csv"))
 
 
 # which calibration pattern a kernel's reads are (mostly) made of; its writes are 4 or 16 B per lane coalesced
-READ_PATTERN = {"zg_k_sweep": "mixed_sweep", "zg_k_flat": "mixed_flat", "zg_k_seqpost": "copy16", "zg_k_seq": "copy16", "zg_k_huf": "copy16",
-                "zg_k_ftab": "copy16", "zg_k_tables": "copy16", "zg_k_scan": "copy4", "zg_k_lit": "copy4"}
+READ_PATTERN = {"zg_k_sweep": "mixed_sweep", "zg_k_flatten": "mixed_flat", "zg_k_seqpost": "copy16", "zg_k_seq": "copy16", "zg_k_huf": "copy16",
+                "zg_k_ftab": "copy16", "zg_k_tables": "copy16", "zg_k_scan": "copy4", "zg_k_lit": "copy16"}
 
 
 def main():
     if "--reduce" in sys.argv:
-        return reduce()
+        return reduce([a for a in sys.argv[1:] if not a.startswith("-")])
     os.makedirs(OUT, exist_ok=True)
     red = json.load(open(os.path.join(P, "pmc_reduced.json")))
-    shutil.copy(os.path.join(P, "kernel_stats.csv"), os.path.join(OUT, "bench_kernel_stats.csv"))
-    line = [l for l in open(os.path.join(P, "stats.log")) if l.startswith('{"metric"')][-1]
-    bench = json.loads(line)
-    json.dump(bench, open(os.path.join(OUT, "bench_under_rocprof.json"), "w"), indent=1)
     GiB = 1 << 30
     cal = {}
     for name, true_r, true_w in (("zg_k_calib_copy", GiB, GiB), ("zg_k_calib_copy4", GiB, GiB), ("zg_k_calib_gather<unsigned int>", GiB // 64 * 64, 0),
@@ -70,47 +88,61 @@ def main():
     f4 = cal["zg_k_calib_copy4"]["read_factor"] or 1.0
     fg = cal["zg_k_calib_gather<unsigned long>"]["read_factor"] or 1.0
     w16 = cal["zg_k_calib_copy"]["write_factor"] or 1.0
-    D = bench["config"]["plaintext_bytes_job"]
-    res = {"kernels_sha256": hashlib.sha256(open(os.path.join(ROOT, "zstd-rs_amd", "csrc", "zg_kernels.hip"), "rb").read()).hexdigest(),
-           "workload": bench["config"]["name"], "plaintext_bytes": D,
-           "calibration": cal,
-           "method": "FETCH_SIZE / WRITE_SIZE (KiB) from separate rocprofv3 --pmc passes. Reads: a kernel whose reads are wide coalesced loads gets "
-                     "the factor measured on zg_k_calib_copy (16 B/lane); narrow coalesced loads that of zg_k_calib_copy4; random 4/8-byte gathers that "
-                     "of zg_k_calib_gather (64 B per miss assumed true). zg_k_sweep and zg_k_flat mix a known amount of wide reads (scratch words / "
-                     "sequence records) with gathers: the wide part is corrected analytically, the rest keeps the gather factor.",
-           "kernels": {}}
-    total = 0.0
-    # launches per pass: every kernel but the sweep is launched once per pass
-    npass = None
-    for k, (v, n) in red["fetch"].items():
-        if k.startswith("zg_k_flat"):
-            npass = n
-    for k in sorted(set(red["fetch"]) | set(red["write"])):
-        if not k.startswith("zg_k_") or "calib" in k:
+    sha = hashlib.sha256(open(os.path.join(CSRC, "zg_kernels.hip"), "rb").read() + open(os.path.join(CSRC, "zg_flat4.h"), "rb").read()).hexdigest()
+    for w, rw in red["workloads"].items():
+        ks = os.path.join(P, w + "_kernel_stats.csv")
+        if os.path.exists(ks):
+            shutil.copy(ks, os.path.join(OUT, w + "_kernel_stats.csv"))
+        for f in glob.glob(os.path.join(P, w + "_sq*.csv")):
+            shutil.copy(f, os.path.join(OUT, os.path.basename(f)))
+        lines = [l for l in open(os.path.join(P, w, "stats.log")) if l.startswith('{"metric"')]
+        if not lines:
+            print("no bench line for", w)
             continue
-        f = red["fetch"].get(k, [0.0, 1]); w = red["write"].get(k, [0.0, 1])
-        fraw, wraw = f[0] * 1024.0 / npass, w[0] * 1024.0 / npass             # bytes per pass
-        base = k.split("<")[0]
-        pat = READ_PATTERN.get(base, "copy16")
-        if pat == "copy16":
-            fcor = fraw * f16
-        elif pat == "copy4":
-            fcor = fraw * f4
-        else:
-            wide_true = 4.0 * D if base == "zg_k_sweep" else 1.2 * D      # sweep: the scratch, 4 B per output byte; flat: 12 B per sequence (~1.2 B/byte on text)
-            wide_raw = wide_true / f16
-            fcor = wide_true + max(fraw - wide_raw, 0.0) * fg
-        wcor = wraw * w16
-        res["kernels"][k] = {"launches_per_pass": round(f[1] / npass, 2), "fetch_raw_bytes_per_pass": int(fraw), "write_raw_bytes_per_pass": int(wraw),
-                             "read_pattern": pat, "hbm_bytes_per_pass_calibrated": int(fcor + wcor)}
-        total += fcor + wcor
-    res["pipeline_hbm_bytes_per_pass"] = int(total)
-    res["algorithmic_bytes_per_pass"] = bench["roofline"]["algorithmic_bytes"]
-    json.dump(res, open(os.path.join(OUT, "bench_pmc.json"), "w"), indent=1)
-    for k, v in res["kernels"].items():
-        print("%-34s raw fetch %8.3f GB  raw write %8.3f GB  calibrated %8.3f GB  (%s)" % (k, v["fetch_raw_bytes_per_pass"] / 1e9, v["write_raw_bytes_per_pass"] / 1e9,
-                                                                                  v["hbm_bytes_per_pass_calibrated"] / 1e9, v["read_pattern"]))
-    print("pipeline %.3f GB per pass; algorithmic %.3f GB" % (total / 1e9, res["algorithmic_bytes_per_pass"] / 1e9))
+        bench = json.loads(lines[-1])
+        json.dump(bench, open(os.path.join(OUT, w + "_bench_under_rocprof.json"), "w"), indent=1)
+        D = bench["config"]["plaintext_bytes_job"]
+        plan = bench.get("lz77_plan", {})
+        Dp, Dd = plan.get("pointer_bytes", D), plan.get("direct_bytes", 0)
+        res = {"kernels_sha256": sha, "workload": w, "plaintext_bytes": D, "lz77_plan": plan, "calibration": cal,
+               "method": "FETCH_SIZE / WRITE_SIZE (KiB) from separate rocprofv3 --pmc passes, summed over all launches of a kernel and divided by the "
+                         "passes of the run. Reads: a kernel whose reads are wide coalesced loads gets the factor measured on zg_k_calib_copy "
+                         "(16 B/lane); narrow coalesced loads that of zg_k_calib_copy4; random 4/8-byte gathers that of zg_k_calib_gather (64 B per "
+                         "miss assumed true). zg_k_sweep and zg_k_flatten mix a known amount of wide reads (sweep: the scratch words of the "
+                         "pointer-mode units, 4 B per byte; flatten: sequence records, ~1.2 B per byte of a unit with sequences) with gathers: "
+                         "the wide part is corrected analytically, the rest keeps the gather factor.",
+               "kernels": {}}
+        once = [n for k, (v, n) in rw["fetch"].items() if k.split("<")[0] in ("zg_k_scan", "zg_k_flatten", "zg_k_seq", "zg_k_ftab")]
+        npass = min(once) if once else 4
+        total = 0.0
+        for k in sorted(set(rw["fetch"]) | set(rw["write"])):
+            if not k.startswith("zg_k_") or "calib" in k:
+                continue
+            f = rw["fetch"].get(k, [0.0, 1]); wv = rw["write"].get(k, [0.0, 1])
+            fraw, wraw = f[0] * 1024.0 / npass, wv[0] * 1024.0 / npass             # bytes per pass
+            base = k.split("<")[0]
+            pat = READ_PATTERN.get(base, "copy16")
+            if pat == "copy16":
+                fcor = fraw * f16
+            elif pat == "copy4":
+                fcor = fraw * f4
+            else:
+                wide_true = 4.0 * Dp if base == "zg_k_sweep" else 1.2 * (Dp + Dd)
+                wide_raw = min(wide_true / f16, fraw)
+                fcor = wide_raw * f16 + (fraw - wide_raw) * fg
+            wcor = wraw * w16
+            res["kernels"][k] = {"launches_per_pass": round(f[1] / npass, 2), "fetch_raw_bytes_per_pass": int(fraw), "write_raw_bytes_per_pass": int(wraw),
+                                 "read_pattern": pat, "hbm_bytes_per_pass_calibrated": int(fcor + wcor)}
+            total += fcor + wcor
+        res["passes_in_run"] = npass
+        res["pipeline_hbm_bytes_per_pass"] = int(total)
+        res["algorithmic_bytes_per_pass"] = bench["roofline"]["algorithmic_bytes"]
+        json.dump(res, open(os.path.join(OUT, w + "_pmc.json"), "w"), indent=1)
+        print("== %s (%d passes)" % (w, npass))
+        for k, v in res["kernels"].items():
+            print("%-34s x%-7.2f raw fetch %8.3f GB  raw write %8.3f GB  calibrated %8.3f GB  (%s)" % (k, v["launches_per_pass"], v["fetch_raw_bytes_per_pass"] / 1e9,
+                  v["write_raw_bytes_per_pass"] / 1e9, v["hbm_bytes_per_pass_calibrated"] / 1e9, v["read_pattern"]))
+        print("pipeline %.3f GB per pass; algorithmic %.3f GB" % (total / 1e9, res["algorithmic_bytes_per_pass"] / 1e9))
 
 
 if __name__ == "__main__":

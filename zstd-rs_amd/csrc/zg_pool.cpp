@@ -299,6 +299,29 @@ int zgpu_pool_timings(const zgpu_pool* p, uint32_t g, float* ms, int n, uint64_t
   return ZGPU_OK;
 }
 
+// the LZ77 plan of GPU g's resident jobs (after a run): out[0] units, [1] direct units (resolved to bytes by the flatten), [2] units
+// without sequences, [3] pointer-mode units (scratch words + a sweep step), [4] sweep steps, [5] plaintext bytes of the pointer-mode
+// units, [6] of the direct units (both from the frames' sizes by block share: what the traffic accounting of the profiles needs)
+int zgpu_pool_plan_stats(const zgpu_pool* p, uint32_t g, uint64_t* out, int n) {
+  if (!p || g >= p->eng.size() || !out || n < 7) return ZGPU_E_BAD_ARG;
+  for (int i = 0; i < n; i++) out[i] = 0;
+  for (const Staged& s : p->staged) {
+    if (s.gpu != g || !s.batch) continue;
+    const zg::BatchBuilder& bb = s.batch->bb;
+    out[4] += bb.steps.size();
+    for (const ZgUnit& u : bb.units) {
+      out[0]++;
+      const ZgFrame& fr = bb.frames[u.frame];
+      const uint64_t fsz = u.frame < s.batch->frame_out.size() ? s.batch->frame_out[u.frame].out_size : 0;
+      const uint64_t share = fr.nblocks ? fsz * u.nblocks / fr.nblocks : 0;
+      if (u.noseq & ZG_UNIT_DIRECT) { out[1]++; out[6] += share; }
+      else if (u.noseq || fr.sparse) out[2]++;
+      else { out[3]++; out[5] += share; }
+    }
+  }
+  return ZGPU_OK;
+}
+
 // result of staged entry i after a run: which GPU took it, size and status of its (first) frame
 int zgpu_pool_frame(zgpu_pool* p, uint32_t i, int* gpu, uint64_t* out_size, uint32_t* status) {
   if (!p || i >= p->nframes) return ZGPU_E_BAD_ARG;

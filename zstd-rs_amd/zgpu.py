@@ -56,7 +56,7 @@ EXPORTS = [
     "zgpu_decoder_bytes_read_from_source", "zgpu_decoder_content_size", "zgpu_decoder_checksum_from_data",
     "zgpu_decoder_calculated_checksum", "zgpu_decode_all_alloc", "zgpu_free", "zgpu_decoder_collect_to_writer", "zgpu_streaming_create",
     "zgpu_streaming_destroy", "zgpu_streaming_decoder", "zgpu_streaming_read", "zgpu_pool_create", "zgpu_pool_create_on", "zgpu_pool_destroy",
-    "zgpu_pool_num_gpus", "zgpu_pool_decode_all", "zgpu_pool_plan", "zgpu_pool_stage", "zgpu_pool_run", "zgpu_pool_frame", "zgpu_pool_read", "zgpu_pool_timings",
+    "zgpu_pool_num_gpus", "zgpu_pool_decode_all", "zgpu_pool_plan", "zgpu_pool_stage", "zgpu_pool_run", "zgpu_pool_frame", "zgpu_pool_read", "zgpu_pool_timings", "zgpu_pool_plan_stats",
     "zgpu_frame_begin", "zgpu_frame_end", "zgpu_blocks_submit", "zgpu_sync", "zgpu_available", "zgpu_read", "zgpu_device_output",
     "zgpu_frame_checksum", "zgpu_frame_blocks_decoded", "zgpu_decoder_device_bytes",
 ]
@@ -165,6 +165,7 @@ def load_library():
     L.zgpu_pool_frame.argtypes = [vp, C.c_uint32, P(C.c_int), P(C.c_uint64), P(C.c_uint32)]
     L.zgpu_pool_read.argtypes = [vp, C.c_uint32, vp, sz, P(sz)]
     L.zgpu_pool_timings.argtypes = [vp, C.c_uint32, P(C.c_float), C.c_int, P(C.c_uint64), P(C.c_uint64), P(C.c_uint32), P(C.c_uint32)]
+    L.zgpu_pool_plan_stats.argtypes = [vp, C.c_uint32, P(C.c_uint64), C.c_int]
     _LIB = L
     return L
 
@@ -536,6 +537,14 @@ class Pool:
             raise ZgpuError(st)
         self.last_njobs = nj.value
         return dict(zip(["tables", "huf", "seq", "seqpost", "scan", "lit", "flat", "sweep", "lz", "total"], list(a))), pb.value, cb.value, nb.value
+
+    def plan_stats(self, g=0):
+        """the LZ77 plan of GPU g's resident jobs after a run (zgpu_pool_plan_stats)"""
+        a = (C.c_uint64 * 7)()
+        st = self.L.zgpu_pool_plan_stats(self.h, g, a, 7)
+        if st:
+            raise ZgpuError(st)
+        return dict(zip(["units", "direct_units", "noseq_units", "pointer_units", "sweep_steps", "pointer_bytes", "direct_bytes"], [int(x) for x in a]))
 
     def frame(self, i):
         gpu, size, st = C.c_int(), C.c_uint64(), C.c_uint32()
