@@ -53,6 +53,7 @@ def lib():
         L.zgemu_frame_plan.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32 * 7)]
         L.zgemu_seq_block.argtypes = [C.c_void_p, C.c_uint32]
         L.zgemu_seq_block.restype = C.c_uint32
+        L.zgemu_exact.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
         _LIB = L
     return _LIB
 
@@ -113,6 +114,14 @@ class EmuBatch:
         b, s, st, _ = self.frame(f)
         p = self.L.zgemu_output(self.h)
         return C.string_at(C.addressof(p.contents) + b, s), st
+
+    def exact(self, drain_rule=0, dict_len=0, prior_out=0, prior_reach=0, prior_counted=0):
+        """zg_k_exact's source (zg_exact.h) on this submit: [(status, bad_block, counted)] per frame; status 0 = the reference's
+        DecodeBuffer bookkeeping has nothing to object to in the blocks the entropy stages accepted"""
+        n = self.nframes
+        st, bad, cnt = (C.c_uint32 * n)(), (C.c_uint32 * n)(), (C.c_uint64 * n)()
+        assert self.L.zgemu_exact(self.h, drain_rule, dict_len, prior_out, prior_reach, prior_counted, st, bad, cnt) == 0
+        return [(st[i], bad[i], cnt[i]) for i in range(n)]
 
     def block(self, b):
         a = (C.c_uint32 * 12)()

@@ -1,0 +1,154 @@
+"""zg_k_exact's source (zstd-rs_amd/csrc/zg_exact.h) on the CPU, against the oracle: the reference's DecodeBuffer decides what a
+match may reach by what is still IN the buffer (FrameDecoder::decode_all drains it every MiB, frame_decoder.rs:541-577) and
+which of its two "offset too far" errors applies by a counter that skips raw and RLE blocks and dictionary-only matches
+(decode_buffer.rs:62-72,144-179). The frames here are hand-made (no conforming encoder emits an offset beyond its window):
+raw / RLE / literal-only blocks to move the buffer length and the counter apart, then one-sequence blocks that reach far back."""
+import os
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+import emu
+import oracle
+from golden_io import read_pack
+
+WINDOW_LOG = 17                     # 128 KiB: window descriptor 0x38
+
+
+def seq_block(offset, lits=b"abcd", last=False):
+    """compressed block: raw literals, ONE sequence (ll 0, ml 3, a new offset), LL / ML predefined, OF in RLE mode"""
+    val = offset + 3
+    of_code = val.bit_length() - 1
+    extra = val - (1 << of_code)
+    acc, accn = 1, 1
+    for v, w in ((0, 6), (0, 6), (extra, of_code)):       # top-down: marker, LL state, (OF state: 0 bits), ML state, extra bits of OF
+        acc = (acc << w) | (v & ((1 << w) - 1))
+        accn += w
+    stream = acc.to_bytes((accn + 7) // 8, "little")
+    body = bytes([len(lits) << 3]) + lits + bytes([1, 0x10, of_code]) + stream
+    return (((len(body) << 3) | (2 << 1) | (1 if last else 0)).to_bytes(3, "little")) + body
+
+
+def lit_block(n, last=False):
+    """compressed block without sequences: n raw literals (what DecodeBuffer::push counts)"""
+    assert n < (1 << 12)
+    lits = bytes((i * 13 + 5) & 255 for i in range(n))
+    body = bytes([0x04 | ((n & 15) << 4), n >> 4]) + lits + bytes([0])     # raw literals, 12-bit size format; 0 sequences
+    return (((len(body) << 3) | (2 << 1) | (1 if last else 0)).to_bytes(3, "little")) + body
+
+
+def raw_block(n, seed=0, last=False):
+    data = bytes(((i * 7 + seed) & 255) for i in range(256)) * (n // 256) + bytes(n % 256)
+    return ((n << 3) | (1 if last else 0)).to_bytes(3, "little") + data
+
+
+def rle_block(n, byte=0x5A, last=False):
+    return ((n << 3) | (1 << 1) | (1 if last else 0)).to_bytes(3, "little") + bytes([byte])
+
+
+def frame(*blocks):
+    return bytes([0x28, 0xB5, 0x2F, 0xFD, 0x00, (WINDOW_LOG - 10) << 3]) + b"".join(blocks)
+
+
+def oracle_all(z):
+    st, out = oracle.FrameDecoder().decode_all(z, 1 << 26)
+    return st
+
+
+def oracle_blocks(z, dict_raw=None, did=None):
+    o = oracle.FrameDecoder()
+    if dict_raw is not None:
+        assert o.add_dict(dict_raw) == did
+    st, c, _, _ = o.init(z)
+    assert st == 0
+    if dict_raw is not None:
+        assert o.force_dict(did) == 0
+    st, _, _ = o.decode_blocks(z[c:], oracle.STRAT_ALL)
+    return st
+
+
+K = 128 << 10
+
+CASES = [
+    # (name, blocks): every frame ends with a one-sequence block carrying the `last` flag
+    ("in_window", [raw_block(K, 1), raw_block(K, 2), seq_block(1000, last=True)]),
+    ("beyond_window_nothing_drained", [raw_block(K, 1)] * 6 + [seq_block(5 * K, last=True)]),
+    ("beyond_window_after_a_drain", [raw_block(K, 1)] * 20 + [seq_block(16 * K, last=True)]),          # decode_all: two rounds drained, 640 KiB left
+    ("just_inside_what_a_drain_left", [raw_block(K, 1)] * 20 + [seq_block(5 * K, last=True)]),
+    ("edge_of_what_a_drain_left", [raw_block(K, 1)] * 20 + [seq_block(5 * K + 1, last=True)]),
+    ("beyond_everything_counter_small", [raw_block(K, 1)] * 3 + [seq_block(3 * K + 1, last=True)]),     # raw blocks are not counted: the dictionary leaf
+    ("beyond_everything_counter_big", [lit_block(4000)] * 40 + [seq_block(40 * 4000 + 1, last=True)]),  # literal blocks are: the other leaf
+    ("beyond_everything_counter_at_window", [lit_block(4096 - 1)] * 32 + [lit_block(32 - 4)] + [seq_block(K, last=True)]),
+    ("rle_blocks_then_far", [rle_block(K)] * 12 + [lit_block(100), seq_block(9 * K, last=True)]),
+    ("two_seq_blocks_first_fails", [raw_block(K, 3), seq_block(K + 10), seq_block(5, last=True)]),
+    ("second_frame_starts_fresh", None),
+]
+
+
+def build(name, blocks):
+    if name == "second_frame_starts_fresh":
+        return frame(*([raw_block(K, 1)] * 9 + [seq_block(8 * K, last=True)])) + frame(raw_block(K, 2), seq_block(2 * K, last=True))
+    return frame(*blocks)
+
+
+@pytest.mark.parametrize("name,blocks", CASES, ids=[c[0] for c in CASES])
+def test_buffer_bookkeeping_matches_the_oracle(name, blocks):
+    z = build(name, blocks)
+    e = emu.EmuBatch(z)
+    assert e.parse_status == 0
+    # FrameDecoder::decode_all: the first failing frame's error, else success
+    want_all = oracle_all(z)
+    got = [st for st, _, _ in e.exact(drain_rule=1)]
+    first = next((s for s in got if s), 0)
+    assert first == want_all, (name, got, want_all)
+    # FrameDecoder::decode_blocks(All): nothing is drained inside the run (first frame only: the surface takes one frame)
+    want_blk = oracle_blocks(z)
+    assert e.exact(drain_rule=0)[0][0] == want_blk, (name, want_blk)
+
+
+def test_counter_and_reach_carry_across_submits():
+    """a frame continued by a second submit: what the caller still holds (prior_reach) and the counter so far (prior_counted)
+    decide, not what the frame has produced in total"""
+    tail = frame(seq_block(300000, last=True))          # the block that a second submit would bring
+    e = emu.EmuBatch(tail)
+    # 1 MiB decoded before, all of it still held, counter beyond the window: in reach
+    assert e.exact(0, prior_out=1 << 20, prior_reach=1 << 20, prior_counted=1 << 20)[0][0] == 0
+    # only the window is still held: out of reach, and the counter says OffsetTooBig ...
+    assert e.exact(0, prior_out=1 << 20, prior_reach=K, prior_counted=1 << 20)[0][0] == 52
+    # ... unless the earlier blocks were raw / RLE (not counted): the dictionary leaf
+    assert e.exact(0, prior_out=1 << 20, prior_reach=K, prior_counted=0)[0][0] == 53
+
+
+def test_dictionary_reach_ends_with_the_counter():
+    """a match that starts in the dictionary is served while total_output_counter <= window_size and fails with OffsetTooBig after
+    that, however much of the frame is still in the buffer (decode_buffer.rs:144-179)"""
+    raw = read_pack("dict_tests.pack")["dictionary"]
+    did = 618557512
+    o = oracle.FrameDecoder()
+    assert o.add_dict(raw) == did
+    cases = {
+        "into_dict_early": [lit_block(1000), seq_block(1000 + 50, last=True)],
+        "dict_only_matches_are_not_counted": [lit_block(10)] + [seq_block(5000, lits=b"")] * 3 + [seq_block(5000, last=True)],
+        "into_dict_counter_beyond_window": [lit_block(4000)] * 33 + [seq_block(33 * 4000 + 50, last=True)],
+        "into_dict_counter_kept_small_by_raw_blocks": [raw_block(K, 1), raw_block(K, 2), lit_block(10), seq_block(2 * K + 10 + 50, last=True)],
+        "beyond_the_dictionary": [lit_block(1000), seq_block(1000 + (1 << 22), last=True)],
+    }
+    # the dictionary's content length: a match that needs one byte more than it has must fail, one that needs exactly it must not
+    lo, hi = 1, len(raw)
+    probe = lambda n: oracle_blocks(frame(seq_block(n, lits=b"", last=True)), raw, did)
+    assert probe(lo) == 0 and probe(hi + 1) != 0
+    while lo < hi:
+        mid = (lo + hi + 1) // 2
+        if probe(mid) == 0:
+            lo = mid
+        else:
+            hi = mid - 1
+    dict_len = lo
+    for name, blocks in cases.items():
+        z = frame(*blocks)
+        want = oracle_blocks(z, raw, did)
+        e = emu.EmuBatch(z)
+        got = e.exact(0, dict_len=dict_len)[0][0]
+        assert got == want, (name, got, want, dict_len)

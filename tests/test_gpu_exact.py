@@ -1,0 +1,120 @@
+"""The reference's DecodeBuffer bookkeeping on the GPU (zg_k_exact, zstd-rs_amd/csrc/zg_exact.h): hand-made frames whose matches
+reach beyond their window, across the drain points of FrameDecoder::decode_all, or into a dictionary after
+total_output_counter has passed window_size. Every surface must decide like the oracle: same bytes, or the same error leaf."""
+import os
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "zstd-rs_amd"))
+import oracle
+from golden_io import read_pack
+from test_exact_cpu import CASES, K, build, frame, lit_block, raw_block, seq_block
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import zgpu
+    c = zgpu.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def pool():
+    import zgpu
+    p = zgpu.Pool(devices=[0])
+    yield p
+    p.close()
+
+
+@pytest.mark.parametrize("name,blocks", CASES, ids=[c[0] for c in CASES])
+def test_decode_all_and_decode_blocks_decide_like_the_oracle(ctx, pool, name, blocks):
+    import zgpu
+    z = build(name, blocks)
+    # FrameDecoder::decode_all (drains every MiB): zgpu_decode_all and the queue's decode_all
+    ost, oout = oracle.FrameDecoder().decode_all(z, 1 << 26)
+    for surface in ("ctx", "pool"):
+        try:
+            if surface == "ctx":
+                out, st = ctx.decode_all(z, 1 << 26), 0
+            else:
+                out, st = pool.decode_all(z, 1 << 26), 0
+        except zgpu.ZgpuError as e:
+            out, st = None, e.status
+        assert st == ost, (name, surface, st, ost)
+        if st == 0:
+            assert out == oout, (name, surface)
+    # FrameDecoder::decode_blocks(All) on the first frame: nothing is drained inside the run
+    d, o = zgpu.FrameDecoder(ctx), oracle.FrameDecoder()
+    st, c, _, _ = d.reset(z)
+    ost, oc, _, _ = o.init(z)
+    assert (st, c) == (ost, oc) == (0, 6)
+    st, used, fin = d.decode_blocks(z[c:], zgpu.STRAT_ALL)
+    ost, oused, ofin = o.decode_blocks(z[c:], oracle.STRAT_ALL)
+    assert (st, fin) == (ost, ofin), (name, st, ost)
+    if st == 0:
+        assert used == oused and d.collect() == o.collect(), name
+    d.close()
+
+
+def test_streamed_runs_keep_the_counter_and_the_reach(ctx):
+    """the same frame block run by block run with reads in between (what StreamingDecoder does): what the caller has drained is
+    out of reach, and the counter carried from run to run picks the error leaf"""
+    import zgpu
+    for blocks in ([raw_block(K, 1)] * 12 + [seq_block(11 * K, last=True)],
+                   [lit_block(4000)] * 70 + [seq_block(69 * 4000, last=True)],
+                   [raw_block(K, 1)] * 12 + [seq_block(K - 100, last=True)]):
+        z = frame(*blocks)
+        for per_run in (1, 5):
+            d, o = zgpu.FrameDecoder(ctx), oracle.FrameDecoder()
+            st, c, _, _ = d.reset(z)
+            ost, oc, _, _ = o.init(z)
+            assert (st, c) == (ost, oc)
+            pos, got, want = c, b"", b""
+            while True:
+                st, used, fin = d.decode_blocks(z[pos:], zgpu.STRAT_UPTO_BLOCKS, per_run)
+                ost, oused, ofin = o.decode_blocks(z[pos:], oracle.STRAT_UPTO_BLOCKS, per_run)
+                assert (st, fin) == (ost, ofin), (len(blocks), per_run, st, ost)
+                if st:
+                    break
+                assert used == oused
+                pos += used
+                got += d.read(1 << 30)
+                want += o.read(1 << 30)
+                assert got == want
+                if fin:
+                    break
+            d.close()
+
+
+def test_dictionary_reach_ends_with_the_counter(ctx):
+    import zgpu
+    raw = read_pack("dict_tests.pack")["dictionary"]
+    cases = {
+        "into_dict_early": [lit_block(1000), seq_block(1000 + 50, last=True)],
+        "dict_only_matches_are_not_counted": [lit_block(10)] + [seq_block(5000, lits=b"")] * 3 + [seq_block(5000, last=True)],
+        "into_dict_counter_beyond_window": [lit_block(4000)] * 33 + [seq_block(33 * 4000 + 50, last=True)],
+        "into_dict_counter_kept_small_by_raw_blocks": [raw_block(K, 1), raw_block(K, 2), lit_block(10), seq_block(2 * K + 10 + 50, last=True)],
+        "beyond_the_dictionary": [lit_block(1000), seq_block(1000 + (1 << 22), last=True)],
+    }
+    d = zgpu.FrameDecoder(ctx)
+    did = d.add_dict(raw)
+    for name, blocks in cases.items():
+        z = frame(*blocks)
+        o = oracle.FrameDecoder()
+        assert o.add_dict(raw) == did
+        st, c, _, _ = d.reset(z)
+        ost, oc, _, _ = o.init(z)
+        assert (st, c) == (ost, oc)
+        assert d.force_dict(did) == o.force_dict(did) == 0
+        st, used, fin = d.decode_blocks(z[c:], zgpu.STRAT_ALL)
+        ost, oused, ofin = o.decode_blocks(z[c:], oracle.STRAT_ALL)
+        assert (st, fin) == (ost, ofin), (name, st, ost)
+        if st == 0:
+            assert d.collect() == o.collect(), name
+    d.close()

@@ -260,6 +260,7 @@ int zgpu_decode_all(zgpu_ctx* c, const uint8_t* src, size_t len, uint8_t* dst, s
     return decode_all_per_frame(c, src, len, dst, cap, written);
   }
   if (st) { zgpu_batch_destroy(zb); return st; }   // the reference returns the first error of the walk
+  zb->b->drain_rule = ZG_DRAIN_DECODE_ALL;          // decode_all drains its DecodeBuffer every MiB (frame_decoder.rs:560-563): zg_exact.h
   uint64_t total = 0;
   uint32_t bf = 0, bs = 0;
   if ((st = zgpu_batch_run(zb)) || (st = zgpu_batch_sync(zb, &total, &bf, &bs))) { zgpu_batch_destroy(zb); return st; }
@@ -294,6 +295,7 @@ int zgpu_decode_all_alloc(zgpu_ctx* c, const uint8_t* src, size_t len, uint8_t**
     }
   }
   if (st) { zgpu_batch_destroy(zb); return st; }
+  zb->b->drain_rule = ZG_DRAIN_DECODE_ALL;          // decode_all_to_vec runs the same loop as decode_all (:580-591)
   uint64_t total = 0;
   uint32_t bf = 0, bs = 0;
   if ((st = zgpu_batch_run(zb)) || (st = zgpu_batch_sync(zb, &total, &bf, &bs))) { zgpu_batch_destroy(zb); return st; }

@@ -214,7 +214,7 @@ Batch::~Batch() {
 }
 
 void FrameState::reset() {
-  base = 0; have = 0; produced = 0; hist[0] = 1; hist[1] = 4; hist[2] = 8;
+  base = 0; have = 0; produced = 0; counted = 0; hist[0] = 1; hist[1] = 4; hist[2] = 8;
   logs[0] = logs[1] = logs[2] = logs[3] = 0; huf_maxbits = 0; carry_mask = 0; window_size = 0;
 }
 void FrameState::release() { d_out.release(); d_fse.release(); d_huf.release(); }
@@ -473,6 +473,7 @@ int Batch::run() {
   ZG_HIP(hipMemcpyAsync(totals, d.totals, 16, hipMemcpyDeviceToHost, s));
   ZG_HIP(hipStreamSynchronize(s));
   total_out = (uint64_t)totals[0] | ((uint64_t)totals[1] << 32);
+  far_seen = totals[3] != 0;
   int st = 0;
   bool any_fast = false;
   for (const ZgFrameOut& fo : frame_out) any_fast |= fo.fast != 0;
@@ -484,6 +485,7 @@ int Batch::run() {
     ZgFrame& fr = bb.frames[0];
     fr.prior_out = fs->produced;
     fr.prior_reach = keep_bytes < fs->have ? keep_bytes : fs->have;
+    fr.prior_counted = fs->counted;
     fr.dict_len = fs->base;
     fr.out_base_fixed = fs->base + fs->have;
     ZG_HIP(hipMemcpyAsync((void*)d.frames, bb.frames.data(), sizeof(ZgFrame), hipMemcpyHostToDevice, s));
@@ -579,6 +581,24 @@ int Batch::sync() {
     split_sweep = false;
   }
   ZG_HIP(hipMemcpy(frame_out.data(), dev.frame_out, (size_t)dev.nframes * sizeof(ZgFrameOut), hipMemcpyDeviceToHost));
+  {
+    // The fast path treats every byte the frame has produced as reachable and approximates which of the two "offset too far"
+    // errors applies; the reference's DecodeBuffer is stricter (zg_exact.h). Where that can change a verdict — an offset beyond
+    // the window was seen, a frame ended with one of those errors, a dictionary is involved — the exact bookkeeping is replayed.
+    bool need = far_seen;
+    for (uint32_t f = 0; f < dev.nframes && !need; f++) {
+      const ZgFrame& fr = bb.frames[f];
+      const uint32_t st = frame_out[f].status;
+      need = st == (uint32_t)ZG_EXE_OFFSET_TOO_BIG || st == (uint32_t)ZG_EXE_DICT_TOO_SMALL || fr.dict_len != 0 ||
+             fr.hist_init[0] > fr.window_size || fr.hist_init[1] > fr.window_size || fr.hist_init[2] > fr.window_size;
+    }
+    if (need && !getenv("ZGPU_DEBUG_NO_EXACT")) {
+      zg_launch_exact(dev, eng->stream_, drain_rule);
+      ZG_HIP(hipStreamSynchronize(eng->stream_));
+      ZG_HIP(hipMemcpy(frame_out.data(), dev.frame_out, (size_t)dev.nframes * sizeof(ZgFrameOut), hipMemcpyDeviceToHost));
+      exact_ran = true;
+    }
+  }
   hipEvent_t* ev = sc->ev;
   for (int i = 0; i < ZG_T_TOTAL; i++) {
     float m = 0;
@@ -598,6 +618,7 @@ int Batch::commit(FrameState* st) {
   st->produced += fo.out_size;
   st->have += fo.out_size;
   st->hist[0] = fo.hist_end[0]; st->hist[1] = fo.hist_end[1]; st->hist[2] = fo.hist_end[2];
+  st->counted += fo.counted;
   if (fo.status) return ZG_OK;   // the frame failed: the caller reports it; tables are not needed any more
   const Lineage fl = bb.final_lineage();
   hipStream_t s = eng->stream_;

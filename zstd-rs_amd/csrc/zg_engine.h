@@ -45,6 +45,7 @@ struct FrameState {
   uint64_t have = 0;             // frame bytes on the device (the most recent ones)
   uint64_t produced = 0;         // frame bytes decoded so far
   uint32_t hist[3] = {1, 4, 8};  // scratch.rs:44
+  uint64_t counted = 0;          // DecodeBuffer::total_output_counter so far (decode_buffer.rs:16): decides between the two "offset too far" errors
   DevBuf d_fse;                  // carried FSE tables, one arena slot (ZG_FSE_SLOT_U32 packed entries)
   DevBuf d_huf;                  // carried Huffman table (ZG_HUF_SLOT_U16 entries)
   uint8_t logs[4] = {0, 0, 0, 0};// accuracy logs LL, OF, ML of the carried FSE tables
@@ -89,6 +90,9 @@ class Batch {
   int parse_status = 0;                  // frame-layer error that stops decode_all (first failing frame's status)
   uint64_t src_len = 0;
   uint64_t keep_bytes = 0;               // streaming submits: frame bytes that must stay reachable on the device (FrameState::make_room)
+  uint32_t drain_rule = 0;               // how the caller's surface drains the reference's DecodeBuffer inside this submit (zg_exact.h: ZG_DRAIN_*)
+  bool far_seen = false;                 // run(): a sequence set an offset beyond its frame's window (zg_k_seqpost)
+  bool exact_ran = false;                // sync(): zg_k_exact replayed the reference's buffer bookkeeping for this submit (tests)
 
   // Enqueue the kernel pipeline on the engine's streams. Two phases with one host round trip in between: the entropy
   // stages and the scan run first; the host reads the exact output size of every frame, sizes the output and the flatten

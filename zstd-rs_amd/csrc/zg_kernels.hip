@@ -1141,7 +1141,9 @@ __global__ void __launch_bounds__(ZG_SCAN_T) zg_k_scan(ZgBatchDev d) {
   uint64_t carry_size = 0;
   ZgHistMap carry_map = zg_map_identity();
   uint32_t good = fr.nblocks, bad_status = 0;
-  if (t == 0) s_slow = 0;
+  __shared__ unsigned long long s_counted;   // output of the good compressed blocks (what DecodeBuffer counts, decode_buffer.rs:74-77,108)
+  uint64_t my_counted = 0;
+  if (t == 0) { s_slow = 0; s_counted = 0; }
   for (uint32_t c0 = 0; c0 < fr.nblocks; c0 += ZG_SCAN_T) {
     uint32_t i = c0 + t;
     bool have = i < fr.nblocks;
@@ -1167,6 +1169,7 @@ __global__ void __launch_bounds__(ZG_SCAN_T) zg_k_scan(ZgBatchDev d) {
     __syncthreads();
     const uint32_t bad = s_bad;
     if (t >= bad) { size = 0; m = zg_map_identity(); }  // the failing block and everything after it produce nothing
+    if (have && d.blocks[b].btype == ZG_BT_COMPRESSED) my_counted += size;
     // inclusive scans over the chunk: inside the wave with shuffles, across the waves through LDS
     uint64_t isz = size;
     ZgHistMap im = m;
@@ -1218,8 +1221,11 @@ __global__ void __launch_bounds__(ZG_SCAN_T) zg_k_scan(ZgBatchDev d) {
     carry_map = zg_map_compose(carry_map, tmap);
     __syncthreads();
   }
+  if (my_counted) atomicAdd(&s_counted, (unsigned long long)my_counted);
+  __syncthreads();
   if (t == 0) {
     ZgFrameOut fo;
+    fo.counted = s_counted;
     fo.out_base = 0; fo.out_size = carry_size; fo.status = bad_status; fo.bad_block = good;
     fo.hist_end[0] = zg_sym_resolve(carry_map.s[0], fr.hist_init);
     fo.hist_end[1] = zg_sym_resolve(carry_map.s[1], fr.hist_init);
@@ -1700,6 +1706,14 @@ __global__ void __launch_bounds__(T, 4) zg_k_flatten(ZgBatchDev d) {
   }
 }
 
+// zg_k_exact: the reference's DecodeBuffer bookkeeping replayed exactly (zg_exact.h), one workgroup per frame; launched by the
+// host only for submits it can matter to (Batch::sync)
+#include "zg_exact.h"
+__global__ void __launch_bounds__(256) zg_k_exact(ZgBatchDev d, uint32_t drain_rule) {
+  __shared__ ZgExactLds<256> s_l;
+  zg_exact_frame<256>(d, blockIdx.x, drain_rule, s_l);
+}
+
 // zg_k_swprep: one thread per (step, unit) entry: everything a sweep workgroup needs about its unit in one 32-byte
 // descriptor, so that a sweep launch starts with ONE dependent scalar load instead of a chain of five.
 __global__ void __launch_bounds__(256) zg_k_swprep(ZgBatchDev d, uint32_t n) {
@@ -2119,6 +2133,9 @@ bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* step
   }
   if (d.nframes) hipLaunchKernelGGL(zg_k_fin, dim3((d.nframes + 255) / 256), dim3(256), 0, s, d);
   return split;
+}
+void zg_launch_exact(const ZgBatchDev& d, hipStream_t s, uint32_t drain_rule) {
+  if (d.nframes) hipLaunchKernelGGL(zg_k_exact, dim3(d.nframes), dim3(256), 0, s, d, drain_rule);
 }
 void zg_launch_lz(const ZgBatchDev& d, hipStream_t s) {
   hipLaunchKernelGGL(zg_k_lz, dim3(d.nframes), dim3(ZG_LZ_T), 0, s, d);

@@ -393,7 +393,7 @@ int zgpu_pool_decode_all(zgpu_pool* p, const uint8_t* src, size_t len, uint8_t* 
       j.worker = w;
       j.status = eng->prepare(src + j.begin, (size_t)(j.end - j.begin), &j.batch);
       if (!j.status && j.batch->parse_status) j.status = j.batch->parse_status;
-      if (!j.status) j.status = j.batch->run();
+      if (!j.status) { j.batch->drain_rule = ZG_DRAIN_DECODE_ALL; j.status = j.batch->run(); }
       if (!j.status) j.status = j.batch->sync();
       if (!j.status)
         for (const ZgFrameOut& fo : j.batch->frame_out)

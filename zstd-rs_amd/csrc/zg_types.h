@@ -127,6 +127,7 @@ struct ZgFrame {
   uint32_t seq_first, seq_count;   // the frame's blocks that have sequences: a range of the batch's seq_blocks list
   uint32_t sparse;                 // so few sequences (literal-heavy data) that its matches are copied in order by one wave (zg_k_sparse)
   uint32_t pad2;                   //   instead of going through the sweep: a chain of launches per unit would cost more than the copies
+  uint64_t prior_counted;          // DecodeBuffer::total_output_counter (decode_buffer.rs:16,74-77,108) after the earlier submits of this frame
 };
 
 // What the table kernel records per block.
@@ -176,7 +177,13 @@ struct ZgFrameOut {
   uint32_t fast;           // 1: every block regenerates <= 128 KiB -> flatten + sweep path; 0: in-order fallback (zg_k_lz)
   uint32_t err_packed;     // (frame-relative block << 8) | status of the first execution error, 0xFFFFFFFF if none
   uint64_t og_base;        // where the frame's flatten scratch starts (in u32): the scratch is indexed by output position
+  uint64_t counted;        // what this submit adds to total_output_counter: the output of its compressed blocks (raw and RLE blocks are not
+                           // counted, decode_buffer.rs:62-72), minus matches served from the dictionary alone (:159-172) once zg_k_exact ran
 };
+
+// how the caller's surface drains the reference's DecodeBuffer inside one submit (zg_exact.h)
+#define ZG_DRAIN_NONE 0u        // not at all (FrameDecoder::decode_blocks, decode_from_to, the thin boundary: the caller drains between submits)
+#define ZG_DRAIN_DECODE_ALL 1u  // FrameDecoder::decode_all: rounds of UptoBytes(1 MiB), each followed by a drain down to window_size
 
 // LZ77 execution works on units: runs of consecutive blocks of one frame that zg_k_flat resolves together.
 // noseq: bit 0: none of the unit's blocks has sequences: all of it is literal bytes, final after zg_k_lit; bit 1 (ZG_UNIT_DIRECT):
