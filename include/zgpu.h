@@ -64,10 +64,9 @@ enum zgpu_status {
   ZGPU_E_EXE_DICT_TOO_SMALL = 53,
   ZGPU_E_DICT_DECODE = 60,
   /* Input the reference tolerates but this engine rejects. No conforming encoder produces any of it:
-   *  - 4-stream Huffman literals whose first three streams do not hold (regen + 3) / 4 symbols each (the spec's split;
-   *    ruzstd only checks the total): reported as ZGPU_E_LIT_COUNT_MISMATCH;
-   *  - offsets >= 2^30 (offset codes 30, 31): reported as ZGPU_E_EXE_OFFSET_TOO_BIG — in the reference they fail the same way
-   *    unless >= 1 GiB of output is still undrained;
+   *  - offsets >= 2^30 (offset codes 30, 31) while >= 1 GiB of the frame is held undrained (FrameDecoder::decode_blocks(All) on a
+   *    frame beyond 1 GiB that nobody reads from): ZGPU_E_UNSUPPORTED. With less than 1 GiB held — always the case in decode_all
+   *    and the streaming decoder — such an offset fails in the reference too, and with the same error here;
    *  - a block that regenerates >= 2^31 bytes: ZGPU_E_UNSUPPORTED.
    * Blocks regenerating more than 128 KiB (beyond Block_Maximum_Size) are decoded, by the in-order kernel. */
   ZGPU_E_UNSUPPORTED = 80,

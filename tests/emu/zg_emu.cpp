@@ -131,10 +131,40 @@ static void k_huf(EmuBatch& e) {
       } else { sp = pay; slen = total; doff = 0; cap = regen; }
       uint32_t count = 0; int32_t endbits = 0;
       int st = zg_huf_decode_stream(sp, slen, tab, max_bits, lit + doff, cap, &count, &endbits);
-      if (!st && blk.nstreams == 4 && endbits != -(int32_t)max_bits) st = ZG_LIT_BITSTREAM_MISMATCH;
+      if (!st && blk.nstreams == 4 && count <= cap && endbits != -(int32_t)max_bits) st = ZG_LIT_BITSTREAM_MISMATCH;   // (count > cap: the routine stopped early; the pass below looks at the stream's end)
       if (!st && count != cap) st = ZG_LIT_COUNT_MISMATCH;
       set_status(e, b, st);
     }
+  }
+  // zg_k_huf_uneven: four streams that end on their last bit and add up to the section's size, split differently from the
+  // format's (regen + 3) / 4: valid for the reference (it compares the total only, literals_section_decoder.rs:150-155)
+  for (uint32_t b = 0; b < e.bb.blocks.size(); b++) {
+    const ZgBlock blk = e.bb.blocks[b];
+    if (blk.nstreams != 4 || blk.lit_type < ZG_LT_COMPRESSED || blk.huf_slot < 0 || e.status[b] != (uint32_t)ZG_LIT_COUNT_MISMATCH) continue;
+    unsigned max_bits = e.hufmax[blk.huf_slot];
+    if (max_bits == 0 || max_bits > 11) continue;
+    const uint16_t* tab = e.huf.data() + (size_t)blk.huf_slot * ZG_HUF_SLOT_U16;
+    uint32_t desc = blk.lit_type == ZG_LT_COMPRESSED ? e.aux[b].huf_desc_bytes : 0;
+    const uint8_t* pay = e.src + blk.src_off + blk.lit_off + desc;
+    uint32_t total = blk.lit_comp_size - desc, regen = blk.regen_size;
+    uint32_t j[5] = {0, zg_ld16(pay), 0, 0, total - 6};
+    j[2] = j[1] + zg_ld16(pay + 2); j[3] = j[2] + zg_ld16(pay + 4);
+    std::vector<uint8_t> tmp[4];
+    uint64_t sum = 0;
+    bool clean = true;
+    for (int k = 0; k < 4 && clean; k++) {
+      tmp[k].assign(regen + 16, 0);
+      uint32_t count = 0; int32_t endbits = 0;
+      int st = zg_huf_decode_stream(pay + 6 + j[k], j[k + 1] - j[k], tab, max_bits, tmp[k].data(), regen, &count, &endbits);
+      if (st || endbits != -(int32_t)max_bits || count > regen) clean = false;
+      tmp[k].resize(count);
+      sum += count;
+    }
+    if (!clean) { e.status[b] = ZG_LIT_BITSTREAM_MISMATCH; continue; }   // a stream's end outranks any count (:116-121 comes first)
+    if (sum != regen) continue;
+    uint8_t* lit = e.lit.data() + blk.lit_base;
+    for (int k = 0; k < 4; k++) { memcpy(lit, tmp[k].data(), tmp[k].size()); lit += tmp[k].size(); }
+    e.status[b] = 0;
   }
 }
 

@@ -83,10 +83,9 @@ ZG_HD int zg_seq_decode_block(const uint8_t* bs, uint32_t bs_len, uint32_t nseq,
     // execution bookkeeping (sequence_execution.rs:10-39), done here because this lane walks the block in order.
     // The reference decodes the whole section before executing, so a bitstream error outranks these.
     if (exe_status == ZG_OK) {
-      const bool big = of > 3u && of - 3u >= (1u << 30);   // offsets >= 2^30 would collide with the symbolic tags (zg_k_seqpost: `big`)
-      uint32_t actual = zg_hist_step(big ? 4u : of, ll, h0, h1, h2);
+      const bool big = of > 3u && of - 3u >= (1u << 30);   // offsets >= 2^30 would collide with the symbolic tags: they travel as ZG_OFF_HUGE (zg_k_seqpost)
+      uint32_t actual = zg_hist_step(big ? ZG_OFF_HUGE + 3u : of, ll, h0, h1, h2);
       if (actual == 0) exe_status = ZG_EXE_ZERO_OFFSET;
-      else if (big) exe_status = ZG_EXE_OFFSET_TOO_BIG;
       else if ((uint64_t)lit_pos + ll > regen_size) exe_status = ZG_EXE_NOT_ENOUGH_LITERALS;
       else if ((uint64_t)out_pos + ll + ml >= (1ull << 31)) exe_status = ZG_UNSUPPORTED;
       else {
@@ -193,9 +192,8 @@ ZG_HD bool zg_seq_step(EmuSeqState& st, const ZgWin& cur, bool last, TabPtr t_ll
   // so a bitstream error outranks these: keep decoding after the first execution error.
   if (st.exe_status == ZG_OK) {
     const bool big = of > 3u && of - 3u >= (1u << 30);
-    uint32_t actual = zg_hist_step(big ? 4u : of, ll, st.h0, st.h1, st.h2);
+    uint32_t actual = zg_hist_step(big ? ZG_OFF_HUGE + 3u : of, ll, st.h0, st.h1, st.h2);
     if (actual == 0) st.exe_status = ZG_EXE_ZERO_OFFSET;
-    else if (big) st.exe_status = ZG_EXE_OFFSET_TOO_BIG;
     else if ((uint64_t)st.lit_pos + ll > regen_size) st.exe_status = ZG_EXE_NOT_ENOUGH_LITERALS;
     else if ((uint64_t)st.out_pos + ll + ml >= (1ull << 31)) st.exe_status = ZG_UNSUPPORTED;
     else {

@@ -84,8 +84,8 @@ def test_streamed_runs_keep_the_counter_and_the_reach(ctx):
                     break
                 assert used == oused
                 pos += used
-                got += d.read(1 << 30)
-                want += o.read(1 << 30)
+                got += d.read(1 << 22)
+                want += o.read(1 << 22)
                 assert got == want
                 if fin:
                     break

@@ -643,6 +643,26 @@ def test_streaming_window_stays_bounded(ctx):
     s.close()
 
 
+def test_uneven_four_stream_split(ctx):
+    """4-stream Huffman literals split differently from the format's (regen + 3) / 4 rule: the reference compares only the total
+    (literals_section_decoder.rs:150-155), so must the engine (zg_k_huf counts every stream to its end, zg_k_huf_uneven places
+    them); a wrong total and a stream that does not end on its last bit keep their errors"""
+    import zgpu
+    from test_lane_logic_cpu import uneven_split_cases
+    seen = set()
+    for name, z, plain in uneven_split_cases():
+        ost, oout = oracle.FrameDecoder().decode_all(z, 1 << 20)
+        try:
+            out, st = ctx.decode_all(z, 1 << 20), 0
+        except zgpu.ZgpuError as e:
+            out, st = None, e.status
+        assert st == ost, (name, st, ost)
+        if st == 0:
+            assert out == oout == plain, name
+        seen.add(st)
+    assert seen == {0, 34, 35}, seen
+
+
 @pytest.mark.parametrize("of_code", [29, 30, 31])
 def test_offsets_of_2_pow_30_and_more(ctx, of_code):
     """offset codes 30 / 31: zg_k_seqpost must not take an offset >= 2^30 for a symbolic history reference"""
@@ -653,7 +673,7 @@ def test_offsets_of_2_pow_30_and_more(ctx, of_code):
     assert st in (52, 53)
     with pytest.raises(zgpu.ZgpuError) as e:
         ctx.decode_all(z, 1 << 20)
-    assert e.value.status in (52, 53)
+    assert e.value.status == st
 
 
 def _run_batch(z, env):

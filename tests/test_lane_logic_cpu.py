@@ -152,10 +152,52 @@ def big_offset_frame(of_code, extra=0):
 @pytest.mark.parametrize("of_code", [29, 30, 31])
 def test_offsets_of_2_pow_30_and_more(of_code):
     """offset codes 30 and 31 (offset >= 2^30) must not be taken for the symbolic history references the engine tags with the
-    top two bits: oracle and lane model both end in one of the two "offset too far" errors"""
+    top two bits: they travel as ZG_OFF_HUGE, the serial model rejects them, and zg_k_exact's source picks the reference's leaf"""
     z = big_offset_frame(of_code, extra=5)
     st, _ = oracle.FrameDecoder().decode_all(z, 1 << 20)
     e = emu.EmuBatch(z)
     est = e.parse_status or e.frame(0)[2]
     assert st in (52, 53), st
     assert est in (52, 53), est
+    assert e.exact(drain_rule=1)[0][0] == st
+    # with 1 GiB held undrained the reference could serve such an offset; the engine has lost its value: ZGPU_E_UNSUPPORTED
+    if of_code >= 30:
+        assert e.exact(drain_rule=0, prior_out=3 << 30, prior_reach=3 << 30, prior_counted=3 << 30)[0][0] == 80
+
+
+def uneven_split_cases():
+    """(name, frame, plaintext or None): the four literal streams of a libzstd block written back with other splits"""
+    import os
+    import random
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import zgdata
+    import uneven
+    rng = random.Random(5)
+    plain = bytes(rng.choice(b"aaaaaaabbbbccdeefghijklmnop qrstu") for _ in range(20000))
+    z = zgdata.zstd_compress(plain)
+    out = [("format_split", uneven.resplit(z, (0, 0, 0))[0], plain)]
+    for i, deltas in enumerate(((5, -3, 7), (-100, 200, -50), (300, 300, 300), (-4000, -4000, -4000), (1, 0, 0))):
+        out.append(("uneven_%d" % i, uneven.resplit(z, deltas)[0], plain))
+    # and what must still fail: a wrong total, a stream that does not end on its last bit (with the format's split and another one)
+    out.append(("wrong_total_plus", uneven.resplit(z, (2, 2, 2), regen_bias=1)[0], None))
+    out.append(("wrong_total_minus", uneven.resplit(z, (-9, 2, 2), regen_bias=-1)[0], None))
+    out.append(("spare_bit_format_split", uneven.resplit(z, (0, 0, 0), spare_bits=(0, 1, 0, 0))[0], None))
+    out.append(("spare_bits_uneven", uneven.resplit(z, (40, -7, 3), spare_bits=(0, 0, 3, 0))[0], None))
+    out.append(("spare_bits_first_overfull", uneven.resplit(z, (500, -7, 3), spare_bits=(2, 0, 0, 0))[0], None))
+    return out
+
+
+def test_uneven_four_stream_split_is_accepted_like_the_reference():
+    """4-stream Huffman literals whose streams do not hold (regen + 3) / 4 symbols each: the reference only checks the total
+    (literals_section_decoder.rs:150-155); the engine must decode them to the same bytes"""
+    seen = set()
+    for name, z, plain in uneven_split_cases():
+        st, out = oracle.FrameDecoder().decode_all(z, 1 << 20)
+        assert (st == 0 and out == plain) if plain is not None else st != 0, (name, st)
+        e = emu.EmuBatch(z)
+        assert e.parse_status == 0 and e.frame(0)[2] == st, (name, e.frame(0), st)
+        if st == 0:
+            assert e.frame_bytes(0)[0] == plain, name
+        seen.add(st)
+    assert seen == {0, 34, 35}, seen       # ok, BitstreamReadMismatch, DecodedLiteralCountMismatch

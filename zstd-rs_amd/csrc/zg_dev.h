@@ -271,6 +271,7 @@ ZG_HD int zg_huf_build(const uint8_t* weights, int nweights, uint16_t* out, int*
 // A history slot / resolved offset is a u32: top two bits 0 → a concrete offset (< 2^30); top two bits t in 1..3 →
 // "slot t-1 of the block's initial history, minus k (saturating)" with k in the low 30 bits. Blocks decode their
 // sequences in parallel before the previous block's final history is known; the scan kernel resolves the symbols.
+#define ZG_OFF_HUGE 0x3FFFFFFFu   // stands for every offset >= 2^30 (the largest real one below that is 2^30 - 4): see zg_k_seqpost
 #define ZG_SYM_TAG(v) ((v) >> 30)
 #define ZG_SYM_K(v) ((v) & 0x3FFFFFFFu)
 ZG_HD uint32_t zg_sym_dec(uint32_t v) {  // saturating "minus one" (sequence_execution.rs:74); selects only (the callers are wave code)

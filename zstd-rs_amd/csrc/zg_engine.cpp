@@ -376,7 +376,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
       (st = up(sc->d_stepunits, bb.step_units.data(), bb.step_units.size() * 4)) ||
       (st = sc->d_aux.reserve((size_t)nb * sizeof(ZgBlockAux) + 16)) || (st = sc->d_slot_log.reserve((size_t)nslots * 4)) ||
       (st = sc->d_fse.reserve((size_t)nslots * ZG_FSE_SLOT_U32 * 4)) || (st = sc->d_huf.reserve((size_t)(bb.nhuf_slots + 1) * ZG_HUF_SLOT_U16 * 2)) ||
-      (st = sc->d_hufmax.reserve(bb.nhuf_slots + 16)) || (st = sc->d_status.reserve(3 * ((size_t)nb * 4 + 16))) ||
+      (st = sc->d_hufmax.reserve(bb.nhuf_slots + 16)) || (st = sc->d_status.reserve(7 * ((size_t)nb * 4 + 16))) ||
       (st = sc->d_lit.reserve(bb.lit_bytes + 128)) || (st = sc->d_seq.reserve((bb.seq_count + 2) * sizeof(ZgSeq))) ||
       (st = sc->d_raw.reserve((bb.seq_count + 2) * 8)) ||
       (st = sc->d_seqout.reserve((size_t)nb * sizeof(ZgBlockSeqOut) + 16)) || (st = sc->d_pos.reserve((size_t)nb * sizeof(ZgBlockPos) + 16)) ||
@@ -395,6 +395,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   d.aux = sc->d_aux.as<ZgBlockAux>(); d.slot_log = sc->d_slot_log.as<uint8_t>();
   d.fse_arena = sc->d_fse.as<uint32_t>(); d.huf_arena = sc->d_huf.as<uint16_t>(); d.huf_maxbits = sc->d_hufmax.as<uint8_t>();
   d.status = sc->d_status.as<uint32_t>(); d.tab_status = d.status + nb + 4; d.lit_status = d.tab_status + nb + 4;
+  d.lit_counts = d.lit_status + nb + 4;     // [4 * nblocks], written by zg_k_huf (no reset needed)
   d.lit_arena = sc->d_lit.as<uint8_t>() + 64;   // (zg_k_flat4 reads literal windows that start up to 7 bytes in front of a block's literals)
   d.seq_arena = sc->d_seq.as<ZgSeq>(); d.raw_arena = sc->d_raw.as<ZgRaw>();
   d.seq_out = sc->d_seqout.as<ZgBlockSeqOut>(); d.pos = sc->d_pos.as<ZgBlockPos>(); d.frame_out = sc->d_frameout.as<ZgFrameOut>();

@@ -70,6 +70,8 @@ ZX_DEV void zg_exact_frame(const ZgBatchDev& d, const uint32_t f, const uint32_t
         uint32_t before = sx - v, all = 0;
         for (uint32_t w = 0; w < (uint32_t)T / 64u; w++) { const uint32_t x = L.wsum[w]; if (w < wv) before += x; all += x; }
         if (have && off == 0) zx_min_lds64(&L.bad, ((unsigned long long)j << 8) | (uint32_t)ZG_EXE_ZERO_OFFSET);   // sequence_execution.rs:28-30 (comes before repeat())
+        if (have && off >= ZG_OFF_HUGE - 2u && !outside)               // an offset >= 2^30 (zg_k_seqpost) with 1 GiB held undrained: the one case the engine
+          zx_min_lds64(&L.bad, ((unsigned long long)j << 8) | (uint32_t)ZG_UNSUPPORTED);   // cannot decide like the reference (its value is gone)
         if (outside) {
           const uint64_t c = cnt + m0 - (dict_only + before);        // total_output_counter at this repeat(): literals of this sequence included
           uint32_t st = 0;

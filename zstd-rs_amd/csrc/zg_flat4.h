@@ -129,7 +129,7 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
           // the first failing sequence (in order) decides, like the reference's in-order execution; which of the two
           // "too far" errors it is (repeat_from_dict, decode_buffer.rs:144-179) is worked out off the hot path
           if (off == 0) zx_min_lds64(&L.bad, ((unsigned long long)i << 32) | (m0 << 8) | (uint32_t)ZG_EXE_ZERO_OFFSET);              // sequence_execution.rs:28-30
-          else if (!reach_all && off > reach32 + m0) zx_min_lds64(&L.bad, ((unsigned long long)i << 32) | (m0 << 8) | (uint32_t)ZG_EXE_OFFSET_TOO_BIG);
+          else if ((!reach_all && off > reach32 + m0) || off >= ZG_OFF_HUGE - 2u) zx_min_lds64(&L.bad, ((unsigned long long)i << 32) | (m0 << 8) | (uint32_t)ZG_EXE_OFFSET_TOO_BIG);
         } else if (i == nseq) {
           lstart = so.sum_ll; a = so.sum_ll + so.sum_ml; m0 = m1 = S;
           off = 0x3FFFFFFFu;          // (tile bytes behind the block's end are classified like any others: as roots, not as their own parents)

@@ -558,21 +558,73 @@ __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
         if (at + i < cap) dst[at + i] = sym[64 * i];
       }
     }
-    if (ndone + wtot > cap) overflow = true;                   // more symbols than the section holds
+    if (ndone + wtot > cap) overflow = true;                   // more symbols than its share of the section holds
     ndone += wtot;
     // the last active lane's exit is the next entry; it is <= 0 when that lane's chunk reaches the stream start
     const uint32_t nact = (uint32_t)((top + cb - 1) / cb);
     top = __shfl(E, (int)(nact < 64u ? nact - 1u : 63u), 64);
-    if (overflow) break;
+    // (one of four streams: the reference only compares the TOTAL with the section's size, literals_section_decoder.rs:150-155 —
+    //  the count goes on, without writes, so that zg_k_huf_uneven can tell a different split from a wrong total)
+    if (overflow && blk.nstreams != 4) break;
   }
+  if (blk.nstreams == 4 && lane == 0) d.lit_counts[4u * b + k] = ndone;
   int st = ZG_OK;
-  if (overflow) st = ZG_LIT_COUNT_MISMATCH;
-  else if (blk.nstreams == 4 && top != 0) st = ZG_LIT_BITSTREAM_MISMATCH;   // bits_remaining != -max_bits (:116-121)
-  else if (ndone != cap) st = ZG_LIT_COUNT_MISMATCH;                        // :150-155 (per stream, spec split)
+  if (blk.nstreams == 4 && top != 0) st = ZG_LIT_BITSTREAM_MISMATCH;        // bits_remaining != -max_bits (:116-121)
+  else if (overflow || ndone != cap) st = ZG_LIT_COUNT_MISMATCH;            // :150-155 (per stream, the format's split: zg_k_huf_uneven looks at the total)
   // The reference decodes the streams in order and checks each one's end as it goes (:116-121); the symbol count is compared
   // once, after the last stream (:150-155): a stream's BitstreamReadMismatch outranks any count mismatch, an earlier stream a
   // later one.
   if (lane == 0) zg_set_lit_status(d.lit_status, b, st == ZG_LIT_BITSTREAM_MISMATCH ? k : 8u, st);
+}
+
+// zg_k_huf_uneven: four streams whose symbols add up to the section's size but are not split the way the format says
+// ((regen + 3) / 4 each, the rest in the fourth). ruzstd decodes the streams one after the other into one buffer and
+// compares only the total (literals_section_decoder.rs:94-155), so such a section is valid for it; zg_k_huf wrote every
+// stream where the format's split puts it and reported a count mismatch. No encoder emits this: the repair is a plain
+// serial decode, one lane per stream, with the counts zg_k_huf left behind. One wave per block; a block that is not
+// affected costs its wave one load.
+__global__ void __launch_bounds__(256) zg_k_huf_uneven(ZgBatchDev d) {
+  __shared__ uint16_t s_tab[4][ZG_HUF_SLOT_U16];
+  const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u, b = blockIdx.x * 4u + wv;
+  if (b >= d.nblocks) return;
+  if (d.lit_status[b] != (((255u - 8u) << 8) | (uint32_t)ZG_LIT_COUNT_MISMATCH)) return;   // every stream ended on its last bit, some count differs
+  const ZgBlock blk = d.blocks[b];
+  if (blk.nstreams != 4 || blk.lit_type < ZG_LT_COMPRESSED || blk.huf_slot < 0) return;
+  const uint32_t regen = blk.regen_size;
+  const uint32_t c0 = d.lit_counts[4u * b], c1 = d.lit_counts[4u * b + 1], c2 = d.lit_counts[4u * b + 2], c3 = d.lit_counts[4u * b + 3];
+  if ((uint64_t)c0 + c1 + c2 + c3 != regen) return;            // DecodedLiteralCountMismatch stands
+  const unsigned max_bits = d.huf_maxbits[blk.huf_slot];
+  if (max_bits == 0 || max_bits > 11) return;
+  const uint16_t* g = d.huf_arena + (uint64_t)blk.huf_slot * ZG_HUF_SLOT_U16;
+  for (uint32_t i = lane; i < (1u << max_bits); i += 64) s_tab[wv][i] = g[i];
+  zg_wave_publish();
+  if (lane < 4) {
+    const uint32_t k = lane;
+    const uint32_t desc = blk.lit_type == ZG_LT_COMPRESSED ? d.aux[b].huf_desc_bytes : 0;
+    const uint8_t* pay = d.src + blk.src_off + blk.lit_off + desc;
+    const uint32_t total = blk.lit_comp_size - desc;
+    const uint32_t j1 = zg_ld16(pay), j2 = j1 + zg_ld16(pay + 2), j3 = j2 + zg_ld16(pay + 4);
+    const uint32_t start = k == 0 ? 0 : k == 1 ? j1 : k == 2 ? j2 : j3;
+    const uint32_t end = k == 0 ? j1 : k == 1 ? j2 : k == 2 ? j3 : total - 6;
+    const uint8_t* sp = pay + 6 + start;
+    const int32_t slen = (int32_t)(end - start);
+    const uint32_t cnt = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3;
+    uint8_t* dst = d.lit_arena + blk.lit_base + (k == 0 ? 0u : k == 1 ? c0 : k == 2 ? c0 + c1 : c0 + c1 + c2);
+    const uint32_t pmask = (1u << max_bits) - 1u;
+    int32_t P = (slen - 1) * 8 + (int32_t)zg_hbit(sp[slen - 1]) - 1;   // bits of the stream (zg_k_huf checked the final-bit marker)
+    for (uint32_t n = 0; n < cnt && P > 0; n++) {
+      const int32_t q = P - (int32_t)max_bits;                 // the code's bits: [q, P); below the stream's first bit: zeros
+      uint32_t v = 0;
+#pragma unroll
+      for (int i = 0; i < 3; i++) { const int32_t at = (q >> 3) + i; if (at >= 0 && at < slen) v |= (uint32_t)sp[at] << (8 * i); }
+      const uint32_t e = s_tab[wv][(v >> (q & 7)) & pmask];
+      dst[n] = (uint8_t)e;
+      const int32_t nb = (int32_t)(e >> 8);
+      P -= nb > 1 ? nb : 1;
+    }
+  }
+  zg_wave_publish();
+  if (lane == 0) d.lit_status[b] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1022,16 +1074,17 @@ __global__ void __launch_bounds__(ZG_SP_T, 4) zg_k_seqpost(ZgBatchDev d) {
     }
     // history inside the thread's run, relative to its start; thread totals
     uint32_t h0 = 1u << 30, h1 = 2u << 30, h2 = 3u << 30, tl = 0, to = 0, act[ZG_SP_S];
-    uint32_t big = 0;
     bool far = false;
 #pragma unroll
     for (int j = 0; j < ZG_SP_S; j++) {
       act[j] = 1;
       if (of[j]) {
+        // offsets >= 2^30 (offset codes 30 and 31) would collide with the symbolic slots: they travel as ZG_OFF_HUGE, which no
+        // real offset equals and which is out of reach as long as fewer than 2^30 bytes are held — the case in which the
+        // reference rejects them too (zg_k_exact picks its error; with 1 GiB held undrained it answers ZG_UNSUPPORTED)
         const bool tb = of[j] > 3u && of[j] - 3u >= (1u << 30);
-        big |= tb ? 1u << j : 0u;
-        far = far || (of[j] > 3u && of[j] - 3u > wlim);
-        act[j] = zg_hist_step(tb ? 4u : of[j], ll[j], h0, h1, h2);
+        far = far || tb || (of[j] > 3u && of[j] - 3u > wlim);
+        act[j] = zg_hist_step(tb ? ZG_OFF_HUGE + 3u : of[j], ll[j], h0, h1, h2);
       }
       tl += ll[j]; to += ll[j] + ml[j];
     }
@@ -1081,7 +1134,6 @@ __global__ void __launch_bounds__(ZG_SP_T, 4) zg_k_seqpost(ZgBatchDev d) {
           uint32_t e = ZG_OK;
           if ((uint64_t)out_pos + ll[j] + ml[j] >= (1ull << 31)) e = ZG_UNSUPPORTED;
           if ((uint64_t)lit_pos + ll[j] > regen) e = ZG_EXE_NOT_ENOUGH_LITERALS;   // sequence_execution.rs:14-19
-          if ((big >> j) & 1u) e = ZG_EXE_OFFSET_TOO_BIG;
           if (actual == 0) e = ZG_EXE_ZERO_OFFSET;                                  // :28-30
           if (e && bad == 0xFFFFFFFFu) bad = ((t * ZG_SP_S + (uint32_t)j) << 8) | e;
           const uint32_t mdst = out_pos + ll[j];
@@ -1439,7 +1491,7 @@ __device__ __forceinline__ void zg_flat1_unit(const ZgBatchDev& d, const uint32_
           // the first failing sequence (in order) decides, like the reference's in-order execution; which of the two
           // "too far" errors it is (repeat_from_dict, decode_buffer.rs:144-179) is worked out off the hot path
           if (off == 0) atomicMin(&L.bad, ((unsigned long long)i << 32) | (m0 << 8) | (uint32_t)ZG_EXE_ZERO_OFFSET);              // sequence_execution.rs:28-30
-          else if (!reach_all && off > reach32 + m0) atomicMin(&L.bad, ((unsigned long long)i << 32) | (m0 << 8) | (uint32_t)ZG_EXE_OFFSET_TOO_BIG);
+          else if ((!reach_all && off > reach32 + m0) || off >= ZG_OFF_HUGE - 2u) atomicMin(&L.bad, ((unsigned long long)i << 32) | (m0 << 8) | (uint32_t)ZG_EXE_OFFSET_TOO_BIG);
         } else {
           lstart = so.sum_ll; a = so.sum_ll + so.sum_ml; m0 = m1 = S;
         }
@@ -1916,7 +1968,7 @@ __global__ void __launch_bounds__(ZG_LZ_T) zg_k_lz(ZgBatchDev d) {
         if (lit_rle) { const uint8_t v = lit[0]; for (uint32_t k = 0; k < ll; k++) o[k] = v; }
         else { const uint8_t* s = lit + lit_start; for (uint32_t k = 0; k < ll; k++) o[k] = s[k]; }
         if (off == 0) { atomicCAS(&s_err, 0u, (uint32_t)ZG_EXE_ZERO_OFFSET); }
-        else if ((uint64_t)off > dpos + fr.prior_reach + (fr.prior_reach == fr.prior_out ? fr.dict_len : 0ull)) { atomicCAS(&s_err, 0u, (uint32_t)(dpos + fr.prior_out <= fr.window_size ? ZG_EXE_DICT_TOO_SMALL : ZG_EXE_OFFSET_TOO_BIG)); }
+        else if ((uint64_t)off > dpos + fr.prior_reach + (fr.prior_reach == fr.prior_out ? fr.dict_len : 0ull) || off >= ZG_OFF_HUGE - 2u) { atomicCAS(&s_err, 0u, (uint32_t)(dpos + fr.prior_out <= fr.window_size ? ZG_EXE_DICT_TOO_SMALL : ZG_EXE_OFFSET_TOO_BIG)); }
         else pending = ml > 0;
       }
       carry_out = to; carry_lit = tl;
@@ -2001,7 +2053,9 @@ void zg_launch_tables(const ZgBatchDev& d, hipStream_t s, int part) {
   else hipLaunchKernelGGL(zg_k_ftab, dim3((n + ZG_FT_W - 1) / ZG_FT_W), dim3(64 * ZG_FT_W), 0, s, d);
 }
 void zg_launch_huf(const ZgBatchDev& d, hipStream_t s) {
-  if (d.nhuf_groups) hipLaunchKernelGGL(zg_k_huf, dim3(d.nhuf_groups), dim3(ZG_HUF_T), 0, s, d);
+  if (!d.nhuf_groups) return;
+  hipLaunchKernelGGL(zg_k_huf, dim3(d.nhuf_groups), dim3(ZG_HUF_T), 0, s, d);
+  hipLaunchKernelGGL(zg_k_huf_uneven, dim3((d.nblocks + 3) / 4), dim3(256), 0, s, d);
 }
 void zg_launch_seq(const ZgBatchDev& d, hipStream_t s) {
   if (d.nseq_blocks) hipLaunchKernelGGL(zg_k_seq, dim3((d.nseq_blocks + ZG_SEQ_G - 1) / ZG_SEQ_G), dim3(128), 0, s, d);

@@ -231,6 +231,7 @@ struct ZgBatchDev {
   uint32_t* status;            // [nblocks] first error per block (ZgStatus), 0 = ok
   uint32_t* tab_status;        // [nblocks] what zg_k_tables left in status (zg_k_huf runs beside zg_k_seq and must not see its errors)
   uint32_t* lit_status;        // [nblocks] zg_k_huf's errors, folded into status by zg_k_merge (literals are decoded before sequences: they outrank)
+  uint32_t* lit_counts;        // [4 * nblocks] symbols each of the four streams of a block's literals holds (zg_k_huf -> zg_k_huf_uneven)
   uint8_t* lit_arena;          // regenerated Huffman literals
   ZgSeq* seq_arena;            // decoded sequences
   ZgRaw* raw_arena;            // zg_k_seq's raw records, 4 x u16 {OF, ML, LL table entries, bits taken}, same indexing as seq_arena
