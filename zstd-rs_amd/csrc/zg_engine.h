@@ -151,6 +151,7 @@ class Engine {
   int prepare_blocks(const uint8_t* src, size_t len, const HostBlock* hb, size_t n, FrameState* fs, uint64_t keep, Batch** out);
   hipStream_t stream() const { return stream_; }
   hipStream_t copy_stream() const { return stream2_; }
+  hipStream_t download_stream() const { return stream3_; }   // D2H of a finished submit while the next one runs (zgpu_pool_decode_all): nothing else uses it then
   int device() const { return device_; }
   int compute_units() const { return cus_; }
   std::string last_error;

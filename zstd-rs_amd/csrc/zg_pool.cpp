@@ -2,6 +2,7 @@
 // one engine (HIP streams, device buffers) per GPU, no data-path collective. The reference's counterpart is
 // the frame loop of FrameDecoder::decode_all (ruzstd/src/decoding/frame_decoder.rs:541-577), which decodes the frames of a
 // buffer one after the other.
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <atomic>
@@ -365,10 +366,14 @@ int zgpu_pool_decode_all(zgpu_pool* p, const uint8_t* src, size_t len, uint8_t* 
   struct Job { uint64_t begin, end; Batch* batch = nullptr; int status = 0; uint32_t worker = 0; uint64_t out_off = 0, out_size = 0, want_size = 0; bool placed = false; };
   std::vector<Job> jobs;
   const uint64_t nw = p->eng.size();
-  // jobs: about eight per GPU (four per engine) so that the copies of one overlap the kernels of another, but not below 32 MiB of
-  // input (a submit costs ~2 ms whatever its size: the length of one block's sequence chain) nor above 512 MiB
-  uint64_t kJob = (uint64_t)len / (8 * nw);
-  if (kJob < (32ull << 20)) kJob = 32ull << 20;
+  // jobs: about sixteen per GPU (eight per engine) so that the copies of one overlap the kernels of another, but not below 32 MiB of
+  // input (a submit costs ~2 ms whatever its size: the length of one block's sequence chain) nor above 512 MiB. Measured on 1 GiB of
+  // 64 MiB frames (tools/dev/e2e.py): 4 / 8 / 16 jobs per GPU 30.5 / 36.1 / 40.5 GB/s, 16 with a 16 MiB floor 37.4
+  uint64_t per_gpu = 16, floor_mb = 32;
+  { const char* e = getenv("ZGPU_DA_SPLIT"); if (e && atoi(e) > 0) per_gpu = (uint64_t)atoi(e); }      // (measurement) jobs per GPU aimed at
+  { const char* e = getenv("ZGPU_DA_FLOOR_MB"); if (e && atoi(e) > 0) floor_mb = (uint64_t)atoi(e); }  // (measurement) smallest job, MiB of input
+  uint64_t kJob = (uint64_t)len / (per_gpu * nw);
+  if (kJob < (floor_mb << 20)) kJob = floor_mb << 20;
   if (kJob > (512ull << 20)) kJob = 512ull << 20;
   bool sizes_known = true;
   for (const FrameSpan& s : spans) {
@@ -386,6 +391,15 @@ int zgpu_pool_decode_all(zgpu_pool* p, const uint8_t* src, size_t len, uint8_t* 
   std::atomic<uint32_t> next(0);
   p->run_on_workers([&](uint32_t w) {
     Engine* eng = w < nw ? p->eng[w] : p->eng2[w - nw];
+    // the download of a finished job runs on the engine's third stream while the worker is already at its next job: the wait for
+    // it comes one job later (H2D of job k+1 and D2H of job k use different DMA directions; the kernels in between hide both)
+    Job* downloading = nullptr;
+    auto land = [&]() {
+      if (!downloading) return;
+      if (hipStreamSynchronize(eng->download_stream()) != hipSuccess && !downloading->status) downloading->status = ZGPU_E_HIP;
+      delete downloading->batch; downloading->batch = nullptr;
+      downloading = nullptr;
+    };
     for (;;) {
       const uint32_t k = next.fetch_add(1);
       if (k >= order.size()) break;
@@ -400,13 +414,15 @@ int zgpu_pool_decode_all(zgpu_pool* p, const uint8_t* src, size_t len, uint8_t* 
           if (fo.status) { j.status = (int)fo.status; break; }
       if (!j.status) j.out_size = j.batch->total_out;
       if (!j.status && direct_out && j.out_size == j.want_size) {
-        j.status = j.batch->read_output(0, dst + j.out_off, j.out_size);
+        land();                            // (at most one download in flight per engine: its buffers are this job's predecessor's)
+        j.status = j.batch->read_output_async(0, dst + j.out_off, j.out_size, eng->download_stream());
         j.placed = true;
-        delete j.batch; j.batch = nullptr;
+        downloading = &j;
       } else if (j.batch) {
         j.batch->release_scratch();        // only the plaintext stays on the device until its place is known
       }
     }
+    land();
   });
   int st = 0;
   uint64_t total = 0;
