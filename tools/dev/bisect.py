@@ -23,8 +23,8 @@ ok = len(out) == size and (want is None or hashlib.sha256(out).digest() == want)
 print("RESULT", "OK" if ok else "WRONG", flush=True)
 ''' % (ROOT, ROOT, ROOT)
 for which in sys.argv[1:] or ["corpus", "many", "one"]:
-    for sw in ["", "ZGPU_FLAT=old", "ZGPU_DIRECT=0", "ZGPU_DEBUG_NO_SWEEP=1", "ZGPU_DEBUG_NO_LITRUN=1", "ZGPU_DEBUG_NO_SWEEP=1,ZGPU_DEBUG_NO_LITRUN=1",
-               "ZGPU_DIRECT=0,ZGPU_DEBUG_NO_SWEEP=1,ZGPU_DEBUG_NO_LITRUN=1", "ZGPU_UNIT_BLOCKS=15", "ZGPU_UNIT_BLOCKS=15,ZGPU_DEBUG_NO_SWEEP=1,ZGPU_DEBUG_NO_LITRUN=1", "ZGPU_FLAT_T=512"]:
+    for sw in ["", "ZGPU_DIRECT=0", "ZGPU_DEBUG_NO_SWEEP=1", "ZGPU_DIRECT=0,ZGPU_DEBUG_NO_SWEEP=1", "ZGPU_UNIT_BLOCKS=15",
+               "ZGPU_UNIT_BLOCKS=15,ZGPU_DEBUG_NO_SWEEP=1", "ZGPU_FLAT_T=512"]:
         env = dict(os.environ)
         for kv in sw.split(","):
             if kv:
