@@ -1414,7 +1414,10 @@ __device__ __forceinline__ void zg_flat1_unit(const ZgBatchDev& d, const uint32_
   const uint64_t unit_abs0 = d.pos[un.first_block].out_base;     // frame-relative position of the unit's first byte
   uint8_t* out_u = d.dst + fo.out_base + unit_abs0;
   uint32_t* og = d.og + fo.og_base + unit_abs0;
-  const __amdgpu_buffer_rsrc_t og_rs = zg_make_rsrc(og, un.nblocks * (ZG_FLAT_MAX * 4u));
+  // (a frame whose few matches zg_k_sparse copies in order has no sweep step either: nobody reads its scratch words, so they are
+  //  not written — an empty resource turns the stores into no-ops; on literal-heavy data they were most of the kernel's traffic)
+  const bool no_scratch = d.frames[un.frame].sparse != 0u;
+  const __amdgpu_buffer_rsrc_t og_rs = zg_make_rsrc(og, no_scratch ? 0u : un.nblocks * (ZG_FLAT_MAX * 4u));
   if (t == 0) { L.err = 0; L.bad = ~0ull; }
   uint32_t unit_size = 0;
 #ifdef ZG_PROFILE_FLAT   // per-phase cycle counters (tools/dev/flat_phases.py); costs registers, off in the product build
@@ -1432,7 +1435,7 @@ __device__ __forceinline__ void zg_flat1_unit(const ZgBatchDev& d, const uint32_
     const uint32_t bu0 = (uint32_t)(p.out_base - unit_abs0);      // unit-relative position of the block
     if (blk.btype != ZG_BT_COMPRESSED || blk.nseq == 0) {        // all of it is final already (zg_k_lit): effective offset 0
       const uint32_t n = blk.regen_size;
-      if (!un.noseq) for (uint32_t i = t; i < n; i += T) og[bu0 + i] = 0u;   // (a unit without sequences has no sweep step: nobody reads its scratch)
+      if (!un.noseq && !no_scratch) for (uint32_t i = t; i < n; i += T) og[bu0 + i] = 0u;   // (a unit without sequences has no sweep step: nobody reads its scratch)
       unit_size = bu0 + n;
       continue;
     }
