@@ -1852,10 +1852,10 @@ __global__ void __launch_bounds__(ZG_SW_T) __attribute__((amdgpu_waves_per_eu(2,
       const bool nB = uy && !(ux && q.y == q.x) && !(uw && q.y == q.w);
       const bool nC = uz && !(ux && q.z == q.x) && !(uw && q.z == q.w) && !(uy && q.z == q.y);
       rA[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, (dbgmode != 2 && ux) ? (wrel - q.x) & ~3u : ZG_OOB, 0, 0);
-      rD[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, (dbgmode != 2 && nD) ? (wrel - q.w) & ~3u : ZG_OOB, 0, 0);
-      rB[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, (dbgmode != 2 && nB) ? (wrel - q.y) & ~3u : ZG_OOB, 0, 0);
-      rC[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, (dbgmode != 2 && nC) ? (wrel - q.z) & ~3u : ZG_OOB, 0, 0);
-      rW[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, (dbgmode != 2 && any && !all) ? wrel & ~3u : ZG_OOB, 0, 0);
+      rD[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, (dbgmode != 2 && dbgmode < 3 && nD) ? (wrel - q.w) & ~3u : ZG_OOB, 0, 0);
+      rB[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, (dbgmode != 2 && dbgmode < 3 && nB) ? (wrel - q.y) & ~3u : ZG_OOB, 0, 0);
+      rC[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, (dbgmode != 2 && dbgmode < 3 && nC) ? (wrel - q.z) & ~3u : ZG_OOB, 0, 0);
+      rW[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, (dbgmode != 2 && dbgmode < 4 && any && !all) ? wrel & ~3u : ZG_OOB, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);                          // keep the issue order: all gathers, then the next scratch words, then the uses
     load_og(i + 1 < nb ? b0 + i + 1 : b0 + i, onx);            // (the last batch is simply requested again: no branch)
