@@ -321,7 +321,7 @@ const uint32_t* zgemu_fse_slot(void* h, uint32_t slot, uint8_t* logs) {
   EmuBatch* e = (EmuBatch*)h; memcpy(logs, e->slot_log.data() + (size_t)slot * 4, 4); return e->fse.data() + (size_t)slot * ZG_FSE_SLOT_U32;
 }
 // the host's plan for the LZ77 stages (zg_host_parse.cpp, finish()): units, sweep steps, per-frame sequence ranges. No decode:
-// only the block walk. flat_slots as the engine would pass it (workgroups zg_k_flat can hold at once).
+// only the block walk. flat_slots as the engine would pass it (workgroups zg_k_flatten can hold at once).
 void* zgemu_plan(const uint8_t* src, size_t len, uint32_t flat_slots, uint32_t unit_blocks) {
   EmuBatch* e = new EmuBatch();
   e->src_store.assign(len + 128, 0);

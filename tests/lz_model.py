@@ -1,4 +1,4 @@
-"""numpy model of what zg_k_flat must leave in its scratch (test infrastructure).
+"""numpy model of what zg_k_flatten must leave in its scratch (test infrastructure).
 
 For every output byte of a unit (a run of consecutive blocks of one frame): 0 for a literal byte (and every byte of a
 raw / RLE block), else the effective offset e with byte[pos] = byte[pos - e], where pos - e is a literal byte or lies

@@ -425,7 +425,7 @@ def test_streaming_decoder(ctx):
 
 
 def test_dense_sequences_cut_tiles(ctx):
-    """blocks with 3-6 output bytes per sequence (up to 42 K sequences per block): zg_k_flat's tiles end early when they
+    """blocks with 3-6 output bytes per sequence (up to 42 K sequences per block): zg_k_flatten's tiles end early when they
     hold more sequences than fit (two per thread), both tile shapes"""
     import numpy as np
     import zgdata

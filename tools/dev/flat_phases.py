@@ -1,4 +1,4 @@
-"""Phase split of zg_k_flat from a build with -DZG_PROFILE_FLAT (make EXTRA=-DZG_PROFILE_FLAT OUT=../libzgpu_prof.so):
+"""Phase split of zg_k_flatten from a build with -DZG_PROFILE_FLAT (make EXTRA=-DZG_PROFILE_FLAT OUT=../libzgpu_prof.so):
 ZGPU_LIB=zstd-rs_amd/libzgpu_prof.so python tools/dev/flat_phases.py [size]"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,4 @@
-"""zg_k_flat's scratch against the numpy model (tests/lz_model.py), without the sweep: flatcheck.py [golden frame names ...]"""
+"""zg_k_flatten's scratch against the numpy model (tests/lz_model.py), without the sweep: flatcheck.py [golden frame names ...]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "zstd-rs_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))

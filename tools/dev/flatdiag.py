@@ -1,4 +1,4 @@
-"""diagnostic: zg_k_flat4's scratch words against tests/lz_model.py, per frame of a multi-frame submit (ZGPU_DEBUG_NO_SWEEP), printing where they differ"""
+"""diagnostic: zg_k_flatten's scratch words against tests/lz_model.py, per frame of a multi-frame submit (ZGPU_DEBUG_NO_SWEEP), printing where they differ"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "zstd-rs_amd")); sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,4 +1,4 @@
-"""What the sweep has to do, from zg_k_flat's scratch of a generated text frame: share of literal bytes, of match bytes whose
+"""What the sweep has to do, from zg_k_flatten's scratch of a generated text frame: share of literal bytes, of match bytes whose
 final source is a literal byte inside their unit, and of match bytes that copy from in front of their unit; lengths of runs of
 equal offset. usage: og_classes.py [size] [unit blocks]"""
 import os, sys

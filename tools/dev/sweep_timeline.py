@@ -1,10 +1,10 @@
 """Timeline of the sweep launches of the last pass in a rocprofv3 --kernel-trace CSV: which launches overlap.
 usage: sweep_timeline.py <kernel_trace.csv>   (tails: small grids on the main stream; heads: large grids on the side stream)"""
 import csv, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "zg_k_sweep" in r["Kernel_Name"] or "zg_k_flat" in r["Kernel_Name"] or "zg_k_fin" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "zg_k_sweep" in r["Kernel_Name"] or "zg_k_flatten" in r["Kernel_Name"] or "zg_k_fin" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # last pass = after the last flat
-last = max(i for i, r in enumerate(rows) if "zg_k_flat" in r["Kernel_Name"])
+last = max(i for i, r in enumerate(rows) if "zg_k_flatten" in r["Kernel_Name"])
 rows = rows[last:]
 t0 = int(rows[0]["End_Timestamp"])
 import collections

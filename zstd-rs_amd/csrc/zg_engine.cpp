@@ -349,7 +349,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   { const char* e = getenv("ZGPU_DIRECT"); if (e && e[0] == '0') b->bb.direct_units = false; }
   { const char* e = getenv("ZGPU_RAMP"); if (e) b->bb.ramp_percent = (uint32_t)atoi(e); }   // (measurement) N > 0: one long frame in units growing by +-N %, the sweep chain beside the flatten
   { const char* e = getenv("ZGPU_SPARSE_MAX"); if (e) { b->bb.sparse_max = (uint32_t)atoi(e); b->bb.sparse_per_block = 1u << 20; } }   // (tests) sequences per frame up to which zg_k_sparse replaces the sweep, whatever their density; 0: never
-  b->bb.flat_slots = (uint32_t)cus_ * (flat_shape_ == 0 ? 1u : 2u);   // zg_k_flat: workgroups the device holds at once
+  b->bb.flat_slots = (uint32_t)cus_ * (flat_shape_ == 0 ? 1u : 2u);   // zg_k_flatten: workgroups the device holds at once
   b->bb.finish();
   BatchBuilder& bb = b->bb;
   Scratch* sc = b->sc = acquire();
@@ -396,7 +396,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   d.fse_arena = sc->d_fse.as<uint32_t>(); d.huf_arena = sc->d_huf.as<uint16_t>(); d.huf_maxbits = sc->d_hufmax.as<uint8_t>();
   d.status = sc->d_status.as<uint32_t>(); d.tab_status = d.status + nb + 4; d.lit_status = d.tab_status + nb + 4;
   d.lit_counts = d.lit_status + nb + 4;     // [4 * nblocks], written by zg_k_huf (no reset needed)
-  d.lit_arena = sc->d_lit.as<uint8_t>() + 64;   // (zg_k_flat4 reads literal windows that start up to 7 bytes in front of a block's literals)
+  d.lit_arena = sc->d_lit.as<uint8_t>() + 64;   // (zg_k_flatten reads literal windows that start up to 7 bytes in front of a block's literals)
   d.seq_arena = sc->d_seq.as<ZgSeq>(); d.raw_arena = sc->d_raw.as<ZgRaw>();
   d.seq_out = sc->d_seqout.as<ZgBlockSeqOut>(); d.pos = sc->d_pos.as<ZgBlockPos>(); d.frame_out = sc->d_frameout.as<ZgFrameOut>();
   d.dst = nullptr; d.dst_cap = 0; d.og = nullptr;

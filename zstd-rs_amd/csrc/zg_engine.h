@@ -160,7 +160,7 @@ class Engine {
   friend class Batch;
   int device_ = 0;
   int cus_ = 256;                // compute units of the device (MI355X: 256)
-  int flat_shape_ = 0;           // zg_k_flat shape: 0 = 1024 threads x 16 KiB tiles (one workgroup per CU), 1 = 512 x 8 KiB (two)
+  int flat_shape_ = 0;           // zg_k_flatten shape: 0 = 1024 threads x 16 KiB tiles (one workgroup per CU), 1 = 512 x 8 KiB (two)
   hipStream_t stream_ = nullptr, stream2_ = nullptr, stream3_ = nullptr;   // stream3_: the flatten, when the sweep chain runs beside it
   std::vector<Scratch*> free_;   // finished submits' buffers, for reuse
   Scratch* acquire();

@@ -235,7 +235,7 @@ void BatchBuilder::finish() {
   }
   seq_blocks.clear(); huf_items.clear(); huf_groups.clear(); units.clear(); step_units.clear(); steps.clear();
   ramped = false;
-  // blocks per unit: zg_k_flat runs flat_slots workgroups at once, one per unit, so aim at ~flat_slots units over the whole
+  // blocks per unit: zg_k_flatten runs flat_slots workgroups at once, one per unit, so aim at ~flat_slots units over the whole
   // submit (more blocks per unit = fewer sweep steps, but less parallelism in the flatten pass). What costs there are the
   // blocks that have sequences: a literal-heavy frame gets smaller units in proportion, so that few literal-only blocks share a
   // unit — scratch words, a sweep step — with a block that needs them.

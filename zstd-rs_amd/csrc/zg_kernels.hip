@@ -9,19 +9,24 @@
 //   literals chain (low-priority stream, beside zg_k_seq)
 //     zg_k_tables   one wave per block         Huffman tree descriptions -> Huffman arena
 //     zg_k_huf      one wave per stream        Huffman literal streams, self-synchronising -> literals arena
+//     zg_k_huf_uneven  one wave per block      (rare) four streams split differently from the format's rule: placed again by their counts
 //   then, on the first stream
 //     zg_k_merge    one thread per block       literals errors into the block status
 //     zg_k_scan     one workgroup per frame    block output positions + offset-history resolution (function-composition scan)
 //     zg_k_scanf    one workgroup              frame output positions and scratch bases
 //     zg_k_lit      one workgroup per block    raw and RLE blocks, blocks without sequences -> output
 //     zg_k_flatten  one workgroup per unit     every byte of a run of blocks -> its effective offset (to a literal byte, or to a byte in
-//                                              front of the unit); literals -> output
+//                                              front of the unit); literals -> output. A frame's FIRST unit instead becomes plaintext
+//                                              right here (zg_flat4.h: nothing in front of it to copy from): no scratch, no sweep step
 //     zg_k_swprep   one thread per unit        sweep descriptors
 //     zg_k_sweep    one launch per unit index  the units' tails, unit after unit: match bytes gathered from finished output;
 //                   + one per 16 indices       their heads beside the chain on the second stream (split sweep)
 //     zg_k_sparse   one wave per frame         frames with hardly any sequences: their matches in order, instead of sweep steps
 //     zg_k_fin      one thread per frame       execution errors -> frame status
 //     zg_k_lz       one workgroup per frame    in-order fallback (blocks regenerating > 128 KiB)
+//   and, from Batch::sync(), only for submits it can matter to
+//     zg_k_exact    one workgroup per frame    the reference's DecodeBuffer bookkeeping replayed exactly (zg_exact.h): which bytes are
+//                                              still in reach, which of the two "offset too far" errors applies
 //
 // The reference functions each kernel reproduces are cited at the lane routines in zg_dev.h.
 #include <stdlib.h>
@@ -1350,7 +1355,7 @@ __global__ void __launch_bounds__(256) zg_k_lit(ZgBatchDev d) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// zg_k_flat + zg_k_sweep: LZ77 execution (execute_sequences, sequence_execution.rs:5-54; DecodeBuffer::repeat,
+// zg_k_flatten + zg_k_sweep: LZ77 execution (execute_sequences, sequence_execution.rs:5-54; DecodeBuffer::repeat,
 // decode_buffer.rs:79-141) without walking the frame's sequences one after the other.
 //
 // Chains of matches (a match copying the output of an earlier match ...) are what makes in-order execution slow on
@@ -1358,7 +1363,7 @@ __global__ void __launch_bounds__(256) zg_k_lit(ZgBatchDev d) {
 // resolved to an "effective offset" e: byte[pos] = byte[pos - e], where pos - e is a byte that is final before the
 // byte's unit is swept — a literal byte anywhere, or any byte before the unit (a unit = a run of consecutive blocks of
 // one frame). Literal bytes have e = 0. No byte VALUES travel through this stage: only offsets.
-//   zg_k_flat  (all units at once, one workgroup per unit) walks the unit in tiles held in LDS. A tile byte points to
+//   zg_k_flatten  (all units at once, one workgroup per unit) walks the unit in tiles held in LDS. A tile byte points to
 //              its parent byte (position - offset); pointer jumping inside the tile (u16 pointers) shortens every chain
 //              to its tile root: a literal byte, or a match byte whose parent lies before the tile. Such a parent is in
 //              an earlier tile of the unit (its e is final: one gather from the scratch, e = offset + e[parent]) or
@@ -1383,7 +1388,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t zg_make_rsrc(const void* p, ui
 // the same value, but new to the compiler: what is computed from it is computed again here instead of being kept in a register
 #define ZG_FRESH(v) ({ uint32_t v_ = (v); asm volatile("" : "+v"(v_)); v_; })
 
-// zg_k_flat<T, TS, SPT>: T threads resolve TS-byte tiles; a thread owns the tile bytes t, t + T, t + 2T ... through all phases
+// zg_k_flatten<T, TS, SPT>: T threads resolve TS-byte tiles; a thread owns the tile bytes t, t + T, t + 2T ... through all phases
 // (consecutive lanes = consecutive bytes: LDS accesses are conflict-free and, above all, the scratch gathers of adjacent
 // lanes fall into the same cache lines — bytes of one match have adjacent parents). SPT = sequences a thread places per
 // tile; a tile that would hold more than SPT * T sequences is cut short. No phase has a data-dependent branch: loads and
@@ -1886,7 +1891,7 @@ __global__ void __launch_bounds__(ZG_SW_T) __attribute__((amdgpu_waves_per_eu(2,
   }
 }
 
-// after the last sweep step: an execution error found by zg_k_flat becomes the frame's status
+// after the last sweep step: an execution error found by zg_k_flatten becomes the frame's status
 __global__ void __launch_bounds__(256) zg_k_fin(ZgBatchDev d) {
   const uint32_t f = blockIdx.x * 256 + threadIdx.x;
   if (f >= d.nframes || d.totals[2]) return;
@@ -2087,7 +2092,7 @@ void zg_launch_lit(const ZgBatchDev& d, hipStream_t s) {
 }
 // ------------------------------------------------------------------------------------------------------------
 // zg_k_sparse: the matches of a frame that has hardly any (literal-heavy data: a sequence or two in one block out of twenty).
-// zg_k_flat has placed the literals and checked the offsets; what is left is a few hundred short copies per frame, which one
+// zg_k_flatten has placed the literals and checked the offsets; what is left is a few hundred short copies per frame, which one
 // wave does in order (a match may copy from an earlier one) in the time of a few sweep launches — of which the frame would
 // need one per unit. One wave per frame, 64 sequences at a time, the same "copy what no pending match can still write"
 // rule as zg_k_lz.
@@ -2098,7 +2103,7 @@ __global__ void __launch_bounds__(64) zg_k_sparse(ZgBatchDev d) {
   const ZgFrame fr = d.frames[f];
   if (!fr.sparse) return;
   const ZgFrameOut fo = d.frame_out[f];
-  if (!fo.fast || fo.err_packed != 0xFFFFFFFFu) return;        // the in-order path has it / zg_k_flat found a sequence that cannot be executed
+  if (!fo.fast || fo.err_packed != 0xFFFFFFFFu) return;        // the in-order path has it / zg_k_flatten found a sequence that cannot be executed
   uint8_t* frame_out = d.dst + fo.out_base;
   for (uint32_t e = 0; e < fr.seq_count; e++) {
     const uint32_t b = d.seq_blocks[fr.seq_first + e];

@@ -185,7 +185,7 @@ struct ZgFrameOut {
 #define ZG_DRAIN_NONE 0u        // not at all (FrameDecoder::decode_blocks, decode_from_to, the thin boundary: the caller drains between submits)
 #define ZG_DRAIN_DECODE_ALL 1u  // FrameDecoder::decode_all: rounds of UptoBytes(1 MiB), each followed by a drain down to window_size
 
-// LZ77 execution works on units: runs of consecutive blocks of one frame that zg_k_flat resolves together.
+// LZ77 execution works on units: runs of consecutive blocks of one frame that zg_k_flatten resolves together.
 // noseq: bit 0: none of the unit's blocks has sequences: all of it is literal bytes, final after zg_k_lit; bit 1 (ZG_UNIT_DIRECT):
 // the frame's first unit, resolved to bytes by the flatten itself (zg_flat4.h). Either way: no scratch words, no sweep step.
 // flatten stage (zg_flat4.h): parent markers of a tile byte, and the largest block output the flatten path handles
@@ -249,7 +249,7 @@ struct ZgBatchDev {
   uint32_t nhuf_groups;
   uint32_t* totals;            // [4]: [0..1] total output bytes (u64), [2] overflow flag, [3] a match reaches further back than its frame's window (zg_k_seqpost)
   uint32_t sweep_window;       // 0: a frame's window size bounds its matches (checked); else this many bytes instead (tests)
-  uint32_t flags;              // bit 0: force the in-order fallback for every frame (tests); bits 2-3: shape of zg_k_flat (0: 1024 threads x 16 KiB tiles, 1: 512 x 8 KiB)
+  uint32_t flags;              // bit 0: force the in-order fallback for every frame (tests); bits 2-3: shape of zg_k_flatten (0: 1024 threads x 16 KiB tiles, 1: 512 x 8 KiB)
   uint64_t og_words;           // size of the flatten scratch in u32
   uint32_t* og;                // flatten scratch: one u32 "effective offset" per output byte of a unit (0 = literal byte, final already)
   const ZgUnit* units;

@@ -289,7 +289,7 @@ class Batch:
         return int(self.L.zgpu_batch_debug_sweep_mode(self.h))
 
     def units(self):
-        """[(first_block, nblocks, scratch_base, size, noseq)] — the units zg_k_flat4 worked on (size valid after sync); noseq: bit 0: no
+        """[(first_block, nblocks, scratch_base, size, noseq)] — the units zg_k_flatten worked on (size valid after sync); noseq: bit 0: no
         block of the unit has sequences, bit 1: direct unit (resolved to bytes by the flatten itself); either way it has no scratch
         words and no sweep step"""
         out = []
