@@ -465,7 +465,7 @@ int Batch::run() {
   ZG_HIP(hipStreamWaitEvent(s, sc->ev_huf[1], 0));
   zg_launch_merge(d, s);
   ZG_HIP(hipEventRecord(ev[4], s));
-  zg_launch_scan(d, s);
+  { uint32_t mb = 0; for (const ZgFrame& fr : bb.frames) mb = fr.nblocks > mb ? fr.nblocks : mb; zg_launch_scan(d, s, mb); }
   ZG_HIP(hipEventRecord(ev[5], s));
   // ---- the one host round trip: exact output size of every frame -> output buffer and flatten scratch sized to it
   frame_out.resize(d.nframes);

@@ -1186,7 +1186,9 @@ __global__ void __launch_bounds__(ZG_SP_T, 4) zg_k_seqpost(ZgBatchDev d) {
 // The history recurrence (sequence_execution.rs:59-118; never reset between blocks, scratch.rs:22) is a
 // composition of per-block maps on three symbolic slots, so it is scanned like a prefix sum.
 // ------------------------------------------------------------------------------------------------------------
-#define ZG_SCAN_T 1024
+// ZG_SCAN_T threads per frame: 1024 for frames of many blocks, one wave for a submit of short frames (16384 single-block frames:
+// 16384 workgroups of 1024 threads that hold one block each took 0.69 ms)
+template <int ZG_SCAN_T>
 __global__ void __launch_bounds__(ZG_SCAN_T) zg_k_scan(ZgBatchDev d) {
   __shared__ uint64_t s_size[ZG_SCAN_T / 64];
   __shared__ ZgHistMap s_map[ZG_SCAN_T / 64];
@@ -2083,8 +2085,9 @@ void zg_launch_merge(const ZgBatchDev& d, hipStream_t s) {
 void zg_launch_seqpost(const ZgBatchDev& d, hipStream_t s) {
   if (d.nseq_blocks) hipLaunchKernelGGL(zg_k_seqpost, dim3(d.nseq_blocks), dim3(ZG_SP_T), 0, s, d);
 }
-void zg_launch_scan(const ZgBatchDev& d, hipStream_t s) {
-  hipLaunchKernelGGL(zg_k_scan, dim3(d.nframes), dim3(ZG_SCAN_T), 0, s, d);
+void zg_launch_scan(const ZgBatchDev& d, hipStream_t s, uint32_t max_frame_blocks) {
+  if (max_frame_blocks <= 64u) hipLaunchKernelGGL((zg_k_scan<64>), dim3(d.nframes), dim3(64), 0, s, d);
+  else hipLaunchKernelGGL((zg_k_scan<1024>), dim3(d.nframes), dim3(1024), 0, s, d);
   hipLaunchKernelGGL(zg_k_scanf, dim3(1), dim3(1024), 0, s, d);
 }
 void zg_launch_lit(const ZgBatchDev& d, hipStream_t s) {
