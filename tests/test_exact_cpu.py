@@ -152,3 +152,75 @@ def test_dictionary_reach_ends_with_the_counter():
         e = emu.EmuBatch(z)
         got = e.exact(0, dict_len=dict_len)[0][0]
         assert got == want, (name, got, want, dict_len)
+
+
+def multi_seq_block(offsets, lits=b"wxyz", last=False):
+    """compressed block: raw literals, len(offsets) sequences (each ll 0, ml 3), LL / ML predefined (their state 0 stays state 0 when
+    the update bits are zero: symbol 0 both), OF in RLE mode: every offset value shares one code, offsets[i] + 3 in [2^c, 2^(c+1))"""
+    vals = [o + 3 for o in offsets]
+    of_code = vals[0].bit_length() - 1
+    assert all(v.bit_length() - 1 == of_code for v in vals)
+    n = len(vals)
+    acc = 1
+    for v, w in ((0, 6), (0, 6)):                         # LL state, (OF: 0 bits), ML state
+        acc = (acc << w) | v
+    for i, v in enumerate(vals):
+        acc = (acc << of_code) | (v - (1 << of_code))     # extra bits: OF (ML and LL codes 0 carry none)
+        if i + 1 < n:
+            acc <<= 4 + 6                                 # state updates LL (4 bits), ML (6 bits), OF (RLE: none): all zero
+    stream = acc.to_bytes((acc.bit_length() + 7) // 8, "little")
+    assert n < 0x7F00
+    nb = bytes([n]) if n < 128 else bytes([(n >> 8) + 128, n & 255])
+    body = bytes([len(lits) << 3]) + lits + nb + bytes([0x10, of_code]) + stream
+    return (((len(body) << 3) | (2 << 1) | (1 if last else 0)).to_bytes(3, "little")) + body
+
+
+def test_many_sequences_per_block_counter_prefix_sums():
+    """blocks of hundreds of sequences (several chunks of 256, all four waves): the counter a sequence sees is the block's start
+    value + its position - the dictionary-only matches in front of it, wherever in the block those are"""
+    import random
+    raw = read_pack("dict_tests.pack")["dictionary"]
+    did = 618557512
+    rng = random.Random(77)
+    probe = lambda n: oracle_blocks(frame(seq_block(n, lits=b"", last=True)), raw, did)
+    lo, hi = 1, len(raw)
+    while lo < hi:
+        mid = (lo + hi + 1) // 2
+        if probe(mid) == 0:
+            lo = mid
+        else:
+            hi = mid - 1
+    dict_len = lo
+    seen = set()
+    for case in range(24):
+        n = rng.choice([5, 200, 255, 256, 257, 600, 1100])
+        pre = rng.choice([0, 100, 3000])                       # literal bytes in front (counted)
+        code_lo = 1 << (17 if case % 3 == 0 else 15 if case % 3 == 1 else 16)   # offsets + 3 in [2^c, 2^(c+1)): beyond the 132000 counted bytes in front (c = 17), inside the dictionary (15)
+        # position of sequence i's match: pre + 3 i ; in reach of the buffer if offset <= that, else the dictionary serves it (while
+        # the counter allows and the dictionary is long enough)
+        offs = []
+        for i in range(n):
+            kind = rng.randrange(4) if case % 3 != 1 else 4       # case % 3 == 1: only offsets the dictionary (or the frame) can serve
+            at = pre + 3 * i
+            if kind == 0:
+                o = code_lo - 3 + rng.randrange(0, 200)                         # just beyond everything the frame has: dictionary only or partly
+            elif kind == 1:
+                o = min(code_lo - 3 + at + rng.randrange(0, 40), 2 * code_lo - 4)
+            elif kind == 4:
+                o = code_lo - 3 + rng.randrange(0, max(1, min(dict_len - (code_lo - 3), code_lo - 1)))
+            elif kind == 2:
+                o = code_lo - 3 + rng.randrange(0, min(dict_len, 60000))
+            else:
+                o = code_lo - 3 + rng.randrange(0, 65000)
+            offs.append(o)
+        blocks = ([lit_block(pre)] if pre else []) + [multi_seq_block(offs, last=True)]
+        if case % 3 == 0:                                       # a window-sized run of counted bytes in front: the dictionary is closed
+            blocks = [lit_block(4000)] * 33 + blocks
+        z = frame(*blocks)
+        want = oracle_blocks(z, raw, did)
+        e = emu.EmuBatch(z)
+        assert e.parse_status == 0
+        got = e.exact(0, dict_len=dict_len)[0][0]
+        assert got == want, (case, n, pre, got, want)
+        seen.add(want)
+    assert seen == {0, 52, 53}, seen

@@ -118,3 +118,51 @@ def test_dictionary_reach_ends_with_the_counter(ctx):
         if st == 0:
             assert d.collect() == o.collect(), name
     d.close()
+
+
+def test_many_sequences_per_block_with_dictionary(ctx):
+    """blocks of hundreds of one-byte-code sequences that reach into the dictionary, into the frame, or nowhere: status and bytes as the
+    oracle's, whichever sequence of the block is the first the reference objects to"""
+    import random
+    import zgpu
+    from test_exact_cpu import multi_seq_block
+    raw = read_pack("dict_tests.pack")["dictionary"]
+    d = zgpu.FrameDecoder(ctx)
+    did = d.add_dict(raw)
+    rng = random.Random(78)
+    seen = set()
+    for case in range(18):
+        n = rng.choice([5, 255, 257, 600, 1100])
+        pre = rng.choice([0, 100, 3000])
+        code_lo = 1 << (17 if case % 3 == 0 else 15 if case % 3 == 1 else 16)
+        offs = []
+        for i in range(n):
+            kind = rng.randrange(4) if case % 3 != 1 else 4
+            at = pre + 3 * i
+            if kind == 0:
+                o = code_lo - 3 + rng.randrange(0, 200)
+            elif kind == 1:
+                o = min(code_lo - 3 + at + rng.randrange(0, 40), 2 * code_lo - 4)
+            elif kind == 4:
+                o = code_lo - 3 + rng.randrange(0, 8000)          # well inside the dictionary's content
+            else:
+                o = code_lo - 3 + rng.randrange(0, 60000)
+            offs.append(o)
+        blocks = ([lit_block(pre)] if pre else []) + [multi_seq_block(offs, last=True)]
+        if case % 3 == 0:
+            blocks = [lit_block(4000)] * 33 + blocks
+        z = frame(*blocks)
+        o = oracle.FrameDecoder()
+        assert o.add_dict(raw) == did
+        st, c, _, _ = d.reset(z)
+        ost, oc, _, _ = o.init(z)
+        assert (st, c) == (ost, oc)
+        assert d.force_dict(did) == o.force_dict(did) == 0
+        st, used, fin = d.decode_blocks(z[c:], zgpu.STRAT_ALL)
+        ost, oused, ofin = o.decode_blocks(z[c:], oracle.STRAT_ALL)
+        assert (st, fin) == (ost, ofin), (case, n, pre, st, ost)
+        if st == 0:
+            assert d.collect() == o.collect(), case
+        seen.add(st)
+    assert seen == {0, 52, 53}, seen
+    d.close()
