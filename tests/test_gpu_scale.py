@@ -250,3 +250,26 @@ def test_pool_over_all_visible_gpus():
         pool.decode_all(blob, len(want) - 1)
     assert e.value.status == zgpu.E_TARGET_TOO_SMALL
     pool.close()
+
+
+def test_pool_decode_all_places_jobs_around_a_lying_content_size(ctx, monkeypatch):
+    """Frame_Content_Size is never checked by FrameDecoder::decode_all (frame_decoder.rs:541-577): a frame that declares fewer (or
+    more) bytes than it holds still decodes, and what follows it lands right behind what it really produced. The queue places a
+    job straight into the caller's buffer when its declared size turns out right — the jobs around a lying one must keep their bytes
+    while everything is moved to its final place (understated first frame: its download is longer than the gap left for it;
+    overstated: shorter)."""
+    monkeypatch.setenv("ZGPU_DA_FLOOR_MB", "1")                     # every frame below is a job of its own (> 1 MiB of input each)
+    plains = [zgdata.text_like((5 << 20) + 4096 * i, seed=0x7700 + i) for i in range(5)]
+    zs = [zgdata.zstd_compress(p) for p in plains]
+    want = b"".join(plains)
+
+    def lie(z, delta):                                             # Frame_Header: magic(4) descriptor(1) window(1) FCS(4): frame.rs:6-85
+        assert (z[4] >> 6) == 2 and not (z[4] >> 5) & 1 and not z[4] & 3, "expected a 4-byte FCS behind a window descriptor"
+        fcs = int.from_bytes(z[6:10], "little") + delta
+        return z[:6] + fcs.to_bytes(4, "little") + z[10:]
+    pool = zgpu.Pool(devices=[0])
+    for which, delta in ((0, -100000), (0, +100000), (2, -70000), (4, -5)):
+        blob = b"".join(lie(z, delta) if k == which else z for k, z in enumerate(zs))
+        out = pool.decode_all(blob, len(want) + (1 << 20))
+        assert len(out) == len(want) and _sha(out) == _sha(want), (which, delta)
+    pool.close()

@@ -156,6 +156,59 @@ def test_errors_name_the_block(ctx):
     assert e.value.status == zgpu.E_WINDOW_SIZE_TOO_BIG
 
 
+def test_execution_errors_cut_the_output_at_the_failing_block(ctx):
+    """a sequence that cannot be executed (ExecuteSequencesError: zero offset, offset beyond what the buffer holds) is found by
+    the LZ77 stages, after the sizes of all blocks were laid out: what zgpu_read hands out must still end with the last good block
+    (what the reference's buffer holds when decode_block_content returns the error, sequence_execution.rs:5-54)"""
+    import zgpu
+    from test_exact_cpu import frame, lit_block, raw_block, seq_block
+    for bad_block in (seq_block(1 << 22), seq_block(70000)):          # beyond everything produced so far
+        z = frame(lit_block(3000), raw_block(5000, 3), lit_block(2500), bad_block, lit_block(700), lit_block(100, last=True))
+        hl, window, fcs, did, _ = parse_frame_header(z)
+        blocks, _ = walk_blocks(z, hl)
+        o = oracle.FrameDecoder()
+        st, c, _, _ = o.init(z)
+        assert st == 0
+        ost, _, _ = o.decode_blocks(z[c:], oracle.STRAT_ALL)
+        assert ost != 0 and o.blocks_decoded() == 3
+        for cut in (len(blocks), 2):                                   # one submit; the failing block in a second submit
+            f = zgpu.BlockFrame(ctx, window, fcs, did)
+            f.submit(z, blocks[:cut])
+            if cut < len(blocks):
+                assert f.sync() == (None, 0)
+                f.submit(z, blocks[cut:])
+            bad, st = f.sync()
+            assert (bad, st) == (3, ost)
+            assert f.blocks_decoded() == 3
+            got = f.read(1 << 20, True)
+            assert len(got) == 3000 + 5000 + 2500 and got == o.collect()[:len(got)]
+            f.close()
+
+
+def test_host_rejected_first_block_is_a_sticky_verdict(ctx):
+    """a block the host checks reject (reserved type, block_decoder.rs:226-228) gives the same sticky verdict whether it is the first
+    block of a submit or a later one: zgpu_blocks_submit returns OK, zgpu_sync names the block"""
+    import zgpu
+    z = read_pack("synthetic.pack")["text_1m_l3.zst"]
+    hl, window, fcs, did, _ = parse_frame_header(z)
+    blocks, _ = walk_blocks(z, hl)
+    reserved = (blocks[2][0], blocks[2][1], 3, 0, 0)
+    for first in (True, False):
+        f = zgpu.BlockFrame(ctx, window, fcs, did)
+        if first:
+            f.submit(z, blocks[:2])
+            assert f.sync() == (None, 0)
+            f.submit(z, [reserved] + blocks[3:5])
+        else:
+            f.submit(z, blocks[:2] + [reserved] + blocks[3:5])
+        bad, st = f.sync()
+        assert (bad, st) == (2, zgpu.E_RESERVED_BLOCK), (first, bad, st)
+        f.submit(z, blocks[3:5])                                       # the frame has failed: later submits are ignored
+        assert f.sync() == (2, zgpu.E_RESERVED_BLOCK)
+        assert f.blocks_decoded() == 2
+        f.close()
+
+
 def test_device_output_view(ctx):
     import zgpu
     z = read_pack("synthetic.pack")["text_1m_l3.zst"]

@@ -1,5 +1,6 @@
 """One data set, several engine variants (environment switches read when a Context is created): kernel times side by side.
-usage: variants.py [size] [text|iso|blocks] -- VAR=VALUE[,VAR=VALUE] ..."""
+usage: variants.py [size] [text|iso|blocks|many] -- VAR=VALUE[,VAR=VALUE] ...
+(many: 64 MiB text frames, 16 distinct ones repeated up to `size` bytes, in one submit: one GPU's share of BASELINE config 4)"""
 import hashlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "zstd-rs_amd")); sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -15,10 +16,23 @@ if kind == "blocks":     # single-block frames: every unit is a first unit, the 
     plain = b"".join(parts)
     z = b"".join(zgdata.zstd_compress(q) for q in parts)
     size = len(plain)
+elif kind == "many":
+    parts = [zgdata.text_like(64 << 20, seed=0xE9 + i) for i in range(16)]
+    reps = max(size // (16 * (64 << 20)), 1)
+    z = b"".join(zgdata.zstd_compress(q) for q in parts) * reps
+    plain = None
+    size = reps * 16 * (64 << 20)
+    h = hashlib.sha256()
+    for _ in range(reps):
+        for q in parts:
+            h.update(q)
+    want = h.digest()
 else:
     plain = zgdata.text_like(size) if kind == "text" else zgdata.iso_like(size)
     z = zgdata.zstd_compress(plain)
-want = hashlib.sha256(plain).digest()
+if plain is not None:
+    want = hashlib.sha256(plain).digest()
+    del plain
 for v in variants:
     sets = [kv.split("=") for kv in v.split(",") if kv]
     for k, val in sets:

@@ -382,6 +382,7 @@ struct zgpu_decoder {
   size_t head = 0;
   Xxh64 hash;
   size_t held() const { return buf.size() - head; }
+  uint32_t drain_rule = ZG_DRAIN_NONE;   // how the surface driving this decoder drains the reference's DecodeBuffer inside one run (zg_exact.h)
 };
 
 static size_t dec_drain(zgpu_decoder* d, size_t n, uint8_t* dst) {  // DecodeBuffer::drain_to decode_buffer.rs:256-314
@@ -433,9 +434,10 @@ static int decode_run(zgpu_decoder* d, const uint8_t* src, size_t len, uint32_t 
   const int parse_status = b->parse_status;
   const size_t nb = b->bb.blocks.size();
   if (nb == 0) { delete b; return parse_status ? parse_status : ZGPU_E_INTERNAL; }
+  b->drain_rule = d->drain_rule;
   if ((st = b->run()) || (st = b->sync())) { delete b; return st; }
   if (b->frame_out.empty()) { delete b; return ZGPU_E_INTERNAL; }
-  const ZgFrameOut fo = b->frame_out[0];
+  const ZgFrameOut fo = b->frame_out[0];   // (a failed frame: out_size ends with its last good block, Batch::sync)
   if ((st = b->commit(&d->fs))) { delete b; return st; }
   // bring the new bytes to the host buffer the collect/read calls drain
   const size_t old = d->buf.size();
@@ -649,10 +651,14 @@ static int frame_finish_pending(zgpu_frame* f) {
   f->pending = nullptr;
   zgpu_decoder* d = &f->dec;
   int st = b->sync();
-  if (st) { delete b; return st; }
-  if (b->frame_out.empty()) { delete b; return ZGPU_E_INTERNAL; }
-  const ZgFrameOut fo = b->frame_out[0];
-  if ((st = b->commit(&d->fs))) { delete b; return st; }
+  if (!st && b->frame_out.empty()) st = ZGPU_E_INTERNAL;
+  const ZgFrameOut fo = st ? ZgFrameOut() : b->frame_out[0];   // (a failed frame: out_size ends with its last good block, Batch::sync)
+  if (!st) st = b->commit(&d->fs);
+  if (st) {   // the engine failed: the frame cannot go on (a later submit must not continue with these blocks missing)
+    if (!f->sticky) { f->sticky = st; f->bad_block = f->pending_first; }
+    delete b;
+    return st;
+  }
   const size_t old = d->buf.size();
   d->buf.resize(old + fo.out_size);
   if (fo.out_size && hipMemcpy(d->buf.data() + old, (const uint8_t*)d->fs.out_ptr() + fo.out_base, fo.out_size, hipMemcpyDeviceToHost) != hipSuccess) {
@@ -717,7 +723,15 @@ int zgpu_blocks_submit(zgpu_frame* f, const uint8_t* src, size_t src_len, const 
   Batch* b = nullptr;
   st = d->ctx->eng->prepare_blocks(src, src_len, hb.data(), nblocks, &d->fs, d->held(), &b);
   if (st) return st;
-  if (b->bb.blocks.empty()) { delete b; return ZGPU_E_INTERNAL; }
+  if (b->bb.blocks.empty()) {
+    // the first block of the submit failed the host's checks (reserved type, size beyond 128 KiB, body out of range): the same
+    // sticky verdict a later block of a submit gets, reported by zgpu_sync
+    const int ps = b->parse_status;
+    delete b;
+    if (!ps) return ZGPU_E_INTERNAL;
+    f->sticky = ps; f->bad_block = f->submitted;
+    return ZGPU_OK;
+  }
   if ((st = b->run())) { delete b; return st; }
   f->pending = b;
   f->pending_first = f->submitted;
@@ -884,6 +898,7 @@ static int decode_all_per_frame(zgpu_ctx* c, const uint8_t* src, size_t len, uin
   zgpu_decoder* d = nullptr;
   int st = zgpu_decoder_create(c, &d);
   if (st) return st;
+  d->drain_rule = ZG_DRAIN_DECODE_ALL;   // one decode_blocks(All) per frame stands for the reference's rounds of UptoBytes(1 MiB) + read(): same verdicts
   size_t p = 0, total = 0;
   while (p < len) {
     size_t used = 0;

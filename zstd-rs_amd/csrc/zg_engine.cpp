@@ -210,7 +210,13 @@ int split_frames(const uint8_t* src, size_t len, std::vector<FrameSpan>* out) {
 }
 
 Batch::~Batch() {
-  if (sc && eng) { (void)hipSetDevice(eng->device_); (void)hipStreamSynchronize(eng->stream_); eng->recycle(sc); }
+  // a run uses all three of the engine's streams (Huffman chain and sweep heads on the second, the ramped chain on the third) and
+  // joins them by events only when it reaches its end: nothing may be in flight on any of them when the buffers go back
+  if (sc && eng) {
+    (void)hipSetDevice(eng->device_);
+    (void)hipStreamSynchronize(eng->stream_); (void)hipStreamSynchronize(eng->stream2_); (void)hipStreamSynchronize(eng->stream3_);
+    eng->recycle(sc);
+  }
 }
 
 void FrameState::reset() {
@@ -378,7 +384,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
       (st = sc->d_fse.reserve((size_t)nslots * ZG_FSE_SLOT_U32 * 4)) || (st = sc->d_huf.reserve((size_t)(bb.nhuf_slots + 1) * ZG_HUF_SLOT_U16 * 2)) ||
       (st = sc->d_hufmax.reserve(bb.nhuf_slots + 16)) || (st = sc->d_status.reserve(7 * ((size_t)nb * 4 + 16))) ||
       (st = sc->d_lit.reserve(bb.lit_bytes + 128)) || (st = sc->d_seq.reserve((bb.seq_count + 2) * sizeof(ZgSeq))) ||
-      (st = sc->d_raw.reserve((bb.seq_count + 2) * 8)) ||
+      (st = sc->d_raw.reserve((bb.seq_count + 8) * 4)) ||
       (st = sc->d_seqout.reserve((size_t)nb * sizeof(ZgBlockSeqOut) + 16)) || (st = sc->d_pos.reserve((size_t)nb * sizeof(ZgBlockPos) + 16)) ||
       (st = sc->d_frameout.reserve((size_t)nf * sizeof(ZgFrameOut) + 16)) || (st = sc->d_totals.reserve(64)) ||
       (st = sc->d_swdesc.reserve(bb.step_units.size() * sizeof(ZgSweepDesc) + 32)) ||
@@ -397,7 +403,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   d.status = sc->d_status.as<uint32_t>(); d.tab_status = d.status + nb + 4; d.lit_status = d.tab_status + nb + 4;
   d.lit_counts = d.lit_status + nb + 4;     // [4 * nblocks], written by zg_k_huf (no reset needed)
   d.lit_arena = sc->d_lit.as<uint8_t>() + 64;   // (zg_k_flatten reads literal windows that start up to 7 bytes in front of a block's literals)
-  d.seq_arena = sc->d_seq.as<ZgSeq>(); d.raw_arena = sc->d_raw.as<ZgRaw>();
+  d.seq_arena = sc->d_seq.as<ZgSeq>(); d.raw_arena = sc->d_raw.as<uint32_t>();
   d.seq_out = sc->d_seqout.as<ZgBlockSeqOut>(); d.pos = sc->d_pos.as<ZgBlockPos>(); d.frame_out = sc->d_frameout.as<ZgFrameOut>();
   d.dst = nullptr; d.dst_cap = 0; d.og = nullptr;
   d.dict = nullptr;
@@ -416,6 +422,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   d.dbg = getenv("ZGPU_DEBUG_TIMERS") ? sc->d_dbg.as<unsigned long long>() : nullptr;
   { const char* e = getenv("ZGPU_FORCE_INORDER"); d.flags = (e && e[0] == '1') ? 1u : 0u; }
   d.flags |= (uint32_t)flat_shape_ << 2;
+  { const char* e = getenv("ZGPU_FLAT_MODE"); if (e) d.flags |= ((uint32_t)atoi(e) & 3u) << 4; }   // (timing experiments) zg_k_flatten without scratch stores / gathers
   { const char* e = getenv("ZGPU_SWEEP_W"); d.sweep_window = (e && atoi(e) > 0) ? (uint32_t)atoi(e) : 0u; }
   if (hipStreamSynchronize(stream_) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
   *out = b;
@@ -599,6 +606,16 @@ int Batch::sync() {
       ZG_HIP(hipMemcpy(frame_out.data(), dev.frame_out, (size_t)dev.nframes * sizeof(ZgFrameOut), hipMemcpyDeviceToHost));
       exact_ran = true;
     }
+  }
+  // a frame that failed in the execution stage (zg_k_flatten / zg_k_exact / zg_k_lz) still carries the size of all its blocks:
+  // what it produced ends with its last good block, as for the entropy errors zg_k_scan trims itself
+  for (uint32_t f = 0; f < dev.nframes; f++) {
+    ZgFrameOut& fo = frame_out[f];
+    const ZgFrame& fr = bb.frames[f];
+    if (!fo.status || fo.good_blocks >= fr.nblocks) continue;
+    ZgBlockPos p;
+    ZG_HIP(hipMemcpy(&p, dev.pos + fr.first_block + fo.good_blocks, sizeof p, hipMemcpyDeviceToHost));
+    if (p.out_base < fo.out_size) fo.out_size = p.out_base;
   }
   hipEvent_t* ev = sc->ev;
   for (int i = 0; i < ZG_T_TOTAL; i++) {

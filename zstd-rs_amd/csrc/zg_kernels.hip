@@ -81,7 +81,7 @@ __device__ __forceinline__ void zg_wave_publish() {
 //               length b owns 2^(max_bits - b) consecutive entries (:327-403). Long runs are written by the whole wave,
 //               short ones by their lane, into LDS; the finished table leaves with 16-byte stores.
 // ------------------------------------------------------------------------------------------------------------
-#define ZG_HT_W 4      // blocks (waves) per workgroup
+#define ZG_HT_W 2      // blocks (waves) per workgroup: 11.8 KB of LDS, so that a workgroup fits beside two zg_k_seq workgroups (147,472 of the CU's 163,840 bytes)
 #define ZG_TAB_HDR 160 // bytes of a literals section staged for parsing (a tree description is at most 129 bytes)
 struct ZgHufTabLds {
   int16_t probs[256];
@@ -588,9 +588,11 @@ __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
 // stream where the format's split puts it and reported a count mismatch. No encoder emits this: the repair is a plain
 // serial decode, one lane per stream, with the counts zg_k_huf left behind. One wave per block; a block that is not
 // affected costs its wave one load.
-__global__ void __launch_bounds__(256) zg_k_huf_uneven(ZgBatchDev d) {
-  __shared__ uint16_t s_tab[4][ZG_HUF_SLOT_U16];
-  const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u, b = blockIdx.x * 4u + wv;
+__global__ void __launch_bounds__(64) zg_k_huf_uneven(ZgBatchDev d) {
+  // (one wave and one table per workgroup: 4 KB of LDS, which fits beside two zg_k_seq workgroups; with four tables per workgroup
+  //  this kernel — one load per block on conforming input — waited for the sequences chain to leave the CUs)
+  __shared__ uint16_t s_tab[1][ZG_HUF_SLOT_U16];
+  const uint32_t wv = 0, lane = threadIdx.x & 63u, b = blockIdx.x;
   if (b >= d.nblocks) return;
   if (d.lit_status[b] != (((255u - 8u) << 8) | (uint32_t)ZG_LIT_COUNT_MISMATCH)) return;   // every stream ended on its last bit, some count differs
   const ZgBlock blk = d.blocks[b];
@@ -931,13 +933,13 @@ __global__ void __launch_bounds__(128) zg_k_seq(ZgBatchDev d) {
           if (piece_ok[pi]) { piece[pi] = *(const zg_gv4u*)addr; piece_addr[pi] = addr; }
         }
       }
-      // (4) flush
+      // (4) flush: the three states of a sequence fit 26 bits — 4 bytes per record in memory (zg_k_seqpost is bound by what it reads)
 #pragma unroll
       for (int i = 0; i < (ZG_SEQ_CH + 3) / 4; i++) {
         const uint32_t k = role + 4u * (uint32_t)i;
-        if (k < cnt) ((zg_gv2u*)dstp)[k] = rec[i];
+        if (k < cnt) ((__attribute__((address_space(1))) uint32_t*)dstp)[k] = ZG_RAW_PACK(rec[i].x & 0xFFu, (rec[i].x >> 16) & 0x1FFu, rec[i].y & 0x1FFu);
       }
-      dstp += (uint64_t)cnt * sizeof(uint2);
+      dstp += (uint64_t)cnt * 4u;
       if (!more) break;
     }
   }
@@ -1004,7 +1006,7 @@ __global__ void __launch_bounds__(ZG_SP_T, 4) zg_k_seqpost(ZgBatchDev d) {
   const uint32_t nseq = blk.nseq, regen = blk.regen_size;
   const uint32_t wlim = zg_sweep_window(d, d.frames[blk.frame]);
   const uint8_t* bs = d.src + blk.src_off + d.aux[b].seq_bits_off;
-  const uint2* raw = (const uint2*)(d.raw_arena + blk.seq_base);
+  const uint32_t* raw = d.raw_arena + blk.seq_base;
   ZgSeq* out = d.seq_arena + blk.seq_base;
   if (t == 0) s_err = 0xFFFFFFFFu;
   if (t < 36) s_llb[t] = ZG_LL_BASE[t] | ((uint32_t)ZG_LL_BITS[t] << 24);
@@ -1016,16 +1018,16 @@ __global__ void __launch_bounds__(ZG_SP_T, 4) zg_k_seqpost(ZgBatchDev d) {
   for (uint32_t i0 = 0; i0 < nseq; i0 += ZG_SP_T * ZG_SP_S) {
     const uint32_t ib = i0 + t * ZG_SP_S;
     const uint32_t n = ib < nseq ? (nseq - ib < ZG_SP_S ? nseq - ib : ZG_SP_S) : 0u;
-    uint2 r[ZG_SP_S];
+    uint32_t r[ZG_SP_S];
     if (n == ZG_SP_S) {
 #pragma unroll
-      for (int j = 0; j < ZG_SP_S; j += 2) {
+      for (int j = 0; j < ZG_SP_S; j += 4) {
         const zg_v4u v = *(const zg_gv4u*)(raw + ib + j);
-        r[j] = make_uint2(v.x, v.y); r[j + 1] = make_uint2(v.z, v.w);
+        r[j] = v.x; r[j + 1] = v.y; r[j + 2] = v.z; r[j + 3] = v.w;
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < ZG_SP_S; j++) r[j] = (uint32_t)j < n ? raw[ib + j] : make_uint2(0u, 0u);
+      for (int j = 0; j < ZG_SP_S; j++) r[j] = (uint32_t)j < n ? raw[ib + j] : 0u;
     }
     // symbols and bit counts from the recorded states: a sequence takes its three codes' extra bits and, unless it is the
     // block's last one, the three state updates (:203-206)
@@ -1035,7 +1037,7 @@ __global__ void __launch_bounds__(ZG_SP_T, 4) zg_k_seqpost(ZgBatchDev d) {
       uint32_t tx = 0;
 #pragma unroll
       for (int j = 0; j < ZG_SP_S; j++) {
-        const uint32_t e_of = s_t[ZG_FSE_OF_OFF + (r[j].x & 255u)], e_ml = s_t[ZG_FSE_ML_OFF + ((r[j].x >> 16) & 511u)], e_ll = s_t[ZG_FSE_LL_OFF + (r[j].y & 511u)];
+        const uint32_t e_of = s_t[ZG_FSE_OF_OFF + ZG_RAW_OF(r[j])], e_ml = s_t[ZG_FSE_ML_OFF + ZG_RAW_ML(r[j])], e_ll = s_t[ZG_FSE_LL_OFF + ZG_RAW_LL(r[j])];
         const uint32_t of_code = (e_of >> 4) & 31u, ml_code = e_ml >> 4, ll_code = e_ll >> 4;
         const uint32_t vl = s_llb[ll_code < 36 ? ll_code : 0], vm = s_mlb[ml_code < 53 ? ml_code : 0];
         const uint32_t upd = ib + (uint32_t)j + 1u == nseq ? 0u : (e_of & 15u) + (e_ml & 15u) + (e_ll & 15u);
@@ -1424,7 +1426,11 @@ __device__ __forceinline__ void zg_flat1_unit(const ZgBatchDev& d, const uint32_
   // (a frame whose few matches zg_k_sparse copies in order has no sweep step either: nobody reads its scratch words, so they are
   //  not written — an empty resource turns the stores into no-ops; on literal-heavy data they were most of the kernel's traffic)
   const bool no_scratch = d.frames[un.frame].sparse != 0u;
-  const __amdgpu_buffer_rsrc_t og_rs = zg_make_rsrc(og, no_scratch ? 0u : un.nblocks * (ZG_FLAT_MAX * 4u));
+  // (timing experiments, ZGPU_FLAT_MODE: bit 0 drops the scratch stores, bit 1 the cross-tile scratch gathers — wrong results, what is
+  //  left is what the kernel costs without that traffic)
+  const uint32_t fdbg = (d.flags >> 4) & 3u;
+  const __amdgpu_buffer_rsrc_t og_rs = zg_make_rsrc(og, (no_scratch || (fdbg & 1u)) ? 0u : un.nblocks * (ZG_FLAT_MAX * 4u));
+  const __amdgpu_buffer_rsrc_t og_ld = zg_make_rsrc(og, (no_scratch || (fdbg & 2u)) ? 0u : un.nblocks * (ZG_FLAT_MAX * 4u));
   if (t == 0) { L.err = 0; L.bad = ~0ull; }
   uint32_t unit_size = 0;
 #ifdef ZG_PROFILE_FLAT   // per-phase cycle counters (tools/dev/flat_phases.py); costs registers, off in the product build
@@ -1587,7 +1593,7 @@ __device__ __forceinline__ void zg_flat1_unit(const ZgBatchDev& d, const uint32_
           int32_t go = c_in ? -1 : y4;
           go = c_lit ? -1 : go;
           go = c_live ? go : -1;
-          wadd[k] = __builtin_amdgcn_raw_buffer_load_b32(og_rs, (uint32_t)go, 0, 0);
+          wadd[k] = __builtin_amdgcn_raw_buffer_load_b32(og_ld, (uint32_t)go, 0, 0);
           // (bytes behind the tile's end write too: their slots are not used by anything)
           uint32_t par = c_in ? x - off : (uint32_t)ZG_PAR_EXIT;
           par = c_lit ? (uint32_t)ZG_PAR_LIT : par;
@@ -1795,6 +1801,9 @@ __global__ void __launch_bounds__(256) zg_k_swprep(ZgBatchDev d, uint32_t n) {
 // The split sweep (part 1 / 2): a match reaches at most `window` bytes back, so everything a later unit can copy from is
 // the TAIL of the units in front of it. Only the tails (part 1) form the chain of steps; the heads (part 2) are filled
 // beside it, many units per launch, on the engine's second stream. part 0 is the whole unit.
+// OGM (timing experiments only, ZGPU_SWEEP_MODE 5..8: wrong results): how many bytes of scratch a group reads — 5: 8, 6: 4, 8: 12,
+// 7: 8 and then 8 more at an address that depends on the first (what a directory + entries format would cost a step)
+template <int OGM>
 __global__ void __launch_bounds__(ZG_SW_T) __attribute__((amdgpu_waves_per_eu(2, 3))) zg_k_sweep(ZgBatchDev d, uint32_t list_off, uint32_t nbatch, uint32_t dbgmode, uint32_t part) {
   if (d.overlap_epoch) {
     // the flatten may still be at this unit (it runs beside the chain): one lane polls the unit's flag. A step that finds it set
@@ -1836,8 +1845,15 @@ __global__ void __launch_bounds__(ZG_SW_T) __attribute__((amdgpu_waves_per_eu(2,
 #pragma unroll
     for (int k = 0; k < ZG_SW_B; k++) {
       const uint32_t g = bt * BG + t + k * ZG_SW_T;
-      const zg_v4u v = *(const zg_gv4u*)(og + 4 * (uint64_t)(g < n4 ? g : 0u));
-      o[k] = make_uint4(v.x, v.y, v.z, v.w);
+      const uint64_t gi = g < n4 ? g : 0u;
+      if (OGM == 0) { const zg_v4u v = *(const zg_gv4u*)(og + 4 * gi); o[k] = make_uint4(v.x, v.y, v.z, v.w); }
+      else if (OGM == 6) { const uint32_t v = og[gi]; o[k] = make_uint4(v, v, v, v); }
+      else if (OGM == 8) { const zg_v3u v = *(const zg_gv3u*)(og + 3 * gi); o[k] = make_uint4(v.x, v.y, v.z, v.x); }
+      else {
+        const zg_v2u v = *(const zg_gv2u*)(og + 2 * gi);
+        o[k] = make_uint4(v.x, v.y, v.x, v.y);
+        if (OGM == 7) { const zg_v2u w = *(const zg_gv2u*)(og + 2 * ((gi & ~63ull) + (v.x & 63u))); o[k].z = w.x; o[k].w = w.y; }
+      }
     }
   };
   uint4 o[ZG_SW_B], onx[ZG_SW_B];
@@ -2065,7 +2081,7 @@ void zg_launch_tables(const ZgBatchDev& d, hipStream_t s, int part) {
 void zg_launch_huf(const ZgBatchDev& d, hipStream_t s) {
   if (!d.nhuf_groups) return;
   hipLaunchKernelGGL(zg_k_huf, dim3(d.nhuf_groups), dim3(ZG_HUF_T), 0, s, d);
-  hipLaunchKernelGGL(zg_k_huf_uneven, dim3((d.nblocks + 3) / 4), dim3(256), 0, s, d);
+  hipLaunchKernelGGL(zg_k_huf_uneven, dim3(d.nblocks), dim3(64), 0, s, d);
 }
 void zg_launch_seq(const ZgBatchDev& d, hipStream_t s) {
   if (d.nseq_blocks) hipLaunchKernelGGL(zg_k_seq, dim3((d.nseq_blocks + ZG_SEQ_G - 1) / ZG_SEQ_G), dim3(128), 0, s, d);
@@ -2154,7 +2170,9 @@ void zg_launch_flat(const ZgBatchDev& d, hipStream_t s) {
 }
 bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* steps, uint32_t nsteps, hipStream_t s2, hipEvent_t* evs, uint32_t nev,
                      uint32_t unit_bytes, uint32_t window_max, uint32_t window_min) {
-  const uint32_t dbgmode = getenv("ZGPU_SWEEP_MODE") ? (uint32_t)atoi(getenv("ZGPU_SWEEP_MODE")) : 0u;   // timing experiments only
+  uint32_t dbgmode = getenv("ZGPU_SWEEP_MODE") ? (uint32_t)atoi(getenv("ZGPU_SWEEP_MODE")) : 0u;   // timing experiments only
+  void (*kern)(ZgBatchDev, uint32_t, uint32_t, uint32_t, uint32_t) = zg_k_sweep<0>;
+  if (dbgmode >= 5u) { kern = dbgmode == 5u ? zg_k_sweep<5> : dbgmode == 6u ? zg_k_sweep<6> : dbgmode == 7u ? zg_k_sweep<7> : zg_k_sweep<8>; dbgmode = 0u; }
   const uint32_t nbatch = getenv("ZGPU_SWEEP_NB") && atoi(getenv("ZGPU_SWEEP_NB")) > 0 ? (uint32_t)atoi(getenv("ZGPU_SWEEP_NB")) : 1u;   // batches per workgroup (more than one did not pay)
   constexpr uint32_t BB = 4u * ZG_SW_T * ZG_SW_B;             // bytes per batch
   uint32_t n = 0;
@@ -2166,7 +2184,7 @@ bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* step
   const bool split = nev >= 3 && contiguous && nsteps > 1 && (uint64_t)tail_batches * BB + 65536u < unit_bytes;
   if (!split) {
     for (uint32_t i = 0; i < nsteps; i++)
-      hipLaunchKernelGGL(zg_k_sweep, dim3((steps[i].slices + nbatch - 1) / nbatch, steps[i].nunits), dim3(ZG_SW_T), 0, s, d, steps[i].list_off, nbatch, dbgmode, 0u);
+      hipLaunchKernelGGL(kern, dim3((steps[i].slices + nbatch - 1) / nbatch, steps[i].nunits), dim3(ZG_SW_T), 0, s, d, steps[i].list_off, nbatch, dbgmode, 0u);
   } else {
     // stream s: tail of step 0, 1, 2, ...; stream s2: the heads of steps [g0, g1) in one launch as soon as the tails of step g1 - 2
     // are done (the heads of step i copy from the tails of steps < i).
@@ -2184,13 +2202,13 @@ bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* step
       e++;
       // (the heads are bulk work beside a chain of short launches: an unused LDS allocation keeps them to a few workgroups per
       //  CU, so that a tail step always finds free wave slots instead of waiting for head workgroups to retire)
-      hipLaunchKernelGGL(zg_k_sweep, dim3((slices + nbatch - 1) / nbatch, units), dim3(ZG_SW_T), head_lds, s2, d, steps[g0].list_off, nbatch, dbgmode, 2u);
+      hipLaunchKernelGGL(kern, dim3((slices + nbatch - 1) / nbatch, units), dim3(ZG_SW_T), head_lds, s2, d, steps[g0].list_off, nbatch, dbgmode, 2u);
       g0 = g1;
     };
     auto need = [&]() { return (int64_t)(g0 + gs < nsteps ? g0 + gs : nsteps) - 2; };   // the last tail step the next group of heads waits for
     while (g0 < nsteps && need() < 0) heads();
     for (uint32_t i = 0; i < nsteps; i++) {
-      hipLaunchKernelGGL(zg_k_sweep, dim3((tail_batches + nbatch - 1) / nbatch + 1u, steps[i].nunits), dim3(ZG_SW_T), 0, s, d, steps[i].list_off, nbatch, dbgmode, 1u);
+      hipLaunchKernelGGL(kern, dim3((tail_batches + nbatch - 1) / nbatch + 1u, steps[i].nunits), dim3(ZG_SW_T), 0, s, d, steps[i].list_off, nbatch, dbgmode, 1u);
       while (g0 < nsteps && need() <= (int64_t)i) heads();
     }
     (void)hipEventRecord(evs[e], s2);

@@ -435,18 +435,22 @@ int zgpu_pool_decode_all(zgpu_pool* p, const uint8_t* src, size_t len, uint8_t* 
   if (!st && walk) st = walk;
   if (!st && total > cap) st = ZGPU_E_TARGET_TOO_SMALL;
   if (!st && !all_placed) {
-    // sizes were not declared (or a frame lied about its size): place everything now. Jobs already copied out move inside dst
-    // (front to back is safe: a job never moves towards the end... unless sizes were understated, so go through a staging copy)
+    // sizes were not declared, or a frame lied about its size: every job's final place is known only now. Jobs that were copied
+    // out already move inside dst FIRST, before anything else is written (a download into the gap in front of a placed job may be
+    // longer than the gap): the ones that move towards the end last to first, the ones that move towards the front first to
+    // last — their final places are disjoint and in input order, so no move overwrites bytes another move still has to read.
+    std::vector<uint64_t> fin(jobs.size());
     uint64_t off = 0;
-    std::vector<uint8_t> tmp;
-    for (Job& j : jobs) {
-      if (j.placed) {
-        if (j.out_off != off) { tmp.assign(dst + j.out_off, dst + j.out_off + j.out_size); memcpy(dst + off, tmp.data(), j.out_size); }
-      } else if (j.batch) {
-        const int c = j.batch->read_output(0, dst + off, j.out_size);
-        if (c && !st) st = c;
-      }
-      off += j.out_size;
+    for (size_t k = 0; k < jobs.size(); k++) { fin[k] = off; off += jobs[k].out_size; }
+    for (size_t k = jobs.size(); k-- > 0;)
+      if (jobs[k].placed && fin[k] > jobs[k].out_off) memmove(dst + fin[k], dst + jobs[k].out_off, jobs[k].out_size);
+    for (size_t k = 0; k < jobs.size(); k++)
+      if (jobs[k].placed && fin[k] < jobs[k].out_off) memmove(dst + fin[k], dst + jobs[k].out_off, jobs[k].out_size);
+    for (size_t k = 0; k < jobs.size(); k++) {
+      Job& j = jobs[k];
+      if (j.placed || !j.batch) continue;
+      const int c = j.batch->read_output(0, dst + fin[k], j.out_size);
+      if (c && !st) st = c;
     }
   }
   for (Job& j : jobs) delete j.batch;

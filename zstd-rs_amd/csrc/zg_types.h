@@ -210,8 +210,11 @@ struct ZxU2 { uint32_t x, y; };
 struct ZxU3 { uint32_t x, y, z; };
 struct __attribute__((aligned(16))) ZxU4 { uint32_t x, y, z, w; };
 
-// zg_k_seq's record of one sequence: 4 x u16 states {OF, ML, LL, 0} (8 bytes, read and written as one 8-byte word)
-struct ZgRaw { uint32_t x, y; };
+// zg_k_seq's record of one sequence: the three FSE states it was decoded from, packed into 4 bytes (accuracy logs are <= 8 / 9 / 9)
+#define ZG_RAW_PACK(of, ml, ll) ((uint32_t)(of) | ((uint32_t)(ml) << 8) | ((uint32_t)(ll) << 17))
+#define ZG_RAW_OF(r) ((r) & 255u)
+#define ZG_RAW_ML(r) (((r) >> 8) & 511u)
+#define ZG_RAW_LL(r) (((r) >> 17) & 511u)
 
 // Device-side view of one submit (all pointers are device pointers).
 struct ZgBatchDev {
@@ -234,7 +237,7 @@ struct ZgBatchDev {
   uint32_t* lit_counts;        // [4 * nblocks] symbols each of the four streams of a block's literals holds (zg_k_huf -> zg_k_huf_uneven)
   uint8_t* lit_arena;          // regenerated Huffman literals
   ZgSeq* seq_arena;            // decoded sequences
-  ZgRaw* raw_arena;            // zg_k_seq's raw records, 4 x u16 {OF, ML, LL table entries, bits taken}, same indexing as seq_arena
+  uint32_t* raw_arena;         // zg_k_seq's records (ZG_RAW_PACK: the three states of every sequence), same indexing as seq_arena
   ZgBlockSeqOut* seq_out;      // [nblocks]
   ZgBlockPos* pos;             // [nblocks]
   ZgFrameOut* frame_out;       // [nframes]

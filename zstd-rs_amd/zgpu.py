@@ -17,6 +17,7 @@ E_DICT_NOT_PROVIDED = 7
 E_FAILED_READ_BLOCK_HEADER, E_FAILED_READ_BLOCK_BODY, E_FAILED_READ_CHECKSUM = 9, 10, 11
 E_TARGET_TOO_SMALL = 12
 E_FAILED_SKIP_FRAME = 13
+E_RESERVED_BLOCK, E_BLOCK_SIZE_TOO_LARGE = 20, 21
 E_UNSUPPORTED = 80
 E_HIP = 92
 
