@@ -107,6 +107,24 @@ static inline uint32_t zx_shfl_up(uint32_t v, int o) {
   simt::yield(simt::WAVE_WAIT);
   return r;
 }
+// the value lane l of the caller's wave holds (every lane of the wave calls it)
+static inline uint32_t zx_shfl(uint32_t v, int l) {
+  simt::Machine* m = simt::M();
+  const uint32_t me = m->cur, w0 = me & ~63u;
+  m->slot[me] = v;
+  simt::yield(simt::WAVE_WAIT);
+  const uint32_t r = (uint32_t)m->slot[w0 + ((uint32_t)l & 63u)];
+  simt::yield(simt::WAVE_WAIT);
+  return r;
+}
+static inline bool zx_any(bool p) { return zx_ballot(p) != 0ull; }
+// the lanes of a wave run one after the other here: what they wrote to LDS is complete for all of them behind this point
+static inline void zx_wave_sync() { (void)zx_ballot(true); }
+static inline void zx_max_glb(uint32_t* p, uint32_t v) { if (v > *p) *p = v; }
+static inline ZxU4 zx_gld128(const void* p) {
+  if ((uintptr_t)p % 16) { fprintf(stderr, "simt: misaligned 16-byte global load\n"); abort(); }
+  ZxU4 r; memcpy(&r, p, 16); return r;
+}
 static inline void zx_or_lds(uint32_t* p, uint32_t v) { *p |= v; }
 static inline void zx_min_lds(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
 static inline void zx_min_lds64(unsigned long long* p, unsigned long long v) { if (v < *p) *p = v; }

@@ -258,6 +258,8 @@ def test_pool_decode_all_places_jobs_around_a_lying_content_size(ctx, monkeypatc
     job straight into the caller's buffer when its declared size turns out right — the jobs around a lying one must keep their bytes
     while everything is moved to its final place (understated first frame: its download is longer than the gap left for it;
     overstated: shorter)."""
+    import zgdata
+    import zgpu
     monkeypatch.setenv("ZGPU_DA_FLOOR_MB", "1")                     # every frame below is a job of its own (> 1 MiB of input each)
     plains = [zgdata.text_like((5 << 20) + 4096 * i, seed=0x7700 + i) for i in range(5)]
     zs = [zgdata.zstd_compress(p) for p in plains]

@@ -1,5 +1,5 @@
 """One data set, several engine variants (environment switches read when a Context is created): kernel times side by side.
-usage: variants.py [size] [text|iso|blocks|many] -- VAR=VALUE[,VAR=VALUE] ...
+usage: variants.py [size] [text|iso|blocks|many|isomany] -- VAR=VALUE[,VAR=VALUE] ...
 (many: 64 MiB text frames, 16 distinct ones repeated up to `size` bytes, in one submit: one GPU's share of BASELINE config 4)"""
 import hashlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,8 +16,8 @@ if kind == "blocks":     # single-block frames: every unit is a first unit, the 
     plain = b"".join(parts)
     z = b"".join(zgdata.zstd_compress(q) for q in parts)
     size = len(plain)
-elif kind == "many":
-    parts = [zgdata.text_like(64 << 20, seed=0xE9 + i) for i in range(16)]
+elif kind in ("many", "isomany"):
+    parts = [zgdata.text_like(64 << 20, seed=0xE9 + i) for i in range(16)] if kind == "many" else [zgdata.iso_like(64 << 20, seed=0x150 + i) for i in range(16)]
     reps = max(size // (16 * (64 << 20)), 1)
     z = b"".join(zgdata.zstd_compress(q) for q in parts) * reps
     plain = None

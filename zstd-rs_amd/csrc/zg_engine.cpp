@@ -356,6 +356,8 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   { const char* e = getenv("ZGPU_RAMP"); if (e) b->bb.ramp_percent = (uint32_t)atoi(e); }   // (measurement) N > 0: one long frame in units growing by +-N %, the sweep chain beside the flatten
   { const char* e = getenv("ZGPU_SPARSE_MAX"); if (e) { b->bb.sparse_max = (uint32_t)atoi(e); b->bb.sparse_per_block = 1u << 20; } }   // (tests) sequences per frame up to which zg_k_sparse replaces the sweep, whatever their density; 0: never
   b->bb.flat_slots = (uint32_t)cus_ * (flat_shape_ == 0 ? 1u : 2u);   // zg_k_flatten: workgroups the device holds at once
+  b->bb.chain_slots = (uint32_t)cus_ * 32u;                            // zg_k_seq: blocks whose chains run at once
+  { const char* e = getenv("ZGPU_LIT_DIRECT"); if (e && e[0] == '0') b->bb.lit_direct_allowed = false; }
   b->bb.finish();
   BatchBuilder& bb = b->bb;
   Scratch* sc = b->sc = acquire();
@@ -461,9 +463,13 @@ int Batch::run() {
   // when zg_k_seq arrives and push half of its workgroups into a second round.
   ZG_HIP(hipEventRecord(sc->ev_fork, s));
   ZG_HIP(hipStreamWaitEvent(s2, sc->ev_fork, 0));
+  // (literal-heavy submits, BatchBuilder::finish: only the tree descriptions here; the streams are decoded after the scan, when
+  //  the blocks without sequences know their place in the output — phase 2)
+  const bool lit_direct = bb.lit_direct;
+  d.flags &= ~ZG_FLAG_LIT_DIRECT;
   ZG_HIP(hipEventRecord(sc->ev_huf[0], s2));
   zg_launch_tables(d, s2, 0);
-  zg_launch_huf(d, s2);
+  if (!lit_direct) zg_launch_huf(d, s2);
   ZG_HIP(hipEventRecord(sc->ev_huf[1], s2));
   ZG_HIP(hipEventRecord(ev[2], s));
   zg_launch_seq(d, s);
@@ -509,7 +515,14 @@ int Batch::run() {
   if (any_fast && (st = sc->d_og.reserve(og_words * 4 + 64))) return st;
   d.og = sc->d_og.as<uint32_t>();
   d.og_words = og_words;
-  // ---- phase 2: LZ77 execution
+  // ---- phase 2: LZ77 execution (and, for literal-heavy submits, the Huffman streams in front of it)
+  if (lit_direct) {
+    d.flags |= ZG_FLAG_LIT_DIRECT;
+    ZG_HIP(hipEventRecord(sc->ev_huf[0], s));
+    zg_launch_huf(d, s);
+    zg_launch_litfix(d, s);
+    ZG_HIP(hipEventRecord(sc->ev_huf[1], s));
+  }
   zg_launch_lit(d, s);
   ZG_HIP(hipEventRecord(ev[6], s));
   sweep_mode = 0; synced = false;
@@ -623,7 +636,8 @@ int Batch::sync() {
     if (hipEventElapsedTime(&m, ev[i], ev[i + 1]) == hipSuccess) ms[i] = m;
   }
   float m = 0;
-  if (hipEventElapsedTime(&m, sc->ev_huf[0], sc->ev_huf[1]) == hipSuccess) ms[ZG_T_HUF] = m;   // beside seq + seqpost, not in line
+  if (hipEventElapsedTime(&m, sc->ev_huf[0], sc->ev_huf[1]) == hipSuccess) ms[ZG_T_HUF] = m;   // beside seq + seqpost, not in line ...
+  if (dev.flags & ZG_FLAG_LIT_DIRECT) ms[ZG_T_LIT] = ms[ZG_T_LIT] > ms[ZG_T_HUF] ? ms[ZG_T_LIT] - ms[ZG_T_HUF] : 0.f;   // ... or, after the scan, in front of zg_k_lit
   if (hipEventElapsedTime(&m, ev[0], ev[ZG_T_TOTAL]) == hipSuccess) ms[ZG_T_TOTAL] = m;
   synced = true;
   return ZG_OK;
@@ -684,7 +698,14 @@ int Batch::read_literals(uint32_t block, std::vector<uint8_t>* out) {
   out->clear();
   if (b.btype != ZG_BT_COMPRESSED || b.lit_type < ZG_LT_COMPRESSED) return ZG_OK;
   out->resize(b.regen_size);
-  if (b.regen_size) ZG_HIP(hipMemcpy(out->data(), dev.lit_arena + b.lit_base, b.regen_size, hipMemcpyDeviceToHost));
+  const uint8_t* at = dev.lit_arena + b.lit_base;
+  if ((dev.flags & ZG_FLAG_LIT_DIRECT) && b.nseq == 0) {   // zg_k_huf wrote them straight to the block's place in the output
+    ZgBlockPos p;
+    ZG_HIP(hipMemcpy(&p, dev.pos + block, sizeof p, hipMemcpyDeviceToHost));
+    if (b.frame >= frame_out.size() || !p.active) { out->clear(); return ZG_OK; }
+    at = dev.dst + frame_out[b.frame].out_base + p.out_base;
+  }
+  if (b.regen_size) ZG_HIP(hipMemcpy(out->data(), at, b.regen_size, hipMemcpyDeviceToHost));
   return ZG_OK;
 }
 int Batch::read_sequences(uint32_t block, std::vector<ZgSeq>* seqs, ZgBlockSeqOut* so, ZgBlockPos* pos) {

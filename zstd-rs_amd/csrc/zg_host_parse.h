@@ -77,6 +77,12 @@ class BatchBuilder {
   uint64_t seq_count = 0;      // sequence arena size
   uint32_t nhuf_slots = 0;
   uint64_t out_bound = 0;      // upper bound of the output when every compressed block regenerates <= 128 KiB
+  // finish(): the Huffman literals are worth decoding AFTER the position scan, straight into the output where a block has no
+  // sequences (ZG_FLAG_LIT_DIRECT): literal-heavy input, where the arena -> output copy costs more than running the literals
+  // chain behind the sequences chain instead of beside it
+  bool lit_direct = false;
+  bool lit_direct_allowed = true;   // (ZGPU_LIT_DIRECT=0: measurement / tests)
+  uint32_t chain_slots = 8192;      // sequence chains the device runs at once (engine: CUs x 32)
 
   // Start a frame. carry: lineage handed in by a dictionary or an earlier submit (slots are resolved in finish()).
   // carry_mask: bit 0 Huffman, bit 1 LL, bit 2 OF, bit 3 ML — tables that already exist when the frame (or this run of

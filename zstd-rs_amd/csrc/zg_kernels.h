@@ -22,6 +22,7 @@ void zg_launch_huf(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_seq(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_seqpost(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_merge(const ZgBatchDev& d, hipStream_t s);
+void zg_launch_litfix(const ZgBatchDev& d, hipStream_t s);   // ZG_FLAG_LIT_DIRECT: literal verdicts found after the scan -> block and frame statuses
 void zg_launch_scan(const ZgBatchDev& d, hipStream_t s, uint32_t max_frame_blocks);   // max_frame_blocks: of the submit's frames (picks the workgroup size)
 void zg_launch_lit(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_flat(const ZgBatchDev& d, hipStream_t s);

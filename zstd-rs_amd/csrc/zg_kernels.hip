@@ -52,14 +52,9 @@ __device__ __forceinline__ uint32_t zg_ld32_fun(const uint8_t* p) {
 __device__ __forceinline__ void zg_set_status(uint32_t* status, uint32_t b, int st) {
   if (st) atomicCAS(&status[b], 0u, (uint32_t)st);
 }
-// The streams of a block's literals run in different waves: which error is reported must not depend on who is first.
-// rank 0 is the most significant; the word keeps (255 - rank) << 8 | status, the largest wins (zg_k_merge strips the rank).
 // how far back a match of the frame may reach as far as the split sweep is concerned (zg_k_seqpost reports a longer one)
 __device__ __forceinline__ uint32_t zg_sweep_window(const ZgBatchDev& d, const ZgFrame& fr) {
   return d.sweep_window ? d.sweep_window : (fr.window_size > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)fr.window_size);
-}
-__device__ __forceinline__ void zg_set_lit_status(uint32_t* status, uint32_t b, uint32_t rank, int st) {
-  if (st) atomicMax(&status[b], ((255u - rank) << 8) | (uint32_t)st);
 }
 
 // What one lane of a wave wrote to LDS inside a divergent branch is read by the other lanes afterwards: the compiler
@@ -69,6 +64,62 @@ __device__ __forceinline__ void zg_wave_publish() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+// workgroup barrier that orders LDS only: unlike __syncthreads() it does not wait for this wave's global loads/stores
+__device__ __forceinline__ void zg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Buffer resource over [p, p + bytes): loads through it with an offset >= bytes return 0 and cause no traffic. The inputs
+// are wave-uniform; passing them through readfirstlane makes that provable to the compiler, which otherwise wraps every
+// buffer load into a "waterfall" loop (one iteration, but it serialises the loads).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t zg_make_rsrc(const void* p, uint32_t bytes) {
+  const uint64_t a = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+#define ZG_OOB 0xFFFFFFFFu   // an offset no buffer resource covers
+// the same value, but new to the compiler: what is computed from it is computed again here instead of being kept in a register
+#define ZG_FRESH(v) ({ uint32_t v_ = (v); asm volatile("" : "+v"(v_)); v_; })
+
+// ------------------------------------------------------------------------------------------------------------
+// The zx_* primitives: kernel bodies that also run under the CPU emulator (tests/emu/zg_simt.h) are written against them —
+// zg_huf.h (zg_k_huf), zg_flat4.h (direct units of zg_k_flatten), zg_exact.h (zg_k_exact).
+// ------------------------------------------------------------------------------------------------------------
+#define ZX_DEV __device__ __forceinline__
+// "not needed": an offset no resource of the flatten covers (they are all far below 2^31 bytes). Not 0xFFFFFFFF: the compiler narrows
+// a wide load whose first dwords are unused by ADDING to the offset, and 0xFFFFFFFF + 4 is 3 — inside every resource.
+#define ZX_OOB 0x80000000u
+#define ZX_FRESH(v) ZG_FRESH(v)
+typedef __amdgpu_buffer_rsrc_t ZxBuf;
+ZX_DEV uint32_t zx_tid() { return threadIdx.x; }
+ZX_DEV void zx_barrier() { zg_lds_barrier(); }
+// every wave's global stores have reached memory, then the barrier (the builtin, not inline asm: the compiler then knows
+// that nothing is in flight here and does not protect registers of earlier loads with waits that also cover later ones)
+ZX_DEV void zx_barrier_vm() { __builtin_amdgcn_s_waitcnt(0x0F70); zg_lds_barrier(); }
+ZX_DEV unsigned long long zx_ballot(bool p) { return __ballot(p); }
+ZX_DEV uint32_t zx_shfl_up(uint32_t v, int o) { return __shfl_up(v, o, 64); }
+ZX_DEV void zx_or_lds(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+ZX_DEV void zx_min_lds(uint32_t* p, uint32_t v) { atomicMin(p, v); }
+ZX_DEV void zx_min_lds64(unsigned long long* p, unsigned long long v) { atomicMin(p, v); }
+ZX_DEV void zx_min_glb(uint32_t* p, uint32_t v) { atomicMin(p, v); }
+ZX_DEV ZxBuf zx_buf(const void* base, uint32_t bytes) { return zg_make_rsrc(base, bytes); }
+ZX_DEV uint32_t zx_ld32(ZxBuf b, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b32(b, off, 0, 0); }
+ZX_DEV ZxU2 zx_ld64(ZxBuf b, uint32_t off) { const zg_v2u v = __builtin_amdgcn_raw_buffer_load_b64(b, off, 0, 0); ZxU2 r; r.x = v.x; r.y = v.y; return r; }
+ZX_DEV ZxU3 zx_ld96(ZxBuf b, uint32_t off) { const zg_v3u v = __builtin_amdgcn_raw_buffer_load_b96(b, off, 0, 0); ZxU3 r; r.x = v.x; r.y = v.y; r.z = v.z; return r; }
+ZX_DEV void zx_st8(ZxBuf b, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v, b, off, 0, 0); }
+ZX_DEV void zx_st32(ZxBuf b, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, b, off, 0, 0); }
+ZX_DEV uint32_t zx_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+typedef short zg_v2s __attribute__((ext_vector_type(2)));
+// packed 16-bit lanes (v_pk_sub_i16, v_pk_ashrrev_i16): a - b per lane; 0xFFFF per lane whose signed value is negative
+ZX_DEV uint32_t zx_pksub16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (zg_v2s)(__builtin_bit_cast(zg_v2s, a) - __builtin_bit_cast(zg_v2s, b))); }
+// (as an instruction: written as a shift the compiler turns what is done with the result — lane masks for v_bfi — into a compare and a select per lane)
+ZX_DEV uint32_t zx_pksign16(uint32_t a) { uint32_t r; asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a)); return r; }
+ZX_DEV uint32_t zx_shfl(uint32_t v, int l) { return (uint32_t)__shfl((int)v, l, 64); }
+ZX_DEV bool zx_any(bool p) { return __any(p) != 0; }
+ZX_DEV void zx_max_glb(uint32_t* p, uint32_t v) { atomicMax(p, v); }
+ZX_DEV ZxU4 zx_gld128(const void* p) { const zg_v4u v = *(const zg_gv4u*)p; ZxU4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }   // 16 bytes of global memory, 16-byte aligned
+// what the lanes of a wave wrote to LDS is read by the other lanes afterwards (a wave runs in lockstep: no hardware barrier, but the
+// compiler must not move the reads ahead)
+ZX_DEV void zx_wave_sync() { zg_wave_publish(); }
 
 // ------------------------------------------------------------------------------------------------------------
 // zg_k_tables: Huffman tree descriptions of the literals sections (HuffmanTable::build_decoder, huff0_decoder.rs:117-124
@@ -405,181 +456,14 @@ __global__ void __launch_bounds__(64 * ZG_FT_W) zg_k_ftab(ZgBatchDev d) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// zg_k_huf: Huffman literal streams (literals_section_decoder.rs:40-158; HuffmanDecoder huff0_decoder.rs:25-53).
-// A stream is a serial chain (peek max_bits bits -> table -> consume num_bits), up to 32 K symbols long, but Huffman
-// codes SELF-SYNCHRONISE: a decoder started at a wrong bit position falls onto the true code boundaries after a few
-// symbols. So one WAVE decodes one stream, 64 x 64 bits at a time (a window): lane l guesses that a code ends exactly at
-// the top of its 64-bit chunk and decodes the chunk; then every lane whose entry differs from its upper neighbour's exit
-// decodes again from that exit, until all agree — lane 0 starts at the true position, so by induction all of them are
-// then on the true path. Most chunks converge after the second pass. Symbols are staged per lane in LDS, counted,
-// prefix-summed and written out; the exit of the last lane is the next window's true entry.
-// One workgroup = up to ZG_HUF_GROUP streams that share a table, the table staged once per workgroup.
+// zg_k_huf: Huffman literal streams, one wave per stream, self-synchronising chunks — the body is zg_huf.h (zx_* primitives:
+// the same source runs under the CPU emulator)
 // ------------------------------------------------------------------------------------------------------------
+#include "zg_huf.h"
 #define ZG_HUF_T (64 * ZG_HUF_GROUP)
-#define ZG_HP_CB 128                        // bits per lane and window ...
-#define ZG_HP_CB_DENSE 32                   // ... or this many, once a chunk held more than ZG_HP_ROWS symbols
-#define ZG_HP_ROWS 48                       // symbols a lane can record per chunk (LDS, and with it the number of streams a CU decodes at once)
-#define ZG_HP_WARM 32                       // bits a lane starts above its chunk, to be on a code boundary when it enters it
-#define ZG_HP_WBYTES (64 * ZG_HP_CB / 8)    // stream bytes covered by a window
-#define ZG_HP_STAGE (ZG_HP_WBYTES + 64)     // staged: the window, 2 bytes below it (an 11-bit peek), alignment slack, 16+ bytes above
-
 __global__ void __launch_bounds__(ZG_HUF_T) zg_k_huf(ZgBatchDev d) {
-  __shared__ uint16_t s_tab[ZG_HUF_SLOT_U16];
-  __shared__ __attribute__((aligned(16))) uint8_t s_win[ZG_HUF_GROUP][ZG_HP_STAGE];
-  // [symbol index][lane]. A chunk of cb bits holds at most cb symbols, but 128 rows per wave would be most of the kernel's LDS
-  // for a case that needs codes of < 3 bits on average: a window in which a chunk overflows ZG_HP_ROWS is decoded again,
-  // and the rest of the stream with it, in chunks of ZG_HP_CB_DENSE bits (which cannot overflow).
-  __shared__ uint8_t s_sym[ZG_HUF_GROUP][ZG_HP_ROWS][64];
-  static_assert(ZG_HP_CB_DENSE <= ZG_HP_ROWS && ZG_HP_CB_DENSE <= ZG_HP_CB, "the dense chunk size must fit the rows");
-  const ZgHufGroup grp = d.huf_groups[blockIdx.x];
-  const uint32_t t = threadIdx.x, wv = t >> 6, lane = t & 63;
-  unsigned max_bits = grp.slot >= 0 ? d.huf_maxbits[grp.slot] : 0;
-  if (max_bits > 11) max_bits = 0;
-  if (max_bits) {
-    const uint16_t* g = d.huf_arena + (uint64_t)grp.slot * ZG_HUF_SLOT_U16;
-    for (uint32_t i = t; i < (1u << max_bits); i += ZG_HUF_T) s_tab[i] = g[i];
-  }
-  __syncthreads();
-  if (wv >= grp.nitems) return;                       // whole waves leave: no workgroup barrier below
-  const uint32_t item = d.huf_items[grp.first_item + wv];
-  const uint32_t b = item >> 2, k = item & 3;
-  const ZgBlock blk = d.blocks[b];
-  // the checks of the stream header: every lane computes the same, lane 0 reports
-  int hst = ZG_OK;
-  const uint8_t* sp = nullptr;
-  uint32_t slen = 0, doff = 0, cap = 0;
-  if (max_bits == 0) hst = ZG_LIT_UNINIT_HUF;                                     // literals_section_decoder.rs:60-63
-  else if (d.tab_status[b]) return;                                                // its own tree description failed
-  else {
-    const uint32_t desc = blk.lit_type == ZG_LT_COMPRESSED ? d.aux[b].huf_desc_bytes : 0;
-    if (desc > blk.lit_comp_size) hst = ZG_INTERNAL;
-    else {
-      const uint8_t* pay = d.src + blk.src_off + blk.lit_off + desc;
-      const uint32_t total = blk.lit_comp_size - desc, regen = blk.regen_size;
-      if (blk.nstreams == 4) {
-        if (total < 6) hst = ZG_LIT_MISSING_JUMP;
-        else {
-          const uint32_t j1 = zg_ld16(pay), j2 = j1 + zg_ld16(pay + 2), j3 = j2 + zg_ld16(pay + 4);
-          const uint32_t rest = total - 6;
-          if (rest < j3) hst = ZG_LIT_MISSING_BYTES;
-          else {
-            const uint32_t start = k == 0 ? 0 : k == 1 ? j1 : k == 2 ? j2 : j3;
-            const uint32_t end = k == 0 ? j1 : k == 1 ? j2 : k == 2 ? j3 : rest;
-            sp = pay + 6 + start; slen = end - start;
-            const uint32_t seg = (regen + 3) / 4;
-            doff = k * seg; if (doff > regen) doff = regen;
-            cap = k < 3 ? seg : regen - doff;
-            if (cap > regen - doff) cap = regen - doff;
-          }
-        }
-      } else { sp = pay; slen = total; doff = 0; cap = regen; }
-    }
-  }
-  uint32_t lastb = 0;
-  if (!hst) {
-    lastb = slen ? sp[slen - 1] : 0;
-    if (slen == 0 || lastb == 0) hst = ZG_LIT_EXTRA_PADDING;                       // :98-109
-  }
-  if (hst) { if (lane == 0) zg_set_lit_status(d.lit_status, b, 0u, hst); return; }
-  const uint32_t hb = zg_hbit(lastb) - 1;                     // payload bits of the last byte (below the marker)
-  const int32_t T = (int32_t)((slen - 1) * 8 + hb);           // bits of the stream; position P = bits not yet consumed
-  const int64_t A = (int64_t)(uint64_t)sp;                    // address of stream bit 0
-  uint8_t* dst = d.lit_arena + blk.lit_base + doff;
-  uint8_t* win = s_win[wv];
-  uint8_t* sym = &s_sym[wv][0][lane];
-  const uint32_t pmask = (1u << max_bits) - 1u;
-  int32_t top = T;                                            // true entry position of the window
-  uint32_t ndone = 0;
-  bool overflow = false;
-  int32_t cb = ZG_HP_CB;                                      // bits per lane in this window
-  while (top > 0) {
-    // ---- stage the bytes that hold bits [top - 4096 - 16, top + 8): 16-byte pieces, zeros below the stream start
-    const int64_t lowbit = (int64_t)top - 64 * ZG_HP_CB - 16;   // staged up to top + 128 bits at least (warm-up + a two-dword read)
-    const int64_t wb0 = (A + (lowbit >> 3)) & ~15ll;          // address of staged byte 0 (may lie below the stream)
-    for (uint32_t pc = lane; pc < ZG_HP_STAGE / 16; pc += 64) {
-      const int64_t addr = wb0 + 16 * (int64_t)pc;
-      zg_v4u v = {0, 0, 0, 0};
-      if (addr + 16 > A) {
-        v = *(const zg_gv4u*)(uint64_t)addr;
-        if (addr < A) {                                       // piece straddles the stream start: zero the bytes below it
-          const uint32_t zb = (uint32_t)(A - addr);           // 1..15
-          uint32_t q[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int i = 0; i < 4; i++) { const uint32_t lo = 4u * i; q[i] = zb >= lo + 4 ? 0u : zb > lo ? q[i] & (0xFFFFFFFFu << (8 * (zb - lo))) : q[i]; }
-          v = zg_v4u{q[0], q[1], q[2], q[3]};
-        }
-      }
-      *(zg_v4u*)(win + 16 * pc) = v;
-    }
-    const int32_t wq0 = (int32_t)((wb0 - A) * 8);             // stream bit index of staged bit 0 (LDS of one wave is in order: no barrier)
-    const uint32_t* win32 = (const uint32_t*)win;
-    // one pass over the lane's chunk from position `from`: symbols to s_sym, returns the exit position
-    const int32_t U = top - (int32_t)lane * cb, L = U - cb > 0 ? U - cb : 0;
-    bool spill = false;                                         // more symbols in the chunk than rows
-    uint32_t n = 0;
-    int32_t entry = U;                                          // where the lane's recorded symbols start
-    auto pass = [&](int32_t from) -> int32_t {
-      int32_t P = from;
-      while (P > U) {                                           // warm-up above the chunk: not recorded
-        const uint32_t rb = (uint32_t)(P - (int32_t)max_bits - wq0);
-        const uint32_t d0 = win32[rb >> 5], d1 = win32[(rb >> 5) + 1];
-        P -= (int32_t)(s_tab[__builtin_amdgcn_alignbit(d1, d0, rb & 31u) & pmask] >> 8);
-      }
-      entry = P;
-      n = 0;
-      while (P > L) {
-        const int32_t q = P - (int32_t)max_bits;              // >= -11: inside the staged zeros below the stream
-        const uint32_t rb = (uint32_t)(q - wq0);
-        const uint32_t d0 = win32[rb >> 5], d1 = win32[(rb >> 5) + 1];
-        const uint32_t e = s_tab[__builtin_amdgcn_alignbit(d1, d0, rb & 31u) & pmask];
-        if (n >= ZG_HP_ROWS) { spill = true; break; }
-        sym[64 * n++] = (uint8_t)e;
-        const int32_t nb = (int32_t)(e >> 8);
-        P -= nb > 1 ? nb : 1;                                  // (every code has >= 1 bit; the max keeps a corrupted entry from stalling the loop)
-      }
-      return P;
-    };
-    const bool active = U > 0;
-    int32_t E = U;
-    if (active) E = pass(lane ? U + ZG_HP_WARM : U);           // lane 0 starts at the true position
-    for (int round = 0; round < 64; round++) {
-      const int32_t pe = __shfl_up(E, 1, 64);
-      const bool need = active && lane > 0 && pe != entry;
-      if (!__any(need)) break;
-      if (need) E = pass(pe);
-    }
-    if (__any(spill)) {                                          // only possible with cb == ZG_HP_CB
-      cb = ZG_HP_CB_DENSE;
-      continue;                                                 // the same window again (the staged bytes cover the smaller one)
-    }
-    // ---- all lanes are on the true path: count, place, write
-    uint32_t incl = active ? n : 0u;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += v; }
-    const uint32_t wtot = __shfl(incl, 63, 64);
-    const uint32_t at = ndone + incl - (active ? n : 0u);
-    if (active) {
-      for (uint32_t i = 0; i < n; i++) {
-        if (at + i < cap) dst[at + i] = sym[64 * i];
-      }
-    }
-    if (ndone + wtot > cap) overflow = true;                   // more symbols than its share of the section holds
-    ndone += wtot;
-    // the last active lane's exit is the next entry; it is <= 0 when that lane's chunk reaches the stream start
-    const uint32_t nact = (uint32_t)((top + cb - 1) / cb);
-    top = __shfl(E, (int)(nact < 64u ? nact - 1u : 63u), 64);
-    // (one of four streams: the reference only compares the TOTAL with the section's size, literals_section_decoder.rs:150-155 —
-    //  the count goes on, without writes, so that zg_k_huf_uneven can tell a different split from a wrong total)
-    if (overflow && blk.nstreams != 4) break;
-  }
-  if (blk.nstreams == 4 && lane == 0) d.lit_counts[4u * b + k] = ndone;
-  int st = ZG_OK;
-  if (blk.nstreams == 4 && top != 0) st = ZG_LIT_BITSTREAM_MISMATCH;        // bits_remaining != -max_bits (:116-121)
-  else if (overflow || ndone != cap) st = ZG_LIT_COUNT_MISMATCH;            // :150-155 (per stream, the format's split: zg_k_huf_uneven looks at the total)
-  // The reference decodes the streams in order and checks each one's end as it goes (:116-121); the symbol count is compared
-  // once, after the last stream (:150-155): a stream's BitstreamReadMismatch outranks any count mismatch, an earlier stream a
-  // later one.
-  if (lane == 0) zg_set_lit_status(d.lit_status, b, st == ZG_LIT_BITSTREAM_MISMATCH ? k : 8u, st);
+  __shared__ ZgHufLds<ZG_HUF_GROUP> s_l;
+  zg_huf_group<ZG_HUF_GROUP>(d, blockIdx.x, s_l);
 }
 
 // zg_k_huf_uneven: four streams whose symbols add up to the section's size but are not split the way the format says
@@ -600,6 +484,10 @@ __global__ void __launch_bounds__(64) zg_k_huf_uneven(ZgBatchDev d) {
   const uint32_t regen = blk.regen_size;
   const uint32_t c0 = d.lit_counts[4u * b], c1 = d.lit_counts[4u * b + 1], c2 = d.lit_counts[4u * b + 2], c3 = d.lit_counts[4u * b + 3];
   if ((uint64_t)c0 + c1 + c2 + c3 != regen) return;            // DecodedLiteralCountMismatch stands
+  // (where zg_k_huf put them: the arena, or the block's place in the output — zg_huf.h)
+  const bool direct = (d.flags & ZG_FLAG_LIT_DIRECT) != 0u && blk.nseq == 0u;
+  if (direct && !d.pos[b].active) return;
+  uint8_t* lits = direct ? d.dst + d.frame_out[blk.frame].out_base + d.pos[b].out_base : d.lit_arena + blk.lit_base;
   const unsigned max_bits = d.huf_maxbits[blk.huf_slot];
   if (max_bits == 0 || max_bits > 11) return;
   const uint16_t* g = d.huf_arena + (uint64_t)blk.huf_slot * ZG_HUF_SLOT_U16;
@@ -616,7 +504,7 @@ __global__ void __launch_bounds__(64) zg_k_huf_uneven(ZgBatchDev d) {
     const uint8_t* sp = pay + 6 + start;
     const int32_t slen = (int32_t)(end - start);
     const uint32_t cnt = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3;
-    uint8_t* dst = d.lit_arena + blk.lit_base + (k == 0 ? 0u : k == 1 ? c0 : k == 2 ? c0 + c1 : c0 + c1 + c2);
+    uint8_t* dst = lits + (k == 0 ? 0u : k == 1 ? c0 : k == 2 ? c0 + c1 : c0 + c1 + c2);
     const uint32_t pmask = (1u << max_bits) - 1u;
     int32_t P = (slen - 1) * 8 + (int32_t)zg_hbit(sp[slen - 1]) - 1;   // bits of the stream (zg_k_huf checked the final-bit marker)
     for (uint32_t n = 0; n < cnt && P > 0; n++) {
@@ -1355,6 +1243,7 @@ __global__ void __launch_bounds__(256) zg_k_lit(ZgBatchDev d) {
   if (blk.btype == ZG_BT_RLE) { zg_wg_fill(out, body[0], blk.regen_size, t, 256); return; }
   if (blk.nseq) return;
   if (blk.lit_type == ZG_LT_RLE) zg_wg_fill(out, body[blk.lit_off], blk.regen_size, t, 256);
+  else if (blk.lit_type >= ZG_LT_COMPRESSED && (d.flags & ZG_FLAG_LIT_DIRECT)) return;   // zg_k_huf wrote them here itself (zg_huf.h)
   else zg_wg_copy(out, blk.lit_type == ZG_LT_RAW ? body + blk.lit_off : d.lit_arena + blk.lit_base, blk.regen_size, t, 256);
 }
 
@@ -1376,21 +1265,6 @@ __global__ void __launch_bounds__(256) zg_k_lit(ZgBatchDev d) {
 //              and needs no co-residency assumption): every match byte of the unit is one independent gather from
 //              bytes that are final by then.
 // ------------------------------------------------------------------------------------------------------------
-
-// workgroup barrier that orders LDS only: unlike __syncthreads() it does not wait for this wave's global loads/stores
-__device__ __forceinline__ void zg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// Buffer resource over [p, p + bytes): loads through it with an offset >= bytes return 0 and cause no traffic. The inputs
-// are wave-uniform; passing them through readfirstlane makes that provable to the compiler, which otherwise wraps every
-// buffer load into a "waterfall" loop (one iteration, but it serialises the loads).
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t zg_make_rsrc(const void* p, uint32_t bytes) {
-  const uint64_t a = (uint64_t)p;
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
-}
-#define ZG_OOB 0xFFFFFFFFu   // an offset no buffer resource covers
-// the same value, but new to the compiler: what is computed from it is computed again here instead of being kept in a register
-#define ZG_FRESH(v) ({ uint32_t v_ = (v); asm volatile("" : "+v"(v_)); v_; })
 
 // zg_k_flatten<T, TS, SPT>: T threads resolve TS-byte tiles; a thread owns the tile bytes t, t + T, t + 2T ... through all phases
 // (consecutive lanes = consecutive bytes: LDS accesses are conflict-free and, above all, the scratch gathers of adjacent
@@ -1698,37 +1572,8 @@ __device__ __forceinline__ void zg_flat1_unit(const ZgBatchDev& d, const uint32_
 
 // ------------------------------------------------------------------------------------------------------------
 // zg_flat4_unit: the flatten of a frame's first unit at dword granularity, resolved to byte values (direct unit) — the body is
-// zg_flat4.h, written against the zx_* primitives below so that tests/emu runs the same source on the CPU.
+// zg_flat4.h, written against the zx_* primitives above so that tests/emu runs the same source on the CPU.
 // ------------------------------------------------------------------------------------------------------------
-#define ZX_DEV __device__ __forceinline__
-// "not needed": an offset no resource of the flatten covers (they are all far below 2^31 bytes). Not 0xFFFFFFFF: the compiler narrows
-// a wide load whose first dwords are unused by ADDING to the offset, and 0xFFFFFFFF + 4 is 3 — inside every resource.
-#define ZX_OOB 0x80000000u
-#define ZX_FRESH(v) ZG_FRESH(v)
-typedef __amdgpu_buffer_rsrc_t ZxBuf;
-ZX_DEV uint32_t zx_tid() { return threadIdx.x; }
-ZX_DEV void zx_barrier() { zg_lds_barrier(); }
-// every wave's global stores have reached memory, then the barrier (the builtin, not inline asm: the compiler then knows
-// that nothing is in flight here and does not protect registers of earlier loads with waits that also cover later ones)
-ZX_DEV void zx_barrier_vm() { __builtin_amdgcn_s_waitcnt(0x0F70); zg_lds_barrier(); }
-ZX_DEV unsigned long long zx_ballot(bool p) { return __ballot(p); }
-ZX_DEV uint32_t zx_shfl_up(uint32_t v, int o) { return __shfl_up(v, o, 64); }
-ZX_DEV void zx_or_lds(uint32_t* p, uint32_t v) { atomicOr(p, v); }
-ZX_DEV void zx_min_lds(uint32_t* p, uint32_t v) { atomicMin(p, v); }
-ZX_DEV void zx_min_lds64(unsigned long long* p, unsigned long long v) { atomicMin(p, v); }
-ZX_DEV void zx_min_glb(uint32_t* p, uint32_t v) { atomicMin(p, v); }
-ZX_DEV ZxBuf zx_buf(const void* base, uint32_t bytes) { return zg_make_rsrc(base, bytes); }
-ZX_DEV uint32_t zx_ld32(ZxBuf b, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b32(b, off, 0, 0); }
-ZX_DEV ZxU2 zx_ld64(ZxBuf b, uint32_t off) { const zg_v2u v = __builtin_amdgcn_raw_buffer_load_b64(b, off, 0, 0); ZxU2 r; r.x = v.x; r.y = v.y; return r; }
-ZX_DEV ZxU3 zx_ld96(ZxBuf b, uint32_t off) { const zg_v3u v = __builtin_amdgcn_raw_buffer_load_b96(b, off, 0, 0); ZxU3 r; r.x = v.x; r.y = v.y; r.z = v.z; return r; }
-ZX_DEV void zx_st8(ZxBuf b, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v, b, off, 0, 0); }
-ZX_DEV void zx_st32(ZxBuf b, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, b, off, 0, 0); }
-ZX_DEV uint32_t zx_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
-typedef short zg_v2s __attribute__((ext_vector_type(2)));
-// packed 16-bit lanes (v_pk_sub_i16, v_pk_ashrrev_i16): a - b per lane; 0xFFFF per lane whose signed value is negative
-ZX_DEV uint32_t zx_pksub16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (zg_v2s)(__builtin_bit_cast(zg_v2s, a) - __builtin_bit_cast(zg_v2s, b))); }
-// (as an instruction: written as a shift the compiler turns what is done with the result — lane masks for v_bfi — into a compare and a select per lane)
-ZX_DEV uint32_t zx_pksign16(uint32_t a) { uint32_t r; asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a)); return r; }
 #include "zg_flat4.h"
 
 // everything a sweep workgroup needs to know about its unit, in one 32-byte descriptor
@@ -2097,6 +1942,38 @@ __global__ void __launch_bounds__(256) zg_k_merge(ZgBatchDev d) {
 }
 void zg_launch_merge(const ZgBatchDev& d, hipStream_t s) {
   if (d.nblocks) hipLaunchKernelGGL(zg_k_merge, dim3((d.nblocks + 255) / 256), dim3(256), 0, s, d);
+}
+// ZG_FLAG_LIT_DIRECT: the literal streams were decoded AFTER the scan had laid the frames out, so a literals error is found
+// late. One workgroup per frame: the first block (in frame order) whose literals failed — in front of, or at, the block the frame
+// stopped at so far: a block's literals are decoded before its sequences (block_decoder.rs:131-150), so their error outranks a
+// sequences error of the same block, but not a header or tree-description error — becomes the frame's failing block; it and
+// everything behind it is not executed. (zg_k_merge, launched again in front of this kernel, has folded the literal verdicts into
+// the block statuses.)
+__global__ void __launch_bounds__(256) zg_k_litfix(ZgBatchDev d) {
+  __shared__ uint32_t s_first;
+  const uint32_t f = blockIdx.x, t = threadIdx.x;
+  const ZgFrame fr = d.frames[f];
+  const ZgFrameOut fo = d.frame_out[f];
+  if (t == 0) s_first = 0xFFFFFFFFu;
+  __syncthreads();
+  const uint32_t lim = fo.good_blocks < fr.nblocks ? fo.good_blocks + 1u : fr.nblocks;
+  for (uint32_t i = t; i < lim; i += 256) {
+    const uint32_t b = fr.first_block + i;
+    if (d.lit_status[b] && !d.blocks[b].host_status && !d.tab_status[b]) atomicMin(&s_first, i);
+  }
+  __syncthreads();
+  const uint32_t first = s_first;
+  if (first == 0xFFFFFFFFu) return;
+  for (uint32_t i = first + t; i < fr.nblocks; i += 256) d.pos[fr.first_block + i].active = 0u;
+  if (t == 0) {
+    ZgFrameOut* o = &d.frame_out[f];
+    o->status = d.lit_status[fr.first_block + first] & 0xFFu;
+    o->bad_block = first; o->good_blocks = first;
+  }
+}
+void zg_launch_litfix(const ZgBatchDev& d, hipStream_t s) {
+  zg_launch_merge(d, s);
+  if (d.nframes) hipLaunchKernelGGL(zg_k_litfix, dim3(d.nframes), dim3(256), 0, s, d);
 }
 void zg_launch_seqpost(const ZgBatchDev& d, hipStream_t s) {
   if (d.nseq_blocks) hipLaunchKernelGGL(zg_k_seqpost, dim3(d.nseq_blocks), dim3(ZG_SP_T), 0, s, d);

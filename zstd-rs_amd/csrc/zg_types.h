@@ -216,6 +216,10 @@ struct __attribute__((aligned(16))) ZxU4 { uint32_t x, y, z, w; };
 #define ZG_RAW_ML(r) (((r) >> 8) & 511u)
 #define ZG_RAW_LL(r) (((r) >> 17) & 511u)
 
+// The Huffman literals are decoded AFTER the position scan (literal-heavy submits, chosen by the host): the literals of a block
+// without sequences go straight to the block's place in the output instead of through the arena and zg_k_lit's copy.
+#define ZG_FLAG_LIT_DIRECT 0x40u
+
 // Device-side view of one submit (all pointers are device pointers).
 struct ZgBatchDev {
   const uint8_t* src;          // compressed bytes of the whole submit (padded by >= 16 bytes at the end)
@@ -252,7 +256,8 @@ struct ZgBatchDev {
   uint32_t nhuf_groups;
   uint32_t* totals;            // [4]: [0..1] total output bytes (u64), [2] overflow flag, [3] a match reaches further back than its frame's window (zg_k_seqpost)
   uint32_t sweep_window;       // 0: a frame's window size bounds its matches (checked); else this many bytes instead (tests)
-  uint32_t flags;              // bit 0: force the in-order fallback for every frame (tests); bits 2-3: shape of zg_k_flatten (0: 1024 threads x 16 KiB tiles, 1: 512 x 8 KiB)
+  uint32_t flags;              // bit 0: force the in-order fallback for every frame (tests); bits 2-3: shape of zg_k_flatten (0: 1024 threads x 16 KiB tiles, 1: 512 x 8 KiB);
+                               // bits 4-5: timing experiments of zg_k_flatten; bit 6: ZG_FLAG_LIT_DIRECT
   uint64_t og_words;           // size of the flatten scratch in u32
   uint32_t* og;                // flatten scratch: one u32 "effective offset" per output byte of a unit (0 = literal byte, final already)
   const ZgUnit* units;
