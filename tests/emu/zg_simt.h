@@ -138,6 +138,8 @@ static inline uint32_t zx_ld32(const ZxBuf& b, uint32_t off) { return zx__dw(b, 
 #define ZX_ALIGNED(off, a) do { if ((off) != ZX_OOB && (off) < b.bytes && (((uintptr_t)b.base + (off)) % (a))) { fprintf(stderr, "simt: misaligned buffer access %u %% %d at %s:%d\n", (unsigned)(off), (int)(a), __FILE__, __LINE__); abort(); } } while (0)
 static inline ZxU2 zx_ld64(const ZxBuf& b, uint32_t off) { ZX_ALIGNED(off, 4); ZxU2 r; r.x = zx__dw(b, off); r.y = zx__dw(b, (uint64_t)off + 4); return r; }
 static inline ZxU3 zx_ld96(const ZxBuf& b, uint32_t off) { ZX_ALIGNED(off, 4); ZxU3 r; r.x = zx__dw(b, off); r.y = zx__dw(b, (uint64_t)off + 4); r.z = zx__dw(b, (uint64_t)off + 8); return r; }
+static inline uint32_t zx_ld8(const ZxBuf& b, uint32_t off) { return off < b.bytes ? b.base[off] : 0u; }
+static inline void zx_add_lds(uint32_t* p, uint32_t v) { *p += v; }
 static inline void zx_st8(const ZxBuf& b, uint32_t off, uint32_t v) { if (off < b.bytes) b.base[off] = (uint8_t)v; }
 static inline void zx_st32(const ZxBuf& b, uint32_t off, uint32_t v) { ZX_ALIGNED(off, 4); if ((uint64_t)off + 4 <= b.bytes) memcpy(b.base + off, &v, 4); }
 static inline uint32_t zx_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sh & 31u)); }

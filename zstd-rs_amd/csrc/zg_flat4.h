@@ -22,14 +22,14 @@
 #include <stdint.h>
 #include "zg_types.h"
 #include "zg_dev.h"
+#include "zg_flat1.h"
 
 
 
 // four 16-bit lanes (a01 = lanes 0 and 1, a23 = lanes 2 and 3) -> one byte each: the lanes' low / high bytes
 ZX_DEV uint32_t zg_lanes_lo(uint32_t a23, uint32_t a01) { return (a01 & 0xFFu) | ((a01 >> 8) & 0xFF00u) | ((a23 << 16) & 0xFF0000u) | ((a23 << 8) & 0xFF000000u); }
 ZX_DEV uint32_t zg_lanes_hi(uint32_t a23, uint32_t a01) { return ((a01 >> 8) & 0xFFu) | ((a01 >> 16) & 0xFF00u) | ((a23 << 8) & 0xFF0000u) | (a23 & 0xFF000000u); }
-// (a & m) | (b & ~m)
-ZX_DEV uint32_t zx_bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
+// (zx_bfi(m, a, b) = (a & m) | (b & ~m): zg_flat1.h)
 
 template <int T, int TS, int SPT>
 struct ZgFlat4Lds {
