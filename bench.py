@@ -18,7 +18,7 @@ generation and compression stay in seconds), every frame's output is compared wi
               sizes), sharded over the GPUs in LPT order (strong scaling, bounded by the largest frame).
   blocks      configs[3]  128 x 64 MiB text frames = 8 GiB of 128 KiB blocks (ratio 3.19) per GPU: one GPU's share of the 64 GiB
               run (16 distinct frames x 8). Weak scaling.
-  blocks4b    variant 4b  16384 single-block frames (128 KiB each, 2 GiB) per GPU.
+  blocks4b    variant 4b  65536 single-block frames (128 KiB each, 8 GiB: one GPU's share of 524288) per GPU (2048 distinct x 32).
   iso         configs[4]  128 x 64 MiB iso_like frames, ratio 1.18 (Huffman-literal dominated), 8 GiB per GPU (8 distinct x 16).
 
 --gpus N: under torch.distributed.run (WORLD_SIZE set) there is one process per GPU and each rank's pool holds its own GPU
@@ -44,7 +44,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 SILESIA_SIZES = [51220480, 41458703, 33553445, 21606400, 10192446, 10085684, 9970564, 8474240, 7251944, 6627202, 6152192, 5345280]
 KERNELS = ("tables", "huf", "seq", "seqpost", "scan", "lit", "flat", "sweep", "lz")
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r04")
+KERNEL_SOURCES = ("zg_kernels.hip", "zg_flat1.h", "zg_flat4.h", "zg_huf.h", "zg_exact.h", "zg_dev.h", "zg_types.h")   # what the device code is built from
 
 
 def build_workload(name, gpu, size, small=False):
@@ -77,7 +78,7 @@ def build_workload(name, gpu, size, small=False):
         plains = [zgdata.text_like(64 << 20, seed=0xE9 + 16 * gpu + i) for i in range(16)]
         return "%d x 64 MiB text_like frames (%d GiB of 128 KiB blocks: 16 distinct x %d) per GPU | libzstd -3" % (16 * rep, rep, rep), plains, rep, False, "synthetic"
     if name == "blocks4b":
-        rep = 1 if small else 8
+        rep = 1 if small else 32
         big = zgdata.text_like(256 << 20, seed=0xE9 + gpu)
         plains = [big[i:i + (128 << 10)] for i in range(0, len(big), 128 << 10)]
         return "%d single-block frames (128 KiB each: 2048 distinct x %d) per GPU | libzstd -3" % (2048 * rep, rep), plains, rep, False, "synthetic"
@@ -163,7 +164,14 @@ def check_frames(pool, plains, repeat, first=0):
         assert np.array_equal(got, ref), "GPU output differs (frame %d)" % k
 
 
-def roofline(kern, A, workload, pass_ms=None, njobs=1):
+def kernels_sha256():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "zstd-rs_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
+def roofline(kern, A, workload, pass_ms=None, njobs=1, plaintext_bytes=None):
     """roofline block of one workload on one GPU. kern: per-kernel ms of a pass (HIP events on the engines' streams, summed over
     the GPU's resident jobs); A: algorithmic bytes of the pass (every compressed byte read once + every plaintext byte written
     once); pass_ms: how long the GPU took for the pass — with one job that is the sum of its kernels, with several jobs
@@ -173,15 +181,15 @@ def roofline(kern, A, workload, pass_ms=None, njobs=1):
     pipe = A / (t_pipe / 1e3) / 1e9 if t_pipe > 0 else 0.0
     ach_dom = A / (kern[dom] / 1e3) / 1e9 if kern[dom] > 0 else 0.0
     traffic, traffic_src = None, None
-    try:   # HBM bytes from the committed rocprofv3 PMC passes; refused when the kernels changed since they were taken
+    try:   # HBM bytes from the committed rocprofv3 PMC passes; refused when the kernels or the workload differ from what they were taken on
         pm = json.load(open(os.path.join(PROFILE_DIR, "%s_pmc.json" % workload)))
-        cur = hashlib.sha256(open(os.path.join(ROOT, "zstd-rs_amd", "csrc", "zg_kernels.hip"), "rb").read() +
-                             open(os.path.join(ROOT, "zstd-rs_amd", "csrc", "zg_flat4.h"), "rb").read()).hexdigest()
-        if pm.get("kernels_sha256") == cur:
-            traffic = pm["pipeline_hbm_bytes_per_pass"]
-            traffic_src = "profiles/r03/%s_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per-kernel calibration; all kernels of one pass)" % workload
+        if pm.get("kernels_sha256") != kernels_sha256():
+            traffic_src = "profiles/r04/%s_pmc.json is stale for this build: not reported" % workload
+        elif plaintext_bytes is not None and pm.get("plaintext_bytes") != plaintext_bytes:
+            traffic_src = "profiles/r04/%s_pmc.json was taken on %s plaintext bytes, this run decodes %s: not reported" % (workload, pm.get("plaintext_bytes"), plaintext_bytes)
         else:
-            traffic_src = "profiles/r03/%s_pmc.json is stale for this build: not reported" % workload
+            traffic = pm["pipeline_hbm_bytes_per_pass"]
+            traffic_src = "profiles/r04/%s_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per-kernel calibration; all kernels of one pass)" % workload
     except Exception:
         pass
     return {"bound": "hbm", "achieved": round(pipe, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pipe / HBM_PEAK_GBS, 6),
@@ -231,7 +239,7 @@ def other_workload(name, device, min_seconds):
     pool.close()
     return {"workload": desc, "plaintext_bytes": D, "compressed_bytes": Cb, "frames": len(zs) * rep, "blocks": nb, "passes": pps,
             "GBps": round(D * pps / dt / 1e9, 3), "ms_per_pass": round(dt / pps * 1e3, 3), "kernel_ms_per_pass": round(busy[0], 3),
-            "kernel_ms": {k: round(v, 4) for k, v in kern.items()}, "lz77_plan": plan, "roofline": roofline(kern, Cb + D, name, busy[0], pool_jobs), "host_prepare_s": round(prep, 2)}
+            "kernel_ms": {k: round(v, 4) for k, v in kern.items()}, "lz77_plan": plan, "roofline": roofline(kern, Cb + D, name, busy[0], pool_jobs, D), "host_prepare_s": round(prep, 2)}
 
 
 def e2e_rate(device, zs_list, plain_total):
@@ -354,7 +362,7 @@ def main():
                        "queue": ("one process, zgpu_pool_create(%d): LPT order, one worker thread + engine per GPU; GPUs used: %s" % (args.gpus, sorted(used_gpus)))
                                 if world == 1 else "one process per GPU (torch.distributed.run); frames -> ranks by zgpu_dist.shard_frames (the queue's LPT rule)",
                        "gpus_requested": args.gpus, "host_prepare_s": round(prep_s, 3)},
-            "roofline": roofline(kern, C0 + D0, args.workload, per_gpu_busy[0], pool.last_njobs),
+            "roofline": roofline(kern, C0 + D0, args.workload, per_gpu_busy[0], pool.last_njobs, D0),
             "read_GBps": round(C0 / (kern["total"] / 1e3) / 1e9, 3) if kern["total"] > 0 else 0.0,
             "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
             "lz77_plan": pool.plan_stats(0),

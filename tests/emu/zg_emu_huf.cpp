@@ -46,6 +46,8 @@ int zgemu_huf(void* h, int direct, uint8_t* lit_out, uint8_t* dst_out, uint32_t*
   d.dst = dst.data() + 256; d.dst_cap = total;
   d.huf_items = bb.huf_items.data(); d.huf_groups = bb.huf_groups.data(); d.nhuf_groups = (uint32_t)bb.huf_groups.size();
   d.flags = direct ? ZG_FLAG_LIT_DIRECT : 0u;
+  uint32_t totals[4] = {0, 0, 0, 0};
+  d.totals = totals;
   static ZgHufLds<ZG_HUF_GROUP> L;
   for (uint32_t g = 0; g < d.nhuf_groups; g++) simt::run(64 * ZG_HUF_GROUP, [&]() { zg_huf_group<ZG_HUF_GROUP>(d, g, L); });
   memcpy(lit_out, lit.data() + 64, bb.lit_bytes);

@@ -121,6 +121,10 @@ static inline bool zx_any(bool p) { return zx_ballot(p) != 0ull; }
 // the lanes of a wave run one after the other here: what they wrote to LDS is complete for all of them behind this point
 static inline void zx_wave_sync() { (void)zx_ballot(true); }
 static inline void zx_max_glb(uint32_t* p, uint32_t v) { if (v > *p) *p = v; }
+static inline void zx_gst128(void* p, const ZxU4& v) {
+  if ((uintptr_t)p % 16) { fprintf(stderr, "simt: misaligned 16-byte global store\n"); abort(); }
+  memcpy(p, &v, 16);
+}
 static inline ZxU4 zx_gld128(const void* p) {
   if ((uintptr_t)p % 16) { fprintf(stderr, "simt: misaligned 16-byte global load\n"); abort(); }
   ZxU4 r; memcpy(&r, p, 16); return r;

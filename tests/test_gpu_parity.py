@@ -740,3 +740,32 @@ def test_sparse_frames_copy_their_matches_in_order():
     zt = zgdata.zstd_compress(text)
     out, mode, bad = _run_batch(zt + z, {"ZGPU_SPARSE_MAX": "100000000"})     # both frames through zg_k_sparse
     assert bad == 0 and out == text + iso
+
+
+def test_output_sized_in_advance_and_frames_that_lie(ctx, monkeypatch):
+    """Every frame declares its content size: the engine sizes the output before the run and enqueues the LZ77 stages behind the scan
+    without waiting for the host. Frame_Content_Size is never checked by FrameDecoder::decode_all (frame_decoder.rs:541-577), so a
+    frame may hold more (the device notices, the stages are repeated with the sizes the scan found) or less than it declares, and
+    frames without the field take the sized-after-the-scan path: same bytes every time, and the same bytes with the shortcut off."""
+    import zgdata
+    import zgpu
+    plains = [zgdata.text_like(700000 + 4099 * i, seed=0x4400 + i) for i in range(4)] + [zgdata.iso_like(300000, seed=0x44)]
+    zs = [zgdata.zstd_compress(p) for p in plains]
+    want = b"".join(plains)
+
+    def lie(z, delta):                                             # Frame_Header: magic(4) descriptor(1) window(1) FCS(4): frame.rs:6-85
+        assert (z[4] >> 6) == 2 and not (z[4] >> 5) & 1 and not z[4] & 3, "expected a 4-byte FCS behind a window descriptor"
+        fcs = int.from_bytes(z[6:10], "little") + delta
+        return z[:6] + fcs.to_bytes(4, "little") + z[10:]
+    nofcs = zgdata.zstd_compress(plains[1], content_size=False)
+    cases = {"honest": b"".join(zs), "understated": zs[0] + lie(zs[1], -250000) + b"".join(zs[2:]), "overstated": lie(zs[0], 90000) + b"".join(zs[1:]),
+             "all understated": b"".join(lie(z, -1000) for z in zs), "one undeclared": zs[0] + nofcs + b"".join(zs[2:])}
+    for name, blob in cases.items():
+        ost, oout = oracle.FrameDecoder().decode_all(blob, len(want) + 16)
+        assert ost == 0 and oout == want, name
+        assert ctx.decode_all(blob, len(want) + 16) == want, name
+    monkeypatch.setenv("ZGPU_PRESIZE", "0")
+    c2 = zgpu.Context(0)
+    for name, blob in cases.items():
+        assert c2.decode_all(blob, len(want) + 16) == want, name
+    c2.close()

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""rocprofv3 outputs of tools/dev/profile.sh (gpurun_out/prof/<workload>/...) -> the summaries kept under profiles/r03/.
+"""rocprofv3 outputs of tools/dev/profile.sh (gpurun_out/prof/<workload>/...) -> the summaries kept under profiles/r04/.
 
   --reduce W..  (on the GPU box) condense the counter CSVs into gpurun_out/prof/pmc_reduced.json: per workload and kernel the summed
                 counter and the number of launches; the SQ-counter CSVs are cut down to the engine's kernels (one row per launch
                 and counter: the raw evidence kept under profiles/). The bulky traces stay behind.
-  (default)     (here) write profiles/r03/: per workload <w>_kernel_stats.csv, <w>_bench_under_rocprof.json and <w>_pmc.json: HBM bytes
+  (default)     (here) write profiles/r04/: per workload <w>_kernel_stats.csv, <w>_bench_under_rocprof.json and <w>_pmc.json: HBM bytes
                 per pass per kernel, raw and calibrated PER ACCESS PATTERN. On gfx950 FETCH_SIZE reports half of a wide coalesced
                 read (MI355X_MICROARCH.md, HBM section); what it reports for the engine's other patterns is measured by the
                 calibration kernels (zg_k_calib_*): the factor applied to a kernel is that of the pattern its reads are made of.
@@ -12,7 +12,7 @@
 import collections, csv, glob, hashlib, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 P = os.path.join(ROOT, "gpurun_out", "prof")
-OUT = os.path.join(ROOT, "profiles", "r03")
+OUT = os.path.join(ROOT, "profiles", "r04")
 CSRC = os.path.join(ROOT, "zstd-rs_amd", "csrc")
 
 
@@ -88,7 +88,9 @@ def main():
     f4 = cal["zg_k_calib_copy4"]["read_factor"] or 1.0
     fg = cal["zg_k_calib_gather<unsigned long>"]["read_factor"] or 1.0
     w16 = cal["zg_k_calib_copy"]["write_factor"] or 1.0
-    sha = hashlib.sha256(open(os.path.join(CSRC, "zg_kernels.hip"), "rb").read() + open(os.path.join(CSRC, "zg_flat4.h"), "rb").read()).hexdigest()
+    sys.path.insert(0, ROOT)
+    import bench
+    sha = bench.kernels_sha256()
     for w, rw in red["workloads"].items():
         ks = os.path.join(P, w + "_kernel_stats.csv")
         if os.path.exists(ks):

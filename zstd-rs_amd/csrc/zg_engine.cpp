@@ -85,6 +85,8 @@ int Engine::create(int device, Engine** out) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->cus_ = prop.multiProcessorCount;
     const char* v = getenv("ZGPU_FLAT_T");
     if (v) e->flat_shape_ = atoi(v) == 512 ? 1 : 0;   // "512": 512 threads x 8 KiB tiles, two workgroups per CU; else the default
+    const char* ps = getenv("ZGPU_PRESIZE");
+    e->no_presize_ = ps && ps[0] == '0';
   }
   // two streams: the sequences chain is the critical one (its kernels last as long as one block's serial chain), so its
   // workgroups are dispatched first; the literals chain fills what is left
@@ -295,6 +297,12 @@ int Engine::prepare(const uint8_t* src, size_t len, Batch** out) {
   b->eng = this;
   b->src_len = len;
   b->parse_status = parse_frames(src, len, max_window, &b->bb, &b->info);
+  b->all_declared = !b->info.empty();
+  for (const FrameInfo& fi : b->info) {
+    if (!fi.header.has_fcs()) { b->all_declared = false; break; }
+    b->declared_total += fi.header.frame_content_size;
+  }
+  if (!b->all_declared || b->declared_total > (1ull << 40)) { b->all_declared = false; b->declared_total = 0; }
   return upload(b, src, len, out);
 }
 
@@ -437,6 +445,17 @@ int Batch::run() {
   ZgBatchDev& d = dev;
   if (d.nframes == 0) { ran = true; total_out = 0; return ZG_OK; }
   hipEvent_t* ev = sc->ev;
+  // every frame declares its content size: output and flatten scratch are sized now, and nothing below waits for the host
+  presized = false;
+  d.dst_cap_pre = 0;
+  if (!fs && all_declared && !eng->no_presize_) {
+    int st = 0;
+    if ((st = sc->d_dst.reserve(kOutFront + declared_total + 64)) || (st = sc->d_og.reserve(declared_total * 4 + 64))) return st;
+    d.dst = sc->d_dst.as<uint8_t>() + kOutFront; d.dst_cap = declared_total;
+    d.og = sc->d_og.as<uint32_t>(); d.og_words = og_words = declared_total;
+    d.dst_cap_pre = declared_total ? declared_total : 1;   // (0 means "not sized in advance")
+    presized = true;
+  }
   ZG_HIP(hipEventRecord(ev[0], s));
   ZG_HIP(hipMemsetAsync(d.status, 0, 3 * ((size_t)d.nblocks * 4 + 16), s));
   ZG_HIP(hipMemsetAsync(d.huf_maxbits, 0, d.nhuf_slots + 16, s));
@@ -480,7 +499,21 @@ int Batch::run() {
   ZG_HIP(hipEventRecord(ev[4], s));
   { uint32_t mb = 0; for (const ZgFrame& fr : bb.frames) mb = fr.nblocks > mb ? fr.nblocks : mb; zg_launch_scan(d, s, mb); }
   ZG_HIP(hipEventRecord(ev[5], s));
-  // ---- the one host round trip: exact output size of every frame -> output buffer and flatten scratch sized to it
+  // ---- the output buffer and the flatten scratch are sized to the frames' exact sizes, which the scan has just computed: one host
+  // round trip — unless every frame declares its content size: then both were sized before the run (above), the LZ77 stages go
+  // behind the scan right away, and the device checks the promise (zg_k_scanf; a frame that produces more than it declared turns
+  // them into no-ops and sync() repeats them the slow way: Frame_Content_Size is never checked by the reference, frame_decoder.rs:541-577).
+  if (!presized) { const int st = size_output(); if (st) return st; }
+  const int st2 = launch_phase2();
+  if (st2) return st2;
+  ZG_HIP(hipGetLastError());
+  ran = true;
+  return ZG_OK;
+}
+
+int Batch::size_output() {
+  hipStream_t s = eng->stream_;
+  ZgBatchDev& d = dev;
   frame_out.resize(d.nframes);
   uint32_t totals[4] = {0, 0, 0, 0};
   ZG_HIP(hipMemcpyAsync(frame_out.data(), d.frame_out, (size_t)d.nframes * sizeof(ZgFrameOut), hipMemcpyDeviceToHost, s));
@@ -515,8 +548,15 @@ int Batch::run() {
   if (any_fast && (st = sc->d_og.reserve(og_words * 4 + 64))) return st;
   d.og = sc->d_og.as<uint32_t>();
   d.og_words = og_words;
+  return ZG_OK;
+}
+
+int Batch::launch_phase2() {
+  hipStream_t s = eng->stream_;
+  ZgBatchDev& d = dev;
+  hipEvent_t* ev = sc->ev;
   // ---- phase 2: LZ77 execution (and, for literal-heavy submits, the Huffman streams in front of it)
-  if (lit_direct) {
+  if (bb.lit_direct) {
     d.flags |= ZG_FLAG_LIT_DIRECT;
     ZG_HIP(hipEventRecord(sc->ev_huf[0], s));
     zg_launch_huf(d, s);
@@ -553,8 +593,6 @@ int Batch::run() {
   ZG_HIP(hipEventRecord(ev[8], s));
   zg_launch_lz(d, s);   // only frames that left the flatten path (a block regenerating > 128 KiB)
   ZG_HIP(hipEventRecord(ev[9], s));
-  ZG_HIP(hipGetLastError());
-  ran = true;
   return ZG_OK;
 }
 
@@ -591,6 +629,26 @@ int Batch::sync() {
   ZG_HIP(hipSetDevice(eng->device_));
   ZG_HIP(hipStreamSynchronize(eng->stream_));
   if (dev.nframes == 0 || !ran) return ZG_OK;
+  if (presized) {
+    // what run() did not wait for: the frames' sizes, and whether they kept their promise
+    uint32_t totals[4] = {0, 0, 0, 0};
+    ZG_HIP(hipMemcpy(totals, dev.totals, 16, hipMemcpyDeviceToHost));
+    total_out = (uint64_t)totals[0] | ((uint64_t)totals[1] << 32);
+    far_seen = totals[3] != 0;
+    frame_out.resize(dev.nframes);
+    if (totals[2]) {
+      // a frame produced more than it declared: the LZ77 stages did nothing (every kernel checks the flag). Size the buffers from
+      // what the scan found and run them now, the way a submit without declared sizes goes.
+      presized = false;
+      dev.dst_cap_pre = 0;
+      uint32_t zero = 0;
+      ZG_HIP(hipMemcpy(dev.totals + 2, &zero, 4, hipMemcpyHostToDevice));
+      int st = size_output();
+      if (!st) st = launch_phase2();
+      if (st) return st;
+      ZG_HIP(hipStreamSynchronize(eng->stream_));
+    }
+  }
   if (split_sweep) {
     uint32_t far = 0;
     ZG_HIP(hipMemcpy(&far, dev.totals + 3, 4, hipMemcpyDeviceToHost));

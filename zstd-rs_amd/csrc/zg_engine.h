@@ -91,7 +91,10 @@ class Batch {
   uint64_t src_len = 0;
   uint64_t keep_bytes = 0;               // streaming submits: frame bytes that must stay reachable on the device (FrameState::make_room)
   uint32_t drain_rule = 0;               // how the caller's surface drains the reference's DecodeBuffer inside this submit (zg_exact.h: ZG_DRAIN_*)
-  bool far_seen = false;                 // run(): a sequence set an offset beyond its frame's window (zg_k_seqpost)
+  bool far_seen = false;                 // a sequence set an offset beyond its frame's window (zg_k_seqpost); valid after sync()
+  uint64_t declared_total = 0;           // sum of the frames' Frame_Content_Size when every frame of the submit declares one (else 0): the
+  bool all_declared = false;             //   output can be sized before the run, and the LZ77 stages enqueued without waiting for the scan
+  bool presized = false;                 // the last run() did that
   bool exact_ran = false;                // sync(): zg_k_exact replayed the reference's buffer bookkeeping for this submit (tests)
 
   // Enqueue the kernel pipeline on the engine's streams. Two phases with one host round trip in between: the entropy
@@ -102,6 +105,8 @@ class Batch {
   int commit(FrameState* fs);
   bool saw_last_block = false;           // the run ended with the frame's last block
   int sync();                            // wait, download per-frame results, compute timings
+  int size_output();                     // after the scan: read the frames' sizes, size output + flatten scratch exactly (one host round trip)
+  int launch_phase2();                   // the LZ77 stages (and, for literal-heavy submits, the Huffman streams in front of them)
   void launch_sweep(bool split, hipStream_t main = nullptr);   // main: the stream of the chain of steps (default: the engine's first)
   bool split_sweep = false;              // the last run used the split sweep: sync() checks that it was entitled to
   bool synced = false;                   // sync() ran after the last run(): outputs may be read
@@ -160,6 +165,7 @@ class Engine {
   friend class Batch;
   int device_ = 0;
   int cus_ = 256;                // compute units of the device (MI355X: 256)
+  bool no_presize_ = false;      // (ZGPU_PRESIZE=0: measurement / tests) never size the output before the run
   int flat_shape_ = 0;           // zg_k_flatten shape: 0 = 1024 threads x 16 KiB tiles (one workgroup per CU), 1 = 512 x 8 KiB (two)
   hipStream_t stream_ = nullptr, stream2_ = nullptr, stream3_ = nullptr;   // stream3_: the flatten, when the sweep chain runs beside it
   std::vector<Scratch*> free_;   // finished submits' buffers, for reuse

@@ -53,6 +53,7 @@ ZX_DEV void zg_huf_set_status(uint32_t* status, uint32_t b, uint32_t rank, int s
 
 template <int GROUP>
 ZX_DEV void zg_huf_group(const ZgBatchDev& d, const uint32_t gi, ZgHufLds<GROUP>& S) {
+  if (d.totals[2]) return;                            // (the output was sized in advance and the frames produce more: Batch::sync() repeats this stage)
   const ZgHufGroup grp = d.huf_groups[gi];
   const uint32_t t = zx_tid(), wv = t >> 6, lane = t & 63;
   unsigned max_bits = grp.slot >= 0 ? d.huf_maxbits[grp.slot] : 0;
@@ -193,6 +194,9 @@ ZX_DEV void zg_huf_group(const ZgBatchDev& d, const uint32_t gi, ZgHufLds<GROUP>
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const uint32_t v = zx_shfl_up(incl, o); if ((int)lane >= o) incl += v; }
     const uint32_t wtot = zx_shfl(incl, 63);
+    // (measured in round 4: packing the window's symbols in LDS and storing them as 16-byte pieces instead of these byte stores
+    //  made the kernel 6 % SLOWER — it is bound by the instructions of the decode passes, not by its stores, and the staging cost
+    //  LDS, i.e. waves per CU)
     const uint32_t at = ndone + incl - (active ? n : 0u);
     if (active) {
       for (uint32_t i = 0; i < n; i++) {

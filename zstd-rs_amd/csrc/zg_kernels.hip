@@ -118,6 +118,7 @@ ZX_DEV uint32_t zx_pksign16(uint32_t a) { uint32_t r; asm("v_pk_ashrrev_i16 %0, 
 ZX_DEV uint32_t zx_shfl(uint32_t v, int l) { return (uint32_t)__shfl((int)v, l, 64); }
 ZX_DEV bool zx_any(bool p) { return __any(p) != 0; }
 ZX_DEV void zx_max_glb(uint32_t* p, uint32_t v) { atomicMax(p, v); }
+ZX_DEV void zx_gst128(void* p, const ZxU4& v) { const zg_v4u w = {v.x, v.y, v.z, v.w}; *(zg_gv4u*)p = w; }   // 16 bytes to global memory, 16-byte aligned
 ZX_DEV ZxU4 zx_gld128(const void* p) { const zg_v4u v = *(const zg_gv4u*)p; ZxU4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }   // 16 bytes of global memory, 16-byte aligned
 // what the lanes of a wave wrote to LDS is read by the other lanes afterwards (a wave runs in lockstep: no hardware barrier, but the
 // compiler must not move the reads ahead)
@@ -479,7 +480,7 @@ __global__ void __launch_bounds__(64) zg_k_huf_uneven(ZgBatchDev d) {
   //  this kernel — one load per block on conforming input — waited for the sequences chain to leave the CUs)
   __shared__ uint16_t s_tab[1][ZG_HUF_SLOT_U16];
   const uint32_t wv = 0, lane = threadIdx.x & 63u, b = blockIdx.x;
-  if (b >= d.nblocks) return;
+  if (b >= d.nblocks || d.totals[2]) return;
   if (d.lit_status[b] != (((255u - 8u) << 8) | (uint32_t)ZG_LIT_COUNT_MISMATCH)) return;   // every stream ended on its last bit, some count differs
   const ZgBlock blk = d.blocks[b];
   if (blk.nstreams != 4 || blk.lit_type < ZG_LT_COMPRESSED || blk.huf_slot < 0) return;
@@ -1214,7 +1215,7 @@ __global__ void __launch_bounds__(1024) zg_k_scanf(ZgBatchDev d) {
     carry += s_v[1023];
     __syncthreads();
   }
-  if (t == 0) { d.totals[0] = (uint32_t)carry; d.totals[1] = (uint32_t)(carry >> 32); d.totals[2] = 0; }
+  if (t == 0) { d.totals[0] = (uint32_t)carry; d.totals[1] = (uint32_t)(carry >> 32); d.totals[2] = (d.dst_cap_pre && carry > d.dst_cap_pre) ? 1u : 0u; }
 }
 
 // ------------------------------------------------------------------------------------------------------------

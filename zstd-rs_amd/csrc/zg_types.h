@@ -268,4 +268,7 @@ struct ZgBatchDev {
   uint32_t pad_ov;
   const uint32_t* step_units;  // sweep step s fills the units step_units[list_off(s) ...] (unit s of every frame that has one)
   unsigned long long* dbg;     // phase cycle counters (profiling builds), diagnostics only
+  uint64_t dst_cap_pre;        // != 0: the output (and the flatten scratch) were sized BEFORE the run from the frames' declared content sizes, and the
+                               // LZ77 stages are already enqueued behind the scan: zg_k_scanf raises totals[2] when the frames produce more than this
+                               // (a frame lied about its size), which turns every later kernel into a no-op; Batch::sync() then sizes and repeats them
 };
