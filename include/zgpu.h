@@ -67,12 +67,8 @@ enum zgpu_status {
    *  - offsets >= 2^30 (offset codes 30, 31) while >= 1 GiB of the frame is held undrained (FrameDecoder::decode_blocks(All) on a
    *    frame beyond 1 GiB that nobody reads from): ZGPU_E_UNSUPPORTED. With less than 1 GiB held — always the case in decode_all
    *    and the streaming decoder — such an offset fails in the reference too, and with the same error here;
-   *  - a block that regenerates >= 2^31 bytes: ZGPU_E_UNSUPPORTED;
-   *  - a match that starts in the dictionary and continues BEHIND bytes the caller has drained (needs a dictionary, a
-   *    total_output_counter kept small by raw / RLE blocks, and an offset beyond the window): ZGPU_E_UNSUPPORTED — the reference
-   *    splices the dictionary's tail with the oldest byte it still holds (decode_buffer.rs:159-163).
-   * Blocks regenerating more than 128 KiB (beyond Block_Maximum_Size) are decoded, by the in-order kernel, and fail with the
-   * reference's own error leaf (the exact buffer bookkeeping of zg_exact.h covers them since round 4). */
+   *  - a block that regenerates >= 2^31 bytes: ZGPU_E_UNSUPPORTED.
+   * Blocks regenerating more than 128 KiB (beyond Block_Maximum_Size) are decoded, by the in-order kernel. */
   ZGPU_E_UNSUPPORTED = 80,
   ZGPU_E_INTERNAL = 90,               /* where the reference would panic */
   ZGPU_E_NOMEM = 91,
@@ -180,7 +176,6 @@ int zgpu_batch_debug_timers(zgpu_batch*, uint64_t out[1024]);
 /* diagnostics for the parity tests of the LZ77 stage: the units a submit was cut into, and raw reads of the flatten
  * scratch (what = 0: one u32 effective offset per output byte of a unit, at scratch_base + position; 1: per-unit sizes) */
 uint32_t zgpu_batch_num_units(const zgpu_batch*);
-uint32_t zgpu_batch_debug_og24(const zgpu_batch*);         /* after sync: width of the flatten scratch words: 0 four bytes, 1 three bytes, 2 three bytes tried, then repeated with four */
 uint32_t zgpu_batch_debug_sweep_mode(const zgpu_batch*);   /* after sync: 0 plain chain of sweep steps, 1 split (tails / heads), 2 split, then repeated plain */
 int zgpu_batch_unit(zgpu_batch*, uint32_t unit, uint32_t* first_block, uint32_t* nblocks, uint64_t* scratch_base);
 int zgpu_batch_debug_scratch(zgpu_batch*, int what, uint64_t off, void* dst, uint64_t n);

@@ -22,8 +22,7 @@ void run_unit(const ZgBatchDev& d, uint32_t ui) {
 template <int T, int TS, int SPT>
 void run_unit1(const ZgBatchDev& d, uint32_t ui) {
   static ZgFlat1Lds<T, TS, SPT> L;
-  if (d.flags & ZG_FLAG_OG24) simt::run(T, [&]() { zg_flat1_unit<T, TS, SPT, true>(d, ui, L); });
-  else simt::run(T, [&]() { zg_flat1_unit<T, TS, SPT, false>(d, ui, L); });
+  simt::run(T, [&]() { zg_flat1_unit<T, TS, SPT>(d, ui, L); });
 }
 
 }  // namespace
@@ -34,19 +33,17 @@ extern "C" {
 // with a nonzero scratch word copies from that many bytes back): direct units through zg_flat4_unit, pointer-mode units through
 // zg_flat1_unit (zg_flat1.h). shape as for zgemu_flat4.
 //   dst_out   [total output bytes] the plaintext after the sweep
-//   og_out    [total output bytes] the flatten scratch as one u32 per output byte (effective offsets; untouched words: 0xEEEEEEEE or,
-//             with p24 — the 24-bit form of the scratch, ZG_FLAG_OG24 — 0xEEEEEE)
-//   ovf24     set when a unit reported that its offsets may not fit 24 bits (totals[4]); may be null
+//   og_out    [total output bytes] the flatten scratch (effective offsets; untouched words: 0xEEEEEEEE)
 //   unit_mode [units] 0 pointer, 1 no sequences, 2 direct; may be null
 // Frames marked sparse (their matches are copied in order by zg_k_sparse, no scratch) take the serial model's bytes.
-int zgemu_flatten(void* h, int shape, int p24, uint8_t* dst_out, uint32_t* og_out, uint32_t* unit_mode, uint32_t* ovf24) {
+int zgemu_flatten(void* h, int shape, uint8_t* dst_out, uint32_t* og_out, uint32_t* unit_mode) {
   EmuBatch* e = (EmuBatch*)h;
   const zg::BatchBuilder& bb = e->bb;
   const uint32_t nb = (uint32_t)bb.blocks.size(), nf = (uint32_t)bb.frames.size(), nu = (uint32_t)bb.units.size();
   uint64_t total = 0;
   for (uint32_t f = 0; f < nf; f++) total = e->fout[f].out_base + e->fout[f].out_size > total ? e->fout[f].out_base + e->fout[f].out_size : total;
   std::vector<uint8_t> dst(256 + total + 64, 0xAA), lit(64 + e->lit.size() + 64, 0);
-  std::vector<uint32_t> og(total + 4 * (size_t)nu + 64, 0xEEEEEEEEu);   // (as bytes: 4 or 3 per output byte + 16 per unit)
+  std::vector<uint32_t> og(total + 64, 0xEEEEEEEEu);
   memcpy(lit.data() + 64, e->lit.data(), e->lit.size());
   std::vector<ZgSeq> seqs(e->seq.size() + 2);
   for (size_t i = 0; i < e->seq.size(); i++) {
@@ -56,7 +53,7 @@ int zgemu_flatten(void* h, int shape, int p24, uint8_t* dst_out, uint32_t* og_ou
   std::vector<ZgUnitInfo> uinfo(nu + 1);
   std::vector<ZgFrameOut> fout(e->fout.begin(), e->fout.begin() + nf);
   for (ZgFrameOut& fo : fout) { fo.fast = 1; fo.err_packed = 0xFFFFFFFFu; fo.og_base = fo.out_base; }
-  uint32_t totals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t totals[4] = {0, 0, 0, 0};
   ZgBatchDev d;
   memset(&d, 0, sizeof d);
   d.src = e->src; d.blocks = bb.blocks.data(); d.nblocks = nb; d.frames = bb.frames.data(); d.nframes = nf;
@@ -64,12 +61,6 @@ int zgemu_flatten(void* h, int shape, int p24, uint8_t* dst_out, uint32_t* og_ou
   d.frame_out = fout.data(); d.dst = dst.data() + 256; d.dst_cap = total; d.totals = totals;
   d.units = bb.units.data(); d.nunits = nu; d.unit_info = uinfo.data();
   d.og = og.data(); d.og_words = total;
-  d.flags = p24 ? ZG_FLAG_OG24 : 0u;
-  auto word = [&](uint32_t u, uint64_t elem0, uint64_t x) -> uint32_t {   // scratch word x of unit u (whose first word is word elem0 of the submit)
-    const uint8_t* b = (const uint8_t*)og.data() + ZG_OG_OFF(p24 != 0, elem0, u);
-    if (p24) return (uint32_t)b[3 * x] | ((uint32_t)b[3 * x + 1] << 8) | ((uint32_t)b[3 * x + 2] << 16);
-    uint32_t v; memcpy(&v, b + 4 * x, 4); return v;
-  };
   // zg_k_lit: raw and RLE blocks and blocks without sequences are final before the flatten runs
   for (uint32_t b = 0; b < nb; b++) {
     const ZgBlock& blk = bb.blocks[b];
@@ -101,8 +92,8 @@ int zgemu_flatten(void* h, int shape, int p24, uint8_t* dst_out, uint32_t* og_ou
     const uint64_t size = uinfo[u].size;
     if (bb.frames[un.frame].sparse || fout[un.frame].err_packed != 0xFFFFFFFFu) { memcpy(dst.data() + 256 + at, e->dst.data() + at, size); continue; }
     uint8_t* o = dst.data() + 256 + at;
-    const uint64_t elem0 = fout[un.frame].og_base + e->pos[un.first_block].out_base;
-    for (uint64_t x = 0; x < size; x++) { const uint32_t w = word(u, elem0, x); if (w) o[x] = *(o + x - (int64_t)w); }
+    const uint32_t* w = og.data() + fout[un.frame].og_base + e->pos[un.first_block].out_base;
+    for (uint64_t x = 0; x < size; x++) if (w[x]) o[x] = *(o + x - (int64_t)w[x]);
   }
   int first_status = 0;
   for (uint32_t f = 0; f < nf; f++) {
@@ -110,16 +101,7 @@ int zgemu_flatten(void* h, int shape, int p24, uint8_t* dst_out, uint32_t* og_ou
     else if (fout[f].status && !first_status) first_status = (int)fout[f].status;
   }
   memcpy(dst_out, dst.data() + 256, total);
-  if (og_out) {
-    for (uint64_t i = 0; i < total; i++) og_out[i] = p24 ? 0xEEEEEEu : 0xEEEEEEEEu;
-    for (uint32_t u = 0; u < nu; u++) {
-      const ZgUnit& un = bb.units[u];
-      if (un.noseq || !e->pos[un.first_block].active) continue;
-      const uint64_t elem0 = fout[un.frame].og_base + e->pos[un.first_block].out_base;
-      for (uint64_t x = 0; x < uinfo[u].size; x++) og_out[elem0 + x] = word(u, elem0, x);
-    }
-  }
-  if (ovf24) *ovf24 = totals[4];
+  if (og_out) memcpy(og_out, og.data(), total * sizeof(uint32_t));
   return first_status;
 }
 

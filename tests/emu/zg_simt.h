@@ -146,10 +146,6 @@ static inline uint32_t zx_ld8(const ZxBuf& b, uint32_t off) { return off < b.byt
 static inline void zx_add_lds(uint32_t* p, uint32_t v) { *p += v; }
 static inline void zx_st8(const ZxBuf& b, uint32_t off, uint32_t v) { if (off < b.bytes) b.base[off] = (uint8_t)v; }
 static inline void zx_st32(const ZxBuf& b, uint32_t off, uint32_t v) { ZX_ALIGNED(off, 4); if ((uint64_t)off + 4 <= b.bytes) memcpy(b.base + off, &v, 4); }
-// (any byte alignment: the flatten's groups of scratch words start where their tile starts)
-static inline void zx__stdw(const ZxBuf& b, uint64_t off64, uint32_t v) { const uint32_t off = (uint32_t)off64; if ((uint64_t)off + 4 <= b.bytes) memcpy(b.base + off, &v, 4); }
-static inline void zx_st96(const ZxBuf& b, uint32_t off, const ZxU3& v) { zx__stdw(b, off, v.x); zx__stdw(b, (uint64_t)off + 4, v.y); zx__stdw(b, (uint64_t)off + 8, v.z); }
-static inline void zx_st128(const ZxBuf& b, uint32_t off, const ZxU4& v) { zx__stdw(b, off, v.x); zx__stdw(b, (uint64_t)off + 4, v.y); zx__stdw(b, (uint64_t)off + 8, v.z); zx__stdw(b, (uint64_t)off + 12, v.w); }
 static inline uint32_t zx_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sh & 31u)); }
 // packed 16-bit lanes: a - b per lane; 0xFFFF per lane whose signed value is negative
 static inline uint32_t zx_pksub16(uint32_t a, uint32_t b) { return ((a - b) & 0xFFFFu) | (((a >> 16) - (b >> 16)) << 16); }

@@ -24,11 +24,11 @@ def _lib():
     L = emu.lib()
     L.zgemu_decode3.restype = C.c_void_p
     L.zgemu_decode3.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64, C.c_int, C.c_uint32, C.c_uint32]
-    L.zgemu_flatten.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.zgemu_flatten.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     return L
 
 
-def run_flatten(z, unit_blocks, shape, p24=False, want_ovf=False):
+def run_flatten(z, unit_blocks, shape):
     """returns (status, plaintext of all frames after the sweep model, scratch words by output position, units [(frame, first_block, nblocks, mode)])"""
     L = _lib()
     h = L.zgemu_decode3(z, len(z), 1 << 31, 1, unit_blocks, 0)
@@ -43,10 +43,7 @@ def run_flatten(z, unit_blocks, shape, p24=False, want_ovf=False):
         dst = np.zeros(total + 1, dtype=np.uint8)
         og = np.zeros(total + 1, dtype=np.uint32)
         modes = np.zeros(nu + 1, dtype=np.uint32)
-        ovf = C.c_uint32(0)
-        st = L.zgemu_flatten(h, shape, 1 if p24 else 0, dst.ctypes.data, og.ctypes.data, modes.ctypes.data, C.byref(ovf))
-        if want_ovf:
-            return st, ovf.value
+        st = L.zgemu_flatten(h, shape, dst.ctypes.data, og.ctypes.data, modes.ctypes.data)
         u4 = (C.c_uint32 * 4)()
         units = []
         for u in range(nu):
@@ -57,9 +54,9 @@ def run_flatten(z, unit_blocks, shape, p24=False, want_ovf=False):
         L.zgemu_free(h)
 
 
-def check_scratch(z, unit_blocks, shape, p24=False):
+def check_scratch(z, unit_blocks, shape):
     """one frame: plaintext == oracle, and the scratch of every pointer-mode unit == the numpy model"""
-    st, got, og, units = run_flatten(z, unit_blocks, shape, p24)
+    st, got, og, units = run_flatten(z, unit_blocks, shape)
     assert st == 0
     assert got == oracle_plain(z)
     want, bounds = lz_model.expected_scratch(z, [u[1] for u in units])
@@ -73,18 +70,16 @@ def check_scratch(z, unit_blocks, shape, p24=False):
     return npointer
 
 
-@pytest.mark.parametrize("p24", [False, True], ids=["words32", "words24"])
 @pytest.mark.parametrize("name", ["text_1m_l3.zst", "mixed_640k_l3.zst", "text_768k_l19.zst", "text_1m_l1.zst"])
-def test_scratch_and_plaintext_small_shape(name, p24):
+def test_scratch_and_plaintext_small_shape(name):
     z = read_pack("synthetic.pack")[name]
-    assert check_scratch(z, 2, 0, p24) >= 2
+    assert check_scratch(z, 2, 0) >= 2
     assert hashlib.sha256(oracle_plain(z)).hexdigest() == read_manifest("synthetic.json")[name]["sha256"]
 
 
-@pytest.mark.parametrize("p24", [False, True], ids=["words32", "words24"])
 @pytest.mark.parametrize("shape,unit_blocks", [(1, 3), (2, 2), (2, 4)])
-def test_scratch_and_plaintext_gpu_shapes(shape, unit_blocks, p24):
-    assert check_scratch(read_pack("synthetic.pack")["text_1m_l3.zst"], unit_blocks, shape, p24) >= 1
+def test_scratch_and_plaintext_gpu_shapes(shape, unit_blocks):
+    assert check_scratch(read_pack("synthetic.pack")["text_1m_l3.zst"], unit_blocks, shape) >= 1
 
 
 def test_no_direct_units_every_unit_through_the_scratch():
@@ -101,8 +96,8 @@ def test_frames_back_to_back_at_odd_offsets():
     parts.insert(3, bytes(1000))
     z = b"".join(zgdata.zstd_compress(q) for q in parts)
     want = b"".join(parts)
-    for shape, p24 in ((0, False), (0, True), (2, True)):
-        st, got, og, units = run_flatten(z, 1, shape, p24)     # one block per unit: every frame has pointer-mode units behind its first
+    for shape in (0, 2):
+        st, got, og, units = run_flatten(z, 1, shape)          # one block per unit: every frame has pointer-mode units behind its first
         assert st == 0
         assert got == want
         assert sum(1 for u in units if u[3] == 0) >= 4
@@ -112,18 +107,7 @@ def test_reference_corpus():
     """the reference's decodecorpus files (tests/decode_corpus.rs) with one block per unit: raw / RLE / compressed blocks of every kind"""
     pack, man = read_pack("decodecorpus.pack"), read_manifest("decodecorpus.json")
     names = sorted(n for n in pack if n.endswith(".zst"))[:40]
-    for k, n in enumerate(names):
-        st, got, og, units = run_flatten(pack[n], 1, 0, p24=bool(k & 1))
+    for n in names:
+        st, got, og, units = run_flatten(pack[n], 1, 0)
         assert st == 0, n
         assert hashlib.sha256(got).hexdigest() == man[n]["sha256"], n
-
-
-def test_offsets_that_may_not_fit_24_bits_are_reported():
-    """a unit whose sequences hold an offset of 2^24 minus the unit's size or more raises the flag Batch::sync() repeats the LZ77 stages
-    for (with 4-byte words); conforming frames with small windows never do"""
-    from test_exact_cpu import frame, lit_block, seq_block
-    z = frame(lit_block(3000), seq_block((1 << 24) - 200000), lit_block(100, last=True))      # (fails in the reference too: the flag comes first)
-    st, ovf = run_flatten(z, 256, 0, p24=True, want_ovf=True)
-    assert ovf == 1
-    st, ovf = run_flatten(read_pack("synthetic.pack")["text_1m_l3.zst"], 2, 0, p24=True, want_ovf=True)
-    assert st == 0 and ovf == 0

@@ -492,12 +492,9 @@ def test_flat_scratch_matches_model(monkeypatch):
     plains = [oracle.decode_frame_all(z)[0] for z in cases]
     monkeypatch.setenv("ZGPU_DEBUG_NO_SWEEP", "1")
     monkeypatch.setenv("ZGPU_SPARSE_MAX", "0")      # (a frame that zg_k_sparse finishes gets no scratch words at all: keep every frame on the sweep path here)
-    # (og24: the scratch words in their 24-bit form — the default where window + unit size allow it — or always four bytes wide)
-    for shape, ub, direct, og24 in (("1024", None, "1", "1"), ("1024", None, "0", "1"), ("1024", None, "0", "0"), ("512", "2", "1", "1"), ("512", "1", "0", "0"),
-                                    ("1024", "1", "1", "1")):
+    for shape, ub, direct in (("1024", None, "1"), ("1024", None, "0"), ("512", "2", "1"), ("512", "1", "0"), ("1024", "1", "1")):
         monkeypatch.setenv("ZGPU_FLAT_T", shape)
         monkeypatch.setenv("ZGPU_DIRECT", direct)
-        monkeypatch.setenv("ZGPU_OG24", og24)
         if ub:
             monkeypatch.setenv("ZGPU_UNIT_BLOCKS", ub)
         else:
@@ -507,7 +504,6 @@ def test_flat_scratch_matches_model(monkeypatch):
             b = c.prepare(z)
             b.run()
             b.sync()
-            assert b.og24_state() == int(og24), (shape, ci, b.og24_state())
             units = b.units()
             e, bounds = lz_model.expected_scratch(z, [u[0] for u in units])
             ndirect = 0
@@ -773,36 +769,3 @@ def test_output_sized_in_advance_and_frames_that_lie(ctx, monkeypatch):
     for name, blob in cases.items():
         assert c2.decode_all(blob, len(want) + 16) == want, name
     c2.close()
-
-
-def test_scratch_words_of_24_bits_fall_back_to_32(ctx):
-    """The flatten scratch holds 3 bytes per output byte when window + unit size of every frame stay below 2^24 — true for what
-    encoders emit. ruzstd itself accepts any offset whose bytes are still in its buffer (decode_buffer.rs:79-111): a frame with a
-    128 KiB window that holds 17 MiB undrained (FrameDecoder::decode_blocks(All)) and copies from 16.9 MiB back is valid for it. The
-    flatten notices the offset, and the LZ77 stages run again with 4-byte words: same bytes as the oracle's."""
-    import zgpu
-    from test_exact_cpu import frame, lit_block, raw_block, seq_block
-    K = 128 << 10
-    far = 135 * K + 777
-    z = frame(*([raw_block(K, i) for i in range(136)] + [lit_block(3000), seq_block(far), seq_block(5000), lit_block(10, last=True)]))
-    d, o = zgpu.FrameDecoder(ctx), oracle.FrameDecoder()
-    st, c, _, _ = d.reset(z)
-    ost, oc, _, _ = o.init(z)
-    assert (st, c) == (ost, oc)
-    st, used, fin = d.decode_blocks(z[c:], zgpu.STRAT_ALL)
-    ost, oused, ofin = o.decode_blocks(z[c:], oracle.STRAT_ALL)
-    assert (st, used, fin) == (ost, oused, ofin) and st == 0
-    assert d.collect() == o.collect()
-    d.close()
-    # the batch surface shows which width was used: a conforming frame stays at 24 bits, this one is repeated at 32
-    import zgdata
-    b = ctx.prepare(zgdata.zstd_compress(zgdata.text_like(3 << 20, seed=5)))
-    b.run(); b.sync()
-    assert b.bad_status == 0 and b.og24_state() == 1
-    b.close()
-    b = ctx.prepare(z)
-    b.run(); b.sync()
-    assert b.og24_state() == 2                 # (decode_all drains every MiB: the offset is out of reach there, as for the oracle)
-    ost, _ = oracle.FrameDecoder().decode_all(z, 1 << 26)
-    assert b.bad_status == ost != 0
-    b.close()

@@ -214,7 +214,6 @@ int zgpu_batch_debug_timers(zgpu_batch* zb, uint64_t out[1024]) { return zb->b->
 int zgpu_batch_debug_scratch(zgpu_batch* zb, int what, uint64_t off, void* dst, uint64_t n) { return zb->b->read_scratch(what, off, dst, n); }
 uint32_t zgpu_batch_num_units(const zgpu_batch* zb) { return (uint32_t)zb->b->bb.units.size(); }
 uint32_t zgpu_batch_debug_sweep_mode(const zgpu_batch* zb) { return zb->b->sweep_mode; }
-uint32_t zgpu_batch_debug_og24(const zgpu_batch* zb) { return zb->b->og24_state(); }
 int zgpu_batch_unit(zgpu_batch* zb, uint32_t u, uint32_t* first_block, uint32_t* nblocks, uint64_t* scratch_base) {
   if (u >= zb->b->bb.units.size()) return ZGPU_E_BAD_ARG;
   const ZgUnit& x = zb->b->bb.units[u];

@@ -366,7 +366,6 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   b->bb.flat_slots = (uint32_t)cus_ * (flat_shape_ == 0 ? 1u : 2u);   // zg_k_flatten: workgroups the device holds at once
   b->bb.chain_slots = (uint32_t)cus_ * 32u;                            // zg_k_seq: blocks whose chains run at once
   { const char* e = getenv("ZGPU_LIT_DIRECT"); if (e && e[0] == '0') b->bb.lit_direct_allowed = false; }
-  { const char* e = getenv("ZGPU_OG24"); if (e && e[0] == '0') b->bb.og24_allowed = false; }
   b->bb.finish();
   BatchBuilder& bb = b->bb;
   Scratch* sc = b->sc = acquire();
@@ -433,8 +432,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   d.dbg = getenv("ZGPU_DEBUG_TIMERS") ? sc->d_dbg.as<unsigned long long>() : nullptr;
   { const char* e = getenv("ZGPU_FORCE_INORDER"); d.flags = (e && e[0] == '1') ? 1u : 0u; }
   d.flags |= (uint32_t)flat_shape_ << 2;
-  { const char* e = getenv("ZGPU_FLAT_MODE"); if (e) d.flags |= ((uint32_t)atoi(e) & 3u) << 4; }
-  if (bb.og24) d.flags |= ZG_FLAG_OG24;   // (timing experiments) zg_k_flatten without scratch stores / gathers
+  { const char* e = getenv("ZGPU_FLAT_MODE"); if (e) d.flags |= ((uint32_t)atoi(e) & 3u) << 4; }   // (timing experiments) zg_k_flatten without scratch stores / gathers
   { const char* e = getenv("ZGPU_SWEEP_W"); d.sweep_window = (e && atoi(e) > 0) ? (uint32_t)atoi(e) : 0u; }
   if (hipStreamSynchronize(stream_) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
   *out = b;
@@ -452,7 +450,7 @@ int Batch::run() {
   d.dst_cap_pre = 0;
   if (!fs && all_declared && !eng->no_presize_) {
     int st = 0;
-    if ((st = sc->d_dst.reserve(kOutFront + declared_total + 64)) || (st = sc->d_og.reserve(og_bytes(declared_total)))) return st;
+    if ((st = sc->d_dst.reserve(kOutFront + declared_total + 64)) || (st = sc->d_og.reserve(declared_total * 4 + 64))) return st;
     d.dst = sc->d_dst.as<uint8_t>() + kOutFront; d.dst_cap = declared_total;
     d.og = sc->d_og.as<uint32_t>(); d.og_words = og_words = declared_total;
     d.dst_cap_pre = declared_total ? declared_total : 1;   // (0 means "not sized in advance")
@@ -513,11 +511,6 @@ int Batch::run() {
   return ZG_OK;
 }
 
-// bytes of the flatten scratch for `words` output bytes: 4 or 3 (ZG_FLAG_OG24) per word, 16 per unit (ZG_OG_OFF)
-size_t Batch::og_bytes(uint64_t words) const {
-  return (size_t)(words * ((dev.flags & ZG_FLAG_OG24) ? 3u : 4u) + 16ull * bb.units.size() + 64);
-}
-
 int Batch::size_output() {
   hipStream_t s = eng->stream_;
   ZgBatchDev& d = dev;
@@ -552,7 +545,7 @@ int Batch::size_output() {
     d.dst = sc->d_dst.as<uint8_t>() + kOutFront; d.dst_cap = total_out;
     og_words = total_out;
   }
-  if (any_fast && (st = sc->d_og.reserve(og_bytes(og_words)))) return st;
+  if (any_fast && (st = sc->d_og.reserve(og_words * 4 + 64))) return st;
   d.og = sc->d_og.as<uint32_t>();
   d.og_words = og_words;
   return ZG_OK;
@@ -651,21 +644,6 @@ int Batch::sync() {
       uint32_t zero = 0;
       ZG_HIP(hipMemcpy(dev.totals + 2, &zero, 4, hipMemcpyHostToDevice));
       int st = size_output();
-      if (!st) st = launch_phase2();
-      if (st) return st;
-      ZG_HIP(hipStreamSynchronize(eng->stream_));
-    }
-  }
-  if (dev.flags & ZG_FLAG_OG24) {
-    // a sequence whose offset may carry an effective offset beyond 24 bits (an offset far beyond its frame's window: legal for the
-    // reference while the bytes are held, emitted by no encoder): the LZ77 stages again, with 4-byte scratch words
-    uint32_t ovf = 0;
-    ZG_HIP(hipMemcpy(&ovf, dev.totals + 4, 4, hipMemcpyDeviceToHost));
-    if (ovf) {
-      dev.flags &= ~ZG_FLAG_OG24;
-      og24_fallback = true;
-      int st = sc->d_og.reserve(og_bytes(og_words));
-      dev.og = sc->d_og.as<uint32_t>();
       if (!st) st = launch_phase2();
       if (st) return st;
       ZG_HIP(hipStreamSynchronize(eng->stream_));
@@ -805,32 +783,11 @@ int Batch::read_fse_slot(uint32_t slot, std::vector<uint32_t>* entries, uint8_t 
   return ZG_OK;
 }
 int Batch::read_scratch(int what, uint64_t off, void* dst, uint64_t n) {
-  if (what == 1) {
-    if (off + n > bb.units.size() * sizeof(ZgUnitInfo)) return ZG_BAD_ARG;
-    if (n) ZG_HIP(hipMemcpy(dst, (const uint8_t*)dev.unit_info + off, n, hipMemcpyDeviceToHost));
-    return ZG_OK;
-  }
-  // what == 0: scratch words as u32, addressed as off = 4 * (unit_scratch_base(u) + position in the unit): a run inside ONE unit
-  if (what != 0 || !dev.og || (off & 3) || (n & 3)) return ZG_BAD_ARG;
-  const uint64_t w0 = off / 4, nw = n / 4;
-  if (w0 + nw > og_words) return ZG_BAD_ARG;
-  for (uint32_t u = 0; u < bb.units.size(); u++) {
-    uint64_t ub = 0;
-    if (unit_scratch_base(u, &ub)) continue;
-    uint64_t ue = og_words;
-    for (uint32_t v = u + 1; v < bb.units.size(); v++) { uint64_t nb2 = 0; if (!unit_scratch_base(v, &nb2) && nb2 >= ub) { ue = nb2; break; } }
-    if (w0 < ub || w0 >= ue) continue;
-    if (w0 + nw > ue) return ZG_BAD_ARG;
-    const bool p24 = (dev.flags & ZG_FLAG_OG24) != 0;
-    const uint8_t* src = (const uint8_t*)dev.og + ZG_OG_OFF(p24, ub, u) + (p24 ? 3 : 4) * (w0 - ub);
-    if (!p24) { if (n) ZG_HIP(hipMemcpy(dst, src, n, hipMemcpyDeviceToHost)); return ZG_OK; }
-    std::vector<uint8_t> tmp(3 * nw + 1);
-    if (nw) ZG_HIP(hipMemcpy(tmp.data(), src, 3 * nw, hipMemcpyDeviceToHost));
-    uint32_t* o = (uint32_t*)dst;
-    for (uint64_t i = 0; i < nw; i++) o[i] = (uint32_t)tmp[3 * i] | ((uint32_t)tmp[3 * i + 1] << 8) | ((uint32_t)tmp[3 * i + 2] << 16);
-    return ZG_OK;
-  }
-  return ZG_BAD_ARG;
+  const uint8_t* base = what == 0 ? (const uint8_t*)dev.og : what == 1 ? (const uint8_t*)dev.unit_info : nullptr;
+  const uint64_t cap = what == 0 ? og_words * 4 : bb.units.size() * sizeof(ZgUnitInfo);
+  if (!base || off + n > cap) return ZG_BAD_ARG;
+  if (n) ZG_HIP(hipMemcpy(dst, base + off, n, hipMemcpyDeviceToHost));
+  return ZG_OK;
 }
 int Batch::unit_scratch_base(uint32_t unit, uint64_t* base) {
   if (unit >= bb.units.size()) return ZG_BAD_ARG;

@@ -105,8 +105,6 @@ class Batch {
   int commit(FrameState* fs);
   bool saw_last_block = false;           // the run ended with the frame's last block
   int sync();                            // wait, download per-frame results, compute timings
-  size_t og_bytes(uint64_t words) const;
-  bool og24_fallback = false;            // sync(): the 24-bit scratch words did not suffice, the LZ77 stages ran again with 4-byte words (tests)
   int size_output();                     // after the scan: read the frames' sizes, size output + flatten scratch exactly (one host round trip)
   int launch_phase2();                   // the LZ77 stages (and, for literal-heavy submits, the Huffman streams in front of them)
   void launch_sweep(bool split, hipStream_t main = nullptr);   // main: the stream of the chain of steps (default: the engine's first)
@@ -116,7 +114,6 @@ class Batch {
   int read_output(uint64_t off, uint8_t* dst, uint64_t n);   // D2H
   int read_output_async(uint64_t off, uint8_t* dst, uint64_t n, hipStream_t s);
   const uint8_t* device_output() const { return dev.dst; }
-  uint32_t og24_state() const { return og24_fallback ? 2u : (dev.flags & ZG_FLAG_OG24) ? 1u : 0u; }   // scratch words: 0 four bytes, 1 three bytes, 2 three bytes tried, four used
   // after sync(): free everything but the plaintext (a finished submit that waits to be read: zgpu_pool_decode_all)
   void release_scratch();
   // intermediates, for parity tests

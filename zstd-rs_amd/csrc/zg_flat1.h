@@ -33,14 +33,12 @@ struct ZgFlat1Lds {
   uint32_t next, cut, err;
   unsigned long long bad;          // first failing sequence of the block: index << 32 | match position << 8 | provisional status
 };
-// P24: the scratch words are 3 bytes wide (ZG_FLAG_OG24) instead of 4
-template <int T, int TS, int SPT, bool P24>
+template <int T, int TS, int SPT>
 ZX_DEV void zg_flat1_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat1Lds<T, TS, SPT>& L) {
-  constexpr uint32_t EB = P24 ? 3u : 4u;        // bytes of a scratch word
   constexpr int PER = TS / T;                   // tile bytes per thread
   constexpr int SOFF = SPT * T;                 // sequences a tile takes; a denser tile is cut short
   constexpr int NW = TS / 32;                   // words of the mark bitmap
-  static_assert(PER * T == TS && PER <= 16 && (PER % 4) == 0 && NW <= T && (NW % 64) == 0 && SPT >= 1 && SPT <= 2, "shape");
+  static_assert(PER * T == TS && PER <= 16 && NW <= T && (NW % 64) == 0 && SPT >= 1 && SPT <= 2, "shape");
   const uint32_t t = zx_tid();
   const ZgUnit un = d.units[ui];
   if (d.totals[2]) return;
@@ -48,10 +46,7 @@ ZX_DEV void zg_flat1_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat1Lds<T, 
   if (!fo.fast) return;
   const uint64_t unit_abs0 = d.pos[un.first_block].out_base;     // frame-relative position of the unit's first byte
   uint8_t* out_u = d.dst + fo.out_base + unit_abs0;
-  // the unit's scratch words, as bytes: word u (unit-relative position) at ogb + EB * u
-  uint8_t* ogb = (uint8_t*)d.og + ZG_OG_OFF(P24, fo.og_base + unit_abs0, ui);
-  // 24-bit words: an effective offset is at most the unit's size plus the largest offset of its sequences (one hop leaves the unit)
-  const uint32_t limit24 = P24 ? ZG_OG24_LIMIT - un.nblocks * ZG_FLAT_MAX : 0xFFFFFFFFu;
+  uint32_t* og = d.og + fo.og_base + unit_abs0;
   // (a frame whose few matches zg_k_sparse copies in order has no sweep step either: nobody reads its scratch words, so they are
   //  not written — an empty resource turns the stores into no-ops; on literal-heavy data they were most of the kernel's traffic)
   const bool no_scratch = d.frames[un.frame].sparse != 0u;
@@ -75,14 +70,7 @@ ZX_DEV void zg_flat1_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat1Lds<T, 
     const uint32_t bu0 = (uint32_t)(p.out_base - unit_abs0);      // unit-relative position of the block
     if (blk.btype != ZG_BT_COMPRESSED || blk.nseq == 0) {        // all of it is final already (zg_k_lit): effective offset 0
       const uint32_t n = blk.regen_size;
-      if (!un.noseq && !no_scratch) {   // (a unit without sequences has no sweep step: nobody reads its scratch)
-        uint8_t* zp = ogb + (uint64_t)EB * bu0;
-        const uint32_t nbz = EB * n, head = nbz < ((4u - ((uint32_t)(uintptr_t)zp & 3u)) & 3u) ? nbz : ((4u - ((uint32_t)(uintptr_t)zp & 3u)) & 3u);
-        const uint32_t ndw = (nbz - head) >> 2, tail = (nbz - head) & 3u;
-        if (t < head) zp[t] = 0;
-        for (uint32_t i = t; i < ndw; i += T) ((uint32_t*)(zp + head))[i] = 0u;
-        if (t < tail) zp[head + 4u * ndw + t] = 0;
-      }
+      if (!un.noseq && !no_scratch) for (uint32_t i = t; i < n; i += T) og[bu0 + i] = 0u;   // (a unit without sequences has no sweep step: nobody reads its scratch)
       unit_size = bu0 + n;
       continue;
     }
@@ -100,7 +88,7 @@ ZX_DEV void zg_flat1_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat1Lds<T, 
     // ones (no predicate per byte) — behind the block's end the stores fall out of range, inside the block they leave values
     // that the next tile, which owns those bytes, overwrites (its stores come after this tile's: zx_barrier_vm in between)
     const ZxBuf out_rs = zx_buf(out_u, bu0 + S);
-    const ZxBuf og_rs = zx_buf(ogb, (no_scratch || (fdbg & 1u)) ? 0u : EB * (bu0 + S) + 3u * EB);   // (words leave in groups of four: up to three words behind the block's last one)
+    const ZxBuf og_rs = zx_buf(og, (no_scratch || (fdbg & 1u)) ? 0u : 4u * (bu0 + S));
     // bytes of the frame (and dictionary) that exist before this block: the farthest a match may reach. Offsets are < 2^30
     // and positions in the block < 2^17: once 2^31 bytes exist every offset is in reach, else 32-bit arithmetic decides.
     // (once the caller has drained bytes the dictionary is out of reach: DecodeBuffer holds nothing older than what is undrained, and
@@ -144,7 +132,6 @@ ZX_DEV void zg_flat1_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat1Lds<T, 
           off = zg_sym_resolve(qx, p.hist_init);
           // the first failing sequence (in order) decides, like the reference's in-order execution; which of the two
           // "too far" errors it is (repeat_from_dict, decode_buffer.rs:144-179) is worked out off the hot path
-          if (off >= limit24) d.totals[4] = 1u;       // (ZG_FLAG_OG24: the effective offsets of this unit may not fit 24 bits — Batch::sync() repeats the LZ77 stages with 4-byte words)
           if (off == 0) zx_min_lds64(&L.bad, ((unsigned long long)i << 32) | (m0 << 8) | (uint32_t)ZG_EXE_ZERO_OFFSET);              // sequence_execution.rs:28-30
           else if ((!reach_all && off > reach32 + m0) || off >= ZG_OFF_HUGE - 2u) zx_min_lds64(&L.bad, ((unsigned long long)i << 32) | (m0 << 8) | (uint32_t)ZG_EXE_OFFSET_TOO_BIG);
         } else if (i == nseq) {
@@ -159,9 +146,9 @@ ZX_DEV void zg_flat1_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat1Lds<T, 
         const uint32_t st = (a > t0 ? a : t0) - t0;
         const uint32_t mr = (m0 > t0 ? (m0 < t1o ? m0 : t1o) : t0) - t0;
         // (z: the literal a tile byte x of this sequence stands for is z + x - 2^31; it only has to be right for x >= st)
-        // (w: EB * (unit position of the tile - offset), modulo 2^32: S1c adds EB * x and has the byte offset of the parent's scratch word —
-        //  or, for a parent in front of the unit, a value beyond 2^30: offsets are below 2^30 and units far below 2^28 bytes)
-        { ZxU4 rr; rr.x = off; rr.y = mr; rr.z = 0x80000000u + lstart + (a > t0 ? 0u : t0 - a) - st; rr.w = EB * (bu0 + t0) - EB * off; L.rec[j] = rr; }
+        // (w: 4 * (unit position of the tile - offset), modulo 2^32: S1c adds 4 x and has the byte offset of the parent's scratch word —
+        //  or, for a parent in front of the unit, a value beyond 2^31: offsets are below 2^30 and units far below 2^29 bytes)
+        { ZxU4 rr; rr.x = off; rr.y = mr; rr.z = 0x80000000u + lstart + (a > t0 ? 0u : t0 - a) - st; rr.w = 4u * (bu0 + t0) - 4u * off; L.rec[j] = rr; }
         zx_or_lds(&L.bits[st >> 5], 1u << (st & 31u));
         // the last sequence the tile has room for, and more follow: the tile ends with this one
         if (j == SOFF - 1 && i < nseq && m1 <= t1o) L.cut = m1;
@@ -201,8 +188,7 @@ ZX_DEV void zg_flat1_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat1Lds<T, 
       if (t1 < S) fetch(i_next);                                  // next tile's sequences: in flight behind this tile's work
       // the scratch words of the unit's EARLIER tiles, and nothing else: a parent inside this tile or in front of the unit is out
       // of this resource's range by its position alone (no fetch, no select)
-      // (24-bit words are fetched as the dword that starts with them: one byte more than the last word in range)
-      const ZxBuf og_prev = zx_buf(ogb, (no_scratch || (fdbg & 2u)) ? 0u : EB * tu0 + (P24 ? 1u : 0u));
+      const ZxBuf og_prev = zx_buf(og, (no_scratch || (fdbg & 2u)) ? 0u : 4u * tu0);
       // ---- S1c: every byte finds its sequence (rank of the marks up to it) and becomes a literal, a match byte with its
       // parent inside the tile (pointer), or a root: a match byte whose parent lies before the tile. A root's effective
       // offset is its sequence's offset if the parent lies before the unit, else offset + e[parent]: the parent's scratch
@@ -236,7 +222,7 @@ ZX_DEV void zg_flat1_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat1Lds<T, 
           // the parent's scratch word is wanted for a root whose parent lies in an earlier tile of the unit: 4 * its unit position is in
           // og_prev's range exactly then. A literal byte has no parent: bit 31 puts it out of range. (Bytes behind the tile's end
           // fetch and write too: their slots are not used by anything.)
-          wadd[k] = zx_ld32(og_prev, (rec[g].w + EB * x) | (lm & ZX_OOB));
+          wadd[k] = zx_ld32(og_prev, (rec[g].w + 4u * x) | (lm & ZX_OOB));
           const uint32_t par = (c_in ? x - off : (uint32_t)ZG_PAR_EXIT) | lm;   // (as u16: 0xFFFF = ZG_PAR_LIT for a literal)
           L.par[x] = (uint16_t)par;
           L.word[x] = zx_bfi(lm, rec[g].z + x, off);                      // (the word of a byte whose parent lies in the tile is never looked at: it is no root)
@@ -275,46 +261,36 @@ ZX_DEV void zg_flat1_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat1Lds<T, 
       // ---- S3a: the scratch words requested in S1c have arrived: the roots' effective offsets are completed in LDS
       const uint32_t t3 = ZX_FRESH(t);
 #pragma unroll
-      for (int k = 0; k < PER; k++) zx_add_lds(&L.word[t3 + k * T], P24 ? wadd[k] & 0xFFFFFFu : wadd[k]);   // ds_add_u32; 0 where nothing was requested
+      for (int k = 0; k < PER; k++) zx_add_lds(&L.word[t3 + k * T], wadd[k]);   // ds_add_u32; 0 where nothing was requested
       zx_barrier();
       ZG_TICK(4)
       if (L.err) break;
       // ---- S3b: every byte's effective offset = its root's + the distance to the root (a literal root counts 0) -> scratch;
-      // the tile's literal bytes are fetched and go to the output. A thread takes GROUPS of four consecutive bytes here (group t,
-      // t + T, ...): their four scratch words leave in one store — 12 bytes in the 24-bit form.
-      constexpr int GPT = PER / 4, GB = GPT < 2 ? GPT : 2;        // groups per thread; groups per batch (their loads are in flight together)
+      // the tile's literal bytes are fetched and go to the output
+      constexpr int H = PER < 8 ? PER : 8;                        // bytes per batch (their loads are in flight together)
 #pragma unroll
-      for (int j0 = 0; j0 < GPT; j0 += GB) {
-        ZxU2 pq[GB];
-        uint32_t pr[GB][4], w[GB][4], lb[GB][4], da[GB][4];
+      for (int k0 = 0; k0 < PER; k0 += H) {
+        uint32_t lb[H], da[H], pr[H], w[H];
+        // (three passes over the batch, so that its LDS reads go out together: one round trip for the pointers, one for the words)
 #pragma unroll
-        for (int g = 0; g < GB; g++) pq[g] = *(const ZxU2*)&L.par[4u * (t3 + (uint32_t)(j0 + g) * T)];
+        for (int h = 0; h < H; h++) pr[h] = L.par[t3 + (k0 + h) * T];
+        // (each of these loops takes its inputs last first: the one wait in front of the first use then covers the whole batch,
+        //  where first-to-last order costs a wait instruction per element; the kernel is bound by instructions issued)
 #pragma unroll
-        for (int g = GB - 1; g >= 0; g--) {
-          pr[g][0] = pq[g].x & 0xFFFFu; pr[g][1] = pq[g].x >> 16; pr[g][2] = pq[g].y & 0xFFFFu; pr[g][3] = pq[g].y >> 16;
+        for (int h = H - 1; h >= 0; h--) { const uint32_t x = t3 + (k0 + h) * T; w[h] = L.word[pr[h] >= ZG_PAR_EXIT ? x : pr[h]]; }
 #pragma unroll
-          for (int i = 3; i >= 0; i--) { const uint32_t x = 4u * (t3 + (uint32_t)(j0 + g) * T) + (uint32_t)i; w[g][i] = L.word[pr[g][i] >= ZG_PAR_EXIT ? x : pr[g][i]]; }
+        for (int h = H - 1; h >= 0; h--) {
+          const uint32_t x = t3 + (k0 + h) * T, ux = tu0 + x;
+          const uint32_t r = pr[h] >= ZG_PAR_EXIT ? x : pr[h];
+          const uint32_t e = ((w[h] >> 31) ? 0u : w[h]) + (x - r);
+          const bool isl = pr[h] == ZG_PAR_LIT;                           // a literal byte: w carries where its value is
+          lb[h] = zx_ld8(lit_rs, isl ? w[h] & 0x7FFFFFFFu : ZX_OOB);
+          da[h] = isl ? ux : ZX_OOB;                                      // where its value goes
+          zx_st32(og_rs, 4u * ux, e);
         }
 #pragma unroll
-        for (int g = GB - 1; g >= 0; g--) {
-          const uint32_t x0 = 4u * (t3 + (uint32_t)(j0 + g) * T), ux0 = tu0 + x0;
-          uint32_t e[4];
-#pragma unroll
-          for (int i = 3; i >= 0; i--) {
-            const uint32_t x = x0 + (uint32_t)i;
-            const uint32_t r = pr[g][i] >= ZG_PAR_EXIT ? x : pr[g][i];
-            e[i] = ((w[g][i] >> 31) ? 0u : w[g][i]) + (x - r);
-            const bool isl = pr[g][i] == ZG_PAR_LIT;                      // a literal byte: w carries where its value is
-            lb[g][i] = zx_ld8(lit_rs, isl ? w[g][i] & 0x7FFFFFFFu : ZX_OOB);
-            da[g][i] = isl ? ux0 + (uint32_t)i : ZX_OOB;                  // where its value goes
-          }
-          if (P24) { ZxU3 v; v.x = e[0] | (e[1] << 24); v.y = (e[1] >> 8) | (e[2] << 16); v.z = (e[2] >> 16) | (e[3] << 8); zx_st96(og_rs, 3u * ux0, v); }
-          else { ZxU4 v; v.x = e[0]; v.y = e[1]; v.z = e[2]; v.w = e[3]; zx_st128(og_rs, 4u * ux0, v); }
-        }
-#pragma unroll
-        for (int g = 0; g < GB; g++)
-#pragma unroll
-          for (int i = 0; i < 4; i++) zx_st8(out_rs, da[g][i], (uint8_t)(lb[g][i] | lit_fill));
+        for (int h = 0; h < H; h++)   // (lb[0] was requested last)
+          zx_st8(out_rs, da[h], (uint8_t)(lb[h] | lit_fill));
       }
       zx_barrier();  // L.par / L.word / the records are reused by the next tile
       ZG_TICK(5)

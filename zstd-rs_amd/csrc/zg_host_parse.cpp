@@ -247,16 +247,6 @@ void BatchBuilder::finish() {
     if (ub > 256) ub = 256;   // unit-relative positions stay far below 2^30
   }
   unit_blocks_used = ub;
-  // 24-bit scratch words: blocks a pointer-mode unit of each frame may hold at most, (2^24 - one block - window) / block size
-  std::vector<uint32_t> cap24(frames.size(), 0);
-  og24 = og24_allowed && !ramp_percent;
-  for (uint32_t f = 0; f < frames.size(); f++) {
-    const uint64_t w = frames[f].window_size, room = (uint64_t)ZG_OG24_LIMIT - kMaxBlockSize;
-    cap24[f] = w < room ? (uint32_t)((room - w) / kMaxBlockSize) : 0u;
-    bool seqs = false;
-    for (uint32_t i = 0; i < frames[f].nblocks && !seqs; i++) seqs = blocks[frames[f].first_block + i].btype == ZG_BT_COMPRESSED && blocks[frames[f].first_block + i].nseq;
-    if (seqs && cap24[f] < 8) og24 = false;
-  }
   uint32_t max_units = 0;
   for (uint32_t f = 0; f < frames.size(); f++) {
     ZgFrame& fr = frames[f];
@@ -293,9 +283,6 @@ void BatchBuilder::finish() {
         take = upto - done_blocks;
         if (take > 256) take = 256;
       }
-      // (what may become a direct unit — below — keeps its size: it has no scratch words)
-      const bool direct_cand = i == 0 && direct_units && !fr.fixed_base && !fr.sparse && (fr.nblocks + ubf - 1) / ubf <= direct_max_units;
-      if (og24 && !direct_cand && take > cap24[f]) take = cap24[f];
       ZgUnit u;
       u.frame = f; u.first_block = fr.first_block + i; u.desc = 0xFFFFFFFFu; u.pad = 0;
       u.nblocks = fr.nblocks - i < take ? fr.nblocks - i : take; u.noseq = 1;

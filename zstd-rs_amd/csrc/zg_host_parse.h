@@ -80,11 +80,6 @@ class BatchBuilder {
   // finish(): the Huffman literals are worth decoding AFTER the position scan, straight into the output where a block has no
   // sequences (ZG_FLAG_LIT_DIRECT): literal-heavy input, where the arena -> output copy costs more than running the literals
   // chain behind the sequences chain instead of beside it
-  // finish(): the flatten scratch in its 24-bit form (ZG_FLAG_OG24: 3 bytes per output byte instead of 4). Possible when, for every
-  // frame that goes through the scratch, window + unit size stay below 2^24 (the largest effective offset of a conforming frame);
-  // pointer-mode units are cut to fit. Offsets beyond the window (legal for the reference, emitted by nobody) are caught by the flatten.
-  bool og24 = false;
-  bool og24_allowed = true;         // (ZGPU_OG24=0: measurement / tests)
   bool lit_direct = false;
   bool lit_direct_allowed = true;   // (ZGPU_LIT_DIRECT=0: measurement / tests)
   uint32_t chain_slots = 8192;      // sequence chains the device runs at once (engine: CUs x 32)

@@ -109,8 +109,6 @@ ZX_DEV uint32_t zx_ld8(ZxBuf b, uint32_t off) { return __builtin_amdgcn_raw_buff
 ZX_DEV void zx_add_lds(uint32_t* p, uint32_t v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // ds_add_u32
 ZX_DEV void zx_st8(ZxBuf b, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v, b, off, 0, 0); }
 ZX_DEV void zx_st32(ZxBuf b, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, b, off, 0, 0); }
-ZX_DEV void zx_st96(ZxBuf b, uint32_t off, const ZxU3& v) { const zg_v3u w = {v.x, v.y, v.z}; __builtin_amdgcn_raw_buffer_store_b96(w, b, off, 0, 0); }
-ZX_DEV void zx_st128(ZxBuf b, uint32_t off, const ZxU4& v) { const zg_v4u w = {v.x, v.y, v.z, v.w}; __builtin_amdgcn_raw_buffer_store_b128(w, b, off, 0, 0); }
 ZX_DEV uint32_t zx_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 typedef short zg_v2s __attribute__((ext_vector_type(2)));
 // packed 16-bit lanes (v_pk_sub_i16, v_pk_ashrrev_i16): a - b per lane; 0xFFFF per lane whose signed value is negative
@@ -1286,7 +1284,7 @@ __device__ __forceinline__ ZgSweepDesc zg_sweep_desc(const ZgBatchDev& d, uint32
   const ZgFrameOut fo = d.frame_out[un.frame];
   ZgSweepDesc sd;
   sd.out = (uint64_t)(d.dst + fo.out_base + d.pos[un.first_block].out_base);
-  sd.og = (uint64_t)((uint8_t*)d.og + ZG_OG_OFF((d.flags & ZG_FLAG_OG24) != 0u, fo.og_base + d.pos[un.first_block].out_base, u));   // (bytes)
+  sd.og = (uint64_t)(d.og + fo.og_base + d.pos[un.first_block].out_base);
   sd.size = size;
   const uint32_t w = zg_sweep_window(d, d.frames[un.frame]);
   sd.head = sd.size > w ? (sd.size - w) / (4u * ZG_SW_T * ZG_SW_B) : 0u;
@@ -1306,8 +1304,7 @@ __global__ void __launch_bounds__(T, 4) zg_k_flatten(ZgBatchDev d) {
   __shared__ union { ZgFlat1Lds<T, TS, SPT> p; ZgFlat4Lds<T, TS, SPT> v; } s_u;
   if (threadIdx.x == 0) { d.unit_info[blockIdx.x].size = 0; d.unit_info[blockIdx.x].noseq = 0; }
   if (d.units[blockIdx.x].noseq & ZG_UNIT_DIRECT) zg_flat4_unit<T, TS, SPT>(d, blockIdx.x, s_u.v);
-  else if (d.flags & ZG_FLAG_OG24) zg_flat1_unit<T, TS, SPT, true>(d, blockIdx.x, s_u.p);
-  else zg_flat1_unit<T, TS, SPT, false>(d, blockIdx.x, s_u.p);
+  else zg_flat1_unit<T, TS, SPT>(d, blockIdx.x, s_u.p);
   // The sweep chain runs beside this kernel (one long frame in units that grow along it: see BatchBuilder::finish): the unit is
   // handed to its sweep step here — descriptor, then everything this workgroup wrote made visible to the whole device (release),
   // then the flag the step polls. (Producer recipe of the hardware guide: plain stores -> workgroup barrier -> one lane's
@@ -1353,8 +1350,7 @@ __global__ void __launch_bounds__(256) zg_k_swprep(ZgBatchDev d, uint32_t n) {
 // beside it, many units per launch, on the engine's second stream. part 0 is the whole unit.
 // OGM (timing experiments only, ZGPU_SWEEP_MODE 5..8: wrong results): how many bytes of scratch a group reads — 5: 8, 6: 4, 8: 12,
 // 7: 8 and then 8 more at an address that depends on the first (what a directory + entries format would cost a step)
-// P24: the scratch words are 3 bytes wide (ZG_FLAG_OG24): 12 bytes per group
-template <int OGM, bool P24>
+template <int OGM>
 __global__ void __launch_bounds__(ZG_SW_T) __attribute__((amdgpu_waves_per_eu(2, 3))) zg_k_sweep(ZgBatchDev d, uint32_t list_off, uint32_t nbatch, uint32_t dbgmode, uint32_t part) {
   if (d.overlap_epoch) {
     // the flatten may still be at this unit (it runs beside the chain): one lane polls the unit's flag. A step that finds it set
@@ -1397,11 +1393,7 @@ __global__ void __launch_bounds__(ZG_SW_T) __attribute__((amdgpu_waves_per_eu(2,
     for (int k = 0; k < ZG_SW_B; k++) {
       const uint32_t g = bt * BG + t + k * ZG_SW_T;
       const uint64_t gi = g < n4 ? g : 0u;
-      if (P24) {
-        const zg_v3u v = *(const zg_gv3u*)((const zg_gu8*)og + 12 * gi);
-        o[k] = make_uint4(v.x & 0xFFFFFFu, __builtin_amdgcn_alignbit(v.y, v.x, 24u) & 0xFFFFFFu, __builtin_amdgcn_alignbit(v.z, v.y, 16u) & 0xFFFFFFu, v.z >> 8);
-      }
-      else if (OGM == 0) { const zg_v4u v = *(const zg_gv4u*)(og + 4 * gi); o[k] = make_uint4(v.x, v.y, v.z, v.w); }
+      if (OGM == 0) { const zg_v4u v = *(const zg_gv4u*)(og + 4 * gi); o[k] = make_uint4(v.x, v.y, v.z, v.w); }
       else if (OGM == 6) { const uint32_t v = og[gi]; o[k] = make_uint4(v, v, v, v); }
       else if (OGM == 8) { const zg_v3u v = *(const zg_gv3u*)(og + 3 * gi); o[k] = make_uint4(v.x, v.y, v.z, v.x); }
       else {
@@ -1459,7 +1451,7 @@ __global__ void __launch_bounds__(ZG_SW_T) __attribute__((amdgpu_waves_per_eu(2,
   // tail bytes of the unit (size not a multiple of four): by the workgroup that would hold their group
   if (part != 2u && (size & 3u) && n4 >= b0 * BG && n4 < (b0 + nbatch) * BG && t < (size & 3u)) {
     const uint32_t x = (n4 << 2) + t;
-    const uint32_t e = P24 ? (uint32_t)((const zg_gu8*)og)[3u * x] | ((uint32_t)((const zg_gu8*)og)[3u * x + 1u] << 8) | ((uint32_t)((const zg_gu8*)og)[3u * x + 2u] << 16) : og[x];
+    const uint32_t e = og[x];
     if (e) out[x] = out[(int64_t)x - (int64_t)e];
   }
 }
@@ -1758,11 +1750,8 @@ void zg_launch_flat(const ZgBatchDev& d, hipStream_t s) {
 bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* steps, uint32_t nsteps, hipStream_t s2, hipEvent_t* evs, uint32_t nev,
                      uint32_t unit_bytes, uint32_t window_max, uint32_t window_min) {
   uint32_t dbgmode = getenv("ZGPU_SWEEP_MODE") ? (uint32_t)atoi(getenv("ZGPU_SWEEP_MODE")) : 0u;   // timing experiments only
-  void (*kern)(ZgBatchDev, uint32_t, uint32_t, uint32_t, uint32_t) = (d.flags & ZG_FLAG_OG24) ? zg_k_sweep<0, true> : zg_k_sweep<0, false>;
-  if (dbgmode >= 5u && !(d.flags & ZG_FLAG_OG24)) {
-    kern = dbgmode == 5u ? zg_k_sweep<5, false> : dbgmode == 6u ? zg_k_sweep<6, false> : dbgmode == 7u ? zg_k_sweep<7, false> : zg_k_sweep<8, false>;
-    dbgmode = 0u;
-  }
+  void (*kern)(ZgBatchDev, uint32_t, uint32_t, uint32_t, uint32_t) = zg_k_sweep<0>;
+  if (dbgmode >= 5u) { kern = dbgmode == 5u ? zg_k_sweep<5> : dbgmode == 6u ? zg_k_sweep<6> : dbgmode == 7u ? zg_k_sweep<7> : zg_k_sweep<8>; dbgmode = 0u; }
   const uint32_t nbatch = getenv("ZGPU_SWEEP_NB") && atoi(getenv("ZGPU_SWEEP_NB")) > 0 ? (uint32_t)atoi(getenv("ZGPU_SWEEP_NB")) : 1u;   // batches per workgroup (more than one did not pay)
   constexpr uint32_t BB = 4u * ZG_SW_T * ZG_SW_B;             // bytes per batch
   uint32_t n = 0;

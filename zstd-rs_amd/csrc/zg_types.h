@@ -220,15 +220,6 @@ struct __attribute__((aligned(16))) ZxU4 { uint32_t x, y, z, w; };
 // without sequences go straight to the block's place in the output instead of through the arena and zg_k_lit's copy.
 #define ZG_FLAG_LIT_DIRECT 0x40u
 
-// The flatten scratch in its 24-bit form: 3 bytes per output byte instead of 4 (a quarter off what zg_k_flatten writes and gathers
-// and zg_k_sweep reads). Chosen by the host (BatchBuilder::finish) when window + unit size of every frame stay below 2^24; a sequence
-// whose offset could carry an effective offset beyond that raises totals[4] and Batch::sync() repeats the LZ77 stages with 4-byte words.
-// Where a unit's words start in the scratch (bytes): ZG_OG_OFF — dword-aligned (zg_k_sweep reads a group of four words at once), and
-// 16 bytes further per unit: the flatten stores whole groups of four words, up to three words behind a unit's last one.
-#define ZG_FLAG_OG24 0x80u
-#define ZG_OG_OFF(p24, elem, unit) ((p24) ? (((uint64_t)(elem) * 3u + 3u) & ~3ull) + 16ull * (unit) : (uint64_t)(elem) * 4u + 16ull * (unit))
-#define ZG_OG24_LIMIT (1u << 24)
-
 // Device-side view of one submit (all pointers are device pointers).
 struct ZgBatchDev {
   const uint8_t* src;          // compressed bytes of the whole submit (padded by >= 16 bytes at the end)
@@ -263,14 +254,12 @@ struct ZgBatchDev {
   const uint32_t* huf_items;   // (block << 2) | stream
   const ZgHufGroup* huf_groups;
   uint32_t nhuf_groups;
-  uint32_t* totals;            // [0..1] total output bytes (u64), [2] overflow flag, [3] a match reaches further back than its frame's window (zg_k_seqpost),
-                               // [4] an effective offset may not fit the 24-bit scratch (zg_k_flatten, ZG_FLAG_OG24)
+  uint32_t* totals;            // [4]: [0..1] total output bytes (u64), [2] overflow flag, [3] a match reaches further back than its frame's window (zg_k_seqpost)
   uint32_t sweep_window;       // 0: a frame's window size bounds its matches (checked); else this many bytes instead (tests)
   uint32_t flags;              // bit 0: force the in-order fallback for every frame (tests); bits 2-3: shape of zg_k_flatten (0: 1024 threads x 16 KiB tiles, 1: 512 x 8 KiB);
                                // bits 4-5: timing experiments of zg_k_flatten; bit 6: ZG_FLAG_LIT_DIRECT
-  uint64_t og_words;           // size of the flatten scratch in words (one per output byte)
-  uint32_t* og;                // flatten scratch: one "effective offset" per output byte of a unit (0 = literal byte, final already): a u32 at
-                               // [og_base + position], or with ZG_FLAG_OG24 three bytes at byte ZG_OG24_OFF(og_base + unit start, unit) + 3 * (position in the unit)
+  uint64_t og_words;           // size of the flatten scratch in u32
+  uint32_t* og;                // flatten scratch: one u32 "effective offset" per output byte of a unit (0 = literal byte, final already)
   const ZgUnit* units;
   uint32_t nunits;
   ZgUnitInfo* unit_info;       // [nunits]

@@ -51,7 +51,7 @@ EXPORTS = [
     "zgpu_decode_all", "zgpu_batch_prepare", "zgpu_batch_run", "zgpu_batch_sync", "zgpu_batch_num_frames", "zgpu_batch_num_blocks",
     "zgpu_batch_compressed_size", "zgpu_batch_frame_info", "zgpu_batch_read", "zgpu_batch_output_device", "zgpu_batch_timings",
     "zgpu_batch_destroy", "zgpu_batch_block_info", "zgpu_batch_block_literals", "zgpu_batch_block_sequences", "zgpu_batch_fse_slot",
-    "zgpu_batch_huf_slot", "zgpu_batch_debug_timers", "zgpu_batch_num_units", "zgpu_batch_debug_sweep_mode", "zgpu_batch_debug_og24", "zgpu_batch_unit", "zgpu_batch_debug_scratch", "zgpu_debug_calibrate", "zgpu_add_dict", "zgpu_decoder_force_dict",
+    "zgpu_batch_huf_slot", "zgpu_batch_debug_timers", "zgpu_batch_num_units", "zgpu_batch_debug_sweep_mode", "zgpu_batch_unit", "zgpu_batch_debug_scratch", "zgpu_debug_calibrate", "zgpu_add_dict", "zgpu_decoder_force_dict",
     "zgpu_decoder_decode_from_to", "zgpu_decoder_create", "zgpu_decoder_destroy", "zgpu_decoder_init", "zgpu_decoder_decode_blocks",
     "zgpu_decoder_can_collect", "zgpu_decoder_collect", "zgpu_decoder_read", "zgpu_decoder_is_finished", "zgpu_decoder_blocks_decoded",
     "zgpu_decoder_bytes_read_from_source", "zgpu_decoder_content_size", "zgpu_decoder_checksum_from_data",
@@ -110,8 +110,6 @@ def load_library():
     L.zgpu_batch_num_units.restype = C.c_uint32
     L.zgpu_batch_debug_sweep_mode.argtypes = [vp]
     L.zgpu_batch_debug_sweep_mode.restype = C.c_uint32
-    L.zgpu_batch_debug_og24.argtypes = [vp]
-    L.zgpu_batch_debug_og24.restype = C.c_uint32
     L.zgpu_batch_unit.argtypes = [vp, C.c_uint32, P(C.c_uint32), P(C.c_uint32), P(C.c_uint64)]
     L.zgpu_batch_debug_scratch.argtypes = [vp, C.c_int, C.c_uint64, vp, C.c_uint64]
     L.zgpu_debug_calibrate.argtypes = [vp, C.c_uint64]
@@ -290,11 +288,6 @@ class Batch:
     def sweep_mode(self):
         """after sync: 0 plain chain of sweep steps, 1 split into tails and heads, 2 split and then repeated as a plain chain"""
         return int(self.L.zgpu_batch_debug_sweep_mode(self.h))
-
-    def og24_state(self):
-        """after sync: width of the flatten scratch words of this submit: 0 four bytes, 1 three bytes, 2 three bytes tried and the LZ77 stages
-        repeated with four (a sequence whose offset may carry an effective offset beyond 24 bits)"""
-        return int(self.L.zgpu_batch_debug_og24(self.h))
 
     def units(self):
         """[(first_block, nblocks, scratch_base, size, noseq)] — the units zg_k_flatten worked on (size valid after sync); noseq: bit 0: no
