@@ -35,7 +35,13 @@ int zgemu_exact(void* h, uint32_t drain_rule, uint64_t dict_len, uint64_t prior_
     uint32_t good = 0;
     while (good < fr.nblocks && !bb.blocks[fr.first_block + good].host_status && !e->status[fr.first_block + good]) good++;
     ZgFrameOut& fo = fout[f];
-    fo.fast = 1; fo.err_packed = 0xFFFFFFFFu; fo.good_blocks = good; fo.counted = 0;
+    // (a block that regenerates more than 128 KiB sends its frame to the in-order path, zg_k_scan: its records' position fields wrap)
+    bool slow = false;
+    for (uint32_t i = 0; i < good; i++) {
+      const ZgBlock& bk = bb.blocks[fr.first_block + i];
+      if (bk.btype == ZG_BT_COMPRESSED && bk.nseq && (uint64_t)bk.regen_size + e->seqout[fr.first_block + i].sum_ml > ZG_FLAT_MAX) slow = true;
+    }
+    fo.fast = slow ? 0u : 1u; fo.err_packed = 0xFFFFFFFFu; fo.good_blocks = good; fo.counted = 0;
     if (fo.status >= ZG_EXE_NOT_ENOUGH_LITERALS && fo.status <= ZG_EXE_DICT_TOO_SMALL) fo.status = 0;   // the serial model's execution verdict: not wanted here
   }
   uint32_t totals[4] = {0, 0, 0, 0};

@@ -31,6 +31,23 @@ def seq_block(offset, lits=b"abcd", last=False):
     return (((len(body) << 3) | (2 << 1) | (1 if last else 0)).to_bytes(3, "little")) + body
 
 
+def big_seq_block(offset, n_rle, fill=0x41, last=False):
+    """compressed block that regenerates MORE than 128 KiB (no conforming encoder emits one; ruzstd never checks the size, and the
+    engine takes such a frame through its in-order path): n_rle RLE literals, one sequence (ll 0, ml 3, a new offset) in front of them"""
+    val = offset + 3
+    of_code = val.bit_length() - 1
+    extra = val - (1 << of_code)
+    acc, accn = 1, 1
+    for v, w in ((0, 6), (0, 6), (extra, of_code)):
+        acc = (acc << w) | (v & ((1 << w) - 1))
+        accn += w
+    stream = acc.to_bytes((accn + 7) // 8, "little")
+    assert n_rle < (1 << 20)
+    lit_hdr = bytes([1 | (3 << 2) | ((n_rle & 15) << 4), (n_rle >> 4) & 255, (n_rle >> 12) & 255, fill])   # RLE literals, 20-bit size (literals_section.rs:147-153)
+    body = lit_hdr + bytes([1, 0x10, of_code]) + stream
+    return (((len(body) << 3) | (2 << 1) | (1 if last else 0)).to_bytes(3, "little")) + body
+
+
 def lit_block(n, last=False):
     """compressed block without sequences: n raw literals (what DecodeBuffer::push counts)"""
     assert n < (1 << 12)
@@ -84,6 +101,11 @@ CASES = [
     ("rle_blocks_then_far", [rle_block(K)] * 12 + [lit_block(100), seq_block(9 * K, last=True)]),
     ("two_seq_blocks_first_fails", [raw_block(K, 3), seq_block(K + 10), seq_block(5, last=True)]),
     ("second_frame_starts_fresh", None),
+    # frames with a block beyond 128 KiB (the in-order path): the same bookkeeping, positions rebuilt from the lengths
+    ("big_block_in_reach", [raw_block(K, 1), big_seq_block(1000, 200000), seq_block(150000, last=True)]),
+    ("big_block_far_counter_small", [raw_block(K, 1)] * 3 + [big_seq_block(3 * K + 1, 150000, last=True)]),
+    ("big_block_then_far_counter_big", [big_seq_block(5, 300000), seq_block(300000 + 20, last=True)]),
+    ("big_block_after_a_drain", [raw_block(K, 1)] * 20 + [big_seq_block(16 * K, 140000, last=True)]),
 ]
 
 

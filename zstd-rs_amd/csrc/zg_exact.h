@@ -25,6 +25,7 @@ template <int T>
 struct ZgExactLds {
   unsigned long long bad;       // first failing sequence of the block: index << 8 | status
   uint32_t wsum[T / 64];        // per wave: dictionary-only match bytes of the chunk
+  uint32_t wpos[T / 64];        // per wave: output bytes (literals + match) of the chunk's sequences
 };
 
 template <int T>
@@ -32,11 +33,13 @@ ZX_DEV void zg_exact_frame(const ZgBatchDev& d, const uint32_t f, const uint32_t
   const uint32_t t = zx_tid(), lane = t & 63u, wv = t >> 6;
   const ZgFrame fr = d.frames[f];
   const ZgFrameOut fo = d.frame_out[f];
-  if (d.totals[2] || !fo.fast) return;   // frames on the in-order path (a block beyond 128 KiB: the records' positions wrap) keep zg_k_lz's verdict
+  if (d.totals[2]) return;
   // blocks whose sequences exist: everything in front of the first block the entropy stages or the parser rejected; when the
-  // flatten found a sequence it could not execute, that block is the last one to look at
+  // flatten (or, for a frame on the in-order path, zg_k_lz: it leaves the verdict in the status) found a sequence it could not
+  // execute, that block is the last one to look at
   const bool exec_err = fo.err_packed != 0xFFFFFFFFu;
-  uint32_t nwalk = exec_err ? (fo.err_packed >> 8) + 1u : fo.good_blocks;
+  const bool lz_err = !fo.fast && (fo.status == (uint32_t)ZG_EXE_ZERO_OFFSET || fo.status == (uint32_t)ZG_EXE_OFFSET_TOO_BIG || fo.status == (uint32_t)ZG_EXE_DICT_TOO_SMALL);
+  uint32_t nwalk = exec_err ? (fo.err_packed >> 8) + 1u : lz_err ? fo.good_blocks + 1u : fo.good_blocks;
   if (nwalk > fr.nblocks) nwalk = fr.nblocks;
   uint64_t buf = fr.prior_reach;         // DecodeBuffer::len(): undrained bytes
   uint64_t cnt = fr.prior_counted;       // total_output_counter
@@ -53,11 +56,30 @@ ZX_DEV void zg_exact_frame(const ZgBatchDev& d, const uint32_t f, const uint32_t
       const ZgSeq* sq = d.seq_arena + blk.seq_base;
       if (t == 0) L.bad = ~0ull;
       zx_barrier();
+      const uint32_t sum_ll = d.seq_out[b].sum_ll;
+      uint32_t pos_carry = 0;                                      // output bytes of the block's sequences in front of the chunk
       for (uint32_t j0 = 0; j0 < blk.nseq; j0 += T) {
         const uint32_t j = j0 + t;
         const bool have = j < blk.nseq;
-        uint32_t off = 0, m0 = 0, ml = 0;
-        if (have) { const ZgSeq q = sq[j]; off = zg_sym_resolve(q.of, p.hist_init); m0 = ZG_SEQ_MDST(q); ml = ZG_SEQ_ML(q); }
+        uint32_t off = 0, m0 = 0, ml = 0, ll = 0;
+        if (have) {
+          const ZgSeq q = sq[j];
+          off = zg_sym_resolve(q.of, p.hist_init); ml = ZG_SEQ_ML(q);
+          // where the match starts: the record's position field wraps in a block beyond 128 KiB (frames on the in-order path),
+          // ml and ll = (next literal index - this one) mod 2^17 stay exact (zg_types.h): positions are rebuilt from them
+          const uint32_t nx = j + 1 < blk.nseq ? ZG_SEQ_LIT(sq[j + 1]) : sum_ll;
+          ll = (nx - ZG_SEQ_LIT(q)) & 0x1FFFFu;
+        }
+        {
+          uint32_t sp = ll + ml;
+          for (int o = 1; o < 64; o <<= 1) { const uint32_t pv = zx_shfl_up(sp, o); if ((int)lane >= o) sp += pv; }
+          if (lane == 63u) L.wpos[wv] = sp;
+          zx_barrier();
+          uint32_t before = sp - (ll + ml), all = 0;
+          for (uint32_t w = 0; w < (uint32_t)T / 64u; w++) { const uint32_t x = L.wpos[w]; if (w < wv) before += x; all += x; }
+          m0 = pos_carry + before + ll;
+          pos_carry += all;
+        }
         const uint64_t at = buf + m0;                    // buffer.len() when repeat() is called for this match
         const bool outside = have && (uint64_t)off > at; // :80
         const uint64_t need = outside ? (uint64_t)off - at : 0ull;   // bytes_from_dict :150
