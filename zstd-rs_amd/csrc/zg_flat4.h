@@ -188,7 +188,6 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
       // roots: what a non-root byte receives is never looked at.
       ZxU2 VA[GPT], VB[GPT], LW[GPT];
       uint32_t meta[GPT], litl[GPT];   // meta: [2:0] first byte of the second sequence, [12:8] / [20:16] / [28:24] funnel shifts of the literal / A / B windows; litl: literal bytes (byte mask)
-      uint32_t unresolved = 0;                               // bit 8 i + k: byte i of the thread's k-th group has its parent in the tile
       {
         const uint32_t tc = ZX_FRESH(t);
         const uint32_t lead2 = lead * 0x10001u;
@@ -220,9 +219,6 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
           pp.x = zx_bfi(e01, ZG_PAR_EXIT * 0x10001u, p01) | l01;        // literal: 0xFFFF, root: 0x8000, else the parent
           pp.y = zx_bfi(e23, ZG_PAR_EXIT * 0x10001u, p23) | l23;
           *(ZxU2*)&L.par[x0] = pp;
-          // the high bytes of the four lanes: bit 7 clear = parent in the tile
-          const uint32_t hb = zg_lanes_hi(pp.y, pp.x);
-          unresolved |= ((~hb & 0x80808080u) >> 7) << k;
           uint32_t m = fb;
           const int32_t uA = (int32_t)(tu0a + x0 - rA[k].x), uB = (int32_t)(tu0a + x0 - rB[k].x);   // unit-relative positions where the parents' windows start
           // the literal bytes of a group belong to one sequence (a second literal run would need a whole match between them):
@@ -245,31 +241,34 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
       zx_barrier();
       // ---- S2: asynchronous pointer jumping. A byte's pointer only ever moves to another of its ancestors, so stale reads
       // are harmless and no barrier is needed between visits; a byte is done when its pointer's pointer is a root marker.
-      // Chains are deep on text (a word copied from a copy of a copy ...: half of these bytes are more than one hop from their
-      // root, the deepest of a tile ~20), and a wave lasts as long as its busiest lane, so a visit follows TWO hops (measured on
-      // the CPU model: 112 -> 70 wave iterations per tile) and everything is branch-free: each thread visits up to four of its
-      // still-unresolved bytes per iteration, an empty slot visits a dummy byte (index TS, always a root) and writes to it.
+      // BYTE-STRIDED here (thread t visits tile bytes t, t + T, ...: the ownership of zg_flat1.h), not group-wise like the phases
+      // around it: the four bytes of a group share their fate — same chain, same depth — and a wave lasts as long as its busiest
+      // lane, so group-wise jumping (round 3: two hops per visit, branch-free, 93 vector instructions per round of four visits)
+      // cost twice what the strided loop costs. Which of its bytes still have a parent inside the tile a thread reads off the
+      // pointers themselves (S1c's bit mask belongs to the thread that classified the group).
       {
         const uint32_t t2 = ZX_FRESH(t);
-        for (uint32_t guard = 0; zx_ballot(unresolved != 0u) && guard < (1u << 16); guard++) {
-          uint32_t m = unresolved, kk[4], ad[4], p1[4], p2[4], p3[4];
+        uint32_t open = 0;
+        constexpr int PERB = TS / T;
 #pragma unroll
-          for (int j = 0; j < 4; j++) { kk[j] = m ? (uint32_t)__builtin_ctz(m) : 32u; m &= m - 1; ad[j] = kk[j] < 32u ? 4u * (t2 + (kk[j] & 7u) * T) + (kk[j] >> 3) : (uint32_t)TS; }   // bit 8 i + k: byte i of group k
+        for (int k = 0; k < PERB; k++) open |= L.par[t2 + (uint32_t)k * T] < ZG_PAR_EXIT ? 1u << k : 0u;
+        for (uint32_t guard = 0; open && guard < (1u << 16); guard++) {
+          uint32_t m = open, kk[4], pp[4];
 #pragma unroll
-          for (int j = 0; j < 4; j++) p1[j] = L.par[ad[j]];
+          for (int j = 0; j < 4; j++) { kk[j] = m ? (uint32_t)__builtin_ctz(m) : 32u; m &= m - 1; }
 #pragma unroll
-          for (int j = 0; j < 4; j++) p2[j] = L.par[p1[j] < ZG_PAR_EXIT ? p1[j] : (uint32_t)TS];
+          for (int j = 0; j < 4; j++) pp[j] = kk[j] < 32u ? L.par[t2 + kk[j] * T] : (uint32_t)TS;
 #pragma unroll
-          for (int j = 0; j < 4; j++) p3[j] = L.par[p2[j] < ZG_PAR_EXIT ? p2[j] : (uint32_t)TS];
+          for (int j = 0; j < 4; j++) pp[j] = L.par[pp[j]];               // ([TS]: the dummy root)
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            const bool r2 = p2[j] >= ZG_PAR_EXIT, r3 = p3[j] >= ZG_PAR_EXIT;   // p1 is the root / p2 is the root
-            const uint32_t np = r3 ? p2[j] : p3[j];
-            L.par[r2 ? (uint32_t)TS : ad[j]] = (uint16_t)(r2 ? (uint32_t)ZG_PAR_LIT : np);   // (u16 stores are atomic; the dummy only ever receives a root marker)
-            unresolved &= ((r2 || r3) && kk[j] < 32u) ? ~(1u << (kk[j] & 31u)) : 0xFFFFFFFFu;
+            if (kk[j] < 32u) {
+              if (pp[j] >= ZG_PAR_EXIT) open &= ~(1u << kk[j]);           // its pointer is the root
+              else L.par[t2 + kk[j] * T] = (uint16_t)pp[j];               // u16 stores are atomic
+            }
           }
-          if (guard == (1u << 16) - 1u) L.err = ZG_INTERNAL;   // cannot happen: every visit moves a pointer up its chain (seen by everybody behind the next barrier)
         }
+        if (open) L.err = ZG_INTERNAL;   // cannot happen: every visit moves a pointer up its chain (seen by everybody behind the next barrier)
       }
       // ---- S3a: the windows requested in S1c have arrived: every root's value is published
       {
