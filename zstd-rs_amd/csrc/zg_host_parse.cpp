@@ -270,9 +270,24 @@ void BatchBuilder::finish() {
     const bool ramp = ramp_percent && unit_blocks == 0 && frames.size() == 1 && fr.nblocks >= 64 * ubf && !fr.sparse;
     const uint32_t nun = (fr.nblocks + ubf - 1) / ubf;
     ramped = ramped || ramp;
+    // A frame whose first unit is resolved to bytes by the flatten itself (direct unit, below) and that has more units behind it:
+    // the direct body moves ~30 % more bytes per unit of time than the pointer-mode body (no scratch words to write and gather,
+    // measured in round 4: 1.55 against 1.19 MB/ms per workgroup), and the units of a submit are flattened side by side — so the
+    // first unit gets ~1.3 shares of the frame's blocks and the others one each: they finish together, and less of the frame goes
+    // through the scratch and the sweep.
+    const bool direct_frame = unit_blocks == 0 && !ramp && direct_units && !fr.fixed_base && !fr.sparse && nun >= 2 && nun <= direct_max_units;
+    uint32_t first_take = 0, rest_take = 0;
+    if (direct_frame) {
+      first_take = (uint32_t)((fr.nblocks * 13ull + (10ull * (nun - 1) + 13) - 1) / (10ull * (nun - 1) + 13));
+      if (first_take > 384) first_take = 384;
+      if (first_take < ubf) first_take = ubf;
+      if (first_take >= fr.nblocks) first_take = fr.nblocks;
+      rest_take = fr.nblocks > first_take ? (fr.nblocks - first_take + (nun - 1) - 1) / (nun - 1) : 0;
+      if (rest_take > 256) rest_take = 256;   // (more units than planned, then)
+    }
     uint32_t done_blocks = 0, ui = 0;
     for (uint32_t i = 0; i < fr.nblocks; ui++) {
-      uint32_t take = ubf;
+      uint32_t take = direct_frame ? (i == 0 ? first_take : (rest_take ? rest_take : ubf)) : ubf;
       if (ramp) {
         // cumulative target: blocks in front of unit ui + 1 = integral of the linear ramp
         const double x = (double)(ui + 1) / nun, r = ramp_percent / 100.0;
