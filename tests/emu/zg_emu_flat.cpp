@@ -68,23 +68,6 @@ int zgemu_flatten(void* h, int shape, uint8_t* dst_out, uint32_t* og_out, uint32
     const uint64_t at = e->fout[blk.frame].out_base + e->pos[b].out_base;
     memcpy(dst.data() + 256 + at, e->dst.data() + at, blk.regen_size);
   }
-  // zg_k_litrun: the literal runs of the blocks in pointer-mode units (a sequence's ll literals in front of its match, the rest of
-  // the block's literals behind the last sequence), in plain C: the kernel is a copy loop
-  for (uint32_t b = 0; b < nb; b++) {
-    const ZgBlock& blk = bb.blocks[b];
-    if (!e->pos[b].active || blk.btype != ZG_BT_COMPRESSED || !blk.nseq || (bb.units[blk.unit].noseq & ZG_UNIT_DIRECT)) continue;
-    const uint8_t* body = e->src + blk.src_off;
-    const bool rle = blk.lit_type == ZG_LT_RLE;
-    const uint8_t* lsrc = blk.lit_type <= ZG_LT_RLE ? body + blk.lit_off : lit.data() + 64 + blk.lit_base;
-    uint8_t* o = dst.data() + 256 + e->fout[blk.frame].out_base + e->pos[b].out_base;
-    const EmuSeq* sq = e->seq.data() + blk.seq_base;
-    const uint32_t sum_ll = e->seqout[b].sum_ll, sum_ml = e->seqout[b].sum_ml;
-    for (uint32_t i = 0; i < blk.nseq; i++) {
-      const uint32_t ls = sq[i].lit_start, nx = i + 1 < blk.nseq ? sq[i + 1].lit_start : sum_ll, ll = nx - ls, at = sq[i].mdst - ll;
-      for (uint32_t k = 0; k < ll; k++) o[at + k] = rle ? lsrc[0] : lsrc[ls + k];
-    }
-    for (uint32_t k = 0; sum_ll + k < blk.regen_size; k++) o[(uint64_t)sum_ll + sum_ml + k] = rle ? lsrc[0] : lsrc[sum_ll + k];
-  }
   for (uint32_t u = 0; u < nu; u++) {
     const ZgUnit& un = bb.units[u];
     if (unit_mode) unit_mode[u] = un.noseq;

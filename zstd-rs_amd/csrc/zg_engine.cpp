@@ -44,7 +44,6 @@ int Scratch::init_events() {
     if (hipEventCreate(&e) != hipSuccess) return ZG_HIP_ERROR;
   if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return ZG_HIP_ERROR;
   if (hipEventCreateWithFlags(&ev_fork3, hipEventDisableTiming) != hipSuccess) return ZG_HIP_ERROR;
-  if (hipEventCreateWithFlags(&ev_litrun, hipEventDisableTiming) != hipSuccess) return ZG_HIP_ERROR;
   for (auto& e : ev_sw)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return ZG_HIP_ERROR;
   have_events = true;
@@ -65,7 +64,6 @@ void Scratch::release() {
     if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
   if (ev_fork3) { (void)hipEventDestroy(ev_fork3); ev_fork3 = nullptr; }
-  if (ev_litrun) { (void)hipEventDestroy(ev_litrun); ev_litrun = nullptr; }
   for (auto& e : ev_sw)
     if (e) { (void)hipEventDestroy(e); e = nullptr; }
   have_events = false;
@@ -567,11 +565,6 @@ int Batch::launch_phase2() {
   }
   zg_launch_lit(d, s);
   ZG_HIP(hipEventRecord(ev[6], s));
-  // the literal runs of the pointer-mode units: beside the flatten, on the second stream; whatever reads the output waits for them
-  ZG_HIP(hipEventRecord(sc->ev_fork, s));
-  ZG_HIP(hipStreamWaitEvent(eng->stream2_, sc->ev_fork, 0));
-  zg_launch_litrun(d, eng->stream2_);
-  ZG_HIP(hipEventRecord(sc->ev_litrun, eng->stream2_));
   sweep_mode = 0; synced = false;
   // One long frame in ramped units (BatchBuilder::finish): the flatten goes to its own stream and the sweep chain starts at once;
   // a step waits for its unit's flag (zg_k_flatten sets it, zg_k_sweep polls it). ZGPU_OVERLAP=0: one after the other.
@@ -588,13 +581,11 @@ int Batch::launch_phase2() {
     zg_launch_flat(d, s);
     ZG_HIP(hipEventRecord(ev[7], s));
     ZG_HIP(hipStreamWaitEvent(s3, sc->ev_fork3, 0));
-    ZG_HIP(hipStreamWaitEvent(s3, sc->ev_litrun, 0));
     launch_sweep(true, s3);
     ZG_HIP(hipEventRecord(sc->ev_fork3, s3));
     ZG_HIP(hipStreamWaitEvent(s, sc->ev_fork3, 0));
   } else {
     zg_launch_flat(d, s);
-    ZG_HIP(hipStreamWaitEvent(s, sc->ev_litrun, 0));
     { bool any = false; for (const ZgFrame& fr : bb.frames) any = any || fr.sparse; if (any) zg_launch_sparse(d, s); }
     ZG_HIP(hipEventRecord(ev[7], s));
     if (!getenv("ZGPU_DEBUG_NO_SWEEP")) launch_sweep(true);

@@ -68,7 +68,6 @@ struct Scratch {
   DevBuf d_src, d_blocks, d_frames, d_aux, d_slot_log, d_fse, d_huf, d_hufmax, d_status, d_lit, d_seq, d_seqout, d_pos, d_frameout,
       d_dst, d_seqblocks, d_hufitems, d_hufgroups, d_totals, d_og, d_units, d_unitinfo, d_stepunits, d_swdesc, d_dbg, d_raw;
   hipEvent_t ev[ZG_T_COUNT + 1] = {};
-  hipEvent_t ev_litrun = nullptr;                 // zg_k_litrun runs on the second stream beside zg_k_flatten
   hipEvent_t ev_huf[2] = {}, ev_fork = nullptr, ev_fork3 = nullptr;   // zg_k_huf runs on the engine's second stream beside zg_k_seq
   hipEvent_t ev_sw[80] = {};                      // split sweep: heads on the second stream (zg_launch_sweep)
   bool have_events = false;

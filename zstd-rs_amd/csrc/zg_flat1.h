@@ -1,10 +1,8 @@
 // zg_flat1.h — body of the POINTER-MODE units of zg_k_flatten: LZ77 execution (execute_sequences, sequence_execution.rs:5-54;
 // DecodeBuffer::push / repeat, decode_buffer.rs:74-141) of a unit (a run of consecutive blocks of one frame, one workgroup each)
 // that may copy from in front of itself: every byte is resolved to its EFFECTIVE OFFSET e (byte[pos] = byte[pos - e], where
-// pos - e is a literal byte or lies in front of the unit; 0 for a literal byte) and stored in the flatten scratch; zg_k_sweep
-// resolves the offsets unit after unit. The literal BYTES of these units are placed by zg_k_litrun, run by run, beside this kernel
-// (round 4: a byte load and a byte store per tile byte, of which one in twenty found a literal, were half of this body's memory
-// instructions). (A frame's first unit is resolved to bytes by
+// pos - e is a literal byte or lies in front of the unit; 0 for a literal byte) and stored in the flatten scratch; literal bytes
+// go to the output right away; zg_k_sweep resolves the offsets unit after unit. (A frame's first unit is resolved to bytes by
 // zg_flat4.h instead.) Byte-granular: a thread owns the tile bytes t, t + T, t + 2T ... through all phases.
 //
 // Written against the zx_* primitives (zg_kernels.hip maps them onto gfx950 builtins, tests/emu/zg_simt.h onto the CPU
@@ -27,10 +25,10 @@ template <int T, int TS, int SPT>
 struct ZgFlat1Lds {
   static constexpr int NW = TS / 32, SOFF = SPT * T;
   uint16_t par[TS];                // 0xFFFF literal, 0x8000 match byte with its parent before the tile, else tile-relative parent
-  uint32_t word[TS];               // a root's effective offset; a literal: bit 31
+  uint32_t word[TS];               // a root's effective offset; a literal: tag + index of its value in the block's literals
   uint32_t bits[NW];               // marks: the first tile byte of every sequence
   uint16_t cnt[NW];                // marks before each word of bits
-  ZxU4 rec[SOFF];   // per sequence of the tile, as S1c wants it: {offset, first match byte, 4 * (tile start in the unit - offset), -}
+  ZxU4 rec[SOFF];   // per sequence of the tile, as S1c wants it: {offset, first match byte, 2^31 + literal index of tile byte 0, 4 * offset}
   uint32_t wtot[NW / 64];
   uint32_t next, cut, err;
   unsigned long long bad;          // first failing sequence of the block: index << 32 | match position << 8 | provisional status
@@ -47,6 +45,7 @@ ZX_DEV void zg_flat1_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat1Lds<T, 
   const ZgFrameOut fo = d.frame_out[un.frame];
   if (!fo.fast) return;
   const uint64_t unit_abs0 = d.pos[un.first_block].out_base;     // frame-relative position of the unit's first byte
+  uint8_t* out_u = d.dst + fo.out_base + unit_abs0;
   uint32_t* og = d.og + fo.og_base + unit_abs0;
   // (a frame whose few matches zg_k_sparse copies in order has no sweep step either: nobody reads its scratch words, so they are
   //  not written — an empty resource turns the stores into no-ops; on literal-heavy data they were most of the kernel's traffic)
@@ -79,10 +78,16 @@ ZX_DEV void zg_flat1_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat1Lds<T, 
     const uint32_t S = blk.regen_size + so.sum_ml;               // <= ZG_FLAT_MAX on this path
     unit_size = bu0 + S;
     const uint32_t nseq = blk.nseq;
+    const uint8_t* body = d.src + blk.src_off;
+    const bool lit_rle = blk.lit_type == ZG_LT_RLE;
+    const uint8_t* lit = blk.lit_type <= ZG_LT_RLE ? body + blk.lit_off : d.lit_arena + blk.lit_base;
+    const uint32_t lit_fill = lit_rle ? lit[0] : 0u;
+    const ZxBuf lit_rs = zx_buf(lit, lit_rle ? 0u : blk.regen_size);    // RLE literals: nothing is fetched (0), lit_fill is the value
     const ZxBuf seq_rs = zx_buf(d.seq_arena + blk.seq_base, nseq * 12u);
-    // What S3b stores goes through a resource that ENDS WITH THE BLOCK: tile bytes behind a tile's end are processed like live
+    // What S3b stores goes through resources that END WITH THE BLOCK: tile bytes behind a tile's end are processed like live
     // ones (no predicate per byte) — behind the block's end the stores fall out of range, inside the block they leave values
     // that the next tile, which owns those bytes, overwrites (its stores come after this tile's: zx_barrier_vm in between)
+    const ZxBuf out_rs = zx_buf(out_u, bu0 + S);
     const ZxBuf og_rs = zx_buf(og, (no_scratch || (fdbg & 1u)) ? 0u : 4u * (bu0 + S));
     // bytes of the frame (and dictionary) that exist before this block: the farthest a match may reach. Offsets are < 2^30
     // and positions in the block < 2^17: once 2^31 bytes exist every offset is in reach, else 32-bit arithmetic decides.
@@ -140,9 +145,10 @@ ZX_DEV void zg_flat1_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat1Lds<T, 
         if (!valid || a >= t1o) continue;
         const uint32_t st = (a > t0 ? a : t0) - t0;
         const uint32_t mr = (m0 > t0 ? (m0 < t1o ? m0 : t1o) : t0) - t0;
-        // (z: 4 * (unit position of the tile - offset), modulo 2^32: S1c adds 4 x and has the byte offset of the parent's scratch word —
+        // (z: the literal a tile byte x of this sequence stands for is z + x - 2^31; it only has to be right for x >= st)
+        // (w: 4 * (unit position of the tile - offset), modulo 2^32: S1c adds 4 x and has the byte offset of the parent's scratch word —
         //  or, for a parent in front of the unit, a value beyond 2^31: offsets are below 2^30 and units far below 2^29 bytes)
-        { ZxU4 rr; rr.x = off; rr.y = mr; rr.z = 4u * (bu0 + t0) - 4u * off; rr.w = 0u; L.rec[j] = rr; }
+        { ZxU4 rr; rr.x = off; rr.y = mr; rr.z = 0x80000000u + lstart + (a > t0 ? 0u : t0 - a) - st; rr.w = 4u * (bu0 + t0) - 4u * off; L.rec[j] = rr; }
         zx_or_lds(&L.bits[st >> 5], 1u << (st & 31u));
         // the last sequence the tile has room for, and more follow: the tile ends with this one
         if (j == SOFF - 1 && i < nseq && m1 <= t1o) L.cut = m1;
@@ -216,10 +222,10 @@ ZX_DEV void zg_flat1_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat1Lds<T, 
           // the parent's scratch word is wanted for a root whose parent lies in an earlier tile of the unit: 4 * its unit position is in
           // og_prev's range exactly then. A literal byte has no parent: bit 31 puts it out of range. (Bytes behind the tile's end
           // fetch and write too: their slots are not used by anything.)
-          wadd[k] = zx_ld32(og_prev, (rec[g].z + 4u * x) | (lm & ZX_OOB));
+          wadd[k] = zx_ld32(og_prev, (rec[g].w + 4u * x) | (lm & ZX_OOB));
           const uint32_t par = (c_in ? x - off : (uint32_t)ZG_PAR_EXIT) | lm;   // (as u16: 0xFFFF = ZG_PAR_LIT for a literal)
           L.par[x] = (uint16_t)par;
-          L.word[x] = zx_bfi(lm, 0x80000000u, off);                       // a literal: the tag; (the word of a byte whose parent lies in the tile is never looked at: it is no root)
+          L.word[x] = zx_bfi(lm, rec[g].z + x, off);                      // (the word of a byte whose parent lies in the tile is never looked at: it is no root)
           uint32_t ub = c_in ? 1u << k : 0u;
           ub &= ~lm;
           ub = c_live ? ub : 0u;
@@ -259,23 +265,32 @@ ZX_DEV void zg_flat1_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat1Lds<T, 
       zx_barrier();
       ZG_TICK(4)
       if (L.err) break;
-      // ---- S3b: every byte's effective offset = its root's + the distance to the root (a literal root counts 0) -> scratch
-      constexpr int H = PER < 8 ? PER : 8;                        // bytes per batch (their LDS reads are in flight together)
+      // ---- S3b: every byte's effective offset = its root's + the distance to the root (a literal root counts 0) -> scratch;
+      // the tile's literal bytes are fetched and go to the output
+      constexpr int H = PER < 8 ? PER : 8;                        // bytes per batch (their loads are in flight together)
 #pragma unroll
       for (int k0 = 0; k0 < PER; k0 += H) {
-        uint32_t pr[H], w[H];
-        // (two passes over the batch, so that its LDS reads go out together: one round trip for the pointers, one for the words;
-        //  each loop takes its inputs last first: the one wait in front of the first use then covers the whole batch)
+        uint32_t lb[H], da[H], pr[H], w[H];
+        // (three passes over the batch, so that its LDS reads go out together: one round trip for the pointers, one for the words)
 #pragma unroll
         for (int h = 0; h < H; h++) pr[h] = L.par[t3 + (k0 + h) * T];
+        // (each of these loops takes its inputs last first: the one wait in front of the first use then covers the whole batch,
+        //  where first-to-last order costs a wait instruction per element; the kernel is bound by instructions issued)
 #pragma unroll
         for (int h = H - 1; h >= 0; h--) { const uint32_t x = t3 + (k0 + h) * T; w[h] = L.word[pr[h] >= ZG_PAR_EXIT ? x : pr[h]]; }
 #pragma unroll
         for (int h = H - 1; h >= 0; h--) {
-          const uint32_t x = t3 + (k0 + h) * T;
+          const uint32_t x = t3 + (k0 + h) * T, ux = tu0 + x;
           const uint32_t r = pr[h] >= ZG_PAR_EXIT ? x : pr[h];
-          zx_st32(og_rs, 4u * (tu0 + x), ((w[h] >> 31) ? 0u : w[h]) + (x - r));
+          const uint32_t e = ((w[h] >> 31) ? 0u : w[h]) + (x - r);
+          const bool isl = pr[h] == ZG_PAR_LIT;                           // a literal byte: w carries where its value is
+          lb[h] = zx_ld8(lit_rs, isl ? w[h] & 0x7FFFFFFFu : ZX_OOB);
+          da[h] = isl ? ux : ZX_OOB;                                      // where its value goes
+          zx_st32(og_rs, 4u * ux, e);
         }
+#pragma unroll
+        for (int h = 0; h < H; h++)   // (lb[0] was requested last)
+          zx_st8(out_rs, da[h], (uint8_t)(lb[h] | lit_fill));
       }
       zx_barrier();  // L.par / L.word / the records are reused by the next tile
       ZG_TICK(5)

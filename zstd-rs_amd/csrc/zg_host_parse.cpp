@@ -310,7 +310,6 @@ void BatchBuilder::finish() {
       // ... when that saves a noticeable share of the frame's sweep steps: a direct unit takes ~10 % longer to flatten than a
       // pointer-mode one, and all units of a submit are flattened side by side (a frame of hundreds of units gains nothing)
       if (i == 0 && !u.noseq && direct_units && !fr.fixed_base && !fr.sparse && (fr.nblocks + ubf - 1) / ubf <= direct_max_units) u.noseq = ZG_UNIT_DIRECT;
-      for (uint32_t k = 0; k < u.nblocks; k++) blocks[u.first_block + k].unit = (uint32_t)units.size();
       units.push_back(u);
       i += u.nblocks; done_blocks += u.nblocks;
     }

@@ -25,7 +25,6 @@ void zg_launch_merge(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_litfix(const ZgBatchDev& d, hipStream_t s);   // ZG_FLAG_LIT_DIRECT: literal verdicts found after the scan -> block and frame statuses
 void zg_launch_scan(const ZgBatchDev& d, hipStream_t s, uint32_t max_frame_blocks);   // max_frame_blocks: of the submit's frames (picks the workgroup size)
 void zg_launch_lit(const ZgBatchDev& d, hipStream_t s);
-void zg_launch_litrun(const ZgBatchDev& d, hipStream_t s);   // literal runs of the blocks in pointer-mode units (beside the flatten)
 void zg_launch_flat(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_sparse(const ZgBatchDev& d, hipStream_t s);   // the matches of frames marked sparse, in order (after zg_launch_flat)
 bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* steps, uint32_t nsteps, hipStream_t s2, hipEvent_t* evs, uint32_t nev,

@@ -1251,68 +1251,6 @@ __global__ void __launch_bounds__(256) zg_k_lit(ZgBatchDev d) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// zg_k_litrun: the literal runs of the blocks that zg_flat1_unit resolves to effective offsets (DecodeBuffer::push,
-// decode_buffer.rs:74-77, called per sequence by execute_sequences, sequence_execution.rs:20-26, and once more for the literals
-// behind the last sequence, :40-44). One workgroup per block with sequences, a thread per sequence: its ll literals go from the
-// block's literals to where the sequence starts in the output. Runs beside zg_k_flatten on the second stream (it touches nothing
-// the flatten touches) and is done before the sweep, which reads a group's literal bytes back. Text has a literal run of
-// half a byte per sequence on average: most threads have nothing to do, a few copy a handful of bytes, and a run of more than 32
-// bytes (literal-heavy data: thousands) is copied by the whole wave. Direct units place their literals themselves (zg_flat4.h).
-// ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) zg_k_litrun(ZgBatchDev d) {
-  if (d.totals[2]) return;
-  const uint32_t b = d.seq_blocks[blockIdx.x], t = threadIdx.x, lane = t & 63u;
-  const ZgBlockPos p = d.pos[b];
-  if (!p.active) return;
-  const ZgBlock blk = d.blocks[b];
-  if (d.units[blk.unit].noseq & ZG_UNIT_DIRECT) return;
-  const ZgFrameOut fo = d.frame_out[blk.frame];
-  if (!fo.fast) return;                                          // (the in-order path places its own)
-  const ZgBlockSeqOut so = d.seq_out[b];
-  const uint32_t nseq = blk.nseq;
-  const uint8_t* body = d.src + blk.src_off;
-  const bool lit_rle = blk.lit_type == ZG_LT_RLE;
-  const uint8_t* lit = blk.lit_type <= ZG_LT_RLE ? body + blk.lit_off : d.lit_arena + blk.lit_base;
-  const uint32_t fill = lit_rle ? lit[0] : 0u;
-  uint8_t* out = d.dst + fo.out_base + p.out_base;
-  const ZgSeq* sq = d.seq_arena + blk.seq_base;
-  for (uint32_t i0 = 0; i0 < nseq; i0 += 256) {
-    const uint32_t i = i0 + t;
-    uint32_t ll = 0, ls = 0, at = 0;
-    if (i < nseq) {
-      const ZgSeq q = sq[i];
-      ls = ZG_SEQ_LIT(q);
-      const uint32_t nx = i + 1 < nseq ? ZG_SEQ_LIT(sq[i + 1]) : so.sum_ll;
-      ll = (nx - ls) & 0x1FFFFu;
-      at = ZG_SEQ_MDST(q) - ll;                                  // where the sequence's literal run starts in the block
-      if ((uint64_t)ls + ll > blk.regen_size) ll = 0;            // (a block zg_k_seqpost rejected never gets here; belt and braces)
-    }
-    // short runs: by their thread
-    if (ll && ll <= 32u) {
-      for (uint32_t k = 0; k < ll; k++) out[at + k] = lit_rle ? (uint8_t)fill : lit[ls + k];
-    }
-    // long runs: one after the other by the whole wave
-    unsigned long long m = __ballot(ll > 32u);
-    while (m) {
-      const int j = __builtin_ctzll(m);
-      m &= m - 1;
-      const uint32_t jl = (uint32_t)__shfl((int)ll, j, 64), js = (uint32_t)__shfl((int)ls, j, 64), ja = (uint32_t)__shfl((int)at, j, 64);
-      for (uint32_t k = lane; k < jl; k += 64) out[ja + k] = lit_rle ? (uint8_t)fill : lit[js + k];
-    }
-  }
-  // the literals behind the last sequence (sequence_execution.rs:40-44)
-  if (blk.regen_size > so.sum_ll) {
-    const uint32_t rest = blk.regen_size - so.sum_ll;
-    uint8_t* o = out + ((uint64_t)so.sum_ll + so.sum_ml);
-    if (lit_rle) zg_wg_fill(o, (uint8_t)fill, rest, t, 256);
-    else zg_wg_copy(o, lit + so.sum_ll, rest, t, 256);
-  }
-}
-void zg_launch_litrun(const ZgBatchDev& d, hipStream_t s) {
-  if (d.nseq_blocks) hipLaunchKernelGGL(zg_k_litrun, dim3(d.nseq_blocks), dim3(256), 0, s, d);
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // zg_k_flatten + zg_k_sweep: LZ77 execution (execute_sequences, sequence_execution.rs:5-54; DecodeBuffer::repeat,
 // decode_buffer.rs:79-141) without walking the frame's sequences one after the other.
 //

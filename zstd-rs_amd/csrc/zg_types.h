@@ -108,7 +108,7 @@ struct ZgBlock {
   uint64_t lit_base;       // offset of this block's regenerated literals in the literals arena
   uint64_t seq_base;       // index of this block's first sequence in the sequence arena
   uint32_t seq_idx;        // position of this block in the list of blocks that have sequences (flatten scratch slot)
-  uint32_t unit;           // index of the flatten unit the block belongs to (BatchBuilder::finish)
+  uint32_t pad1;
 };
 
 // One frame of the batch.
