@@ -145,36 +145,38 @@ ZX_DEV void zg_huf_group(const ZgBatchDev& d, const uint32_t gi, ZgHufLds<GROUP>
     uint32_t n = 0;
     int32_t entry = U;                                          // where the lane's recorded symbols start
     // one pass over the lane's chunk from position `from` (> L): symbols to S.sym, returns the exit position.
-    // Register window: hi:lo = staged dwords q + 2, q + 1 (64 bits), the position lies r5 + 32 bits above bit 0 of lo, so that the
-    // 32 bits below the position are alignbit(hi, lo, r5) whatever r5 is; staged dword q is what a refill shifts in.
+    // Positions are counted in STAGED bits here (ps = position - wq0 > 0). Register window: hi:lo = the staged dwords that hold
+    // bits [32 (ps / 32 - 1), 32 (ps / 32 + 1)): the 32 bits below the position are alignbit(hi, lo, ps) whatever ps is (the
+    // instruction looks at ps % 32 only), and the position has left the upper dword when ps / 32 changes — a code has at most
+    // 11 bits, so that is (ps ^ ps') > 31. The staged dword below lo is what a refill shifts in: requested with every table
+    // entry, used after that entry has arrived, never waited for.
+    const int32_t Us = U - wq0, Ls = L - wq0;
     auto pass = [&](int32_t from) -> int32_t {
-      const uint32_t p = (uint32_t)(from - wq0);                // >= ZG_HP_LOW + 1: staged dwords q .. q + 2 exist
-      uint32_t q = (p >> 5) - 2u, r5 = p & 31u;
-      uint32_t lo = win32[q + 1u], hi = win32[q + 2u];
-      int32_t P = from;
-      entry = from;
-      n = 0;
-      // One loop for the warm-up above the chunk (not recorded: n stays 0 and row 0 is overwritten) and the chunk itself — a wave
-      // lasts as long as its busiest lane, and the lanes' warm-ups differ. No branch inside: a chunk with more symbols than rows
-      // keeps writing its last row and is found out by its count.
-      while (P > L) {
-        const uint32_t nxt = win32[q];                          // requested with the table entry, used after it arrived: never waited for
-        const uint32_t e = S.tab[zx_alignbit(hi, lo, r5) >> psh];
-        const bool rec = P <= U;
-        sym[64u * (n < ZG_HP_ROWS - 1u ? n : ZG_HP_ROWS - 1u)] = (uint8_t)e;
-        uint32_t nb = e >> 8;
-        nb = nb > 1u ? nb : 1u;                                 // every code has >= 1 bit; the max keeps a corrupted entry from stalling the loop
-        P -= (int32_t)nb;
-        n += rec ? 1u : 0u;
-        entry = rec ? entry : P;                                // the position the warm-up ends at is where the recorded symbols start
-        const int32_t tr = (int32_t)r5 - (int32_t)nb;
-        const bool need = tr < 0;                               // the position left the upper dword: shift the window down by one dword
-        r5 = (uint32_t)tr & 31u;
-        hi = need ? lo : hi; lo = need ? nxt : lo;
-        q -= need ? 1u : 0u;
+      uint32_t ps = (uint32_t)(from - wq0);                     // >= ZG_HP_LOW + 1: the three staged dwords exist
+      const uint32_t* qa = win32 + ((ps >> 5) - 2u);            // the dword below lo
+      uint32_t lo = qa[1], hi = qa[2];
+#define ZG_HUF_STEP(BODY)                                                                               \
+      {                                                                                                  \
+        const uint32_t nxt = *qa;                                                                        \
+        const uint32_t e = S.tab[zx_alignbit(hi, lo, ps) >> psh];                                        \
+        BODY                                                                                             \
+        uint32_t nb = e >> 8;                                                                            \
+        nb = nb > 1u ? nb : 1u;   /* every code has >= 1 bit; the max keeps a corrupted entry from stalling the loop */ \
+        const uint32_t pn = ps - nb;                                                                     \
+        const bool need = (ps ^ pn) > 31u;                      /* shift the window down by one dword */ \
+        ps = pn;                                                                                         \
+        hi = need ? lo : hi; lo = need ? nxt : lo;                                                       \
+        qa -= need ? 1 : 0;                                                                              \
       }
+      // the warm-up above the chunk: nothing is recorded (a loop of its own: its step is a third shorter than a recording one)
+      while ((int32_t)ps > Us) ZG_HUF_STEP(;)
+      entry = (int32_t)ps + wq0;                                // where the lane's recorded symbols start
+      n = 0;
+      // the chunk. No branch inside: a chunk with more symbols than rows keeps writing its last row and is found out by its count.
+      while ((int32_t)ps > Ls) ZG_HUF_STEP(sym[64u * (n < ZG_HP_ROWS - 1u ? n : ZG_HP_ROWS - 1u)] = (uint8_t)e; n++;)
+#undef ZG_HUF_STEP
       spill = spill || n > ZG_HP_ROWS;
-      return P;
+      return (int32_t)ps + wq0;
     };
     const bool active = U > 0;
     int32_t E = U;
