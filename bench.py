@@ -332,6 +332,10 @@ def main():
         assert st == 0 and size == len(p), (k, st, size)
         assert np.array_equal(np.frombuffer(pool.read(k, size), dtype=np.uint8), np.frombuffer(p, dtype=np.uint8)), "GPU output differs (frame %d)" % k
 
+    # every GPU this process drives must have taken part (one frame per GPU, or at least as many sharded frames as GPUs)
+    if world == 1 and len(staged_p) >= ngpu_here:
+        assert len(used_gpus) == ngpu_here, ("GPUs used", sorted(used_gpus), "GPUs driven", ngpu_here)
+
     dt, pps, busy = timed_passes(pool, args.steps, args.min_seconds, barrier)
     if world > 1:
         tmax = torch.tensor([dt], device="cuda")
@@ -368,6 +372,8 @@ def main():
             "lz77_plan": pool.plan_stats(0),
             "per_gpu_busy_ms": [round(x, 3) for x in per_gpu_busy],
         }
+        if world == 1 and ngpu_here > 1:   # one process drives all GPUs: the last pass of each, per kernel
+            out["per_gpu_kernel_ms"] = [{k: round(v, 4) for k, v in pool.timings(g)[0].items()} for g in range(ngpu_here)]
         if sharded:
             out["lpt"] = {"loads_compressed_bytes": loads, "bound_speedup": round(sum(job_lens) / max(loads), 3) if max(loads) else float(n_gpus)}
         pool.close(); pool = None

@@ -58,14 +58,28 @@ def test_silesia_sized_12_frames_one_submit(ctx):
     _check_batch(ctx, zs, plains, oracle_on=(10, 11))
 
 
-def test_2048_single_block_frames(ctx):
-    """config 4b: thousands of block-independent frames in one submit (one unit each, one sweep step for all of them)"""
+def test_16384_single_block_frames(ctx):
+    """config 4b: tens of thousands of block-independent frames in one submit — every frame is a direct unit, resolved to bytes by the
+    flatten itself (2048 distinct frames, eight times each: 2 GiB of plaintext; every frame's bytes are compared, three with the oracle)"""
     import zgdata
     big = zgdata.text_like(256 << 20, seed=0x4B)
     plains = [big[i:i + (128 << 10)] for i in range(0, len(big), 128 << 10)]
     zs = [zgdata.zstd_compress(p) for p in plains]
     assert len(zs) == 2048
-    _check_batch(ctx, zs, plains, oracle_on=(0, 1000, 2047))
+    for f in (0, 1000, 2047):
+        assert oracle.decode_frame_all(zs[f])[0] == plains[f]
+    b = ctx.prepare(b"".join(zs) * 8)
+    assert b.parse_status == 0 and b.nframes == 16384
+    b.run()
+    b.sync()
+    assert b.bad_status == 0, (b.bad_frame, b.bad_status)
+    assert b.total_out == 8 * len(big)
+    want = [hashlib.sha256(p).digest() for p in plains]
+    for rep in range(8):
+        out = b.read(rep * len(big), len(big))
+        for f in range(2048):
+            assert hashlib.sha256(out[f << 17:(f + 1) << 17]).digest() == want[f], (rep, f)
+    b.close()
 
 
 def test_640_multi_block_frames(ctx):

@@ -366,6 +366,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   b->bb.flat_slots = (uint32_t)cus_ * (flat_shape_ == 0 ? 1u : 2u);   // zg_k_flatten: workgroups the device holds at once
   b->bb.chain_slots = (uint32_t)cus_ * 32u;                            // zg_k_seq: blocks whose chains run at once
   { const char* e = getenv("ZGPU_LIT_DIRECT"); if (e && e[0] == '0') b->bb.lit_direct_allowed = false; }
+  { const char* e = getenv("ZGPU_DIRECT_SHARE"); if (e && atoi(e) >= 10) b->bb.direct_share10 = (uint32_t)atoi(e); }   // (measurement) tenths
   b->bb.finish();
   BatchBuilder& bb = b->bb;
   Scratch* sc = b->sc = acquire();

@@ -278,7 +278,7 @@ void BatchBuilder::finish() {
     const bool direct_frame = unit_blocks == 0 && !ramp && direct_units && !fr.fixed_base && !fr.sparse && nun >= 2 && nun <= direct_max_units;
     uint32_t first_take = 0, rest_take = 0;
     if (direct_frame) {
-      first_take = (uint32_t)((fr.nblocks * 13ull + (10ull * (nun - 1) + 13) - 1) / (10ull * (nun - 1) + 13));
+      first_take = (uint32_t)(((uint64_t)fr.nblocks * direct_share10 + (10ull * (nun - 1) + direct_share10) - 1) / (10ull * (nun - 1) + direct_share10));
       if (first_take > 384) first_take = 384;
       if (first_take < ubf) first_take = ubf;
       if (first_take >= fr.nblocks) first_take = fr.nblocks;

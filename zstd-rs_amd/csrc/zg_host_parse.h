@@ -72,6 +72,7 @@ class BatchBuilder {
                                // Measured slower than flatten-then-sweep at every ramp (DESIGN.md "what did not work"), so 0 = off.
   bool ramped = false;         // finish() chose ramped units
   uint32_t direct_max_units = 32;   // ... in frames of at most this many units
+  uint32_t direct_share10 = 13;     // tenths of a share of its frame's blocks a direct first unit gets when other units follow (finish())
   uint32_t flat_slots = 256;   // workgroups of zg_k_flatten the device runs at once (engine: CUs x workgroups per CU)
   uint64_t lit_bytes = 0;      // literals arena size
   uint64_t seq_count = 0;      // sequence arena size
