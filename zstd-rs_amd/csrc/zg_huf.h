@@ -30,22 +30,19 @@
 #define ZG_HP_ROWS 48                       // symbols a lane can record per chunk (LDS, and with it the number of streams a CU decodes at once)
 #define ZG_HP_WARM 32                       // bits a lane starts above its chunk, to be on a code boundary when it enters it
 #define ZG_HP_WBYTES (64 * ZG_HP_CB / 8)    // stream bytes covered by a window
-#define ZG_HP_LOW 128                       // staged bits below the window's lowest chunk: an 11-bit peek below a chunk's end + the dwords the register window holds and requests below it
+#define ZG_HP_LOW 96                        // staged bits below the window's lowest chunk: an 11-bit peek below a chunk's end + the two dwords the register window holds below it
 #define ZG_HP_STAGE (ZG_HP_WBYTES + 64)     // staged: the window, ZG_HP_LOW bits below it, alignment slack, the dword above the entry position
 
 template <int GROUP>
 struct ZgHufLds {
   uint16_t tab[ZG_HUF_SLOT_U16];
   __attribute__((aligned(16))) uint8_t win[GROUP][ZG_HP_STAGE];
-  // A lane's symbols, four to a dword: symbol i of lane l is byte i % 4 of dword [i / 4][l] — a lane collects four symbols in a
-  // register and stores them at once (all lanes of a wave are at the same symbol count while they decode: a conflict-free store
-  // every fourth step instead of a byte store per step into dwords four lanes share). A chunk of cb bits holds at most cb
-  // symbols, but 128 rows per wave would be most of the kernel's LDS for a case that needs codes of < 3 bits on average: a
-  // window in which a chunk overflows ZG_HP_ROWS is decoded again, and the rest of the stream with it, in chunks of
-  // ZG_HP_CB_DENSE bits (which cannot overflow).
-  uint32_t sym[GROUP][ZG_HP_ROWS / 4][64];
+  // [symbol index][lane]. A chunk of cb bits holds at most cb symbols, but 128 rows per wave would be most of the kernel's LDS
+  // for a case that needs codes of < 3 bits on average: a window in which a chunk overflows ZG_HP_ROWS is decoded again,
+  // and the rest of the stream with it, in chunks of ZG_HP_CB_DENSE bits (which cannot overflow).
+  uint8_t sym[GROUP][ZG_HP_ROWS][64];
 };
-static_assert(ZG_HP_CB_DENSE <= ZG_HP_ROWS && ZG_HP_CB_DENSE <= ZG_HP_CB && ZG_HP_ROWS % 4 == 0, "the dense chunk size must fit the rows");
+static_assert(ZG_HP_CB_DENSE <= ZG_HP_ROWS && ZG_HP_CB_DENSE <= ZG_HP_CB, "the dense chunk size must fit the rows");
 static_assert(ZG_HP_WBYTES + (ZG_HP_LOW + 7) / 8 + 15 + 8 <= ZG_HP_STAGE, "staged bytes: window + low margin + alignment + the entry's dword");
 
 // The streams of a block's literals run in different waves: which error is reported must not depend on who is first.
@@ -115,7 +112,7 @@ ZX_DEV void zg_huf_group(const ZgBatchDev& d, const uint32_t gi, ZgHufLds<GROUP>
   const int64_t A = (int64_t)(uintptr_t)sp;                   // address of stream bit 0
   uint8_t* dst = direct ? d.dst + d.frame_out[blk.frame].out_base + d.pos[b].out_base + doff : d.lit_arena + blk.lit_base + doff;
   uint8_t* win = S.win[wv];
-  uint32_t* sym = &S.sym[wv][0][lane];                        // the lane's column: dword [j] at sym[64 j]
+  uint8_t* sym = &S.sym[wv][0][lane];
   const uint32_t psh = 32u - max_bits;
   int32_t top = T;                                            // true entry position of the window
   uint32_t ndone = 0;
@@ -156,11 +153,8 @@ ZX_DEV void zg_huf_group(const ZgBatchDev& d, const uint32_t gi, ZgHufLds<GROUP>
     const int32_t Us = U - wq0, Ls = L - wq0;
     auto pass = [&](int32_t from) -> int32_t {
       uint32_t ps = (uint32_t)(from - wq0);                     // >= ZG_HP_LOW + 1: the three staged dwords exist
-      const uint32_t* qa = win32 + ((ps >> 5) - 3u);            // the dword below nxt
-      uint32_t lo = qa[2], hi = qa[3];
-      qa += 1;                                                  // the dword below lo
-      uint32_t acc = 0;                                         // the last (up to four) symbols, newest in the top byte
-      // (the dword below the window is requested with every table entry and used after that entry has arrived: never waited for)
+      const uint32_t* qa = win32 + ((ps >> 5) - 2u);            // the dword below lo
+      uint32_t lo = qa[1], hi = qa[2];
 #define ZG_HUF_STEP(BODY)                                                                               \
       {                                                                                                  \
         const uint32_t nxt = *qa;                                                                        \
@@ -169,7 +163,7 @@ ZX_DEV void zg_huf_group(const ZgBatchDev& d, const uint32_t gi, ZgHufLds<GROUP>
         uint32_t nb = e >> 8;                                                                            \
         nb = nb > 1u ? nb : 1u;   /* every code has >= 1 bit; the max keeps a corrupted entry from stalling the loop */ \
         const uint32_t pn = ps - nb;                                                                     \
-        const bool need = (ps ^ pn) > 31u;                      /* the position left the upper dword: shift the window down by one */ \
+        const bool need = (ps ^ pn) > 31u;                      /* shift the window down by one dword */ \
         ps = pn;                                                                                         \
         hi = need ? lo : hi; lo = need ? nxt : lo;                                                       \
         qa -= need ? 1 : 0;                                                                              \
@@ -178,13 +172,12 @@ ZX_DEV void zg_huf_group(const ZgBatchDev& d, const uint32_t gi, ZgHufLds<GROUP>
       while ((int32_t)ps > Us) ZG_HUF_STEP(;)
       entry = (int32_t)ps + wq0;                                // where the lane's recorded symbols start
       n = 0;
-      // the chunk. Every lane that is still decoding is at the same symbol count n: every fourth step they store a dword together;
-      // a chunk with more symbols than rows keeps writing its last row and is found out by its count.
-      while ((int32_t)ps > Ls)
-        ZG_HUF_STEP(acc = zx_alignbit(e, acc, 8u); if ((n & 3u) == 3u) sym[64u * (n / 4u < ZG_HP_ROWS / 4u - 1u ? n / 4u : ZG_HP_ROWS / 4u - 1u)] = acc; n++;)
+      // (a lane collecting four symbols in a register and storing a dword every fourth step — conflict-free, a quarter of the
+      // LDS stores — measured 4 % slower, 14.50 -> 15.07 ms on 128 x 64 MiB iso-like frames: the byte stores were never the limit,
+      // the longer step is)
+      // the chunk. No branch inside: a chunk with more symbols than rows keeps writing its last row and is found out by its count.
+      while ((int32_t)ps > Ls) ZG_HUF_STEP(sym[64u * (n < ZG_HP_ROWS - 1u ? n : ZG_HP_ROWS - 1u)] = (uint8_t)e; n++;)
 #undef ZG_HUF_STEP
-      // the symbols behind the lane's last full dword (they sit in the top n % 4 bytes)
-      if (n & 3u) sym[64u * (n / 4u < ZG_HP_ROWS / 4u - 1u ? n / 4u : ZG_HP_ROWS / 4u - 1u)] = acc >> (8u * (4u - (n & 3u)));
       spill = spill || n > ZG_HP_ROWS;
       return (int32_t)ps + wq0;
     };
@@ -212,7 +205,7 @@ ZX_DEV void zg_huf_group(const ZgBatchDev& d, const uint32_t gi, ZgHufLds<GROUP>
     const uint32_t at = ndone + incl - (active ? n : 0u);
     if (active) {
       for (uint32_t i = 0; i < n; i++) {
-        if (at + i < cap) dst[at + i] = ((const uint8_t*)(sym + 64u * (i >> 2)))[i & 3u];
+        if (at + i < cap) dst[at + i] = sym[64 * i];
       }
     }
     if (ndone + wtot > cap) overflow = true;                   // more symbols than its share of the section holds
