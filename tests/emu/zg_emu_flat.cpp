@@ -35,7 +35,7 @@ extern "C" {
 //   dst_out   [total output bytes] the plaintext after the sweep
 //   og_out    [total output bytes] the flatten scratch (effective offsets; untouched words: 0xEEEEEEEE)
 //   unit_mode [units] 0 pointer, 1 no sequences, 2 direct; may be null
-// Frames marked sparse (their matches are copied in order by zg_k_sparse, no scratch) take the serial model's bytes.
+// Frames marked sparse (no scratch): zg_flat1_unit places their literal runs, a model of zg_k_sparse copies their matches in order.
 int zgemu_flatten(void* h, int shape, uint8_t* dst_out, uint32_t* og_out, uint32_t* unit_mode) {
   EmuBatch* e = (EmuBatch*)h;
   const zg::BatchBuilder& bb = e->bb;
@@ -90,8 +90,24 @@ int zgemu_flatten(void* h, int shape, uint8_t* dst_out, uint32_t* og_out, uint32
     if (un.noseq || !e->pos[un.first_block].active) continue;
     const uint64_t at = e->fout[un.frame].out_base + e->pos[un.first_block].out_base;
     const uint64_t size = uinfo[u].size;
-    if (bb.frames[un.frame].sparse || fout[un.frame].err_packed != 0xFFFFFFFFu) { memcpy(dst.data() + 256 + at, e->dst.data() + at, size); continue; }
+    if (fout[un.frame].err_packed != 0xFFFFFFFFu) { memcpy(dst.data() + 256 + at, e->dst.data() + at, size); continue; }
     uint8_t* o = dst.data() + 256 + at;
+    if (bb.frames[un.frame].sparse) {
+      // model of zg_k_sparse: zg_flat1_unit has put the literal runs in place; the matches follow in order
+      for (uint32_t k = 0; k < un.nblocks; k++) {
+        const uint32_t b = un.first_block + k;
+        const ZgBlock& blk = bb.blocks[b];
+        if (!e->pos[b].active) break;
+        if (blk.btype != ZG_BT_COMPRESSED || !blk.nseq) continue;
+        uint8_t* ob = dst.data() + 256 + e->fout[un.frame].out_base + e->pos[b].out_base;
+        for (uint32_t i = 0; i < blk.nseq; i++) {
+          const ZgSeq& q = seqs[blk.seq_base + i];
+          const uint32_t off = zg_sym_resolve(q.of, e->pos[b].hist_init), ml = ZG_SEQ_ML(q), md = ZG_SEQ_MDST(q);
+          for (uint32_t x = 0; x < ml; x++) ob[md + x] = *(ob + md + x - (int64_t)off);
+        }
+      }
+      continue;
+    }
     const uint32_t* w = og.data() + fout[un.frame].og_base + e->pos[un.first_block].out_base;
     for (uint64_t x = 0; x < size; x++) if (w[x]) o[x] = *(o + x - (int64_t)w[x]);
   }

@@ -45,6 +45,12 @@ def run_flatten(z, unit_blocks, shape):
         modes = np.zeros(nu + 1, dtype=np.uint32)
         st = L.zgemu_flatten(h, shape, dst.ctypes.data, og.ctypes.data, modes.ctypes.data)
         u4 = (C.c_uint32 * 4)()
+        f7 = (C.c_uint32 * 7)()
+        L.zgemu_frame_plan.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32 * 7)]
+        run_flatten.sparse = []
+        for f in range(L.zgemu_num_frames(h)):
+            L.zgemu_frame_plan(h, f, C.byref(f7))
+            run_flatten.sparse.append(int(f7[6]))
         units = []
         for u in range(nu):
             L.zgemu_unit(h, u, C.byref(u4))
@@ -87,6 +93,23 @@ def test_no_direct_units_every_unit_through_the_scratch():
     z = read_pack("synthetic.pack")["iso_512k_l3.zst"]
     st, got, og, units = run_flatten(z, 2, 0)
     assert st == 0 and got == oracle_plain(z)
+
+
+@pytest.mark.parametrize("shape", [0, 2])
+def test_sparse_frames_literal_runs_placed_without_tiles(shape):
+    """frames whose few matches zg_k_sparse copies in order: zg_flat1_unit checks the offsets and copies the literal runs, the whole
+    workgroup per run (a sequence or two per block) or a wave per run (one block of many sequences in a frame that is sparse on average)"""
+    import zgdata
+    rng = np.random.default_rng(77)
+    noise = rng.integers(0, 256, 30 * 131072, dtype=np.uint8).tobytes()
+    few = bytearray(zgdata.iso_like(700001, seed=5))
+    many = noise + zgdata.text_like(1500, seed=9)                # the last block: tens of short matches
+    rle_lit = noise[:131072] + b"ab" * 5 + b"\x07" * 70000 + noise[:40]   # a block with RLE or near-RLE literals and a match
+    z = zgdata.zstd_compress(bytes(few)) + zgdata.zstd_compress(many) + zgdata.zstd_compress(rle_lit)
+    st, got, og, units = run_flatten(z, 4, shape)
+    assert st == 0
+    assert run_flatten.sparse[:2] == [1, 1], run_flatten.sparse
+    assert got == bytes(few) + many + rle_lit
 
 
 def test_frames_back_to_back_at_odd_offsets():

@@ -97,6 +97,38 @@ ZX_DEV void zg_flat1_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat1Lds<T, 
     const uint64_t reach = p.out_base + frr.prior_reach + (frr.prior_reach == frr.prior_out ? frr.dict_len : 0ull);
     const bool reach_all = reach >= 0x80000000ull;
     const uint32_t reach32 = (uint32_t)reach;
+    if (no_scratch) {
+      // A frame whose matches zg_k_sparse copies in order (literal-heavy data: a sequence or two in one block out of ten). What is
+      // left to do here is to check the offsets and to put the literal runs in place: plain copies, no tiles (through the tile
+      // machinery a block costs 8 x 13 us whatever it holds; measured on 128 x 64 MiB iso-like frames, 2.4 of the pass's 17 ms).
+      // Runs are few and long: the whole workgroup copies one run after the other; a block of many runs (the frame is sparse on
+      // average only) spreads them over its waves. Run i = the literals in front of sequence i; run nseq = the trailing ones.
+      const bool wide = nseq + 1u <= 2u * (T / 64);
+      const uint32_t x0 = wide ? t : (t & 63u), step = wide ? (uint32_t)T : 64u;
+      for (uint32_t i = wide ? 0u : (t >> 6); i <= nseq; i += wide ? 1u : (uint32_t)(T / 64)) {
+        uint32_t lstart = so.sum_ll, a = so.sum_ll + so.sum_ml, m0 = S;
+        if (i < nseq) {
+          const ZxU3 r = zx_ld96(seq_rs, 12u * i);
+          const uint32_t next = i + 1 < nseq ? zx_ld32(seq_rs, 12u * i + 20u) & 0x1FFFFu : so.sum_ll;
+          lstart = r.z & 0x1FFFFu; m0 = r.y & 0x1FFFFu;
+          a = m0 - ((next - lstart) & 0x1FFFFu);
+          const uint32_t off = zg_sym_resolve(r.x, p.hist_init);
+          if (x0 == 0) {                             // the same verdicts as S1a below
+            if (off == 0) zx_min_lds64(&L.bad, ((unsigned long long)i << 32) | (m0 << 8) | (uint32_t)ZG_EXE_ZERO_OFFSET);
+            else if ((!reach_all && off > reach32 + m0) || off >= ZG_OFF_HUGE - 2u) zx_min_lds64(&L.bad, ((unsigned long long)i << 32) | (m0 << 8) | (uint32_t)ZG_EXE_OFFSET_TOO_BIG);
+          }
+        }
+        const uint32_t len = m0 - a;
+        for (uint32_t x = x0; x < len; x += 8u * step) {   // eight bytes per thread in flight
+          uint32_t v[8];
+#pragma unroll
+          for (int h = 0; h < 8; h++) v[h] = zx_ld8(lit_rs, x + h * step < len ? lstart + x + h * step : ZX_OOB);
+#pragma unroll
+          for (int h = 0; h < 8; h++) zx_st8(out_rs, x + h * step < len ? bu0 + a + x + h * step : ZX_OOB, (uint8_t)(v[h] | lit_fill));
+        }
+      }
+      zx_barrier();
+    }
     // the sequences a thread places per tile travel in registers: they are requested one tile ahead
     ZxU3 q[SPT];
     uint32_t qn[SPT];                               // third word of the record behind q (its literal index)
@@ -110,7 +142,7 @@ ZX_DEV void zg_flat1_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat1Lds<T, 
     };
     fetch(0);
     uint32_t i_start = 0;
-    for (uint32_t t0 = 0; t0 < S;) {
+    for (uint32_t t0 = no_scratch ? S : 0u; t0 < S;) {   // (a sparse frame's block is done: only the verdict below is left)
       const uint32_t t1o = t0 + TS < S ? t0 + TS : S;            // where the tile ends unless it holds too many sequences
       if (t == 0) { L.next = 0xFFFFFFFFu; L.cut = 0xFFFFFFFFu; }
       if (t < NW) L.bits[t] = 0;

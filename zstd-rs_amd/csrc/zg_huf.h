@@ -28,7 +28,9 @@
 #define ZG_HP_CB 128                        // bits per lane and window ...
 #define ZG_HP_CB_DENSE 32                   // ... or this many, once a chunk held more than ZG_HP_ROWS symbols
 #define ZG_HP_ROWS 48                       // symbols a lane can record per chunk (LDS, and with it the number of streams a CU decodes at once)
-#define ZG_HP_WARM 32                       // bits a lane starts above its chunk, to be on a code boundary when it enters it
+#ifndef ZG_HP_WARM
+#define ZG_HP_WARM 32                       // bits a lane starts above its chunk, to be on a code boundary when it enters it (<= ZG_HP_CB: they are staged)
+#endif
 #define ZG_HP_WBYTES (64 * ZG_HP_CB / 8)    // stream bytes covered by a window
 #define ZG_HP_LOW 96                        // staged bits below the window's lowest chunk: an 11-bit peek below a chunk's end + the two dwords the register window holds below it
 #define ZG_HP_STAGE (ZG_HP_WBYTES + 64)     // staged: the window, ZG_HP_LOW bits below it, alignment slack, the dword above the entry position
@@ -42,7 +44,7 @@ struct ZgHufLds {
   // and the rest of the stream with it, in chunks of ZG_HP_CB_DENSE bits (which cannot overflow).
   uint8_t sym[GROUP][ZG_HP_ROWS][64];
 };
-static_assert(ZG_HP_CB_DENSE <= ZG_HP_ROWS && ZG_HP_CB_DENSE <= ZG_HP_CB, "the dense chunk size must fit the rows");
+static_assert(ZG_HP_WARM <= ZG_HP_CB && ZG_HP_CB_DENSE <= ZG_HP_ROWS && ZG_HP_CB_DENSE <= ZG_HP_CB, "the dense chunk size must fit the rows");
 static_assert(ZG_HP_WBYTES + (ZG_HP_LOW + 7) / 8 + 15 + 8 <= ZG_HP_STAGE, "staged bytes: window + low margin + alignment + the entry's dword");
 
 // The streams of a block's literals run in different waves: which error is reported must not depend on who is first.
@@ -183,7 +185,7 @@ ZX_DEV void zg_huf_group(const ZgBatchDev& d, const uint32_t gi, ZgHufLds<GROUP>
     };
     const bool active = U > 0;
     int32_t E = U;
-    if (active) E = pass(lane ? U + ZG_HP_WARM : U);           // lane 0 starts at the true position
+    if (active) E = pass(lane ? U + (cb < ZG_HP_WARM ? cb : ZG_HP_WARM) : U);   // lane 0 starts at the true position; nobody above the window's entry
     for (int round = 0; round < 64; round++) {
       const int32_t pe = (int32_t)zx_shfl_up((uint32_t)E, 1);
       const bool need = active && lane > 0 && pe != entry;
