@@ -125,6 +125,7 @@ static inline void zx_gst128(void* p, const ZxU4& v) {
   if ((uintptr_t)p % 16) { fprintf(stderr, "simt: misaligned 16-byte global store\n"); abort(); }
   memcpy(p, &v, 16);
 }
+static inline void zx_gst32u(void* p, uint32_t v) { memcpy(p, &v, 4); }
 static inline ZxU4 zx_gld128(const void* p) {
   if ((uintptr_t)p % 16) { fprintf(stderr, "simt: misaligned 16-byte global load\n"); abort(); }
   ZxU4 r; memcpy(&r, p, 16); return r;

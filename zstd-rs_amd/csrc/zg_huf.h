@@ -35,16 +35,26 @@
 #define ZG_HP_LOW 96                        // staged bits below the window's lowest chunk: an 11-bit peek below a chunk's end + the two dwords the register window holds below it
 #define ZG_HP_STAGE (ZG_HP_WBYTES + 64)     // staged: the window, ZG_HP_LOW bits below it, alignment slack, the dword above the entry position
 
+// (measurement on the CPU emulator only, tools/dev/huf_passes.py: windows, passes, wave steps = the busiest lane's per pass, lane steps)
+#ifdef ZG_HUF_STATS
+extern "C" unsigned long long zg_huf_stats[8];
+#define ZG_HUF_STAT(x) x
+#else
+#define ZG_HUF_STAT(x)
+#endif
+
 template <int GROUP>
 struct ZgHufLds {
   uint16_t tab[ZG_HUF_SLOT_U16];
   __attribute__((aligned(16))) uint8_t win[GROUP][ZG_HP_STAGE];
-  // [symbol index][lane]. A chunk of cb bits holds at most cb symbols, but 128 rows per wave would be most of the kernel's LDS
-  // for a case that needs codes of < 3 bits on average: a window in which a chunk overflows ZG_HP_ROWS is decoded again,
-  // and the rest of the stream with it, in chunks of ZG_HP_CB_DENSE bits (which cannot overflow).
-  uint8_t sym[GROUP][ZG_HP_ROWS][64];
+  // A lane's symbols, four to a dword: symbol i of lane l is byte i % 4 of dword [i / 4][l]. A lane collects four symbols in a
+  // register and stores them at once (all lanes of a wave are at the same symbol count while they decode), and the output loop
+  // moves a dword per iteration. A chunk of cb bits holds at most cb symbols, but 128 rows per wave would be most of the kernel's
+  // LDS for a case that needs codes of < 3 bits on average: a window in which a chunk overflows ZG_HP_ROWS is decoded again, and
+  // the rest of the stream with it, in chunks of ZG_HP_CB_DENSE bits (which cannot overflow).
+  uint32_t sym[GROUP][ZG_HP_ROWS / 4][64];
 };
-static_assert(ZG_HP_WARM <= ZG_HP_CB && ZG_HP_CB_DENSE <= ZG_HP_ROWS && ZG_HP_CB_DENSE <= ZG_HP_CB, "the dense chunk size must fit the rows");
+static_assert(ZG_HP_WARM <= ZG_HP_CB && ZG_HP_CB_DENSE <= ZG_HP_ROWS && ZG_HP_CB_DENSE <= ZG_HP_CB && ZG_HP_ROWS % 4 == 0, "the dense chunk size must fit the rows");
 static_assert(ZG_HP_WBYTES + (ZG_HP_LOW + 7) / 8 + 15 + 8 <= ZG_HP_STAGE, "staged bytes: window + low margin + alignment + the entry's dword");
 
 // The streams of a block's literals run in different waves: which error is reported must not depend on who is first.
@@ -114,7 +124,7 @@ ZX_DEV void zg_huf_group(const ZgBatchDev& d, const uint32_t gi, ZgHufLds<GROUP>
   const int64_t A = (int64_t)(uintptr_t)sp;                   // address of stream bit 0
   uint8_t* dst = direct ? d.dst + d.frame_out[blk.frame].out_base + d.pos[b].out_base + doff : d.lit_arena + blk.lit_base + doff;
   uint8_t* win = S.win[wv];
-  uint8_t* sym = &S.sym[wv][0][lane];
+  uint32_t* sym = &S.sym[wv][0][lane];                        // the lane's column: dword [j] at sym[64 j]
   const uint32_t psh = 32u - max_bits;
   int32_t top = T;                                            // true entry position of the window
   uint32_t ndone = 0;
@@ -157,6 +167,7 @@ ZX_DEV void zg_huf_group(const ZgBatchDev& d, const uint32_t gi, ZgHufLds<GROUP>
       uint32_t ps = (uint32_t)(from - wq0);                     // >= ZG_HP_LOW + 1: the three staged dwords exist
       const uint32_t* qa = win32 + ((ps >> 5) - 2u);            // the dword below lo
       uint32_t lo = qa[1], hi = qa[2];
+      uint32_t acc = 0;                                         // the last (up to four) symbols, newest in the top byte
 #define ZG_HUF_STEP(BODY)                                                                               \
       {                                                                                                  \
         const uint32_t nxt = *qa;                                                                        \
@@ -171,15 +182,20 @@ ZX_DEV void zg_huf_group(const ZgBatchDev& d, const uint32_t gi, ZgHufLds<GROUP>
         qa -= need ? 1 : 0;                                                                              \
       }
       // the warm-up above the chunk: nothing is recorded (a loop of its own: its step is a third shorter than a recording one)
-      while ((int32_t)ps > Us) ZG_HUF_STEP(;)
+      ZG_HUF_STAT(unsigned long long steps_ = 0;)
+      while ((int32_t)ps > Us) ZG_HUF_STEP(ZG_HUF_STAT(steps_++;))
       entry = (int32_t)ps + wq0;                                // where the lane's recorded symbols start
       n = 0;
-      // (a lane collecting four symbols in a register and storing a dword every fourth step — conflict-free, a quarter of the
-      // LDS stores — measured 4 % slower, 14.50 -> 15.07 ms on 128 x 64 MiB iso-like frames: the byte stores were never the limit,
-      // the longer step is)
-      // the chunk. No branch inside: a chunk with more symbols than rows keeps writing its last row and is found out by its count.
-      while ((int32_t)ps > Ls) ZG_HUF_STEP(sym[64u * (n < ZG_HP_ROWS - 1u ? n : ZG_HP_ROWS - 1u)] = (uint8_t)e; n++;)
+      // the chunk. Every lane that is still decoding is at the same symbol count n: every fourth step they store a dword together;
+      // a chunk with more symbols than rows keeps writing its last row and is found out by its count. (With a byte store per
+      // symbol the step is two instructions shorter — measured 4 % faster on its own — but the output loop below then moves a
+      // byte per iteration, and that loop was a fifth of the kernel's instructions.)
+      while ((int32_t)ps > Ls)
+        ZG_HUF_STEP(acc = zx_alignbit(e, acc, 8u); if ((n & 3u) == 3u) sym[64u * (n / 4u < ZG_HP_ROWS / 4u - 1u ? n / 4u : ZG_HP_ROWS / 4u - 1u)] = acc; n++; ZG_HUF_STAT(steps_++;))
 #undef ZG_HUF_STEP
+      // the symbols behind the lane's last full dword (they sit in the top n % 4 bytes)
+      if (n & 3u) sym[64u * (n / 4u < ZG_HP_ROWS / 4u - 1u ? n / 4u : ZG_HP_ROWS / 4u - 1u)] = acc >> (8u * (4u - (n & 3u)));
+      ZG_HUF_STAT(zg_huf_stats[3] += steps_; if (steps_ > zg_huf_stats[7]) zg_huf_stats[7] = steps_;)
       spill = spill || n > ZG_HP_ROWS;
       return (int32_t)ps + wq0;
     };
@@ -189,6 +205,7 @@ ZX_DEV void zg_huf_group(const ZgBatchDev& d, const uint32_t gi, ZgHufLds<GROUP>
     for (int round = 0; round < 64; round++) {
       const int32_t pe = (int32_t)zx_shfl_up((uint32_t)E, 1);
       const bool need = active && lane > 0 && pe != entry;
+      ZG_HUF_STAT(if (lane == 0) { zg_huf_stats[1]++; zg_huf_stats[2] += zg_huf_stats[7]; zg_huf_stats[7] = 0; if (round == 0) zg_huf_stats[0]++; } if (need) zg_huf_stats[4]++;)
       if (!zx_any(need)) break;
       if (need) E = pass(pe);
     }
@@ -206,8 +223,15 @@ ZX_DEV void zg_huf_group(const ZgBatchDev& d, const uint32_t gi, ZgHufLds<GROUP>
     //  LDS, i.e. waves per CU)
     const uint32_t at = ndone + incl - (active ? n : 0u);
     if (active) {
-      for (uint32_t i = 0; i < n; i++) {
-        if (at + i < cap) dst[at + i] = sym[64 * i];
+      // four symbols per iteration: one (unaligned) dword store where all four are symbols and inside the stream's share
+      const uint32_t room = at < cap ? cap - at : 0u, m = n < room ? n : room;
+      uint32_t i = 0;
+      for (; i + 4u <= m; i += 4u) zx_gst32u(dst + at + i, sym[16u * i]);
+      if (i < m) {
+        const uint32_t v = sym[16u * i];
+        dst[at + i] = (uint8_t)v;                                // (one to three symbols; written out, or the compiler builds a vector loop for them)
+        if (i + 1u < m) dst[at + i + 1u] = (uint8_t)(v >> 8);
+        if (i + 2u < m) dst[at + i + 2u] = (uint8_t)(v >> 16);
       }
     }
     if (ndone + wtot > cap) overflow = true;                   // more symbols than its share of the section holds
