@@ -52,7 +52,7 @@ ZX_DEV void zg_flat1_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat1Lds<T, 
   const bool no_scratch = d.frames[un.frame].sparse != 0u;
   // (timing experiments, ZGPU_FLAT_MODE: bit 0 drops the scratch stores, bit 1 the cross-tile scratch gathers — wrong results, what is
   //  left is what the kernel costs without that traffic)
-  const uint32_t fdbg = (d.flags >> 4) & 3u;
+  const uint32_t fdbg = ((d.flags >> 4) & 3u) | ((d.flags >> 5) & 4u);   // (bit 2, flag bit 7: S3b without the literal bytes' loads and stores)
   if (t == 0) { L.err = 0; L.bad = ~0ull; }
   uint32_t unit_size = 0;
 #if defined(ZG_PROFILE_FLAT) && defined(__HIPCC__)   // per-phase cycle counters (tools/dev/flat_phases.py); costs registers, off in the product build
@@ -316,13 +316,13 @@ ZX_DEV void zg_flat1_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat1Lds<T, 
           const uint32_t r = pr[h] >= ZG_PAR_EXIT ? x : pr[h];
           const uint32_t e = ((w[h] >> 31) ? 0u : w[h]) + (x - r);
           const bool isl = pr[h] == ZG_PAR_LIT;                           // a literal byte: w carries where its value is
-          lb[h] = zx_ld8(lit_rs, isl ? w[h] & 0x7FFFFFFFu : ZX_OOB);
+          lb[h] = (fdbg & 4u) ? 0u : zx_ld8(lit_rs, isl ? w[h] & 0x7FFFFFFFu : ZX_OOB);
           da[h] = isl ? ux : ZX_OOB;                                      // where its value goes
           zx_st32(og_rs, 4u * ux, e);
         }
 #pragma unroll
         for (int h = 0; h < H; h++)   // (lb[0] was requested last)
-          zx_st8(out_rs, da[h], (uint8_t)(lb[h] | lit_fill));
+          if (!(fdbg & 4u)) zx_st8(out_rs, da[h], (uint8_t)(lb[h] | lit_fill));
       }
       zx_barrier();  // L.par / L.word / the records are reused by the next tile
       ZG_TICK(5)

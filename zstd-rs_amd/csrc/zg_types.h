@@ -257,7 +257,7 @@ struct ZgBatchDev {
   uint32_t* totals;            // [4]: [0..1] total output bytes (u64), [2] overflow flag, [3] a match reaches further back than its frame's window (zg_k_seqpost)
   uint32_t sweep_window;       // 0: a frame's window size bounds its matches (checked); else this many bytes instead (tests)
   uint32_t flags;              // bit 0: force the in-order fallback for every frame (tests); bits 2-3: shape of zg_k_flatten (0: 1024 threads x 16 KiB tiles, 1: 512 x 8 KiB);
-                               // bits 4-5: timing experiments of zg_k_flatten; bit 6: ZG_FLAG_LIT_DIRECT
+                               // bits 4-5, 7: timing experiments of zg_k_flatten; bit 6: ZG_FLAG_LIT_DIRECT
   uint64_t og_words;           // size of the flatten scratch in u32
   uint32_t* og;                // flatten scratch: one u32 "effective offset" per output byte of a unit (0 = literal byte, final already)
   const ZgUnit* units;
