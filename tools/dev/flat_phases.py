@@ -7,7 +7,7 @@ os.environ['ZGPU_DEBUG_TIMERS'] = '1'
 import zgdata, zgpu
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 256 << 20
 d = zgdata.text_like(size); z = zgdata.zstd_compress(d)
-for var in ("512", "1024", "8"):
+for var in (sys.argv[2:] or ["1024"]):
     os.environ["ZGPU_FLAT_T"] = var
     c = zgpu.Context(0); b = c.prepare(z)
     for _ in range(2): b.run(); b.sync()

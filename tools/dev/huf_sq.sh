@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, GPU call 13: what zg_k_huf waits for (SQ counters on 1 GiB of iso-like frames)
+# what zg_k_huf waits for (SQ counters on 1 GiB of iso-like frames)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT; mkdir -p gpurun_out/huf_sq
 cd /tmp && export TMPDIR=/tmp

@@ -56,8 +56,8 @@ ZX_DEV void zg_flat1_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat1Lds<T, 
   if (t == 0) { L.err = 0; L.bad = ~0ull; }
   uint32_t unit_size = 0;
 #if defined(ZG_PROFILE_FLAT) && defined(__HIPCC__)   // per-phase cycle counters (tools/dev/flat_phases.py); costs registers, off in the product build
-  unsigned long long tc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
-#define ZG_TICK(i) { const unsigned long long n_ = clock64(); tc[i] += n_ - tlast; tlast = n_; }
+  unsigned long long ptc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+#define ZG_TICK(i) { const unsigned long long n_ = clock64(); ptc[i] += n_ - tlast; tlast = n_; }
 #else
 #define ZG_TICK(i)
 #endif
@@ -347,7 +347,7 @@ ZX_DEV void zg_flat1_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat1Lds<T, 
   zx_barrier_vm();
   if (t == 0) { d.unit_info[ui].size = unit_size; d.unit_info[ui].noseq = un.noseq; }
 #if defined(ZG_PROFILE_FLAT) && defined(__HIPCC__)
-  if (t == 0 && d.dbg) { for (int i = 0; i < 8; i++) atomicAdd(&d.dbg[i], tc[i]); }
+  if (t == 0 && d.dbg) { for (int i = 0; i < 8; i++) atomicAdd(&d.dbg[i], ptc[i]); }
 #endif
 #undef ZG_TICK
 }
