@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, final: profiles of every workload (tools/dev/profile.sh), then the default bench line
+# end of a round: profiles of every workload (tools/dev/profile.sh), then the default bench line
 cd ${GRAFT_REPO_ROOT:-.}
 bash tools/dev/profile.sh > gpurun_out/profile_sh.log 2>&1
 tail -8 gpurun_out/profile_sh.log | cut -c1-200
