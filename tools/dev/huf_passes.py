@@ -10,6 +10,7 @@ kind = sys.argv[1] if len(sys.argv) > 1 else "iso"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4 << 20
 emu_dir = os.path.join(ROOT, "tests", "emu")
 so = "/tmp/libzg_emu_stats.so"
+open("/tmp/zg_huf_stats.c", "w").write("unsigned long long zg_huf_stats[8];\n")
 subprocess.check_call("g++ -O2 -std=c++17 -fPIC -shared -DZG_HUF_STATS=1 %s -Wno-unknown-pragmas -fno-strict-aliasing -o %s zg_emu.cpp zg_emu_flat.cpp zg_emu_exact.cpp zg_emu_huf.cpp "
                       "../../zstd-rs_amd/csrc/zg_host_parse.cpp /tmp/zg_huf_stats.c" % (os.environ.get("EXTRA", ""), so), shell=True, cwd=emu_dir)
 L = C.CDLL(so)
