@@ -112,6 +112,22 @@ def test_sparse_frames_literal_runs_placed_without_tiles(shape):
     assert got == bytes(few) + many + rle_lit
 
 
+def test_sparse_frames_offsets_are_checked_without_tiles():
+    """hand-made frames of raw blocks and one-sequence blocks (sparse by construction): an offset that reaches in front of the frame is
+    found by the run-by-run path of zg_flat1_unit with the oracle's verdict, one that does not decodes to the oracle's bytes"""
+    import oracle
+    import test_exact_cpu as X
+    good = X.frame(X.raw_block(3000), X.seq_block(100), X.raw_block(500, seed=3), X.seq_block(3000, last=True))
+    bad = X.frame(X.raw_block(3000), X.seq_block(100), X.raw_block(500, seed=3), X.seq_block(70000, last=True))
+    zero = X.frame(X.raw_block(3000), X.seq_block(100), X.seq_block(3604 + 7, last=True))          # exactly one byte too far
+    for shape in (0, 2):
+        st, got, og, units = run_flatten(good, 4, shape)
+        assert run_flatten.sparse == [1] and st == 0 and got == oracle.FrameDecoder().decode_all(good, 1 << 26)[1]
+        for z in (bad, zero):
+            st, got, og, units = run_flatten(z, 4, shape)
+            assert run_flatten.sparse == [1] and st != 0 and st == X.oracle_all(z), (st, X.oracle_all(z))
+
+
 def test_frames_back_to_back_at_odd_offsets():
     import zgdata
     parts = [zgdata.text_like(300001 + 1237 * i + (i % 4), seed=177 + i) for i in range(4)]
