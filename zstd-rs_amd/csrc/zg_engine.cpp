@@ -457,7 +457,6 @@ int Batch::run() {
     d.dst_cap_pre = declared_total ? declared_total : 1;   // (0 means "not sized in advance")
     presized = true;
   }
-  if (start_after) ZG_HIP(hipStreamWaitEvent(s, start_after, 0));   // (the second stream forks from this one below)
   ZG_HIP(hipEventRecord(ev[0], s));
   ZG_HIP(hipMemsetAsync(d.status, 0, 3 * ((size_t)d.nblocks * 4 + 16), s));
   ZG_HIP(hipMemsetAsync(d.huf_maxbits, 0, d.nhuf_slots + 16, s));
@@ -552,8 +551,6 @@ int Batch::size_output() {
   d.og_words = og_words;
   return ZG_OK;
 }
-
-hipEvent_t Batch::flat_done_event() const { return sc->ev[7]; }
 
 int Batch::launch_phase2() {
   hipStream_t s = eng->stream_;

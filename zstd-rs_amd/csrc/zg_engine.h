@@ -101,10 +101,6 @@ class Batch {
   // stages and the scan run first; the host reads the exact output size of every frame, sizes the output and the flatten
   // scratch to it, and then enqueues the LZ77 stages. Returns when the second phase is enqueued.
   int run();
-  // (pipelined jobs of one GPU, zg_pool.cpp) the run starts on the device once this event of ANOTHER batch has happened; that batch's
-  // run() must have returned before this one's is called. nullptr: start at once.
-  hipEvent_t start_after = nullptr;
-  hipEvent_t flat_done_event() const;    // recorded by run() behind the flatten (before the sweep)
   // streaming submits: after sync(), fold this run into the frame's carried state (tables, history, produced bytes)
   int commit(FrameState* fs);
   bool saw_last_block = false;           // the run ended with the frame's last block

@@ -264,32 +264,7 @@ int zgpu_pool_run(zgpu_pool* p, float* gpu_ms, float* wall_ms) {
     }
     if (any) lane_ms[w] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - a).count();
   };
-  // (measurement, ZGPU_POOL_PIPE=1) the jobs of a GPU as a pipeline: job k + 1 starts on the device when job k's flatten is done, so its
-  // sequence chains (LDS and latency, hardly any memory traffic) run beside job k's sweep (memory, no LDS) and beside nothing else.
-  // One thread per GPU enqueues its jobs in order, then waits for them.
-  const char* pe = getenv("ZGPU_POOL_PIPE");
-  const bool pipe = pe && pe[0] == '1' && p->staged.size() > 1;
-  auto pass_pipe = [&](uint32_t w) {
-    if (w >= nw) return;                                   // lane 0's worker drives the GPU
-    auto a = std::chrono::steady_clock::now();
-    Batch* prev = nullptr;
-    bool any = false;
-    for (Staged& s : p->staged) {
-      if (s.gpu != w || !s.batch) continue;
-      s.batch->start_after = prev ? prev->flat_done_event() : nullptr;
-      s.status = s.batch->run();
-      prev = s.status ? nullptr : s.batch;
-      any = true;
-    }
-    for (Staged& s : p->staged) {
-      if (s.gpu != w || !s.batch) continue;
-      if (!s.status) s.status = s.batch->sync();
-      s.batch->start_after = nullptr;
-    }
-    if (any) lane_ms[w] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - a).count();
-  };
   if (p->staged.size() == 1) pass(p->staged[0].lane * nw + p->staged[0].gpu);      // one job: on the caller's thread
-  else if (pipe) p->run_on_workers(pass_pipe);
   else p->run_on_workers(pass);
   if (wall_ms) *wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   int st = 0;
