@@ -9,7 +9,6 @@
 #include "zg_simt.h"
 #include "../../zstd-rs_amd/csrc/zg_flat4.h"
 #include "../../zstd-rs_amd/csrc/zg_flat1.h"
-#include "../../zstd-rs_amd/csrc/zg_flat5.h"
 #include "zg_emu_batch.h"
 
 namespace {
@@ -26,12 +25,6 @@ void run_unit1(const ZgBatchDev& d, uint32_t ui) {
   simt::run(T, [&]() { zg_flat1_unit<T, TS, SPT>(d, ui, L); });
 }
 
-template <int T, int TS, int SPT>
-void run_unit5(const ZgBatchDev& d, uint32_t ui) {
-  static ZgFlat5Lds<T, TS, SPT> L;
-  simt::run(T, [&]() { zg_flat5_unit<T, TS, SPT>(d, ui, L); });
-}
-
 }  // namespace
 
 extern "C" {
@@ -43,9 +36,7 @@ extern "C" {
 //   og_out    [total output bytes] the flatten scratch (effective offsets; untouched words: 0xEEEEEEEE)
 //   unit_mode [units] 0 pointer, 1 no sequences, 2 direct; may be null
 // Frames marked sparse (no scratch): zg_flat1_unit places their literal runs, a model of zg_k_sparse copies their matches in order.
-int zgemu_flatten(void* h, int shape_in, uint8_t* dst_out, uint32_t* og_out, uint32_t* unit_mode) {
-  const int shape = shape_in & 15;
-  const bool hybrid = (shape_in & 16) != 0;      // pointer-mode units through zg_flat5_unit instead of zg_flat1_unit
+int zgemu_flatten(void* h, int shape, uint8_t* dst_out, uint32_t* og_out, uint32_t* unit_mode) {
   EmuBatch* e = (EmuBatch*)h;
   const zg::BatchBuilder& bb = e->bb;
   const uint32_t nb = (uint32_t)bb.blocks.size(), nf = (uint32_t)bb.frames.size(), nu = (uint32_t)bb.units.size();
@@ -85,11 +76,6 @@ int zgemu_flatten(void* h, int shape_in, uint8_t* dst_out, uint32_t* og_out, uin
       if (shape == 0) run_unit<256, 4096, 2>(d, u);
       else if (shape == 1) run_unit<512, 8192, 2>(d, u);
       else if (shape == 2) run_unit<1024, 16384, 2>(d, u);
-      else return -1;
-    } else if (hybrid && !bb.frames[un.frame].sparse) {       // (experiment: zg_flat5.h, the pointer-mode body at dword granularity)
-      if (shape == 0) run_unit5<256, 4096, 2>(d, u);
-      else if (shape == 1) run_unit5<512, 8192, 2>(d, u);
-      else if (shape == 2) run_unit5<1024, 16384, 2>(d, u);
       else return -1;
     } else {
       if (shape == 0) run_unit1<256, 4096, 2>(d, u);

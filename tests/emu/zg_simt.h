@@ -146,8 +146,6 @@ static inline ZxU3 zx_ld96(const ZxBuf& b, uint32_t off) { ZX_ALIGNED(off, 4); Z
 static inline uint32_t zx_ld8(const ZxBuf& b, uint32_t off) { return off < b.bytes ? b.base[off] : 0u; }
 static inline void zx_add_lds(uint32_t* p, uint32_t v) { *p += v; }
 static inline void zx_st8(const ZxBuf& b, uint32_t off, uint32_t v) { if (off < b.bytes) b.base[off] = (uint8_t)v; }
-static inline ZxU4 zx_ld128(const ZxBuf& b, uint32_t off) { ZX_ALIGNED(off, 4); ZxU4 r; r.x = zx__dw(b, off); r.y = zx__dw(b, (uint64_t)off + 4); r.z = zx__dw(b, (uint64_t)off + 8); r.w = zx__dw(b, (uint64_t)off + 12); return r; }
-static inline void zx_st128(const ZxBuf& b, uint32_t off, const ZxU4& v) { ZX_ALIGNED(off, 4); const uint32_t w[4] = {v.x, v.y, v.z, v.w}; for (int i = 0; i < 4; i++) if ((uint64_t)off + 4 * i + 4 <= b.bytes) memcpy(b.base + off + 4 * i, &w[i], 4); }
 static inline void zx_st32(const ZxBuf& b, uint32_t off, uint32_t v) { ZX_ALIGNED(off, 4); if ((uint64_t)off + 4 <= b.bytes) memcpy(b.base + off, &v, 4); }
 static inline uint32_t zx_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sh & 31u)); }
 // packed 16-bit lanes: a - b per lane; 0xFFFF per lane whose signed value is negative

@@ -433,7 +433,6 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   d.dbg = getenv("ZGPU_DEBUG_TIMERS") ? sc->d_dbg.as<unsigned long long>() : nullptr;
   { const char* e = getenv("ZGPU_FORCE_INORDER"); d.flags = (e && e[0] == '1') ? 1u : 0u; }
   d.flags |= (uint32_t)flat_shape_ << 2;
-  { const char* e = getenv("ZGPU_FLAT5"); if (e && e[0] == '1') d.flags |= ZG_FLAG_FLAT5; }   // (experiment) zg_flat5.h for pointer-mode units
   { const char* e = getenv("ZGPU_FLAT_MODE"); if (e) d.flags |= (((uint32_t)atoi(e) & 3u) << 4) | (((uint32_t)atoi(e) & 4u) << 5); }   // (timing experiments) zg_k_flatten without scratch stores / gathers
   { const char* e = getenv("ZGPU_SWEEP_W"); d.sweep_window = (e && atoi(e) > 0) ? (uint32_t)atoi(e) : 0u; }
   if (hipStreamSynchronize(stream_) != hipSuccess) { delete b; return ZG_HIP_ERROR; }

@@ -108,8 +108,6 @@ ZX_DEV ZxU3 zx_ld96(ZxBuf b, uint32_t off) { const zg_v3u v = __builtin_amdgcn_r
 ZX_DEV uint32_t zx_ld8(ZxBuf b, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b8(b, off, 0, 0); }
 ZX_DEV void zx_add_lds(uint32_t* p, uint32_t v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // ds_add_u32
 ZX_DEV void zx_st8(ZxBuf b, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v, b, off, 0, 0); }
-ZX_DEV ZxU4 zx_ld128(ZxBuf b, uint32_t off) { const zg_v4u v = __builtin_amdgcn_raw_buffer_load_b128(b, off, 0, 0); ZxU4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
-ZX_DEV void zx_st128(ZxBuf b, uint32_t off, const ZxU4& v) { const zg_v4u w = {v.x, v.y, v.z, v.w}; __builtin_amdgcn_raw_buffer_store_b128(w, b, off, 0, 0); }
 ZX_DEV void zx_st32(ZxBuf b, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, b, off, 0, 0); }
 ZX_DEV uint32_t zx_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 typedef short zg_v2s __attribute__((ext_vector_type(2)));
@@ -1282,7 +1280,6 @@ __global__ void __launch_bounds__(256) zg_k_lit(ZgBatchDev d) {
 // zg_flat4.h, written against the zx_* primitives above so that tests/emu runs the same source on the CPU.
 // ------------------------------------------------------------------------------------------------------------
 #include "zg_flat4.h"
-#include "zg_flat5.h"   // (experiment) the pointer-mode body at dword granularity
 
 // everything a sweep workgroup needs to know about its unit, in one 32-byte descriptor
 __device__ __forceinline__ ZgSweepDesc zg_sweep_desc(const ZgBatchDev& d, uint32_t u, uint32_t size) {
@@ -1307,10 +1304,9 @@ __device__ __forceinline__ ZgSweepDesc zg_sweep_desc(const ZgBatchDev& d, uint32
 // lasts as long as its busiest lane), so it is used where it wins: where values can flow.
 template <int T, int TS, int SPT>
 __global__ void __launch_bounds__(T, 4) zg_k_flatten(ZgBatchDev d) {
-  __shared__ union { ZgFlat1Lds<T, TS, SPT> p; ZgFlat4Lds<T, TS, SPT> v; ZgFlat5Lds<T, TS, SPT> h; } s_u;
+  __shared__ union { ZgFlat1Lds<T, TS, SPT> p; ZgFlat4Lds<T, TS, SPT> v; } s_u;
   if (threadIdx.x == 0) { d.unit_info[blockIdx.x].size = 0; d.unit_info[blockIdx.x].noseq = 0; }
   if (d.units[blockIdx.x].noseq & ZG_UNIT_DIRECT) zg_flat4_unit<T, TS, SPT>(d, blockIdx.x, s_u.v);
-  else if ((d.flags & ZG_FLAG_FLAT5) && !d.frames[d.units[blockIdx.x].frame].sparse) zg_flat5_unit<T, TS, SPT>(d, blockIdx.x, s_u.h);
   else zg_flat1_unit<T, TS, SPT>(d, blockIdx.x, s_u.p);
   // The sweep chain runs beside this kernel (one long frame in units that grow along it: see BatchBuilder::finish): the unit is
   // handed to its sweep step here — descriptor, then everything this workgroup wrote made visible to the whole device (release),

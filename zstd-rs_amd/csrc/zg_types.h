@@ -219,7 +219,6 @@ struct __attribute__((aligned(16))) ZxU4 { uint32_t x, y, z, w; };
 // The Huffman literals are decoded AFTER the position scan (literal-heavy submits, chosen by the host): the literals of a block
 // without sequences go straight to the block's place in the output instead of through the arena and zg_k_lit's copy.
 #define ZG_FLAG_LIT_DIRECT 0x40u
-#define ZG_FLAG_FLAT5 0x100u       // (experiment) pointer-mode units of frames that are not sparse go through zg_flat5_unit
 
 // Device-side view of one submit (all pointers are device pointers).
 struct ZgBatchDev {
