@@ -75,7 +75,9 @@ static void k_tables(EmuBatch& e) {
       if (!st) st = zg_huf_build(weights, nw, e.huf.data() + (size_t)blk.huf_slot * ZG_HUF_SLOT_U16, &mb);
       if (!st) { e.hufmax[blk.huf_slot] = (uint8_t)mb; aux.huf_desc_bytes = used; }
     }
+    int fst = ZG_OK;                         // the sequences' table descriptions: their verdict is kept apart (the literal streams' comes first)
     if (!st && blk.nseq > 0) {
+      int& st = fst;
       const uint8_t* p = body + blk.seq_off; uint32_t rem = blk.src_len - blk.seq_off;
       uint32_t* slot = e.fse.data() + (size_t)b * ZG_FSE_SLOT_U32;
       const int kinds[3] = {ZG_KIND_LL, ZG_KIND_OF, ZG_KIND_ML};
@@ -99,6 +101,7 @@ static void k_tables(EmuBatch& e) {
     }
     e.aux[b] = aux;
     set_status(e, b, st);
+    e.fse_status[b] = (uint32_t)fst;
   }
 }
 
@@ -153,10 +156,13 @@ static void k_huf(EmuBatch& e) {
     uint64_t sum = 0;
     bool clean = true;
     for (int k = 0; k < 4 && clean; k++) {
-      tmp[k].assign(regen + 16, 0);
+      // (a stream may hold more symbols than the whole section regenerates — the reference decodes it to its end all the same and
+      //  only then compares the total: room for one symbol per bit)
+      const uint32_t room = 8u * (j[k + 1] - j[k]) + 16u;
+      tmp[k].assign(room + 16, 0);
       uint32_t count = 0; int32_t endbits = 0;
-      int st = zg_huf_decode_stream(pay + 6 + j[k], j[k + 1] - j[k], tab, max_bits, tmp[k].data(), regen, &count, &endbits);
-      if (st || endbits != -(int32_t)max_bits || count > regen) clean = false;
+      int st = zg_huf_decode_stream(pay + 6 + j[k], j[k + 1] - j[k], tab, max_bits, tmp[k].data(), room, &count, &endbits);
+      if (st || endbits != -(int32_t)max_bits || count > room) clean = false;
       tmp[k].resize(count);
       sum += count;
     }
@@ -170,6 +176,9 @@ static void k_huf(EmuBatch& e) {
 
 static void k_seq(EmuBatch& e) {
   const uint32_t nb = (uint32_t)e.bb.blocks.size();
+  // (zg_k_merge: the table descriptions of the sequences, and what the host found in a sequences section header, come behind the literals' verdicts)
+  for (uint32_t b = 0; b < nb; b++) set_status(e, b, (int)e.fse_status[b]);
+  for (uint32_t b = 0; b < nb; b++) if (e.bb.blocks[b].seq_host_status && !e.bb.blocks[b].host_status) set_status(e, b, (int)e.bb.blocks[b].seq_host_status);
   for (uint32_t b : e.bb.seq_blocks) {
     const ZgBlock blk = e.bb.blocks[b];
     int32_t sl[3] = {blk.ll_slot, blk.of_slot, blk.ml_slot};
@@ -285,6 +294,7 @@ void* zgemu_decode3(const uint8_t* src, size_t len, uint64_t max_window, int use
   e->huf.assign((size_t)(e->bb.nhuf_slots + 1) * ZG_HUF_SLOT_U16, 0xFFFF);
   e->hufmax.assign(e->bb.nhuf_slots + 1, 0);
   e->status.assign(nb + 1, 0);
+  e->fse_status.assign(nb + 1, 0);
   e->lit.assign(e->bb.lit_bytes + 64, 0xEE);
   e->seq.resize(e->bb.seq_count + 1);
   e->seqout.resize(nb + 1); e->pos.resize(nb + 1); e->fout.resize(nf + 1);

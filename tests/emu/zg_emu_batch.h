@@ -17,6 +17,7 @@ struct EmuBatch {
   std::vector<uint16_t> huf;
   std::vector<uint8_t> hufmax;
   std::vector<uint32_t> status;
+  std::vector<uint32_t> fse_status;   // verdicts of the FSE table descriptions: they come behind the literals' (zg_k_merge)
   std::vector<uint8_t> lit;
   std::vector<EmuSeq> seq;
   std::vector<ZgBlockSeqOut> seqout;

@@ -43,6 +43,11 @@ int zgemu_exact(void* h, uint32_t drain_rule, uint64_t dict_len, uint64_t prior_
     }
     fo.fast = slow ? 0u : 1u; fo.err_packed = 0xFFFFFFFFu; fo.good_blocks = good; fo.counted = 0;
     if (fo.status >= ZG_EXE_NOT_ENOUGH_LITERALS && fo.status <= ZG_EXE_DICT_TOO_SMALL) fo.status = 0;   // the serial model's execution verdict: not wanted here
+    // ... except what zg_k_seqpost finds itself (a sequence without literals left, an offset of 0): the frame stops at that block with that status
+    if (good < fr.nblocks && !bb.blocks[fr.first_block + good].host_status &&
+        (e->status[fr.first_block + good] == (uint32_t)ZG_EXE_NOT_ENOUGH_LITERALS || e->status[fr.first_block + good] == (uint32_t)ZG_EXE_ZERO_OFFSET)) {
+      fo.status = e->status[fr.first_block + good]; fo.bad_block = good;
+    }
   }
   uint32_t totals[4] = {0, 0, 0, 0};
   ZgBatchDev d;

@@ -63,6 +63,7 @@ ZG_HD int zg_seq_decode_block(const uint8_t* bs, uint32_t bs_len, uint32_t nseq,
   uint32_t h0 = (1u << 30) | 0u, h1 = (2u << 30) | 0u, h2 = (3u << 30) | 0u;
   uint32_t lit_pos = 0, out_pos = 0, sum_ml = 0;
   int status = ZG_OK, exe_status = ZG_OK;
+  uint32_t emitted = 0;
   for (uint32_t i = 0; i < nseq; i++) {
     unsigned of_code = ZG_FSE_SYM(e_of), ml_code = ZG_FSE_SYM(e_ml), ll_code = ZG_FSE_SYM(e_ll);
     unsigned xb_of = ZG_FSE_XB(e_of), xb_ml = ZG_FSE_XB(e_ml), xb_ll = ZG_FSE_XB(e_ll);
@@ -88,19 +89,17 @@ ZG_HD int zg_seq_decode_block(const uint8_t* bs, uint32_t bs_len, uint32_t nseq,
       if (actual == 0) exe_status = ZG_EXE_ZERO_OFFSET;
       else if ((uint64_t)lit_pos + ll > regen_size) exe_status = ZG_EXE_NOT_ENOUGH_LITERALS;
       else if ((uint64_t)out_pos + ll + ml >= (1ull << 31)) exe_status = ZG_UNSUPPORTED;
-      else {
-        EmuSeq q;
-        q.of = actual; q.ml = ml; q.mdst = out_pos + ll; q.lit_start = lit_pos;
-        out[i] = q;
-        lit_pos += ll; out_pos += ll + ml; sum_ml += ml;
-      }
+      EmuSeq q;                                            // (the rejected sequence leaves a record too, like zg_k_seqpost's: zg_k_exact reads its literal index)
+      q.of = actual; q.ml = ml; q.mdst = out_pos + ll; q.lit_start = lit_pos;
+      out[i] = q;
+      if (exe_status == ZG_OK) { lit_pos += ll; out_pos += ll + ml; sum_ml += ml; emitted++; }
     }
   }
   if (status == ZG_OK && P > 0) status = ZG_SEQ_EXTRA_BITS;  // :214-220
   if (status == ZG_OK) status = exe_status;
   sum->sum_ll = lit_pos; sum->sum_ml = sum_ml;
   sum->hist_end[0] = h0; sum->hist_end[1] = h1; sum->hist_end[2] = h2;
-  sum->pad = 0;
+  sum->pad = exe_status ? emitted + 1u : 0u;            // like zg_k_seqpost: 1 + the sequence that cannot be executed
   return status;
 }
 
@@ -196,12 +195,10 @@ ZG_HD bool zg_seq_step(EmuSeqState& st, const ZgWin& cur, bool last, TabPtr t_ll
     if (actual == 0) st.exe_status = ZG_EXE_ZERO_OFFSET;
     else if ((uint64_t)st.lit_pos + ll > regen_size) st.exe_status = ZG_EXE_NOT_ENOUGH_LITERALS;
     else if ((uint64_t)st.out_pos + ll + ml >= (1ull << 31)) st.exe_status = ZG_UNSUPPORTED;
-    else {
-      EmuSeq q;
-      q.of = actual; q.ml = ml; q.mdst = st.out_pos + ll; q.lit_start = st.lit_pos;
-      *slot = q;
-      st.lit_pos += ll; st.out_pos += ll + ml; st.sum_ml += ml; st.emitted++;
-    }
+    EmuSeq q;
+    q.of = actual; q.ml = ml; q.mdst = st.out_pos + ll; q.lit_start = st.lit_pos;
+    *slot = q;
+    if (st.exe_status == ZG_OK) { st.lit_pos += ll; st.out_pos += ll + ml; st.sum_ml += ml; st.emitted++; }
   }
   return true;
 }
@@ -211,7 +208,7 @@ ZG_HD int zg_seq_finish(const EmuSeqState& st, ZgBlockSeqOut* sum) {
   if (status == ZG_OK) status = st.exe_status;
   sum->sum_ll = st.lit_pos; sum->sum_ml = st.sum_ml;
   sum->hist_end[0] = st.h0; sum->hist_end[1] = st.h1; sum->hist_end[2] = st.h2;
-  sum->pad = 0;
+  sum->pad = st.exe_status ? st.emitted + 1u : 0u;      // like zg_k_seqpost: 1 + the sequence that cannot be executed
   return status;
 }
 

@@ -299,6 +299,70 @@ def test_mutated_frames_agree_with_oracle(ctx):
     assert same_ok > 50 and same_err > 200, (same_ok, same_err)
 
 
+def test_twice_mutated_frames_first_error_in_stream_order(ctx):
+    """Two defects in one input: the reference decodes block by block (decode_blocks, frame_decoder.rs:319-375), so a defect inside
+    an early block is reported before a header the walk cannot read further back (a truncated body, a reserved block type, the next
+    frame's magic) — although the engine's host walk meets the latter first. 360 inputs with two or three random mutations each
+    (found by tools/dev/soak.py), plus the hand-made case: a corrupted block in front of a truncation."""
+    import random
+    import zgpu
+    packs, syn = read_pack("decodecorpus.pack"), read_pack("synthetic.pack")
+    bases = [packs["z000033.zst"], packs["z000059.zst"], syn["mixed_640k_l3.zst"], packs["z000000.zst"], packs["z000012.zst"], packs["z000047.zst"]]
+
+    def both(m):
+        ost, oout = oracle.FrameDecoder().decode_all(m, 1 << 24)
+        try:
+            out, gst = ctx.decode_all(m, 1 << 24), 0
+        except zgpu.ZgpuError as e:
+            out, gst = None, e.status
+        return ost, oout, gst, out
+
+    # hand-made: find a byte whose corruption makes a block fail, then cut the frame behind it
+    base = syn["mixed_640k_l3.zst"]
+    found = 0
+    for i in range(40, len(base) // 3, 997):
+        m = bytearray(base); m[i] ^= 0x5A
+        ost, _, _, _ = both(bytes(m))
+        if ost in (0, zgpu.E_FAILED_READ_BLOCK_BODY, zgpu.E_FAILED_READ_BLOCK_HEADER):
+            continue
+        cut = bytes(m[:len(m) - len(m) // 4])
+        o2, _, g2, _ = both(cut)
+        assert o2 == ost and g2 == o2, (i, ost, o2, g2)
+        found += 1
+        if found == 3:
+            break
+    assert found >= 1
+    rng = random.Random(4242)
+    diffs = {}
+    n_walk_second = 0
+    for bi, base in enumerate(bases):
+        for it in range(60):
+            m = bytearray(base)
+            for _ in range(2 + rng.randrange(2)):
+                if len(m) < 16:
+                    break
+                kind = rng.randrange(5)
+                if kind == 0:
+                    i = rng.randrange(4, len(m)); m[i] ^= 1 << rng.randrange(8)
+                elif kind == 1:
+                    i = rng.randrange(4, len(m)); m[i] = rng.randrange(256)
+                elif kind == 2:
+                    m = m[:rng.randrange(8, len(m))]
+                elif kind == 3:
+                    i = rng.randrange(4, len(m) - 4); m[i:i + 2] = bytes([rng.randrange(256), rng.randrange(256)])
+                else:
+                    i = rng.randrange(4, min(len(m), 40)); m[i] = rng.randrange(256)
+            ost, oout, gst, out = both(bytes(m))
+            if ost == 0 and gst == 0:
+                assert out == oout, (bi, it)
+            elif ost != gst:
+                diffs[(ost, gst)] = diffs.get((ost, gst), 0) + 1
+            elif ost not in (zgpu.E_FAILED_READ_BLOCK_BODY, zgpu.E_FAILED_READ_BLOCK_HEADER):
+                n_walk_second += 1
+    assert not diffs, diffs
+    assert n_walk_second > 50
+
+
 def test_inorder_fallback_path(ctx, monkeypatch):
     """the in-order kernel (zg_k_lz) that serves frames with a block regenerating more than 128 KiB: forced on here"""
     monkeypatch.setenv("ZGPU_FORCE_INORDER", "1")

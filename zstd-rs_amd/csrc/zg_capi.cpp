@@ -259,12 +259,21 @@ int zgpu_decode_all(zgpu_ctx* c, const uint8_t* src, size_t len, uint8_t* dst, s
     zgpu_batch_destroy(zb);
     return decode_all_per_frame(c, src, len, dst, cap, written);
   }
-  if (st) { zgpu_batch_destroy(zb); return st; }   // the reference returns the first error of the walk
+  // The walk stopped at a header it could not read (a truncated block, a reserved block type, the next frame's magic ...): the
+  // reference meets that error only after it has decoded everything in front of it (decode_blocks reads and decodes block by
+  // block, frame_decoder.rs:319-375), so an error INSIDE an earlier block comes first. The blocks in front of the stop are in the
+  // batch: they are decoded, and the walk's error is the answer only if none of them fails.
+  int walk = 0;
+  if (st) {
+    if (!zb || zb->b->bb.blocks.empty()) { zgpu_batch_destroy(zb); return st; }
+    walk = st;
+  }
   zb->b->drain_rule = ZG_DRAIN_DECODE_ALL;          // decode_all drains its DecodeBuffer every MiB (frame_decoder.rs:560-563): zg_exact.h
   uint64_t total = 0;
   uint32_t bf = 0, bs = 0;
   if ((st = zgpu_batch_run(zb)) || (st = zgpu_batch_sync(zb, &total, &bf, &bs))) { zgpu_batch_destroy(zb); return st; }
   if (bs) { zgpu_batch_destroy(zb); return (int)bs; }
+  if (walk) { zgpu_batch_destroy(zb); return walk; }
   if (total > cap) { zgpu_batch_destroy(zb); return ZGPU_E_TARGET_TOO_SMALL; }  // frame_decoder.rs:567-569
   st = zgpu_batch_read(zb, 0, dst, total);
   zgpu_batch_destroy(zb);
@@ -294,12 +303,17 @@ int zgpu_decode_all_alloc(zgpu_ctx* c, const uint8_t* src, size_t len, uint8_t**
       return ZGPU_OK;
     }
   }
-  if (st) { zgpu_batch_destroy(zb); return st; }
+  int walk = 0;                                      // (as in zgpu_decode_all: what lies in front of the point where the walk stopped is decoded first)
+  if (st) {
+    if (!zb || zb->b->bb.blocks.empty()) { zgpu_batch_destroy(zb); return st; }
+    walk = st;
+  }
   zb->b->drain_rule = ZG_DRAIN_DECODE_ALL;          // decode_all_to_vec runs the same loop as decode_all (:580-591)
   uint64_t total = 0;
   uint32_t bf = 0, bs = 0;
   if ((st = zgpu_batch_run(zb)) || (st = zgpu_batch_sync(zb, &total, &bf, &bs))) { zgpu_batch_destroy(zb); return st; }
   if (bs) { zgpu_batch_destroy(zb); return (int)bs; }
+  if (walk) { zgpu_batch_destroy(zb); return walk; }
   uint8_t* buf = (uint8_t*)malloc(total ? total : 1);
   if (!buf) { zgpu_batch_destroy(zb); return ZGPU_E_NOMEM; }
   st = zgpu_batch_read(zb, 0, buf, total);

@@ -18,7 +18,7 @@ int DevBuf::reserve(size_t n, bool keep, hipStream_t s) {
   if (p) { const size_t slack = cap / 2 < (256u << 20) ? cap / 2 : (256u << 20); if (ncap < cap + slack) ncap = cap + slack; }
   if (p && !(keep && cap)) { (void)hipFree(p); p = nullptr; cap = 0; }   // nothing to keep: free first (old + new need not fit together)
   void* np = nullptr;
-  if (hipMalloc(&np, ncap) != hipSuccess) return ZG_NOMEM;
+  if (hipMalloc(&np, ncap) != hipSuccess) { (void)hipGetLastError(); return ZG_NOMEM; }   // (the failure must not stay behind as the runtime's last error: the next launch check would report it)
   if (p) {
     if (hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
       (void)hipFree(np);
@@ -238,7 +238,7 @@ int FrameState::make_room(uint64_t extra, uint64_t keep, hipStream_t s) {
   const uint64_t slack = live + extra > (8u << 20) ? (live + extra) / 2 : (4u << 20);
   ncap += slack;
   void* np = nullptr;
-  if (hipMalloc(&np, ncap) != hipSuccess) return ZG_NOMEM;
+  if (hipMalloc(&np, ncap) != hipSuccess) { (void)hipGetLastError(); return ZG_NOMEM; }   // (the failure must not stay behind as the runtime's last error: the next launch check would report it)
   if (d_out.p) {
     hipError_t e = hipSuccess;
     if (base) e = hipMemcpyAsync((uint8_t*)np + kOutFront, out_ptr(), base, hipMemcpyDeviceToDevice, s);
@@ -449,7 +449,9 @@ int Batch::run() {
   // every frame declares its content size: output and flatten scratch are sized now, and nothing below waits for the host
   presized = false;
   d.dst_cap_pre = 0;
-  if (!fs && all_declared && !eng->no_presize_) {
+  // ... and the declared sizes are possible at all: a block regenerates at most 128 KiB on this path, and Frame_Content_Size is a field
+  // the reference never believes (a corrupted one must not become a 600 GB allocation: the sizes are then taken from the scan)
+  if (!fs && all_declared && !eng->no_presize_ && declared_total <= (uint64_t)bb.blocks.size() * kMaxBlockSize) {
     int st = 0;
     if ((st = sc->d_dst.reserve(kOutFront + declared_total + 64)) || (st = sc->d_og.reserve(declared_total * 4 + 64))) return st;
     d.dst = sc->d_dst.as<uint8_t>() + kOutFront; d.dst_cap = declared_total;
@@ -670,6 +672,7 @@ int Batch::sync() {
       const ZgFrame& fr = bb.frames[f];
       const uint32_t st = frame_out[f].status;
       need = st == (uint32_t)ZG_EXE_OFFSET_TOO_BIG || st == (uint32_t)ZG_EXE_DICT_TOO_SMALL || fr.dict_len != 0 ||
+             st == (uint32_t)ZG_EXE_NOT_ENOUGH_LITERALS || st == (uint32_t)ZG_EXE_ZERO_OFFSET ||   // (a sequence in front of the rejected one may reach too far: that comes first)
              fr.hist_init[0] > fr.window_size || fr.hist_init[1] > fr.window_size || fr.hist_init[2] > fr.window_size;
     }
     if (need && !getenv("ZGPU_DEBUG_NO_EXACT")) {

@@ -39,7 +39,13 @@ ZX_DEV void zg_exact_frame(const ZgBatchDev& d, const uint32_t f, const uint32_t
   // execute, that block is the last one to look at
   const bool exec_err = fo.err_packed != 0xFFFFFFFFu;
   const bool lz_err = !fo.fast && (fo.status == (uint32_t)ZG_EXE_ZERO_OFFSET || fo.status == (uint32_t)ZG_EXE_OFFSET_TOO_BIG || fo.status == (uint32_t)ZG_EXE_DICT_TOO_SMALL);
-  uint32_t nwalk = exec_err ? (fo.err_packed >> 8) + 1u : lz_err ? fo.good_blocks + 1u : fo.good_blocks;
+  // zg_k_seqpost rejected a sequence (it asks for more literals than the block has, or its offset is 0: sequence_execution.rs:14-30):
+  // the reference executes the sequences in front of it first, and one of THOSE may reach too far — that error comes first. The
+  // block's records exist up to the rejected sequence (ZgBlockSeqOut::pad): they are walked like any other block's.
+  const bool sp_err = !exec_err && !lz_err && (fo.status == (uint32_t)ZG_EXE_NOT_ENOUGH_LITERALS || fo.status == (uint32_t)ZG_EXE_ZERO_OFFSET) &&
+                      fo.good_blocks < fr.nblocks && d.seq_out[fr.first_block + fo.good_blocks].pad != 0u &&
+                      d.blocks[fr.first_block + fo.good_blocks].host_status == 0u;
+  uint32_t nwalk = exec_err ? (fo.err_packed >> 8) + 1u : (lz_err || sp_err) ? fo.good_blocks + 1u : fo.good_blocks;
   if (nwalk > fr.nblocks) nwalk = fr.nblocks;
   uint64_t buf = fr.prior_reach;         // DecodeBuffer::len(): undrained bytes
   uint64_t cnt = fr.prior_counted;       // total_output_counter
@@ -48,7 +54,9 @@ ZX_DEV void zg_exact_frame(const ZgBatchDev& d, const uint32_t f, const uint32_t
   for (uint32_t i = 0; i < nwalk; i++) {
     const uint32_t b = fr.first_block + i;
     const ZgBlock blk = d.blocks[b];
-    const bool seqs = blk.btype == ZG_BT_COMPRESSED && blk.nseq;
+    const bool cut = sp_err && i == fo.good_blocks;               // only the sequences in front of the rejected one
+    const uint32_t nseq = cut ? d.seq_out[b].pad - 1u : blk.nseq;
+    const bool seqs = blk.btype == ZG_BT_COMPRESSED && nseq;
     const uint64_t size = seqs ? (uint64_t)blk.regen_size + d.seq_out[b].sum_ml : blk.regen_size;
     uint64_t dict_only = 0;              // bytes of the block's matches that came from the dictionary alone
     if (seqs) {
@@ -58,16 +66,16 @@ ZX_DEV void zg_exact_frame(const ZgBatchDev& d, const uint32_t f, const uint32_t
       zx_barrier();
       const uint32_t sum_ll = d.seq_out[b].sum_ll;
       uint32_t pos_carry = 0;                                      // output bytes of the block's sequences in front of the chunk
-      for (uint32_t j0 = 0; j0 < blk.nseq; j0 += T) {
+      for (uint32_t j0 = 0; j0 < nseq; j0 += T) {
         const uint32_t j = j0 + t;
-        const bool have = j < blk.nseq;
+        const bool have = j < nseq;
         uint32_t off = 0, m0 = 0, ml = 0, ll = 0;
         if (have) {
           const ZgSeq q = sq[j];
           off = zg_sym_resolve(q.of, p.hist_init); ml = ZG_SEQ_ML(q);
           // where the match starts: the record's position field wraps in a block beyond 128 KiB (frames on the in-order path),
           // ml and ll = (next literal index - this one) mod 2^17 stay exact (zg_types.h): positions are rebuilt from them
-          const uint32_t nx = j + 1 < blk.nseq ? ZG_SEQ_LIT(sq[j + 1]) : sum_ll;
+          const uint32_t nx = (j + 1 < nseq || cut) ? ZG_SEQ_LIT(sq[j + 1]) : sum_ll;   // (a cut block: the rejected sequence's record follows)
           ll = (nx - ZG_SEQ_LIT(q)) & 0x1FFFFu;
         }
         {
@@ -109,6 +117,7 @@ ZX_DEV void zg_exact_frame(const ZgBatchDev& d, const uint32_t f, const uint32_t
       }
       const unsigned long long bad = L.bad;
       zx_barrier();
+      if (cut && bad == ~0ull) return;                              // nothing in front of the rejected sequence fails: zg_k_seqpost's verdict stands
       if (bad != ~0ull) {
         if (t == 0) {
           ZgFrameOut* o = &d.frame_out[f];

@@ -119,7 +119,7 @@ int BatchBuilder::add_block(const BlockHeader& bh, const uint8_t* body, uint64_t
   b.frame = (uint32_t)frames.size() - 1;
   b.huf_slot = b.ll_slot = b.of_slot = b.ml_slot = ZG_REF_UNINIT;
   const uint32_t bidx = (uint32_t)blocks.size();
-  int st = ZG_OK;
+  int st = ZG_OK, seq_st = ZG_OK;   // seq_st: found in the sequences section header, i.e. behind the literals (ZgBlock::seq_host_status)
   if (bh.type != ZG_BT_COMPRESSED) {
     b.regen_size = bh.decompressed_size;
     out_bound += b.regen_size;
@@ -166,29 +166,29 @@ int BatchBuilder::add_block(const BlockHeader& bh, const uint8_t* body, uint64_t
       // sequences section header (sequence_section.rs:108-167)
       const uint8_t* s = body + need + upper;
       const uint32_t rem = n - need - upper;
-      if (rem == 0) { st = ZG_SEQUENCES_HEADER; break; }
+      if (rem == 0) { seq_st = ZG_SEQUENCES_HEADER; break; }
       unsigned shl;
       bool has_modes = false;
       if (s[0] == 0) { b.nseq = 0; shl = 1; }
       else if (s[0] < 128) {
-        if (rem < 2) { st = ZG_SEQUENCES_HEADER; break; }
+        if (rem < 2) { seq_st = ZG_SEQUENCES_HEADER; break; }
         b.nseq = s[0]; b.seq_modes = s[1]; has_modes = true; shl = 2;
       } else if (s[0] < 255) {
-        if (rem < 2) { st = ZG_SEQUENCES_HEADER; break; }
+        if (rem < 2) { seq_st = ZG_SEQUENCES_HEADER; break; }
         b.nseq = (((uint32_t)s[0] - 128) << 8) + s[1]; shl = 2;
         if (b.nseq != 0) {
-          if (rem < 3) { st = ZG_SEQUENCES_HEADER; break; }
+          if (rem < 3) { seq_st = ZG_SEQUENCES_HEADER; break; }
           b.seq_modes = s[2]; has_modes = true; shl = 3;
         }
       } else {
-        if (rem < 4) { st = ZG_SEQUENCES_HEADER; break; }
+        if (rem < 4) { seq_st = ZG_SEQUENCES_HEADER; break; }
         b.nseq = (uint32_t)s[1] + ((uint32_t)s[2] << 8) + 0x7F00; b.seq_modes = s[3]; has_modes = true; shl = 4;
       }
       b.seq_off = need + upper + shl;
       if (b.nseq == 0) {
-        if (rem != shl) { st = ZG_SEQ_EXTRA_BITS; break; }           // block_decoder.rs:184-190
+        if (rem != shl) { seq_st = ZG_SEQ_EXTRA_BITS; break; }           // block_decoder.rs:184-190
       } else {
-        if (!has_modes) { st = ZG_SEQ_MISSING_MODE; break; }
+        if (!has_modes) { seq_st = ZG_SEQ_MISSING_MODE; break; }
         // maybe_update_fse_tables lineage (sequence_section_decoder.rs:294-410): LL, OF, ML
         int32_t* cur[3] = {&cur_.ll, &cur_.of, &cur_.ml};
         const int modes[3] = {b.seq_modes >> 6, (b.seq_modes >> 4) & 3, (b.seq_modes >> 2) & 3};
@@ -203,15 +203,17 @@ int BatchBuilder::add_block(const BlockHeader& bh, const uint8_t* body, uint64_t
     } while (0);
   }
   if (frame_failed_ && !st) st = ZG_INTERNAL;
+  if (seq_st) { b.nseq = 0; b.seq_modes = 0; b.seq_off = 0; }   // the block's literals are decoded, its sequences never looked at
   b.host_status = (uint32_t)st;
+  b.seq_host_status = st ? 0u : (uint32_t)seq_st;
   if (!st && bh.type == ZG_BT_COMPRESSED) {
     if (b.lit_type >= ZG_LT_COMPRESSED) { b.lit_base = lit_bytes; lit_bytes += b.regen_size; }
     if (b.nseq) { b.seq_base = seq_count; seq_count += b.nseq; }
   }
   blocks.push_back(b);
   frames.back().nblocks++;
-  if (st) frame_failed_ = true;
-  return st;
+  if (st || seq_st) frame_failed_ = true;
+  return st ? st : seq_st;
 }
 
 void BatchBuilder::finish() {

@@ -80,8 +80,14 @@ ZX_DEV void zg_huf_group(const ZgBatchDev& d, const uint32_t gi, ZgHufLds<GROUP>
   const uint32_t b = item >> 2, k = item & 3;
   const ZgBlock blk = d.blocks[b];
   // literals of a block without sequences go straight to its place in the output when the submit decodes them after the scan
-  const bool direct = (d.flags & ZG_FLAG_LIT_DIRECT) != 0u && blk.nseq == 0u;
-  if (direct && !d.pos[b].active) return;            // behind its frame's first failing block: the reference never gets there
+  bool direct = (d.flags & ZG_FLAG_LIT_DIRECT) != 0u && blk.nseq == 0u;
+  if (direct && !d.pos[b].active) {
+    // behind its frame's first failing block: the reference never gets there. The failing block itself, when what stops it is its
+    // sequences section header (the host found that; ZgBlock::seq_host_status): its literals are decoded all the same — their verdict
+    // comes first (zg_k_litfix) — but into the arena: the block has no place in the output
+    if (!blk.seq_host_status || (uint32_t)b != d.frames[blk.frame].first_block + d.frame_out[blk.frame].good_blocks) return;
+    direct = false;
+  }
   // the checks of the stream header: every lane computes the same, lane 0 reports
   int hst = ZG_OK;
   const uint8_t* sp = nullptr;

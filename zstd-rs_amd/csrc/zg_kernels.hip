@@ -491,8 +491,11 @@ __global__ void __launch_bounds__(64) zg_k_huf_uneven(ZgBatchDev d) {
   const uint32_t c0 = d.lit_counts[4u * b], c1 = d.lit_counts[4u * b + 1], c2 = d.lit_counts[4u * b + 2], c3 = d.lit_counts[4u * b + 3];
   if ((uint64_t)c0 + c1 + c2 + c3 != regen) return;            // DecodedLiteralCountMismatch stands
   // (where zg_k_huf put them: the arena, or the block's place in the output — zg_huf.h)
-  const bool direct = (d.flags & ZG_FLAG_LIT_DIRECT) != 0u && blk.nseq == 0u;
-  if (direct && !d.pos[b].active) return;
+  bool direct = (d.flags & ZG_FLAG_LIT_DIRECT) != 0u && blk.nseq == 0u;
+  if (direct && !d.pos[b].active) {                            // (the same rule as zg_huf.h: the block its frame stops at because of its sequences header)
+    if (!blk.seq_host_status || b != d.frames[blk.frame].first_block + d.frame_out[blk.frame].good_blocks) return;
+    direct = false;
+  }
   uint8_t* lits = direct ? d.dst + d.frame_out[blk.frame].out_base + d.pos[b].out_base : d.lit_arena + blk.lit_base;
   const unsigned max_bits = d.huf_maxbits[blk.huf_slot];
   if (max_bits == 0 || max_bits > 11) return;
@@ -1071,7 +1074,8 @@ __global__ void __launch_bounds__(ZG_SP_T, 4) zg_k_seqpost(ZgBatchDev d) {
   if (t == 0) {
     ZgBlockSeqOut so;
     so.sum_ll = lit_carry; so.sum_ml = out_carry - lit_carry;
-    so.hist_end[0] = carry.s[0]; so.hist_end[1] = carry.s[1]; so.hist_end[2] = carry.s[2]; so.pad = 0;
+    so.hist_end[0] = carry.s[0]; so.hist_end[1] = carry.s[1]; so.hist_end[2] = carry.s[2];
+    so.pad = s_err != 0xFFFFFFFFu ? (s_err >> 8) + 1u : 0u;   // 1 + the sequence that cannot be executed (no literals left, offset 0): zg_k_exact looks at the ones in front of it
     d.seq_out[b] = so;
     if (s_err != 0xFFFFFFFFu) zg_set_status(d.status, b, (int)(s_err & 0xFFu));
   }
@@ -1644,6 +1648,7 @@ __global__ void __launch_bounds__(256) zg_k_merge(ZgBatchDev d) {
   if (b >= d.nblocks) return;
   if (d.tab_status[b]) d.status[b] = d.tab_status[b];
   else if (d.lit_status[b]) d.status[b] = d.lit_status[b] & 0xFFu;
+  else if (d.blocks[b].seq_host_status && !d.status[b]) d.status[b] = d.blocks[b].seq_host_status;   // the host found it, but it comes behind the literals
 }
 void zg_launch_merge(const ZgBatchDev& d, hipStream_t s) {
   if (d.nblocks) hipLaunchKernelGGL(zg_k_merge, dim3((d.nblocks + 255) / 256), dim3(256), 0, s, d);

@@ -406,12 +406,16 @@ int zgpu_pool_decode_all(zgpu_pool* p, const uint8_t* src, size_t len, uint8_t* 
       Job& j = jobs[order[k]];
       j.worker = w;
       j.status = eng->prepare(src + j.begin, (size_t)(j.end - j.begin), &j.batch);
-      if (!j.status && j.batch->parse_status) j.status = j.batch->parse_status;
+      // (a walk that stopped inside the job: what lies in front of that point is decoded first — an error there is the one the
+      //  reference meets first, zgpu_decode_all)
+      const int jwalk = (!j.status && j.batch) ? j.batch->parse_status : 0;
+      if (jwalk && j.batch->bb.blocks.empty()) j.status = jwalk;
       if (!j.status) { j.batch->drain_rule = ZG_DRAIN_DECODE_ALL; j.status = j.batch->run(); }
       if (!j.status) j.status = j.batch->sync();
       if (!j.status)
         for (const ZgFrameOut& fo : j.batch->frame_out)
           if (fo.status) { j.status = (int)fo.status; break; }
+      if (!j.status && jwalk) j.status = jwalk;
       if (!j.status) j.out_size = j.batch->total_out;
       if (!j.status && direct_out && j.out_size == j.want_size) {
         land();                            // (at most one download in flight per engine: its buffers are this job's predecessor's)

@@ -108,7 +108,8 @@ struct ZgBlock {
   uint64_t lit_base;       // offset of this block's regenerated literals in the literals arena
   uint64_t seq_base;       // index of this block's first sequence in the sequence arena
   uint32_t seq_idx;        // position of this block in the list of blocks that have sequences (flatten scratch slot)
-  uint32_t pad1;
+  uint32_t seq_host_status; // error the host parser found in the block's SEQUENCES section header: the reference meets it after it has decoded the
+                            // literals (block_decoder.rs:131-190), so the literal stages still run and their errors come first (zg_k_merge)
 };
 
 // One frame of the batch.
@@ -143,7 +144,7 @@ struct ZgBlockSeqOut {
   uint32_t sum_ll;         // Σ literal lengths
   uint32_t sum_ml;         // Σ match lengths (block output size = regen_size + sum_ml)
   uint32_t hist_end[3];    // offset history after the block, symbolic encoding (see zg_dev.h)
-  uint32_t pad;
+  uint32_t pad;            // zg_k_seq -> zg_k_seqpost: bit position of the first sequence; after zg_k_seqpost: 1 + index of the sequence it rejected (0: none)
 };
 
 // One decoded sequence, ready for execution: 12 bytes. Positions are block-relative; on the flatten path a block
