@@ -92,6 +92,21 @@ class Plan:
             L.zgemu_free(h)
 
 
+def decode_all_verdict(m, max_window=128 << 20):
+    """zgpu_decode_all's verdict rule on the CPU harness: the first failing frame in stream order (zg_k_exact's verdict where it has
+    one), else the error of the host walk — what lies in front of the point where the walk stops is decoded first (zg_capi.cpp)"""
+    e = EmuBatch(m, max_window=max_window)
+    if e.nframes == 0 or e.nblocks == 0:
+        return e.parse_status
+    ex = e.exact(drain_rule=1)
+    for f in range(e.nframes):
+        if ex[f][0]:
+            return ex[f][0]
+        if e.frame(f)[2]:
+            return e.frame(f)[2]
+    return e.parse_status
+
+
 class EmuBatch:
     def __init__(self, src, max_window=128 << 20, fast_seq=True):
         self.L = lib()

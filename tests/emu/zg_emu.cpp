@@ -216,7 +216,14 @@ static void k_scan(EmuBatch& e) {  // serial statement of zg_k_scan / zg_k_scanf
       uint32_t b = fr.first_block + i;
       const ZgBlock& blk = e.bb.blocks[b];
       uint32_t st = blk.host_status ? blk.host_status : e.status[b];
-      if (st) { good = i; bad_status = st; for (uint32_t j = i; j < fr.nblocks; j++) e.pos[fr.first_block + j].active = 0; break; }
+      if (st) {
+        good = i; bad_status = st;
+        for (uint32_t j = i; j < fr.nblocks; j++) e.pos[fr.first_block + j].active = 0;
+        // (like zg_k_scan: the failing block still learns where it would start and with which history — zg_k_exact may look at its first sequences)
+        ZgBlockPos p; p.out_base = pos; p.hist_init[0] = h[0]; p.hist_init[1] = h[1]; p.hist_init[2] = h[2]; p.active = 0;
+        e.pos[b] = p;
+        break;
+      }
       ZgBlockPos p; p.out_base = pos; p.hist_init[0] = h[0]; p.hist_init[1] = h[1]; p.hist_init[2] = h[2]; p.active = 1;
       e.pos[b] = p;
       if (blk.btype == ZG_BT_COMPRESSED && blk.nseq) {

@@ -15,20 +15,7 @@ bases = [packs[n] for n in sorted(packs) if n.endswith(".zst")] + [syn[n] for n 
 rng = random.Random(seed)
 
 
-def verdict(m):
-    """zgpu_decode_all's rule: the first failing frame in stream order (zg_k_exact's verdict where it has one), else the walk's error"""
-    e = emu.EmuBatch(m, max_window=128 << 20)
-    if e.nframes == 0 or e.nblocks == 0:
-        return e.parse_status
-    ex = e.exact(drain_rule=1)
-    for f in range(e.nframes):
-        fst = e.frame(f)[2]
-        xst = ex[f][0]
-        if xst:
-            return xst
-        if fst:
-            return fst
-    return e.parse_status
+verdict = emu.decode_all_verdict
 
 
 same_ok = same_err = 0
