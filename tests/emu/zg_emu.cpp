@@ -155,6 +155,7 @@ static void k_huf(EmuBatch& e) {
     std::vector<uint8_t> tmp[4];
     uint64_t sum = 0;
     bool clean = true;
+    int bad_st = 0;
     for (int k = 0; k < 4 && clean; k++) {
       // (a stream may hold more symbols than the whole section regenerates — the reference decodes it to its end all the same and
       //  only then compares the total: room for one symbol per bit)
@@ -162,11 +163,12 @@ static void k_huf(EmuBatch& e) {
       tmp[k].assign(room + 16, 0);
       uint32_t count = 0; int32_t endbits = 0;
       int st = zg_huf_decode_stream(pay + 6 + j[k], j[k + 1] - j[k], tab, max_bits, tmp[k].data(), room, &count, &endbits);
-      if (st || endbits != -(int32_t)max_bits || count > room) clean = false;
+      if (st == ZG_LIT_EXTRA_PADDING) { bad_st = st; clean = false; }             // the first stream, in order, that fails decides
+      else if (st || endbits != -(int32_t)max_bits || count > room) clean = false;
       tmp[k].resize(count);
       sum += count;
     }
-    if (!clean) { e.status[b] = ZG_LIT_BITSTREAM_MISMATCH; continue; }   // a stream's end outranks any count (:116-121 comes first)
+    if (!clean) { e.status[b] = bad_st ? (uint32_t)bad_st : (uint32_t)ZG_LIT_BITSTREAM_MISMATCH; continue; }   // a stream's end outranks any count (:116-121 comes first)
     if (sum != regen) continue;
     uint8_t* lit = e.lit.data() + blk.lit_base;
     for (int k = 0; k < 4; k++) { memcpy(lit, tmp[k].data(), tmp[k].size()); lit += tmp[k].size(); }

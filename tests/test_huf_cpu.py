@@ -184,3 +184,46 @@ def test_corrupted_streams_end_with_the_models_verdict():
             elif k["status"] == 0:
                 assert st[b] == 0, (trial, b, hex(int(st[b])))
     assert hits >= 3
+
+
+def test_two_failing_streams_the_earlier_one_decides():
+    """a four-stream block with TWO defects: a stream that does not end on its last bit, and the all-zero last byte (ExtraPadding) of
+    a LATER stream. The reference decodes the streams in order and checks a stream's padding when its turn comes
+    (literals_section_decoder.rs:94-122): the earlier stream's BitstreamReadMismatch is the verdict. (Found while chasing a soak
+    disagreement: the kernel ranked every ExtraPadding in front of all streams.)"""
+    base = read_pack("synthetic.pack")["text_1m_l3.zst"]
+    st0, c, _, _ = oracle.FrameDecoder().init(base)
+    body = c + 3
+    assert base[body] & 3 == 2 and (base[body] >> 2) & 3 == 3            # compressed literals, four streams, 5-byte header
+    comp = (base[body + 2] >> 6) + (base[body + 3] << 2) + (base[body + 4] << 10)
+    payload = body + 5
+    hb = base[payload]
+    desc = 1 + hb if hb < 128 else 1 + ((hb - 127) + 1) // 2
+    jt = payload + desc
+    j = [int.from_bytes(base[jt + 2 * i:jt + 2 * i + 2], "little") for i in range(3)]
+    s0 = jt + 6
+    starts = [s0, s0 + j[0], s0 + j[0] + j[1], s0 + j[0] + j[1] + j[2]]
+    end3 = payload + comp
+    cases = 0
+    for k in (0, 1, 2):
+        for off, val in ((0, 0xFF), (1, 0xFF), (1, 0x0F), (2, 0xFF)):
+            m = bytearray(base)
+            m[starts[k] + off] = val
+            if oracle.FrameDecoder().decode_all(bytes(m), 1 << 25)[0] != 34:
+                continue
+            m[end3 - 1] = 0                                              # stream 3: ExtraPadding
+            m = bytes(m)
+            want = oracle.FrameDecoder().decode_all(m, 1 << 25)[0]
+            assert want == 34
+            _, _, _, st, _ = run_huf(m)
+            assert int(st[0]) & 0xFF == want, (k, off, hex(int(st[0])))
+            cases += 1
+    assert cases >= 6
+    # and the other way round: the padding defect in the EARLIER stream wins
+    m = bytearray(base)
+    m[starts[1] - 1] = 0                                                  # last byte of stream 0: ExtraPadding
+    m[starts[2] + 1] = 0xFF                                               # stream 2 does not end on its last bit
+    m = bytes(m)
+    assert oracle.FrameDecoder().decode_all(m, 1 << 25)[0] == 33
+    _, _, _, st, _ = run_huf(m)
+    assert int(st[0]) & 0xFF == 33

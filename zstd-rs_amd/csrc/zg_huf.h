@@ -124,7 +124,10 @@ ZX_DEV void zg_huf_group(const ZgBatchDev& d, const uint32_t gi, ZgHufLds<GROUP>
     lastb = slen ? sp[slen - 1] : 0;
     if (slen == 0 || lastb == 0) hst = ZG_LIT_EXTRA_PADDING;                       // :98-109
   }
-  if (hst) { if (lane == 0) zg_huf_set_status(d.lit_status, b, 0u, hst); return; }
+  // (what is wrong with the section as a whole — jump table, sizes, no table — is found before any stream is looked at: rank 0. The
+  //  padding of a stream's last byte is checked when THAT stream's turn comes, literals_section_decoder.rs:98-109: it ranks with its
+  //  stream, behind a bitstream mismatch of an earlier one)
+  if (hst) { if (lane == 0) zg_huf_set_status(d.lit_status, b, hst == ZG_LIT_EXTRA_PADDING ? (uint32_t)k : 0u, hst); return; }
   const uint32_t hb = zg_hbit(lastb) - 1;                     // payload bits of the last byte (below the marker)
   const int32_t T = (int32_t)((slen - 1) * 8 + hb);           // bits of the stream; position P = bits not yet consumed
   const int64_t A = (int64_t)(uintptr_t)sp;                   // address of stream bit 0
