@@ -94,7 +94,11 @@ const char* zgpu_status_name(int status);
 
 /* ---- FrameDecoder::decode_all (frame_decoder.rs:541-577) -------------------------------------------------
  * src holds concatenated frames (skippable frames are skipped); the plaintext of all frames is written back to
- * back into dst. ZGPU_E_TARGET_TOO_SMALL if it does not fit. H2D + kernels + D2H. */
+ * back into dst. ZGPU_E_TARGET_TOO_SMALL if it does not fit. H2D + kernels + D2H.
+ * An input with several defects returns the error the reference meets FIRST in stream order (it decodes block by block,
+ * frame_decoder.rs:319-375): a defect inside a block comes before a header further back that cannot be read, a block's
+ * literals before its sequences, an earlier stream / sequence before a later one — whichever of them the engine's stages
+ * find first. */
 int zgpu_decode_all(zgpu_ctx*, const uint8_t* src, size_t len, uint8_t* dst, size_t cap, size_t* written);
 /* decode_all_to_vec (frame_decoder.rs:591-610): the library sizes the output (exactly: the size of every frame is known on
  * the host before the LZ77 stages run). *out is malloc'ed; release it with zgpu_free. */

@@ -2,7 +2,7 @@
 """The differential soak of soak.py without a GPU: the engine's host parser, verdict rules and zg_k_exact (CPU emulator harness,
 tests/emu) against the oracle on randomly mutated frames. The harness models the entropy kernels serially, so this finds
 disagreements in what is shared with the product: the host walk, the order in which verdicts outrank each other, zg_exact.h.
-usage: soak_cpu.py [mutations per frame] [seed]"""
+usage: soak_cpu.py [mutations per frame] [seed] [concat]   (concat: every input is two corpus frames back to back)"""
 import os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -10,6 +10,7 @@ import emu, oracle
 from golden_io import read_pack
 per = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+concat = len(sys.argv) > 3 and sys.argv[3] == "concat"
 packs, syn = read_pack("decodecorpus.pack"), read_pack("synthetic.pack")
 bases = [packs[n] for n in sorted(packs) if n.endswith(".zst")] + [syn[n] for n in sorted(syn) if n.endswith(".zst") and len(syn[n]) < (1 << 20)]
 rng = random.Random(seed)
@@ -23,7 +24,7 @@ diffs = []
 t0 = time.time()
 for bi, base in enumerate(bases):
     for it in range(per):
-        m = bytearray(base)
+        m = bytearray(base + (bases[rng.randrange(len(bases))] if concat else b""))
         for _ in range(1 + rng.randrange(3)):
             if len(m) < 16:
                 break
