@@ -16,6 +16,23 @@ bases = [packs[n] for n in sorted(packs) if n.endswith(".zst")] + [syn[n] for n 
 rng = random.Random(seed)
 
 
+def block_starts(z):
+    """offsets of the block headers of a (single, valid) frame"""
+    st, c, _, _ = oracle.FrameDecoder().init(z)
+    out, p = [], c
+    while st == 0 and p + 3 <= len(z):
+        h = int.from_bytes(z[p:p + 3], "little")
+        out.append(p)
+        size = 1 if ((h >> 1) & 3) == 1 else h >> 3
+        p += 3 + size
+        if h & 1:
+            break
+    return out
+
+
+starts = [block_starts(b) for b in bases]
+
+
 verdict = emu.decode_all_verdict
 
 
@@ -28,7 +45,7 @@ for bi, base in enumerate(bases):
         for _ in range(1 + rng.randrange(3)):
             if len(m) < 16:
                 break
-            kind = rng.randrange(5)
+            kind = rng.randrange(7)
             if kind == 0:
                 i = rng.randrange(4, len(m)); m[i] ^= 1 << rng.randrange(8)
             elif kind == 1:
@@ -37,8 +54,12 @@ for bi, base in enumerate(bases):
                 m = m[:rng.randrange(8, len(m))]
             elif kind == 3:
                 i = rng.randrange(4, len(m) - 4); m[i:i + 2] = bytes([rng.randrange(256), rng.randrange(256)])
-            else:
+            elif kind == 4:
                 i = rng.randrange(4, min(len(m), 40)); m[i] = rng.randrange(256)
+            else:                                     # the first bytes of a block: its header, its literals / sequences section headers, table descriptions
+                i = starts[bi][rng.randrange(len(starts[bi]))] + rng.randrange(0, 24)
+                if i < len(m):
+                    m[i] = rng.randrange(256) if kind == 5 else m[i] ^ (1 << rng.randrange(8))
         m = bytes(m)
         ost, _ = oracle.FrameDecoder().decode_all(m, 1 << 25)
         gst = verdict(m)
