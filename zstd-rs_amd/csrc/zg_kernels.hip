@@ -121,7 +121,14 @@ ZX_DEV void zx_max_glb(uint32_t* p, uint32_t v) { atomicMax(p, v); }
 ZX_DEV void zx_gst128(void* p, const ZxU4& v) { const zg_v4u w = {v.x, v.y, v.z, v.w}; *(zg_gv4u*)p = w; }   // 16 bytes to global memory, 16-byte aligned
 // a dword to global memory at any byte address: ONE store (gfx950 runs in unaligned access mode; told about the alignment, the
 // compiler takes the dword apart into bytes and reassembles them)
+// (round 4 used __builtin_nontemporal_store here: zg_k_huf's lanes store dwords 16-48 bytes apart, and as streaming "nt" stores those partial
+//  lines went to HBM one by one — 27.9 GB written for 8.6 GB of literals on the iso-like frames; plain stores meet again in the L2)
+struct __attribute__((packed)) ZxU32Unaligned { uint32_t v; };
+#ifdef ZG_HUF_ST_NT
 ZX_DEV void zx_gst32u(void* p, uint32_t v) { __builtin_nontemporal_store(v, (uint32_t*)p); }
+#else
+ZX_DEV void zx_gst32u(void* p, uint32_t v) { ((ZxU32Unaligned*)p)->v = v; }
+#endif
 ZX_DEV ZxU4 zx_gld128(const void* p) { const zg_v4u v = *(const zg_gv4u*)p; ZxU4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }   // 16 bytes of global memory, 16-byte aligned
 // what the lanes of a wave wrote to LDS is read by the other lanes afterwards (a wave runs in lockstep: no hardware barrier, but the
 // compiler must not move the reads ahead)
