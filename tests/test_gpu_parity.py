@@ -363,14 +363,22 @@ def test_twice_mutated_frames_first_error_in_stream_order(ctx):
     assert n_walk_second > 50
 
 
-def test_inorder_fallback_path(ctx, monkeypatch):
-    """the in-order kernel (zg_k_lz) that serves frames with a block regenerating more than 128 KiB: forced on here"""
+def test_inorder_fallback_path(monkeypatch):
+    """the in-order kernel (zg_k_lz) that serves frames with a block regenerating more than 128 KiB: forced on here (the engine reads
+    its switches once, when it is created: the context comes after the switch)"""
+    import zgpu
     monkeypatch.setenv("ZGPU_FORCE_INORDER", "1")
+    ctx = zgpu.Context(0)
     pack, man = read_pack("decodecorpus.pack"), read_manifest("decodecorpus.json")
     for name in sorted(man)[::9]:
         assert _sha(ctx.decode_all(pack[name], man[name]["size"])) == man[name]["sha256"], name
     spack, sman = read_pack("synthetic.pack"), read_manifest("synthetic.json")
     assert _sha(ctx.decode_all(spack["text_1m_l3.zst"], sman["text_1m_l3.zst"]["size"])) == sman["text_1m_l3.zst"]["sha256"]
+    b = ctx.prepare(spack["text_1m_l3.zst"])
+    b.run(); b.sync()
+    assert b.timings()["lz"] > 0.5                             # (ms) it really went through zg_k_lz: a megabyte in order takes milliseconds
+    b.close()
+    ctx.close()
 
 
 # ---- streaming / partial decode surface, dictionaries (SURVEY.md §8b, §8f) ------------------------------------------

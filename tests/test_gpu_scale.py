@@ -131,9 +131,12 @@ def test_ramped_units_chain_beside_flatten(ctx, monkeypatch):
     import zgdata
     plain = zgdata.text_like(200 << 20, seed=0x7A)
     z = zgdata.zstd_compress(plain)
+    import zgpu
     for ramp in ("50", "90"):
-        monkeypatch.setenv("ZGPU_RAMP", ramp)
-        _check_batch(ctx, [z], [plain])
+        monkeypatch.setenv("ZGPU_RAMP", ramp)    # (read when the engine is created: a context per setting)
+        c = zgpu.Context(0)
+        _check_batch(c, [z], [plain])
+        c.close()
     monkeypatch.delenv("ZGPU_RAMP")
     _check_batch(ctx, [z], [plain])
 

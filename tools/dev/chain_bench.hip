@@ -24,9 +24,9 @@
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
-constexpr uint32_t T = 256, TAIL = 2u << 20, G = TAIL / 4, USTRIDE = 3900000u & ~3u, SH = 16, SHS = 32 /* u32 between shards: 128 B */;
+constexpr uint32_t TAIL = 2u << 20, G = TAIL / 4, USTRIDE = 3900000u & ~3u, SH = 16, SHS = 32 /* u32 between shards: 128 B */;
 constexpr uint32_t OOB = 0xFFFFFFFFu;
-struct P { uint8_t* dst; const v4u* og; uint32_t* cnt; uint32_t* top; uint32_t* abort_; uint32_t nsteps, flags; };
+struct P { uint8_t* dst; const v4u* og; uint32_t* cnt; uint32_t* top; uint32_t* abort_; uint32_t nsteps, flags; long long* stamps; };
 
 __host__ __device__ inline uint64_t mix(uint64_t i) { uint64_t z = (i + 1) * 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
 // group g of step s (1-based; step 0 is all literal): four effective offsets (0: literal byte) and the literal values
@@ -66,12 +66,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* p, uint32_
 template <bool SC1> __device__ __forceinline__ v2u ld64(__amdgpu_buffer_rsrc_t rs, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, SC1 ? 16 : 0); }
 
 // one item: groups [g0, g0 + T*B) of step s; wave w owns 64*B consecutive groups, lane l group k*64 + l of them (coalesced scratch reads)
-template <int B> __device__ __forceinline__ void load_og(const P& p, uint32_t s, uint32_t g0, v4u (&o)[B]) {
+template <int B, int T> __device__ __forceinline__ void load_og(const P& p, uint32_t s, uint32_t g0, v4u (&o)[B]) {
   const uint32_t t = threadIdx.x, w = t >> 6, l = t & 63;
 #pragma unroll
   for (int k = 0; k < B; k++) { const uint32_t g = g0 + w * 64 * B + k * 64 + l; o[k] = p.og[(uint64_t)(s - 1) * G + (g < G ? g : 0)]; }
 }
-template <int B, bool SC1, bool ST16> __device__ __forceinline__ void item(const P& p, __amdgpu_buffer_rsrc_t rs, uint32_t s, uint32_t g0, const v4u (&o)[B], uint32_t* lds) {
+template <int B, int T, bool SC1, bool SC1ST, bool ST16, int MASK = 0> __device__ __forceinline__ void item(const P& p, __amdgpu_buffer_rsrc_t rs, uint32_t s, uint32_t g0, const v4u (&o)[B], uint32_t* lds) {
   const uint32_t t = threadIdx.x, w = t >> 6, l = t & 63;
   v2u rA[B], rB[B], rC[B], rD[B], rW[B];
 #pragma unroll
@@ -81,11 +81,20 @@ template <int B, bool SC1, bool ST16> __device__ __forceinline__ void item(const
     const bool ux = q.x != 0, uy = q.y != 0, uz = q.z != 0, uw = q.w != 0, all = ux && uy && uz && uw;
     const bool nD = uw && !(ux && q.w == q.x), nB = uy && !(ux && q.y == q.x) && !(uw && q.y == q.w);
     const bool nC = uz && !(ux && q.z == q.x) && !(uw && q.z == q.w) && !(uy && q.z == q.y);
-    rA[k] = ld64<SC1>(rs, ux ? (wrel - q.x) & ~3u : OOB);
-    rD[k] = ld64<SC1>(rs, nD ? (wrel - q.w) & ~3u : OOB);
-    rB[k] = ld64<SC1>(rs, nB ? (wrel - q.y) & ~3u : OOB);
-    rC[k] = ld64<SC1>(rs, nC ? (wrel - q.z) & ~3u : OOB);
-    rW[k] = ld64<SC1>(rs, (!all && g < G) ? wrel : OOB);      // the bytes in place (16-byte stores rewrite literal bytes too)
+    if (MASK == 1) {                                          // exec-masked: a lane that needs nothing issues nothing
+      rA[k] = rD[k] = rB[k] = rC[k] = rW[k] = (v2u){0u, 0u};
+      if (ux) rA[k] = ld64<SC1>(rs, (wrel - q.x) & ~3u);
+      if (nD) rD[k] = ld64<SC1>(rs, (wrel - q.w) & ~3u);
+      if (nB) rB[k] = ld64<SC1>(rs, (wrel - q.y) & ~3u);
+      if (nC) rC[k] = ld64<SC1>(rs, (wrel - q.z) & ~3u);
+      if (!all && g < G) rW[k] = ld64<SC1>(rs, wrel);
+    } else {
+    rA[k] = ld64<SC1>(rs, (MASK != 3 && ux) ? (wrel - q.x) & ~3u : OOB);
+    rD[k] = ld64<SC1>(rs, (MASK != 3 && nD) ? (wrel - q.w) & ~3u : OOB);
+    if (MASK != 2) rB[k] = ld64<SC1>(rs, (MASK != 3 && nB) ? (wrel - q.y) & ~3u : OOB); else rB[k] = rA[k];
+    if (MASK != 2) rC[k] = ld64<SC1>(rs, (MASK != 3 && nC) ? (wrel - q.z) & ~3u : OOB); else rC[k] = rD[k];
+    rW[k] = ld64<SC1>(rs, (MASK != 3 && !all && g < G) ? wrel : OOB);      // the bytes in place (16-byte stores rewrite literal bytes too)
+    }
   }
 #pragma unroll
   for (int k = 0; k < B; k++) {
@@ -99,73 +108,88 @@ template <int B, bool SC1, bool ST16> __device__ __forceinline__ void item(const
     const uint32_t sz = (ux && q.z == q.x) ? lA : (uw && q.z == q.w) ? sw : (uy && q.z == q.y) ? sy : lC;
     const uint32_t v = ((ux ? lA : lW) & 0xFFu) | ((uy ? sy : lW) & 0xFF00u) | ((uz ? sz : lW) & 0xFF0000u) | ((uw ? sw : lW) & 0xFF000000u);
     if (ST16) lds[w * 64 * B + k * 64 + l] = v;
-    else __builtin_amdgcn_raw_buffer_store_b32(v, rs, g < G ? s * USTRIDE + 4 * g : OOB, 0, SC1 ? 16 : 0);
+    else __builtin_amdgcn_raw_buffer_store_b32(v, rs, g < G ? s * USTRIDE + 4 * g : OOB, 0, SC1ST ? 16 : 0);
   }
   if (ST16) {   // the wave's 64*B dwords leave as 16-byte pieces: lane l < 16*B stores groups 4l .. 4l+3 of the wave's run
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (l < 16 * B) {
       const v4u v = *(const v4u*)(lds + w * 64 * B + 4 * l);
       const uint32_t g = g0 + w * 64 * B + 4 * l;
-      __builtin_amdgcn_raw_buffer_store_b128(v, rs, g < G ? s * USTRIDE + 4 * g : OOB, 0, SC1 ? 16 : 0);
+      __builtin_amdgcn_raw_buffer_store_b128(v, rs, g < G ? s * USTRIDE + 4 * g : OOB, 0, SC1ST ? 16 : 0);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
   }
 }
 
-template <int B> __global__ void __launch_bounds__(T) k_step(P p, uint32_t s) {      // L: one launch per step
+template <int B> __global__ void __launch_bounds__(256) k_step(P p, uint32_t s) {      // L: one launch per step
+  constexpr int T = 256;
   if (p.flags & 32u) return;
   const __amdgpu_buffer_rsrc_t rs = mk_rsrc(p.dst, (p.nsteps + 1) * USTRIDE);
   v4u o[B];
-  load_og<B>(p, s, blockIdx.x * T * B, o);
-  item<B, false, false>(p, rs, s, blockIdx.x * T * B, o, nullptr);
+  load_og<B, T>(p, s, blockIdx.x * T * B, o);
+  item<B, T, false, false, false>(p, rs, s, blockIdx.x * T * B, o, nullptr);
 }
 
-template <int B> __global__ void __launch_bounds__(T) k_persist(P p) {
+template <int B, int T> __global__ void __launch_bounds__(T) k_persist(P p) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[T * B];
+  __shared__ uint32_t s_dead;
   const uint32_t r = blockIdx.x, NW = gridDim.x, t = threadIdx.x, IPS = (G + T * B - 1) / (T * B);
   const uint32_t m = NW < IPS ? NW : IPS;                       // workgroups that have an item in every step
   const __amdgpu_buffer_rsrc_t rs = mk_rsrc(p.dst, (p.nsteps + 1) * USTRIDE);
   const bool two = p.flags & 1u, empty = p.flags & 2u, st4 = p.flags & 4u, late = p.flags & 8u, fenced = p.flags & 16u;
+  const bool pl_ld = p.flags & 64u, pl_st = p.flags & 128u, nodrain = p.flags & 256u, acq = p.flags & 512u;
   bool dead = false;
   for (uint32_t s = 1; s <= p.nsteps && !dead; s++) {
     v4u o[B];
-    if (!empty && !late && r < IPS) load_og<B>(p, s, r * T * B, o);
+    const bool stamp = (p.flags & 1024u) && t == 0;
+    long long* sp = p.stamps + ((size_t)r * (p.nsteps + 1) + s) * 5;
+    if (stamp) sp[0] = wall_clock64();
+    if (!empty && !late && r < IPS) load_og<B, T>(p, s, r * T * B, o);
     if (s > 1) {                                                // every slot of step s-1 stored and drained?
       if (t < 64) {
         const uint32_t want = two ? (t == 0 ? (m < SH ? m : SH) : 0u) : (t < SH && m > t ? (m - t + SH - 1) / SH : 0u);
         const uint32_t* q = t == 63 ? p.abort_ : two ? p.top + (s - 1) * SHS : p.cnt + ((s - 1) * SH + (t < SH ? t : 0)) * SHS;
         for (uint32_t spins = 0;; spins++) {
-          const uint32_t v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t v = (two && t != 0 && t != 63) ? 0u : __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const bool ab = __any(t == 63 && v != 0);
           if (ab) { dead = true; break; }
           if (__all(t == 63 || v >= want)) break;
           if (spins > (1u << 15)) { if (t == 0) __hip_atomic_store(p.abort_, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dead = true; break; }
           __builtin_amdgcn_s_sleep(1);
         }
-        if (fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (fenced || acq) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
-      __shared__ uint32_t s_dead;
       if (t == 0) s_dead = dead;
       __syncthreads();
       dead = s_dead;
       if (dead) break;
     }
+    if (stamp) sp[1] = wall_clock64();
     if (!empty) {
       for (uint32_t j = r; j < IPS; j += NW) {
-        if (late || j != r) load_og<B>(p, s, j * T * B, o);
-        if (fenced) item<B, false, false>(p, rs, s, j * T * B, o, lds);
-        else if (st4) item<B, true, false>(p, rs, s, j * T * B, o, lds);
-        else item<B, true, true>(p, rs, s, j * T * B, o, lds);
+        if (late || j != r) load_og<B, T>(p, s, j * T * B, o);
+        if (fenced) item<B, T, false, false, false>(p, rs, s, j * T * B, o, lds);
+        else if (st4) item<B, T, true, true, false>(p, rs, s, j * T * B, o, lds);
+        else if (pl_ld && pl_st) item<B, T, false, false, true>(p, rs, s, j * T * B, o, lds);
+        else if (pl_ld) item<B, T, false, true, true>(p, rs, s, j * T * B, o, lds);
+        else if (pl_st) item<B, T, true, false, true>(p, rs, s, j * T * B, o, lds);
+        else if ((p.flags >> 11) == 1u) item<B, T, true, true, true, 1>(p, rs, s, j * T * B, o, lds);
+        else if ((p.flags >> 11) == 2u) item<B, T, true, true, true, 2>(p, rs, s, j * T * B, o, lds);
+        else if ((p.flags >> 11) == 3u) item<B, T, true, true, true, 3>(p, rs, s, j * T * B, o, lds);
+        else item<B, T, true, true, true>(p, rs, s, j * T * B, o, lds);
       }
     }
+    if (stamp) sp[2] = wall_clock64();
     if (r < m) {                                                 // arrive: every storing wave drains, ONE lane publishes
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!nodrain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      if (stamp) sp[3] = wall_clock64();
       if (t == 0) {
         if (fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         const uint32_t h = r % SH, exp_h = (m - h + SH - 1) / SH;
         const uint32_t old = __hip_atomic_fetch_add(p.cnt + (s * SH + h) * SHS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (two && old + 1 == exp_h) __hip_atomic_fetch_add(p.top + s * SHS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (stamp) sp[4] = wall_clock64();
       }
     }
   }
@@ -178,6 +202,9 @@ int main(int argc, char** argv) {
   const size_t dst_bytes = (size_t)(nsteps + 1) * USTRIDE + 4096, og_bytes = (size_t)nsteps * G * 16, cnt_bytes = (size_t)(nsteps + 2) * SH * SHS * 4;
   v4u* og; CK(hipMalloc(&p.dst, dst_bytes)); CK(hipMalloc(&og, og_bytes)); CK(hipMalloc(&p.cnt, cnt_bytes)); CK(hipMalloc(&p.top, cnt_bytes)); CK(hipMalloc(&p.abort_, 256));
   p.og = og;
+  const size_t stamp_n = (size_t)1024 * (nsteps + 1) * 5;
+  CK(hipMalloc(&p.stamps, stamp_n * 8));
+  std::vector<long long> stamps(stamp_n);
   hipLaunchKernelGGL(k_init_og, dim3((uint32_t)(((uint64_t)nsteps * G + 255) / 256)), dim3(256), 0, 0, og, nsteps);
   CK(hipDeviceSynchronize());
   // host model
@@ -190,7 +217,7 @@ int main(int argc, char** argv) {
     }
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  auto run = [&](const char* name, uint32_t flags, int B, uint32_t nw) {
+  auto run = [&](const char* name, uint32_t flags, int B, uint32_t nw, int T = 256) {
     p.flags = flags;
     float best = 1e9f; bool ok = true; uint32_t ab = 0;
     for (int rep = 0; rep < 3; rep++) {
@@ -199,41 +226,58 @@ int main(int argc, char** argv) {
       CK(hipEventRecord(e0, st));
       if (nw == 0) {
         for (uint32_t s = 1; s <= nsteps; s++) {
-          if (B == 2) hipLaunchKernelGGL(k_step<2>, dim3((G + T * 2 - 1) / (T * 2)), dim3(T), 0, st, p, s);
-          else hipLaunchKernelGGL(k_step<4>, dim3((G + T * 4 - 1) / (T * 4)), dim3(T), 0, st, p, s);
+          if (B == 2) hipLaunchKernelGGL(k_step<2>, dim3((G + 256 * 2 - 1) / (256 * 2)), dim3(256), 0, st, p, s);
+          else hipLaunchKernelGGL(k_step<4>, dim3((G + 256 * 4 - 1) / (256 * 4)), dim3(256), 0, st, p, s);
         }
       } else {
         CK(hipMemsetAsync(p.cnt, 0, cnt_bytes, st)); CK(hipMemsetAsync(p.top, 0, cnt_bytes, st)); CK(hipMemsetAsync(p.abort_, 0, 256, st));
-        if (B == 1) hipLaunchKernelGGL(k_persist<1>, dim3(nw), dim3(T), 0, st, p);
-        else if (B == 2) hipLaunchKernelGGL(k_persist<2>, dim3(nw), dim3(T), 0, st, p);
-        else hipLaunchKernelGGL(k_persist<4>, dim3(nw), dim3(T), 0, st, p);
+        if (T == 1024) { if (B == 2) hipLaunchKernelGGL((k_persist<2, 1024>), dim3(nw), dim3(1024), 0, st, p); else hipLaunchKernelGGL((k_persist<1, 1024>), dim3(nw), dim3(1024), 0, st, p); }
+        else if (T == 512) { if (B == 2) hipLaunchKernelGGL((k_persist<2, 512>), dim3(nw), dim3(512), 0, st, p); else hipLaunchKernelGGL((k_persist<4, 512>), dim3(nw), dim3(512), 0, st, p); }
+        else if (B == 1) hipLaunchKernelGGL((k_persist<1, 256>), dim3(nw), dim3(256), 0, st, p);
+        else if (B == 2) hipLaunchKernelGGL((k_persist<2, 256>), dim3(nw), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((k_persist<4, 256>), dim3(nw), dim3(256), 0, st, p);
       }
       CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms < best ? ms : best;
       CK(hipMemcpy(&ab, p.abort_, 4, hipMemcpyDeviceToHost));
-      if (!(flags & 34u)) {
+      if (!(flags & 34u) && (flags >> 11) < 2u) {
         for (uint32_t s = 0; s <= nsteps; s++) CK(hipMemcpy(got.data() + (size_t)s * TAIL, p.dst + (size_t)s * USTRIDE, TAIL, hipMemcpyDeviceToHost));
         size_t bad = 0; for (size_t i = 0; i < got.size(); i++) bad += got[i] != ref[i];
         if (bad) { ok = false; printf("   rep %d: %zu wrong bytes\n", rep, bad); }
       }
     }
-    printf("%-58s %8.3f ms  %6.2f us/step  %s%s\n", name, best, best * 1000.f / nsteps, (flags & 34u) ? "(not checked)" : ok ? "OK" : "BAD", ab ? "  GAVE UP" : "");
+    if ((flags & 1024u) && nw) {
+      // where a step's time goes (last repetition): per workgroup and step, stamps at 0 step start, 1 wait over, 2 gathers used / stores issued,
+      // 3 stores drained + workgroup barrier, 4 arrival returned. Units of 10 ns (100 MHz wall clock).
+      CK(hipMemcpy(stamps.data(), p.stamps, stamp_n * 8, hipMemcpyDeviceToHost));
+      double w01 = 0, w12 = 0, w23 = 0, w34 = 0, crit = 0, skew = 0, maxdata = 0; size_t n = 0;
+      for (uint32_t s = 2; s <= nsteps; s++) {
+        long long last_arr = 0, first_go = 1ll << 62, last_go = 0, prev_last_arr = 0; double md = 0;
+        for (uint32_t r = 0; r < nw; r++) {
+          const long long* q = &stamps[((size_t)r * (nsteps + 1) + s) * 5];
+          const long long* qp = &stamps[((size_t)r * (nsteps + 1) + s - 1) * 5];
+          w01 += q[1] - q[0]; w12 += q[2] - q[1]; w23 += q[3] - q[2]; w34 += q[4] - q[3]; n++;
+          last_arr = q[4] > last_arr ? q[4] : last_arr; first_go = q[1] < first_go ? q[1] : first_go; last_go = q[1] > last_go ? q[1] : last_go;
+          prev_last_arr = qp[4] > prev_last_arr ? qp[4] : prev_last_arr;
+          md = (double)(q[3] - q[1]) > md ? (double)(q[3] - q[1]) : md;
+        }
+        crit += (double)(first_go - prev_last_arr); skew += (double)(last_go - first_go); maxdata += md;
+      }
+      const double k = 0.01, ns = nsteps - 1;
+      printf("   per wg+step (us): wait %.2f  gathers+compute %.2f  drain+barrier %.2f  arrive %.2f | per step: last arrival -> first go %.2f, go skew %.2f, slowest wg's data phase %.2f\n",
+             w01 / n * k, w12 / n * k, w23 / n * k, w34 / n * k, crit / ns * k, skew / ns * k, maxdata / ns * k);
+    }
+    printf("%-58s %8.3f ms  %6.2f us/step  %s%s\n", name, best, best * 1000.f / nsteps, (flags & 34u) ? "(sync only)" : ok ? "OK" : "BAD", ab ? "  GAVE UP" : "");
     fflush(stdout);
   };
   run("L  launch per step, B=2 (1024 wg)", 0, 2, 0);
-  run("L  launch per step, B=4 (512 wg)", 0, 4, 0);
-  run("L  launch per step, empty", 32, 2, 0);
-  run("P  persistent, B=4 nw=512, 16-B sc1 stores, 16 shards", 0, 4, 512);
-  run("P  persistent, B=2 nw=1024", 0, 2, 1024);
-  run("P  persistent, B=1 nw=1024 (2 items per step)", 0, 1, 1024);
-  run("P  B=4 nw=512, two-level arrival", 1, 4, 512);
-  run("P  B=2 nw=1024, two-level arrival", 1, 2, 1024);
-  run("P  B=4 nw=512, empty steps", 2, 4, 512);
-  run("P  B=2 nw=1024, empty steps", 2, 2, 1024);
-  run("P  B=4 nw=512, empty steps, two-level", 3, 4, 512);
-  run("P  B=4 nw=512, dword sc1 stores", 4, 4, 512);
-  run("P  B=4 nw=512, scratch words after the wait", 8, 4, 512);
-  run("P  B=4 nw=512, fenced (plain + release/acquire)", 16, 4, 512);
-  run("P  B=4 nw=256 (2 items per step)", 0, 4, 256);
+  run("P  T=1024 B=2 nw=256 16 shards, OOB-predicated loads", 1024, 2, 256, 1024);
+  run("P  T=1024 B=2 nw=256 16 shards, exec-masked loads", 1024 + 2048, 2, 256, 1024);
+  run("P  T=1024 B=2 nw=256 16 shards, 3 of 5 loads (timing)", 1024 + 4096, 2, 256, 1024);
+  run("P  T=1024 B=2 nw=256 16 shards, all loads OOB (timing)", 1024 + 6144, 2, 256, 1024);
+  run("P  B=4 nw=512 two-level, OOB-predicated", 1025, 4, 512);
+  run("P  B=4 nw=512 two-level, exec-masked", 1025 + 2048, 4, 512);
+  run("P  B=4 nw=512 two-level, 3 of 5 loads (timing)", 1025 + 4096, 4, 512);
+  run("P  B=4 nw=512 two-level, all loads OOB (timing)", 1025 + 6144, 4, 512);
   return 0;
 }

@@ -74,6 +74,33 @@ int Engine::fail(hipError_t e, const char* what) {
   return ZG_HIP_ERROR;
 }
 
+Tuning Tuning::from_env() {
+  Tuning t;
+  auto num = [](const char* name, uint32_t* v, bool positive) { const char* e = getenv(name); if (e && (!positive || atoi(e) > 0)) *v = (uint32_t)atoi(e); return e != nullptr; };
+  auto is0 = [](const char* name) { const char* e = getenv(name); return e && e[0] == '0'; };
+  num("ZGPU_UNIT_BLOCKS", &t.unit_blocks, true);
+  t.direct = !is0("ZGPU_DIRECT");
+  num("ZGPU_RAMP", &t.ramp_percent, false);
+  t.sparse_set = num("ZGPU_SPARSE_MAX", &t.sparse_max, false);
+  if (is0("ZGPU_LIT_DIRECT")) t.lit_direct = 0;
+  { uint32_t v = 0; if (num("ZGPU_DIRECT_SHARE", &v, true) && v >= 10) t.direct_share10 = v; }
+  t.debug_timers = getenv("ZGPU_DEBUG_TIMERS") != nullptr;
+  { const char* e = getenv("ZGPU_FORCE_INORDER"); t.force_inorder = e && e[0] == '1'; }
+  num("ZGPU_FLAT_MODE", &t.flat_mode, false);
+  num("ZGPU_SWEEP_W", &t.sweep_w, true);
+  t.overlap = !is0("ZGPU_OVERLAP");
+  t.no_sweep = getenv("ZGPU_DEBUG_NO_SWEEP") != nullptr;
+  t.sweep_split = !is0("ZGPU_SWEEP_SPLIT");
+  t.no_exact = getenv("ZGPU_DEBUG_NO_EXACT") != nullptr;
+  t.no_presize = is0("ZGPU_PRESIZE");
+  { const char* e = getenv("ZGPU_FLAT_T"); t.flat_shape = (e && atoi(e) == 512) ? 1 : 0; }   // "512": 512 threads x 8 KiB tiles, two workgroups per CU; else the default
+  num("ZGPU_SWEEP_MODE", &t.sweep.mode, false);
+  num("ZGPU_SWEEP_NB", &t.sweep.nbatch, true);
+  num("ZGPU_SWEEP_GROUP", &t.sweep.group, true);
+  num("ZGPU_SWEEP_HEAD_LDS", &t.sweep.head_lds, false);
+  return t;
+}
+
 int Engine::create(int device, Engine** out) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device >= n) return ZG_HIP_ERROR;  // no GPU: fail loudly, no CPU path
@@ -83,10 +110,9 @@ int Engine::create(int device, Engine** out) {
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->cus_ = prop.multiProcessorCount;
-    const char* v = getenv("ZGPU_FLAT_T");
-    if (v) e->flat_shape_ = atoi(v) == 512 ? 1 : 0;   // "512": 512 threads x 8 KiB tiles, two workgroups per CU; else the default
-    const char* ps = getenv("ZGPU_PRESIZE");
-    e->no_presize_ = ps && ps[0] == '0';
+    e->tn_ = Tuning::from_env();                        // the only place the engine looks at the environment
+    e->flat_shape_ = e->tn_.flat_shape;
+    e->no_presize_ = e->tn_.no_presize;
   }
   // two streams: the sequences chain is the critical one (its kernels last as long as one block's serial chain), so its
   // workgroups are dispatched first; the literals chain fills what is left
@@ -359,14 +385,15 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   ZG_HIP(hipSetDevice(device_));
   // a frame-layer error after some good frames: the good frames are still uploaded (callers such as the
   // FrameDecoder mirror may want them); decode_all reports parse_status.
-  { const char* e = getenv("ZGPU_UNIT_BLOCKS"); if (e && atoi(e) > 0) b->bb.unit_blocks = (uint32_t)atoi(e); }
-  { const char* e = getenv("ZGPU_DIRECT"); if (e && e[0] == '0') b->bb.direct_units = false; }
-  { const char* e = getenv("ZGPU_RAMP"); if (e) b->bb.ramp_percent = (uint32_t)atoi(e); }   // (measurement) N > 0: one long frame in units growing by +-N %, the sweep chain beside the flatten
-  { const char* e = getenv("ZGPU_SPARSE_MAX"); if (e) { b->bb.sparse_max = (uint32_t)atoi(e); b->bb.sparse_per_block = 1u << 20; } }   // (tests) sequences per frame up to which zg_k_sparse replaces the sweep, whatever their density; 0: never
+  const Tuning& tn = tn_;                                      // (measurement / test switches, read when the engine was created)
+  if (tn.unit_blocks) b->bb.unit_blocks = tn.unit_blocks;
+  if (!tn.direct) b->bb.direct_units = false;
+  b->bb.ramp_percent = tn.ramp_percent;                        // N > 0: one long frame in units growing by +-N %, the sweep chain beside the flatten
+  if (tn.sparse_set) { b->bb.sparse_max = tn.sparse_max; b->bb.sparse_per_block = 1u << 20; }   // (tests) sequences per frame up to which zg_k_sparse replaces the sweep, whatever their density; 0: never
   b->bb.flat_slots = (uint32_t)cus_ * (flat_shape_ == 0 ? 1u : 2u);   // zg_k_flatten: workgroups the device holds at once
   b->bb.chain_slots = (uint32_t)cus_ * 32u;                            // zg_k_seq: blocks whose chains run at once
-  { const char* e = getenv("ZGPU_LIT_DIRECT"); if (e && e[0] == '0') b->bb.lit_direct_allowed = false; }
-  { const char* e = getenv("ZGPU_DIRECT_SHARE"); if (e && atoi(e) >= 10) b->bb.direct_share10 = (uint32_t)atoi(e); }   // (measurement) tenths
+  if (tn.lit_direct == 0) b->bb.lit_direct_allowed = false;
+  if (tn.direct_share10) b->bb.direct_share10 = tn.direct_share10;   // (measurement) tenths
   b->bb.finish();
   BatchBuilder& bb = b->bb;
   Scratch* sc = b->sc = acquire();
@@ -430,11 +457,11 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
     ss.list_off = r.list_off; ss.nunits = r.nunits; ss.slices = r.max_blocks * (kMaxBlockSize / ZG_SW_BATCH); ss.pad = 0;   // zg_k_sweep: ZG_SW_BATCH bytes of output per workgroup
     b->sweep_steps.push_back(ss);
   }
-  d.dbg = getenv("ZGPU_DEBUG_TIMERS") ? sc->d_dbg.as<unsigned long long>() : nullptr;
-  { const char* e = getenv("ZGPU_FORCE_INORDER"); d.flags = (e && e[0] == '1') ? 1u : 0u; }
+  d.dbg = tn.debug_timers ? sc->d_dbg.as<unsigned long long>() : nullptr;
+  d.flags = tn.force_inorder ? 1u : 0u;
   d.flags |= (uint32_t)flat_shape_ << 2;
-  { const char* e = getenv("ZGPU_FLAT_MODE"); if (e) d.flags |= (((uint32_t)atoi(e) & 3u) << 4) | (((uint32_t)atoi(e) & 4u) << 5); }   // (timing experiments) zg_k_flatten without scratch stores / gathers
-  { const char* e = getenv("ZGPU_SWEEP_W"); d.sweep_window = (e && atoi(e) > 0) ? (uint32_t)atoi(e) : 0u; }
+  d.flags |= ((tn.flat_mode & 3u) << 4) | ((tn.flat_mode & 4u) << 5);   // (timing experiments) zg_k_flatten without scratch stores / gathers
+  d.sweep_window = tn.sweep_w;
   if (hipStreamSynchronize(stream_) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
   *out = b;
   return ZG_OK;
@@ -571,8 +598,7 @@ int Batch::launch_phase2() {
   sweep_mode = 0; synced = false;
   // One long frame in ramped units (BatchBuilder::finish): the flatten goes to its own stream and the sweep chain starts at once;
   // a step waits for its unit's flag (zg_k_flatten sets it, zg_k_sweep polls it). ZGPU_OVERLAP=0: one after the other.
-  const char* ov = getenv("ZGPU_OVERLAP");
-  const bool overlap = bb.ramped && !(ov && ov[0] == '0') && !getenv("ZGPU_DEBUG_NO_SWEEP");
+  const bool overlap = bb.ramped && eng->tn_.overlap && !eng->tn_.no_sweep;
   d.overlap_epoch = overlap ? ++epoch_ : 0u;
   if (overlap) {
     // the flatten stays on the main stream and is enqueued FIRST; the chain goes to the third stream. (Should the two streams
@@ -591,7 +617,7 @@ int Batch::launch_phase2() {
     zg_launch_flat(d, s);
     { bool any = false; for (const ZgFrame& fr : bb.frames) any = any || fr.sparse; if (any) zg_launch_sparse(d, s); }
     ZG_HIP(hipEventRecord(ev[7], s));
-    if (!getenv("ZGPU_DEBUG_NO_SWEEP")) launch_sweep(true);
+    if (!eng->tn_.no_sweep) launch_sweep(true);
   }
   ZG_HIP(hipEventRecord(ev[8], s));
   zg_launch_lz(d, s);   // only frames that left the flatten path (a block regenerating > 128 KiB)
@@ -603,8 +629,7 @@ int Batch::launch_phase2() {
 // reaches further back than its frame's window (zg_k_seqpost reports one that does: sync() then repeats the sweep the plain way).
 void Batch::launch_sweep(bool split, hipStream_t main) {
   if (!main) main = eng->stream_;
-  const char* e = getenv("ZGPU_SWEEP_SPLIT");
-  if (e && e[0] == '0') split = false;
+  if (!eng->tn_.sweep_split) split = false;
   uint64_t wmax = 0, wmin = ~0ull;
   for (const ZgFrame& fr : bb.frames) {
     wmax = fr.window_size > wmax ? fr.window_size : wmax;
@@ -616,7 +641,7 @@ void Batch::launch_sweep(bool split, hipStream_t main) {
   if (wmax > 0x7FFFFFFFull) wmax = 0x7FFFFFFFull;
   if (wmin > wmax) wmin = wmax;
   split_sweep = zg_launch_sweep(dev, main, sweep_steps.data(), (uint32_t)sweep_steps.size(), eng->stream2_, sc->ev_sw, split ? 80u : 0u,
-                                bb.unit_blocks_used * kMaxBlockSize, (uint32_t)wmax, (uint32_t)wmin);
+                                bb.unit_blocks_used * kMaxBlockSize, (uint32_t)wmax, (uint32_t)wmin, eng->tn_.sweep);
   sweep_mode = split_sweep ? 1u : sweep_mode;
 }
 
@@ -675,7 +700,7 @@ int Batch::sync() {
              st == (uint32_t)ZG_EXE_NOT_ENOUGH_LITERALS || st == (uint32_t)ZG_EXE_ZERO_OFFSET ||   // (a sequence in front of the rejected one may reach too far: that comes first)
              fr.hist_init[0] > fr.window_size || fr.hist_init[1] > fr.window_size || fr.hist_init[2] > fr.window_size;
     }
-    if (need && !getenv("ZGPU_DEBUG_NO_EXACT")) {
+    if (need && !eng->tn_.no_exact) {
       zg_launch_exact(dev, eng->stream_, drain_rule);
       ZG_HIP(hipStreamSynchronize(eng->stream_));
       ZG_HIP(hipMemcpy(frame_out.data(), dev.frame_out, (size_t)dev.nframes * sizeof(ZgFrameOut), hipMemcpyDeviceToHost));

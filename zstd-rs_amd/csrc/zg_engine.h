@@ -76,6 +76,31 @@ struct Scratch {
   void release_but_output();
 };
 
+// Measurement and test switches (the ZGPU_* environment variables of tools/dev/README.md). They are read ONCE, when an engine is
+// created: nothing on the submit path (prepare / run / sync, zg_launch_sweep) calls getenv. A test that wants a switch sets it before it
+// creates its context.
+struct Tuning {
+  uint32_t unit_blocks = 0;        // ZGPU_UNIT_BLOCKS: blocks per flatten unit (0: chosen by BatchBuilder::finish)
+  bool direct = true;              // ZGPU_DIRECT=0: no direct units
+  uint32_t ramp_percent = 0;       // ZGPU_RAMP
+  bool sparse_set = false;         // ZGPU_SPARSE_MAX given
+  uint32_t sparse_max = 0;
+  int lit_direct = -1;             // ZGPU_LIT_DIRECT: 0 never, else the host's choice
+  uint32_t direct_share10 = 0;     // ZGPU_DIRECT_SHARE (tenths, >= 10)
+  bool debug_timers = false;       // ZGPU_DEBUG_TIMERS
+  bool force_inorder = false;      // ZGPU_FORCE_INORDER=1
+  uint32_t flat_mode = 0;          // ZGPU_FLAT_MODE (timing experiments)
+  uint32_t sweep_w = 0;            // ZGPU_SWEEP_W
+  bool overlap = true;             // ZGPU_OVERLAP=0
+  bool no_sweep = false;           // ZGPU_DEBUG_NO_SWEEP
+  bool sweep_split = true;         // ZGPU_SWEEP_SPLIT=0
+  bool no_exact = false;           // ZGPU_DEBUG_NO_EXACT
+  bool no_presize = false;         // ZGPU_PRESIZE=0
+  int flat_shape = 0;              // ZGPU_FLAT_T=512 -> 1
+  ZgSweepTuning sweep;             // ZGPU_SWEEP_MODE / _NB / _GROUP / _HEAD_LDS
+  static Tuning from_env();
+};
+
 class Engine;
 
 // One submit: parsed input + its device state. Created by Engine::prepare.
@@ -165,6 +190,7 @@ class Engine {
   friend class Batch;
   int device_ = 0;
   int cus_ = 256;                // compute units of the device (MI355X: 256)
+  Tuning tn_;                    // the ZGPU_* switches as they were when the engine was created
   bool no_presize_ = false;      // (ZGPU_PRESIZE=0: measurement / tests) never size the output before the run
   int flat_shape_ = 0;           // zg_k_flatten shape: 0 = 1024 threads x 16 KiB tiles (one workgroup per CU), 1 = 512 x 8 KiB (two)
   hipStream_t stream_ = nullptr, stream2_ = nullptr, stream3_ = nullptr;   // stream3_: the flatten, when the sweep chain runs beside it

@@ -16,6 +16,10 @@
 #endif
 #define ZG_SW_BATCH (4u * ZG_SW_T * ZG_SW_B)
 struct ZgSweepStep { uint32_t list_off, nunits, slices, pad; };
+// measurement switches of the sweep (tools/dev/README.md): read from the environment ONCE, when an engine is created (zg::Tuning) —
+// mode: ZGPU_SWEEP_MODE (timing experiments: wrong results), nbatch: batches per workgroup, group: steps whose heads share a launch,
+// head_lds: unused LDS a head workgroup asks for (keeps the heads to a few workgroups per CU)
+struct ZgSweepTuning { uint32_t mode = 0, nbatch = 1, group = 16, head_lds = 52u * 1024u; };
 
 void zg_launch_tables(const ZgBatchDev& d, hipStream_t s, int part);   // part 0: Huffman trees, part 1: FSE tables
 void zg_launch_huf(const ZgBatchDev& d, hipStream_t s);
@@ -28,7 +32,7 @@ void zg_launch_lit(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_flat(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_sparse(const ZgBatchDev& d, hipStream_t s);   // the matches of frames marked sparse, in order (after zg_launch_flat)
 bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* steps, uint32_t nsteps, hipStream_t s2, hipEvent_t* evs, uint32_t nev,
-                     uint32_t unit_bytes, uint32_t window_max, uint32_t window_min);   // s2 / evs: the side stream of the split sweep (nev == 0: one stream, step by step); returns whether it split
+                     uint32_t unit_bytes, uint32_t window_max, uint32_t window_min, const ZgSweepTuning& tn);   // s2 / evs: the side stream of the split sweep (nev == 0: one stream, step by step); returns whether it split
 void zg_launch_lz(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_exact(const ZgBatchDev& d, hipStream_t s, uint32_t drain_rule);   // zg_exact.h: the reference's DecodeBuffer bookkeeping, exactly (rare path, Batch::sync)
 void zg_launch_calib(const void* src, void* dst, uint64_t bytes, hipStream_t s);

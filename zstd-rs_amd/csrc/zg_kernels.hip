@@ -1763,11 +1763,11 @@ void zg_launch_flat(const ZgBatchDev& d, hipStream_t s) {
   else hipLaunchKernelGGL((zg_k_flatten<1024, 16384, 2>), dim3(d.nunits), dim3(1024), 0, s, d);
 }
 bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* steps, uint32_t nsteps, hipStream_t s2, hipEvent_t* evs, uint32_t nev,
-                     uint32_t unit_bytes, uint32_t window_max, uint32_t window_min) {
-  uint32_t dbgmode = getenv("ZGPU_SWEEP_MODE") ? (uint32_t)atoi(getenv("ZGPU_SWEEP_MODE")) : 0u;   // timing experiments only
+                     uint32_t unit_bytes, uint32_t window_max, uint32_t window_min, const ZgSweepTuning& tn) {
+  uint32_t dbgmode = tn.mode;                                 // timing experiments only (ZGPU_SWEEP_MODE)
   void (*kern)(ZgBatchDev, uint32_t, uint32_t, uint32_t, uint32_t) = zg_k_sweep<0>;
   if (dbgmode >= 5u) { kern = dbgmode == 5u ? zg_k_sweep<5> : dbgmode == 6u ? zg_k_sweep<6> : dbgmode == 7u ? zg_k_sweep<7> : zg_k_sweep<8>; dbgmode = 0u; }
-  const uint32_t nbatch = getenv("ZGPU_SWEEP_NB") && atoi(getenv("ZGPU_SWEEP_NB")) > 0 ? (uint32_t)atoi(getenv("ZGPU_SWEEP_NB")) : 1u;   // batches per workgroup (more than one did not pay)
+  const uint32_t nbatch = tn.nbatch ? tn.nbatch : 1u;          // batches per workgroup (more than one did not pay)
   constexpr uint32_t BB = 4u * ZG_SW_T * ZG_SW_B;             // bytes per batch
   uint32_t n = 0;
   bool contiguous = true;
@@ -1782,10 +1782,10 @@ bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* step
   } else {
     // stream s: tail of step 0, 1, 2, ...; stream s2: the heads of steps [g0, g1) in one launch as soon as the tails of step g1 - 2
     // are done (the heads of step i copy from the tails of steps < i).
-    const uint32_t gmin = getenv("ZGPU_SWEEP_GROUP") && atoi(getenv("ZGPU_SWEEP_GROUP")) > 0 ? (uint32_t)atoi(getenv("ZGPU_SWEEP_GROUP")) : 16u;   // steps whose heads share a launch
+    const uint32_t gmin = tn.group ? tn.group : 16u;          // steps whose heads share a launch
     const uint32_t gs = (nsteps + (nev - 2) - 1) / (nev - 2) > gmin ? (nsteps + (nev - 2) - 1) / (nev - 2) : gmin;
     uint32_t g0 = 0, e = 0;
-    const uint32_t head_lds = getenv("ZGPU_SWEEP_HEAD_LDS") ? (uint32_t)atoi(getenv("ZGPU_SWEEP_HEAD_LDS")) : 52u * 1024u;
+    const uint32_t head_lds = tn.head_lds;
     auto heads = [&]() {
       const uint32_t g1 = g0 + gs < nsteps ? g0 + gs : nsteps;
       uint32_t units = 0, slices = 0;

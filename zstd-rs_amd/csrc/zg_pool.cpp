@@ -62,6 +62,9 @@ struct zgpu_pool {
   std::vector<float> gpu_wall_ms;  // of the last pass, per GPU
   std::vector<uint32_t> frame_worker, frame_slot, frame_count;   // staged entries: which job, first frame of its batch, number of frames (0: skippable only)
   uint32_t nframes = 0;
+  // measurement switches, read from the environment when the pool is created (nothing on the run / decode path calls getenv):
+  // ZGPU_POOL_JOBS (resident jobs per GPU), ZGPU_DA_SPLIT (jobs per GPU zgpu_pool_decode_all aims at), ZGPU_DA_FLOOR_MB (its smallest job)
+  uint32_t tn_pool_jobs = 0, tn_da_split = 0, tn_da_floor_mb = 0;
   // persistent workers: one thread per engine, woken per pass (no thread is created inside a timed region)
   std::vector<std::thread> threads;
   std::mutex mu;
@@ -123,6 +126,9 @@ static int pool_build(const int* devices, int n, zgpu_pool** out) {
     p->eng2.push_back(e2);
   }
   p->gpu_wall_ms.assign(p->eng.size(), 0.f);
+  { const char* e = getenv("ZGPU_POOL_JOBS"); if (e && atoi(e) > 0) p->tn_pool_jobs = (uint32_t)atoi(e); }
+  { const char* e = getenv("ZGPU_DA_SPLIT"); if (e && atoi(e) > 0) p->tn_da_split = (uint32_t)atoi(e); }
+  { const char* e = getenv("ZGPU_DA_FLOOR_MB"); if (e && atoi(e) > 0) p->tn_da_floor_mb = (uint32_t)atoi(e); }
   p->start_workers(2u * (uint32_t)p->eng.size());   // workers [0, n): the GPUs' first engines; [n, 2n): their second ones (decode_all only)
   *out = p;
   return ZGPU_OK;
@@ -192,13 +198,13 @@ int zgpu_pool_stage(zgpu_pool* p, const uint8_t* const* frames, const size_t* le
   // text frames lose (8 GiB of 64 MiB frames: 141 -> 126 / 121 / 114 GB/s with 2 / 4 / 8 jobs: two flattens cannot share a CU's
   // LDS, and a sweep beside anything else runs at a quarter of its speed), literal-heavy frames gain 8 % with two (the Huffman
   // streams of one job beside the flatten of the other).
-  const char* je = getenv("ZGPU_POOL_JOBS");
+  const uint32_t je = p->tn_pool_jobs;
   for (uint32_t w = 0; w < nw; w++) {
     std::vector<uint32_t> mine;
     for (uint32_t i = 0; i < n; i++) if (worker[i] == w) mine.push_back(i);
     if (mine.empty()) continue;
     uint32_t J = 1;
-    if (je && atoi(je) > 0) J = (uint32_t)atoi(je) < mine.size() ? (uint32_t)atoi(je) : (uint32_t)mine.size();
+    if (je) J = je < mine.size() ? je : (uint32_t)mine.size();
     const uint32_t first = (uint32_t)p->staged.size();
     p->staged.resize(first + J);
     for (uint32_t j = 0; j < J; j++) { p->staged[first + j].gpu = w; p->staged[first + j].lane = j & 1u; }
@@ -370,8 +376,8 @@ int zgpu_pool_decode_all(zgpu_pool* p, const uint8_t* src, size_t len, uint8_t* 
   // input (a submit costs ~2 ms whatever its size: the length of one block's sequence chain) nor above 512 MiB. Measured on 1 GiB of
   // 64 MiB frames (tools/dev/e2e.py): 4 / 8 / 16 jobs per GPU 30.5 / 36.1 / 40.5 GB/s, 16 with a 16 MiB floor 37.4
   uint64_t per_gpu = 16, floor_mb = 32;
-  { const char* e = getenv("ZGPU_DA_SPLIT"); if (e && atoi(e) > 0) per_gpu = (uint64_t)atoi(e); }      // (measurement) jobs per GPU aimed at
-  { const char* e = getenv("ZGPU_DA_FLOOR_MB"); if (e && atoi(e) > 0) floor_mb = (uint64_t)atoi(e); }  // (measurement) smallest job, MiB of input
+  if (p->tn_da_split) per_gpu = p->tn_da_split;         // (measurement) jobs per GPU aimed at
+  if (p->tn_da_floor_mb) floor_mb = p->tn_da_floor_mb;  // (measurement) smallest job, MiB of input
   uint64_t kJob = (uint64_t)len / (per_gpu * nw);
   if (kJob < (floor_mb << 20)) kJob = floor_mb << 20;
   if (kJob > (512ull << 20)) kJob = 512ull << 20;
