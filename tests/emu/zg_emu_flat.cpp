@@ -76,11 +76,15 @@ int zgemu_flatten(void* h, int shape, uint8_t* dst_out, uint32_t* og_out, uint32
       if (shape == 0) run_unit<256, 4096, 2>(d, u);
       else if (shape == 1) run_unit<512, 8192, 2>(d, u);
       else if (shape == 2) run_unit<1024, 16384, 2>(d, u);
+      else if (shape == 3) run_unit<1024, 8192, 1>(d, u);      // zg_k_flatten4's default shape (two workgroups per CU)
+      else if (shape == 4) run_unit<512, 4096, 1>(d, u);
+      else if (shape == 5) run_unit<256, 2048, 1>(d, u);
+      else if (shape == 6) run_unit<512, 2048, 1>(d, u);
       else return -1;
     } else {
       if (shape == 0) run_unit1<256, 4096, 2>(d, u);
       else if (shape == 1) run_unit1<512, 8192, 2>(d, u);
-      else if (shape == 2) run_unit1<1024, 16384, 2>(d, u);
+      else if (shape >= 2 && shape <= 6) run_unit1<1024, 16384, 2>(d, u);
       else return -1;
     }
   }
@@ -167,6 +171,14 @@ int zgemu_flat4(void* h, int shape, uint8_t* dst_out, uint32_t* unit_mode) {
       if (shape == 0) run_unit<256, 4096, 2>(d, u);
       else if (shape == 1) run_unit<512, 8192, 2>(d, u);
       else if (shape == 2) run_unit<1024, 16384, 2>(d, u);
+      else if (shape == 3) run_unit<1024, 8192, 1>(d, u);
+      else if (shape == 4) run_unit<512, 4096, 1>(d, u);
+      else if (shape == 5) run_unit<256, 2048, 1>(d, u);
+      else if (shape == 6) run_unit<512, 2048, 1>(d, u);
+      else if (shape == 3) run_unit<1024, 8192, 1>(d, u);      // zg_k_flatten4's default shape (two workgroups per CU)
+      else if (shape == 4) run_unit<512, 4096, 1>(d, u);
+      else if (shape == 5) run_unit<256, 2048, 1>(d, u);
+      else if (shape == 6) run_unit<512, 2048, 1>(d, u);
       else return -1;
     } else {
       // every other unit: the serial model's bytes (what zg_flat1_unit + zg_k_sweep produce on the GPU)

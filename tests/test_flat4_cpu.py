@@ -85,11 +85,13 @@ def test_plaintext_small_shape(name, unit_blocks):
             assert len(modes) == 1
 
 
-@pytest.mark.parametrize("shape", [1, 2])
+@pytest.mark.parametrize("shape", [1, 2, 3, 4, 5, 6])
 def test_plaintext_gpu_shapes(shape):
-    z = syn()["text_1m_l3.zst"]
-    st, got, _ = run_flat4(z, 256, shape)
-    assert st == 0 and got == oracle_plain(z)
+    """shape 3 = 1024 threads x 8 KiB tiles, one sequence per thread: what zg_k_flatten4 runs (two workgroups per CU); 2: round 4's shape"""
+    for name in ("text_1m_l3.zst", "text_768k_l19.zst", "mixed_640k_l3.zst"):
+        z = syn()[name]
+        st, got, _ = run_flat4(z, 256, shape)
+        assert st == 0 and got == oracle_plain(z), name
 
 
 def test_frames_back_to_back_at_odd_offsets():
@@ -102,7 +104,7 @@ def test_frames_back_to_back_at_odd_offsets():
     parts.append(zgdata.text_like(300001, seed=99))      # several blocks, odd size
     z = b"".join(zgdata.zstd_compress(q) for q in parts)
     want = b"".join(parts)
-    for shape in (0, 2):
+    for shape in (0, 2, 3):
         st, got, modes = run_flat4(z, 256, shape)
         assert st == 0
         assert got == want
@@ -119,6 +121,8 @@ def test_reference_corpus():
         assert hashlib.sha256(got).hexdigest() == man[n]["sha256"], n
     # and all of them in one submit, back to back
     blob = b"".join(pack[n] for n in names)
+    st, got, modes = run_flat4(blob, 0, 3)
+    assert st == 0 and hashlib.sha256(got).digest() == hashlib.sha256(b"".join(oracle_plain(pack[n]) for n in names)).digest()
     st, got, modes = run_flat4(blob, 0, 2)
     assert st == 0 and len(got) == sum(man[n]["size"] for n in names)
     assert hashlib.sha256(got).digest() == hashlib.sha256(b"".join(oracle_plain(pack[n]) for n in names)).digest()

@@ -1,6 +1,6 @@
 #!/bin/bash
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/c5
+OUT=$ROOT/gpurun_out/c8
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-( time timeout 500 $ROOT/tools/dev/chain_fill_bench 255 ) > $OUT/chain_fill_bench.log 2>&1
-cat $OUT/chain_fill_bench.log
+timeout 600 python $ROOT/tools/dev/variants.py 2147483648 blocks -- ZGPU_FLAT4=0 ZGPU_FLAT4=4 ZGPU_FLAT4=5 ZGPU_FLAT4=6 ZGPU_FLAT4=7 ZGPU_FLAT4=1 > $OUT/blocks.log 2>&1
+cat $OUT/blocks.log | cut -c1-330

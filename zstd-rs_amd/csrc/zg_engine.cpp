@@ -46,6 +46,8 @@ int Scratch::init_events() {
   if (hipEventCreateWithFlags(&ev_fork3, hipEventDisableTiming) != hipSuccess) return ZG_HIP_ERROR;
   for (auto& e : ev_sw)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return ZG_HIP_ERROR;
+  for (auto& e : ev_flat)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return ZG_HIP_ERROR;
   have_events = true;
   return 0;
 }
@@ -56,7 +58,7 @@ void Scratch::release_but_output() {
 void Scratch::release() {
   DevBuf* all[] = {&d_src, &d_blocks, &d_frames, &d_aux, &d_slot_log, &d_fse, &d_huf, &d_hufmax, &d_status, &d_lit, &d_seq, &d_seqout, &d_pos,
                    &d_frameout, &d_dst, &d_seqblocks, &d_hufitems, &d_hufgroups, &d_totals, &d_og, &d_units, &d_unitinfo, &d_stepunits, &d_swdesc,
-                   &d_dbg, &d_raw};
+                   &d_dbg, &d_raw, &d_unitlist};
   for (DevBuf* b : all) b->release();
   for (auto& e : ev)
     if (e) { (void)hipEventDestroy(e); e = nullptr; }
@@ -65,6 +67,8 @@ void Scratch::release() {
   if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
   if (ev_fork3) { (void)hipEventDestroy(ev_fork3); ev_fork3 = nullptr; }
   for (auto& e : ev_sw)
+    if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  for (auto& e : ev_flat)
     if (e) { (void)hipEventDestroy(e); e = nullptr; }
   have_events = false;
 }
@@ -93,6 +97,7 @@ Tuning Tuning::from_env() {
   t.sweep_split = !is0("ZGPU_SWEEP_SPLIT");
   t.no_exact = getenv("ZGPU_DEBUG_NO_EXACT") != nullptr;
   t.no_presize = is0("ZGPU_PRESIZE");
+  { uint32_t v = 0; if (num("ZGPU_FLAT4", &v, false)) t.flat4 = (int)v; }
   { const char* e = getenv("ZGPU_FLAT_T"); t.flat_shape = (e && atoi(e) == 512) ? 1 : 0; }   // "512": 512 threads x 8 KiB tiles, two workgroups per CU; else the default
   num("ZGPU_SWEEP_MODE", &t.sweep.mode, false);
   num("ZGPU_SWEEP_NB", &t.sweep.nbatch, true);
@@ -418,6 +423,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
       (st = up(sc->d_hufgroups, bb.huf_groups.data(), bb.huf_groups.size() * sizeof(ZgHufGroup))) ||
       (st = up(sc->d_units, bb.units.data(), bb.units.size() * sizeof(ZgUnit))) ||
       (st = up(sc->d_stepunits, bb.step_units.data(), bb.step_units.size() * 4)) ||
+      (st = up(sc->d_unitlist, bb.unit_list.data(), bb.unit_list.size() * 4)) ||
       (st = sc->d_aux.reserve((size_t)nb * sizeof(ZgBlockAux) + 16)) || (st = sc->d_slot_log.reserve((size_t)nslots * 4)) ||
       (st = sc->d_fse.reserve((size_t)nslots * ZG_FSE_SLOT_U32 * 4)) || (st = sc->d_huf.reserve((size_t)(bb.nhuf_slots + 1) * ZG_HUF_SLOT_U16 * 2)) ||
       (st = sc->d_hufmax.reserve(bb.nhuf_slots + 16)) || (st = sc->d_status.reserve(7 * ((size_t)nb * 4 + 16))) ||
@@ -450,6 +456,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   d.totals = sc->d_totals.as<uint32_t>();
   d.units = sc->d_units.as<ZgUnit>(); d.nunits = (uint32_t)bb.units.size(); d.unit_info = sc->d_unitinfo.as<ZgUnitInfo>();
   d.step_units = sc->d_stepunits.as<uint32_t>();
+  d.unit_list = sc->d_unitlist.as<uint32_t>(); d.ndirect = bb.n_direct;
   d.sweep_desc = sc->d_swdesc.as<ZgSweepDesc>();
   b->sweep_steps.clear();
   for (const ZgStepRange& r : bb.steps) {
@@ -596,6 +603,16 @@ int Batch::launch_phase2() {
   zg_launch_lit(d, s);
   ZG_HIP(hipEventRecord(ev[6], s));
   sweep_mode = 0; synced = false;
+  // The direct units (a frame's first unit, resolved to bytes: zg_flat4.h) have a kernel of their own, and with it their own occupancy.
+  // ONE unit is flattened fastest by 1024 threads on 16 KiB tiles (the pointer-mode units' kernel, one workgroup per CU); a submit of
+  // many direct units — single-block frames, BASELINE config 4b — is flattened fastest by small workgroups, eight to a CU, which overlap
+  // each other's barriers (measured on 16384 single-block frames, flatten ms: one kernel 5.23; zg_k_flatten4 with 1024 / 512 / 256 threads
+  // and 8 / 4 / 2 KiB tiles 4.23 / 3.84 / 3.59; on 64 x (1 direct + 1 pointer unit) the one kernel is the fastest: 15.3 against 15.7 - 16.9).
+  int flat4 = eng->tn_.flat4;
+  if (flat4 < 0) {
+    const uint32_t cus = (uint32_t)eng->cus_, nd = d.ndirect;
+    flat4 = nd >= 16u * cus ? 6 : nd >= 8u * cus ? 4 : nd >= 4u * cus ? 1 : 0;
+  }
   // One long frame in ramped units (BatchBuilder::finish): the flatten goes to its own stream and the sweep chain starts at once;
   // a step waits for its unit's flag (zg_k_flatten sets it, zg_k_sweep polls it). ZGPU_OVERLAP=0: one after the other.
   const bool overlap = bb.ramped && eng->tn_.overlap && !eng->tn_.no_sweep;
@@ -607,14 +624,14 @@ int Batch::launch_phase2() {
     hipStream_t s3 = eng->stream3_;
     ZG_HIP(hipMemsetAsync(d.unit_info, 0, (size_t)d.nunits * sizeof(ZgUnitInfo), s));   // the flags of earlier users of this memory
     ZG_HIP(hipEventRecord(sc->ev_fork3, s));
-    zg_launch_flat(d, s);
+    zg_launch_flat(d, s, eng->stream2_, sc->ev_flat, flat4);
     ZG_HIP(hipEventRecord(ev[7], s));
     ZG_HIP(hipStreamWaitEvent(s3, sc->ev_fork3, 0));
     launch_sweep(true, s3);
     ZG_HIP(hipEventRecord(sc->ev_fork3, s3));
     ZG_HIP(hipStreamWaitEvent(s, sc->ev_fork3, 0));
   } else {
-    zg_launch_flat(d, s);
+    zg_launch_flat(d, s, eng->stream2_, sc->ev_flat, flat4);
     { bool any = false; for (const ZgFrame& fr : bb.frames) any = any || fr.sparse; if (any) zg_launch_sparse(d, s); }
     ZG_HIP(hipEventRecord(ev[7], s));
     if (!eng->tn_.no_sweep) launch_sweep(true);

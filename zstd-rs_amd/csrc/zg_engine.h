@@ -66,10 +66,11 @@ enum { ZG_T_TABLES = 0, ZG_T_HUF, ZG_T_SEQ, ZG_T_SEQPOST, ZG_T_SCAN, ZG_T_LIT, Z
 // of a streaming decoder, frames pulled from a work queue) allocates once.
 struct Scratch {
   DevBuf d_src, d_blocks, d_frames, d_aux, d_slot_log, d_fse, d_huf, d_hufmax, d_status, d_lit, d_seq, d_seqout, d_pos, d_frameout,
-      d_dst, d_seqblocks, d_hufitems, d_hufgroups, d_totals, d_og, d_units, d_unitinfo, d_stepunits, d_swdesc, d_dbg, d_raw;
+      d_dst, d_seqblocks, d_hufitems, d_hufgroups, d_totals, d_og, d_units, d_unitinfo, d_stepunits, d_swdesc, d_dbg, d_raw, d_unitlist;
   hipEvent_t ev[ZG_T_COUNT + 1] = {};
   hipEvent_t ev_huf[2] = {}, ev_fork = nullptr, ev_fork3 = nullptr;   // zg_k_huf runs on the engine's second stream beside zg_k_seq
   hipEvent_t ev_sw[80] = {};                      // split sweep: heads on the second stream (zg_launch_sweep)
+  hipEvent_t ev_flat[2] = {};                     // the direct units' flatten on the second stream beside the pointer-mode units' (zg_launch_flat)
   bool have_events = false;
   int init_events();
   void release();
@@ -96,6 +97,10 @@ struct Tuning {
   bool sweep_split = true;         // ZGPU_SWEEP_SPLIT=0
   bool no_exact = false;           // ZGPU_DEBUG_NO_EXACT
   bool no_presize = false;         // ZGPU_PRESIZE=0
+  int flat4 = -1;                  // ZGPU_FLAT4: how the direct units of a submit are flattened — -1 (default): chosen per submit from the number of
+                                   // direct units (Batch::launch_phase2); 0: by the kernel of the pointer-mode units (one 1024-thread workgroup per
+                                   // CU, round 4's form); 1 / 4 / 6: by zg_k_flatten4 with 1024 / 512 / 256 threads and 8 / 4 / 2 KiB tiles (2 / 4 / 8
+                                   // workgroups per CU); 2, 3, 5, 7: other shapes (measurement)
   int flat_shape = 0;              // ZGPU_FLAT_T=512 -> 1
   ZgSweepTuning sweep;             // ZGPU_SWEEP_MODE / _NB / _GROUP / _HEAD_LDS
   static Tuning from_env();

@@ -34,7 +34,8 @@ ZX_DEV uint32_t zg_lanes_hi(uint32_t a23, uint32_t a01) { return ((a01 >> 8) & 0
 template <int T, int TS, int SPT>
 struct ZgFlat4Lds {
   static constexpr int NW = TS / 32, SOFF = SPT * T;
-  ZxU4 rec[SOFF];                                        // per sequence of the tile: {offset, first match byte (tile-relative), 2^31 + literal index of tile byte 0, -}
+  ZxU2 rec[SOFF];                                        // per sequence of the tile: {offset, first match byte (tile-relative, 15 bits) | literal index of tile byte 0 (mod 2^17) << 15}.
+                                                         // (8 bytes since round 5 — 16 before: with 8 KiB tiles the unit's LDS is 34 KB, two 1024-thread workgroups per CU)
   __attribute__((aligned(16))) uint16_t par[TS + 8];     // 0xFFFF literal, 0x8000 match byte with its parent before the tile, else tile-relative parent; [TS]: a dummy byte that is always a root
   __attribute__((aligned(16))) uint8_t val[TS];          // a root's byte value
   uint32_t bits[NW];                                     // marks: the first tile byte of every sequence
@@ -50,6 +51,7 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
   constexpr int SOFF = SPT * T;                // sequences a tile takes; a denser tile is cut short
   constexpr int NW = TS / 32;                  // words of the mark bitmap
   static_assert(GPT * 4 * T == TS && GPT >= 1 && GPT <= 4 && NW <= T && (NW % 64) == 0 && SPT >= 1 && SPT <= 2 && TS <= 0x4000, "shape");
+  static_assert(sizeof(ZgFlat4Lds<T, TS, SPT>) <= 81920 || TS > 8192, "an 8 KiB-tile shape is meant to fit twice into a CU's LDS");
   const uint32_t t = zx_tid();
   const ZgUnit un = d.units[ui];
   if (d.totals[2]) return;
@@ -143,8 +145,8 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
           // (the tile's first sequence owns the dead bytes too: a mark at tile byte 0 keeps every rank query in range)
           const uint32_t st = j == 0 ? 0u : (a > t0 ? a : t0) - t0a;
           const uint32_t mr = (m0 > t0 ? (m0 < t1o ? m0 : t1o) : t0) - t0a;
-          // (z: the literal a tile byte x of this sequence stands for is z + x - 2^31)
-          ZxU4 r; r.x = off; r.y = mr; r.z = 0x80000000u + lstart + t0a - a; r.w = 0;
+          // (the literal a tile byte x of this sequence stands for is lstart + t0a - a + x: an index into the block's literals, below 2^17)
+          ZxU2 r; r.x = off; r.y = mr | (((lstart + t0a - a) & 0x1FFFFu) << 15);
           L.rec[j] = r;
           zx_or_lds(&L.bits[st >> 5], 1u << (st & 31u));
           // the last sequence the tile has room for, and more follow: the tile ends with this one
@@ -194,7 +196,7 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
         uint32_t wordv[GPT], cntv[GPT];
 #pragma unroll
         for (int k = 0; k < GPT; k++) { const uint32_t xw = (tc + k * T) >> 3; wordv[k] = L.bits[xw]; cntv[k] = L.cnt[xw]; }
-        ZxU4 rA[GPT], rB[GPT];
+        ZxU2 rA[GPT], rB[GPT];
         uint32_t fbv[GPT];
 #pragma unroll
         for (int k = 0; k < GPT; k++) {
@@ -211,7 +213,7 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
           const uint32_t x01 = x0 * 0x10001u + 0x10000u, x23 = x01 + 0x20002u;
           const uint32_t mB01 = fb == 1u ? 0xFFFF0000u : 0u, mB23 = fb <= 2u ? 0xFFFFFFFFu : (fb == 3u ? 0xFFFF0000u : 0u);
           const uint32_t oa = rA[k].x < 0x7FF0u ? rA[k].x : 0x7FF0u, ob = rB[k].x < 0x7FF0u ? rB[k].x : 0x7FF0u;   // (a tile is at most 2^14 bytes: a larger offset leads in front of it all the same, and the lanes stay inside 16 signed bits)
-          const uint32_t oa2 = oa * 0x10001u, ob2 = ob * 0x10001u, ma2 = rA[k].y * 0x10001u, mb2 = rB[k].y * 0x10001u;
+          const uint32_t oa2 = oa * 0x10001u, ob2 = ob * 0x10001u, ma2 = (rA[k].y & 0x7FFFu) * 0x10001u, mb2 = (rB[k].y & 0x7FFFu) * 0x10001u;
           const uint32_t p01 = zx_pksub16(x01, zx_bfi(mB01, ob2, oa2)), p23 = zx_pksub16(x23, zx_bfi(mB23, ob2, oa2));   // tile-relative parents
           const uint32_t e01 = zx_pksign16(zx_pksub16(p01, lead2)), e23 = zx_pksign16(zx_pksub16(p23, lead2));           // lanes whose parent lies before the tile's live bytes
           const uint32_t l01 = zx_pksign16(zx_pksub16(x01, zx_bfi(mB01, mb2, ma2))), l23 = zx_pksign16(zx_pksub16(x23, zx_bfi(mB23, mb2, ma2)));   // literal lanes (x < first match byte)
@@ -226,8 +228,8 @@ ZX_DEV void zg_flat4_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat4Lds<T, 
           // literal bytes as a byte mask (the tile's dead bytes are literals by class: not these)
           const uint32_t lb = zg_lanes_lo(l23, l01) & (x0 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8u * lead));
           const uint32_t ilit = lb ? (uint32_t)__builtin_ctz(lb) >> 3 : 0u;
-          const uint32_t zl = ilit < fb ? rA[k].z : rB[k].z;
-          const uint32_t ol = ((zl + x0 + ilit) & 0x7FFFFFFFu) + lit_lo + 4u - ilit;   // offset of the byte group byte 0 would stand for
+          const uint32_t zl = (ilit < fb ? rA[k].y : rB[k].y) >> 15;
+          const uint32_t ol = ((zl + x0 + ilit) & 0x1FFFFu) + lit_lo + 4u - ilit;   // offset of the byte group byte 0 would stand for
           LW[k] = zx_ld64(lit_rs, lb ? ol & ~3u : ZX_OOB);
           litl[k] = lb;
           const uint32_t oA = (uint32_t)uA + ualign + 4u, oB = (uint32_t)uB + ualign + 4u;

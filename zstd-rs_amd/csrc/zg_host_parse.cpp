@@ -235,7 +235,7 @@ void BatchBuilder::finish() {
     }
     if (final_.huf == kCarryHuf) final_.huf = frames[lf].carry_huf_slot;
   }
-  seq_blocks.clear(); huf_items.clear(); huf_groups.clear(); units.clear(); step_units.clear(); steps.clear();
+  seq_blocks.clear(); huf_items.clear(); huf_groups.clear(); units.clear(); step_units.clear(); steps.clear(); unit_list.clear();
   ramped = false;
   // blocks per unit: zg_k_flatten runs flat_slots workgroups at once, one per unit, so aim at ~flat_slots units over the whole
   // submit (more blocks per unit = fewer sweep steps, but less parallelism in the flatten pass). What costs there are the
@@ -318,6 +318,10 @@ void BatchBuilder::finish() {
     fr.nunits = (uint32_t)units.size() - fr.first_unit;
     if (fr.nunits > max_units) max_units = fr.nunits;
   }
+  // launch order of the flatten: the pointer-mode body and the direct body are kernels of their own (zg_k_flatten, zg_k_flatten4)
+  unit_list.clear(); n_direct = 0;
+  for (uint32_t u = 0; u < units.size(); u++) if (!(units[u].noseq & ZG_UNIT_DIRECT)) unit_list.push_back(u);
+  for (uint32_t u = 0; u < units.size(); u++) if (units[u].noseq & ZG_UNIT_DIRECT) { unit_list.push_back(u); n_direct++; }
   // sweep steps: step s takes unit s of every frame that has one (frames are independent; units of a frame go in order).
   // Units without sequences need no step, and a step nobody needs is not launched (literal-heavy frames: most of them).
   for (uint32_t s = 0; s < max_units; s++) {

@@ -60,6 +60,8 @@ class BatchBuilder {
   std::vector<uint32_t> huf_items;
   std::vector<ZgHufGroup> huf_groups;
   std::vector<ZgUnit> units;
+  std::vector<uint32_t> unit_list;      // the units in launch order: pointer-mode units (and units without sequences) first, then the direct ones
+  uint32_t n_direct = 0;                //   (the last n_direct entries): the two bodies of the flatten are two kernels (zg_k_flatten / zg_k_flatten4)
   std::vector<uint32_t> step_units;     // concatenated unit lists of the sweep steps
   std::vector<ZgStepRange> steps;       // sweep step s: units step_units[list_off .. list_off + nunits)
   uint32_t unit_blocks = 0;    // blocks per unit; 0 = choose from the submit size

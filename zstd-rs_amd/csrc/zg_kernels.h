@@ -29,7 +29,7 @@ void zg_launch_merge(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_litfix(const ZgBatchDev& d, hipStream_t s);   // ZG_FLAG_LIT_DIRECT: literal verdicts found after the scan -> block and frame statuses
 void zg_launch_scan(const ZgBatchDev& d, hipStream_t s, uint32_t max_frame_blocks);   // max_frame_blocks: of the submit's frames (picks the workgroup size)
 void zg_launch_lit(const ZgBatchDev& d, hipStream_t s);
-void zg_launch_flat(const ZgBatchDev& d, hipStream_t s);
+void zg_launch_flat(const ZgBatchDev& d, hipStream_t s, hipStream_t s2, hipEvent_t* ev, int flat4);   // s2, ev[2]: the direct units beside the pointer-mode ones
 void zg_launch_sparse(const ZgBatchDev& d, hipStream_t s);   // the matches of frames marked sparse, in order (after zg_launch_flat)
 bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* steps, uint32_t nsteps, hipStream_t s2, hipEvent_t* evs, uint32_t nev,
                      uint32_t unit_bytes, uint32_t window_max, uint32_t window_min, const ZgSweepTuning& tn);   // s2 / evs: the side stream of the split sweep (nev == 0: one stream, step by step); returns whether it split

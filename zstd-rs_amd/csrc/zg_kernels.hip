@@ -1313,12 +1313,15 @@ __device__ __forceinline__ ZgSweepDesc zg_sweep_desc(const ZgBatchDev& d, uint32
 // byte-granular body above (zg_flat1_unit) — measured on the 1e9-byte frame, the dword-granular body in pointer mode issued 23 %
 // more vector instructions than this one (its pointer jumping works on clumps of four bytes that share their fate, and a wave
 // lasts as long as its busiest lane), so it is used where it wins: where values can flow.
+// both != 0: one workgroup per unit of the submit, either body (round 4's form: ZGPU_FLAT4=0, the 512-thread shape, ramped units);
+// both == 0: the first nunits - ndirect entries of unit_list — the direct units have a kernel of their own (zg_k_flatten4 below)
 template <int T, int TS, int SPT>
-__global__ void __launch_bounds__(T, 4) zg_k_flatten(ZgBatchDev d) {
+__global__ void __launch_bounds__(T, 4) zg_k_flatten(ZgBatchDev d, uint32_t both) {
   __shared__ union { ZgFlat1Lds<T, TS, SPT> p; ZgFlat4Lds<T, TS, SPT> v; } s_u;
-  if (threadIdx.x == 0) { d.unit_info[blockIdx.x].size = 0; d.unit_info[blockIdx.x].noseq = 0; }
-  if (d.units[blockIdx.x].noseq & ZG_UNIT_DIRECT) zg_flat4_unit<T, TS, SPT>(d, blockIdx.x, s_u.v);
-  else zg_flat1_unit<T, TS, SPT>(d, blockIdx.x, s_u.p);
+  const uint32_t ui = both ? blockIdx.x : d.unit_list[blockIdx.x];
+  if (threadIdx.x == 0) { d.unit_info[ui].size = 0; d.unit_info[ui].noseq = 0; }
+  if (d.units[ui].noseq & ZG_UNIT_DIRECT) zg_flat4_unit<T, TS, SPT>(d, ui, s_u.v);
+  else zg_flat1_unit<T, TS, SPT>(d, ui, s_u.p);
   // The sweep chain runs beside this kernel (one long frame in units that grow along it: see BatchBuilder::finish): the unit is
   // handed to its sweep step here — descriptor, then everything this workgroup wrote made visible to the whole device (release),
   // then the flag the step polls. (Producer recipe of the hardware guide: plain stores -> workgroup barrier -> one lane's
@@ -1326,13 +1329,25 @@ __global__ void __launch_bounds__(T, 4) zg_k_flatten(ZgBatchDev d) {
   if (d.overlap_epoch) {
     __syncthreads();
     if (threadIdx.x == 0) {
-      const uint32_t de = d.units[blockIdx.x].desc;
-      if (de != 0xFFFFFFFFu) d.sweep_desc[de] = zg_sweep_desc(d, blockIdx.x, d.unit_info[blockIdx.x].size);
+      const uint32_t de = d.units[ui].desc;
+      if (de != 0xFFFFFFFFu) d.sweep_desc[de] = zg_sweep_desc(d, ui, d.unit_info[ui].size);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(&d.unit_info[blockIdx.x].done, d.overlap_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&d.unit_info[ui].done, d.overlap_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+// zg_k_flatten4: the direct units of a submit (a frame's first unit: resolved to bytes, zg_flat4.h) as a kernel of their own, so that they
+// get their own occupancy: with 8 KiB tiles and 8-byte sequence records the body needs 34 KB of LDS and 64 registers — TWO 1024-thread
+// workgroups per CU, where the pointer-mode body's 134 KB (which the direct units inherited while both bodies were one kernel) allows
+// one. A submit of single-block frames (BASELINE config 4b) or of Silesia-sized frames is direct units only. WPE: waves per SIMD asked for.
+template <int T, int TS, int SPT, int WPE>
+__global__ void __launch_bounds__(T, WPE) zg_k_flatten4(ZgBatchDev d) {
+  __shared__ ZgFlat4Lds<T, TS, SPT> s_v;
+  const uint32_t ui = d.unit_list[d.nunits - d.ndirect + blockIdx.x];
+  if (threadIdx.x == 0) { d.unit_info[ui].size = 0; d.unit_info[ui].noseq = 0; }
+  zg_flat4_unit<T, TS, SPT>(d, ui, s_v);
 }
 
 // zg_k_exact: the reference's DecodeBuffer bookkeeping replayed exactly (zg_exact.h), one workgroup per frame; launched by the
@@ -1756,11 +1771,27 @@ __global__ void __launch_bounds__(64) zg_k_sparse(ZgBatchDev d) {
 void zg_launch_sparse(const ZgBatchDev& d, hipStream_t s) {
   if (d.nframes) hipLaunchKernelGGL(zg_k_sparse, dim3(d.nframes), dim3(64), 0, s, d);
 }
-void zg_launch_flat(const ZgBatchDev& d, hipStream_t s) {
+// flat4: how the direct units are flattened (zg::Tuning::flat4) — 0: by zg_k_flatten itself; 1 / 2: by zg_k_flatten4 (8 / 16 KiB tiles), on s2 beside
+// the pointer-mode units when the submit has both (ev[0]: fork, ev[1]: join)
+void zg_launch_flat(const ZgBatchDev& d, hipStream_t s, hipStream_t s2, hipEvent_t* ev, int flat4) {
   if (!d.nunits) return;
   const uint32_t shape = (d.flags >> 2) & 3u;
-  if (shape == 1) hipLaunchKernelGGL((zg_k_flatten<512, 8192, 2>), dim3(d.nunits), dim3(512), 0, s, d);
-  else hipLaunchKernelGGL((zg_k_flatten<1024, 16384, 2>), dim3(d.nunits), dim3(1024), 0, s, d);
+  if (shape == 1) { hipLaunchKernelGGL((zg_k_flatten<512, 8192, 2>), dim3(d.nunits), dim3(512), 0, s, d, 1u); return; }
+  if (flat4 == 0 || d.ndirect == 0 || d.overlap_epoch) { hipLaunchKernelGGL((zg_k_flatten<1024, 16384, 2>), dim3(d.nunits), dim3(1024), 0, s, d, 1u); return; }
+  const uint32_t nptr = d.nunits - d.ndirect;
+  hipStream_t sd = s;
+  if (nptr) { (void)hipEventRecord(ev[0], s); (void)hipStreamWaitEvent(s2, ev[0], 0); sd = s2; }
+  if (flat4 == 2) hipLaunchKernelGGL((zg_k_flatten4<1024, 16384, 2, 4>), dim3(d.ndirect), dim3(1024), 0, sd, d);
+  else if (flat4 == 3) hipLaunchKernelGGL((zg_k_flatten4<512, 8192, 2, 4>), dim3(d.ndirect), dim3(512), 0, sd, d);      // (measurement) two 512-thread workgroups per CU
+  else if (flat4 == 4) hipLaunchKernelGGL((zg_k_flatten4<512, 4096, 1, 8>), dim3(d.ndirect), dim3(512), 0, sd, d);      // (measurement) four
+  else if (flat4 == 5) hipLaunchKernelGGL((zg_k_flatten4<256, 4096, 2, 8>), dim3(d.ndirect), dim3(256), 0, sd, d);
+  else if (flat4 == 6) hipLaunchKernelGGL((zg_k_flatten4<256, 2048, 1, 8>), dim3(d.ndirect), dim3(256), 0, sd, d);
+  else if (flat4 == 7) hipLaunchKernelGGL((zg_k_flatten4<512, 2048, 1, 8>), dim3(d.ndirect), dim3(512), 0, sd, d);
+  else hipLaunchKernelGGL((zg_k_flatten4<1024, 8192, 1, 8>), dim3(d.ndirect), dim3(1024), 0, sd, d);
+  if (nptr) {
+    hipLaunchKernelGGL((zg_k_flatten<1024, 16384, 2>), dim3(nptr), dim3(1024), 0, s, d, 0u);
+    (void)hipEventRecord(ev[1], s2); (void)hipStreamWaitEvent(s, ev[1], 0);
+  }
 }
 bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* steps, uint32_t nsteps, hipStream_t s2, hipEvent_t* evs, uint32_t nev,
                      uint32_t unit_bytes, uint32_t window_max, uint32_t window_min, const ZgSweepTuning& tn) {

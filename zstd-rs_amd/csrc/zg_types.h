@@ -263,6 +263,9 @@ struct ZgBatchDev {
   uint32_t* og;                // flatten scratch: one u32 "effective offset" per output byte of a unit (0 = literal byte, final already)
   const ZgUnit* units;
   uint32_t nunits;
+  const uint32_t* unit_list;   // the units in launch order: [0, nunits - ndirect) pointer-mode units and units without sequences (zg_k_flatten),
+  uint32_t ndirect;            //   the last ndirect entries direct units (zg_k_flatten4)
+  uint32_t pad_ul;
   ZgUnitInfo* unit_info;       // [nunits]
   ZgSweepDesc* sweep_desc;     // one per entry of step_units, written by zg_k_swprep after zg_k_flatten (or by the flatten itself: overlap_epoch)
   uint32_t overlap_epoch;      // != 0: the sweep chain runs beside the flatten; a unit's flatten publishes its descriptor and sets unit_info.done to this
