@@ -12,8 +12,9 @@ generation and compression stay in seconds), every frame's output is compared wi
   enwik9like  configs[1]  enwik9.zst as ONE frame per GPU. $ZGPU_DATA/enwik9 (1e9 bytes) is compressed with libzstd -3 when
               present; else the stand-in text_like(1e9 B, seed 0xE9 + gpu, V=14000) | libzstd -3 (ratio 3.19, 7630 blocks).
               N > 1: every GPU decodes its own frame (a single frame does not shard: replicas, weak scaling).
-  realtext    a real-text single frame per GPU: source code and documentation found in this image (tools/realtext.py, 475 MB,
-              sha256 in tools/realtext_manifest.json) | libzstd -3: what the stand-in is a stand-in for.
+  realtext    a real-text single frame per GPU: source code and documentation found in this image (tools/realtext.py: 393 MB from the
+              directories listed in tools/realtext_manifest.json — the ones every box of the pool holds with the same bytes; a directory
+              that differs is skipped and named) | libzstd -3: what the stand-in is a stand-in for.
   silesia12   configs[2]  12 independent frames ($ZGPU_DATA/silesia/* when present, else 12 synthetic frames of the Silesia
               sizes), sharded over the GPUs in LPT order (strong scaling, bounded by the largest frame).
   blocks      configs[3]  128 x 64 MiB text frames = 8 GiB of 128 KiB blocks (ratio 3.19) per GPU: one GPU's share of the 64 GiB
@@ -44,8 +45,19 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 SILESIA_SIZES = [51220480, 41458703, 33553445, 21606400, 10192446, 10085684, 9970564, 8474240, 7251944, 6627202, 6152192, 5345280]
 KERNELS = ("tables", "huf", "seq", "seqpost", "scan", "lit", "flat", "sweep", "lz")
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r04")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r05")
 KERNEL_SOURCES = ("zg_kernels.hip", "zg_flat1.h", "zg_flat4.h", "zg_huf.h", "zg_exact.h", "zg_dev.h", "zg_types.h")   # what the device code is built from
+
+
+def pmap(fn, items):
+    """fn over items on host threads (the generators and libzstd are C behind ctypes: the GIL is released while they run), results in
+    order: eight GPUs' worth of frames are generated and compressed side by side instead of one after the other"""
+    items = list(items)
+    if len(items) <= 1:
+        return [fn(x) for x in items]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, min(len(items), os.cpu_count() or 1, 64))) as ex:
+        return list(ex.map(fn, items))
 
 
 def build_workload(name, gpu, size, small=False):
@@ -64,18 +76,19 @@ def build_workload(name, gpu, size, small=False):
     if name == "realtext":
         import realtext
         plain, info = realtext.load()
-        return ("real text found in this image (%d files, %d B, sha256 %s.., manifest %s) | libzstd %s -3, one frame per GPU"
-                % (info["files"], info["bytes"], info["sha256"][:16], info["manifest"], zgdata.zstd_version())), [plain], 1, False, "file"
+        return ("real text found in this image (%d files, %d B, sha256 %s.., manifest %s%s) | libzstd %s -3, one frame per GPU"
+                % (info["files"], info["bytes"], info["sha256"][:16], info["manifest"],
+                   "".join("; skipped %s: %s" % (k, why) for k, why in info["skipped"][:4]), zgdata.zstd_version())), [plain], 1, False, "file"
     if name == "silesia12":
         sdir = os.path.join(data_dir, "silesia") if data_dir else None
         if sdir and os.path.isdir(sdir) and len(os.listdir(sdir)) >= 12:
             plains = [open(os.path.join(sdir, f), "rb").read() for f in sorted(os.listdir(sdir))]
             return "Silesia (%d files from $ZGPU_DATA) | libzstd -3, one frame per file" % len(plains), plains, 1, True, "file"
-        plains = [zgdata.text_like(s, seed=0x51 + i) if i % 3 else zgdata.iso_like(s, seed=0x51 + i) for i, s in enumerate(SILESIA_SIZES)]
+        plains = pmap(lambda a: zgdata.text_like(a[1], seed=0x51 + a[0]) if a[0] % 3 else zgdata.iso_like(a[1], seed=0x51 + a[0]), enumerate(SILESIA_SIZES))
         return "Silesia-sized stand-in: 12 frames (text_like / iso_like, sizes of the 12 Silesia files) | libzstd -3", plains, 1, True, "synthetic"
     if name == "blocks":
         rep = 1 if small else 8
-        plains = [zgdata.text_like(64 << 20, seed=0xE9 + 16 * gpu + i) for i in range(16)]
+        plains = pmap(lambda i: zgdata.text_like(64 << 20, seed=0xE9 + 16 * gpu + i), range(16))
         return "%d x 64 MiB text_like frames (%d GiB of 128 KiB blocks: 16 distinct x %d) per GPU | libzstd -3" % (16 * rep, rep, rep), plains, rep, False, "synthetic"
     if name == "blocks4b":
         rep = 1 if small else 32
@@ -84,7 +97,7 @@ def build_workload(name, gpu, size, small=False):
         return "%d single-block frames (128 KiB each: 2048 distinct x %d) per GPU | libzstd -3" % (2048 * rep, rep), plains, rep, False, "synthetic"
     if name == "iso":
         rep = 1 if small else 16
-        plains = [zgdata.iso_like(64 << 20, seed=0x150 + 8 * gpu + i) for i in range(8)]
+        plains = pmap(lambda i: zgdata.iso_like(64 << 20, seed=0x150 + 8 * gpu + i), range(8))
         return "%d x 64 MiB iso_like frames (ratio 1.18: 8 distinct x %d) per GPU | libzstd -3" % (8 * rep, rep), plains, rep, False, "synthetic"
     raise SystemExit("unknown workload " + name)
 
@@ -141,13 +154,22 @@ def cpu_baseline(zs, plain_len, cores):
     t_o1, t_z1 = runs(lambda: oracle_one(one)), runs(lambda: zstd_one(one))
     t_on, t_zn = runs(threaded(oracle_one, cores)), runs(threaded(zstd_one, cores))
     gb = plain_len / 1e9
+    # ... and on every core the box has ("N = nproc, state N"; decode_all.rs:6-11 is the reference's own bench loop)
+    allc = os.cpu_count() or cores
+    if allc > cores:
+        t_oa, t_za = runs(threaded(oracle_one, allc)), runs(threaded(zstd_one, allc))
+    else:
+        t_oa, t_za = t_on, t_zn
     return {"value": round(gb / min(t_o1), 4), "unit": "GB/s", "cores": 1, "kind": "port",
             "sample": "%d-byte frame of the same workload through the oracle's decode_all (FrameDecoder::decode_all semantics), best of 3" % plain_len,
             "oracle_nt_GBps": round(cores * gb / min(t_on), 4), "nt_cores": cores,
             "libzstd_1t_GBps": round(gb / min(t_z1), 4), "libzstd_nt_GBps": round(cores * gb / min(t_zn), 4),
             "libzstd_nt_GBps_runs": [round(cores * gb / t, 2) for t in t_zn], "oracle_nt_GBps_runs": [round(cores * gb / t, 2) for t in t_on],
+            "all_cores": allc, "oracle_all_GBps": round(allc * gb / min(t_oa), 4), "oracle_all_GBps_runs": [round(allc * gb / t, 2) for t in t_oa],
+            "libzstd_all_GBps": round(allc * gb / min(t_za), 4), "libzstd_all_GBps_runs": [round(allc * gb / t, 2) for t in t_za],
             "libzstd_version": zgdata.zstd_version(), "host_cores_available": os.cpu_count(),
-            "note": "nt = one frame per thread on nt_cores threads (all three runs listed: the spread between runs and boxes is large); "
+            "note": "nt = one frame per thread on nt_cores threads, all = the same on every core of the box (all_cores threads; all three runs listed: "
+                    "the spread between runs and boxes is large); "
                     "ruzstd itself is not buildable here (no rustc/cargo)"}
 
 
@@ -184,12 +206,12 @@ def roofline(kern, A, workload, pass_ms=None, njobs=1, plaintext_bytes=None):
     try:   # HBM bytes from the committed rocprofv3 PMC passes; refused when the kernels or the workload differ from what they were taken on
         pm = json.load(open(os.path.join(PROFILE_DIR, "%s_pmc.json" % workload)))
         if pm.get("kernels_sha256") != kernels_sha256():
-            traffic_src = "profiles/r04/%s_pmc.json is stale for this build: not reported" % workload
+            traffic_src = "profiles/r05/%s_pmc.json is stale for this build: not reported" % workload
         elif plaintext_bytes is not None and pm.get("plaintext_bytes") != plaintext_bytes:
-            traffic_src = "profiles/r04/%s_pmc.json was taken on %s plaintext bytes, this run decodes %s: not reported" % (workload, pm.get("plaintext_bytes"), plaintext_bytes)
+            traffic_src = "profiles/r05/%s_pmc.json was taken on %s plaintext bytes, this run decodes %s: not reported" % (workload, pm.get("plaintext_bytes"), plaintext_bytes)
         else:
             traffic = pm["pipeline_hbm_bytes_per_pass"]
-            traffic_src = "profiles/r04/%s_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per-kernel calibration; all kernels of one pass)" % workload
+            traffic_src = "profiles/r05/%s_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per-kernel calibration; all kernels of one pass)" % workload
     except Exception:
         pass
     return {"bound": "hbm", "achieved": round(pipe, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pipe / HBM_PEAK_GBS, 6),
@@ -225,7 +247,7 @@ def other_workload(name, device, min_seconds):
     import zgpu
     t_prep = time.perf_counter()
     desc, plains, rep, _, _ = build_workload(name, 0, 0)
-    zs = [zgdata.zstd_compress(p, level=3) for p in plains]
+    zs = pmap(lambda p: zgdata.zstd_compress(p, level=3), plains)
     pool = zgpu.Pool(devices=[device])
     pool.stage(zs * rep)
     prep = time.perf_counter() - t_prep
@@ -293,14 +315,15 @@ def main():
     ngpu_here = pool.n_gpus                                   # (zgpu_pool_num_gpus: what the node really has)
     n_gpus = world if world > 1 else ngpu_here
     t0 = time.perf_counter()
-    per_gpu = []                                             # (plains, repeat) per GPU of this process
-    sharded = False
-    for g in range(ngpu_here):
-        desc, plains, rep, sharded, data_tag = build_workload(args.workload, (rank if world > 1 else g), args.size)
-        per_gpu.append((plains, rep))
-        if sharded:
-            break
-    zs_gpu = [[zgdata.zstd_compress(p, level=3) for p in plains] for plains, _ in per_gpu]
+    # (host preparation of all GPUs side by side: eight 1e9-byte generations + compressions are ~90 s one after the other)
+    built = pmap(lambda g: build_workload(args.workload, (rank if world > 1 else g), args.size), range(ngpu_here if args.workload != "silesia12" else 1))
+    desc, _, _, sharded, data_tag = built[0]
+    per_gpu = [(b[1], b[2]) for b in built]                  # (plains, repeat) per GPU of this process
+    flat = [(g, i) for g, (plains, _) in enumerate(per_gpu) for i in range(len(plains))]
+    zflat = pmap(lambda gi: zgdata.zstd_compress(per_gpu[gi[0]][0][gi[1]], level=3), flat)
+    zs_gpu = [[] for _ in per_gpu]
+    for (g, _), z in zip(flat, zflat):
+        zs_gpu[g].append(z)
     if sharded:
         job_lens = [len(z) for z in zs_gpu[0]]
         mine = zgpu_dist.shard_frames(job_lens, world)[rank] if world > 1 else list(range(len(job_lens)))

@@ -814,6 +814,40 @@ def test_sparse_frames_copy_their_matches_in_order():
     assert bad == 0 and out == text + iso
 
 
+def test_trailing_frame_without_a_block(ctx):
+    """a valid frame followed by a frame header and a first block header the host walk stops at (truncated, reserved type, too large, body
+    cut): the batch then holds a trailing frame of zero blocks. Same verdict and the same bytes in front of it as the oracle."""
+    import zgpu
+    from test_verdict_order_cpu import _trailing_cases
+    for k, m in enumerate(_trailing_cases()):
+        ost, oout = oracle.FrameDecoder().decode_all(m, 1 << 24)
+        try:
+            out, gst = ctx.decode_all(m, 1 << 24), 0
+        except zgpu.ZgpuError as e:
+            out, gst = None, e.status
+        assert ost != 0 and gst == ost, (k, ost, gst)
+
+
+def test_content_size_that_lies_by_gigabytes_over_tiny_blocks(ctx):
+    """a 1.5 MB frame of 500,000 (mostly empty) raw blocks that declares 60 GiB. The reference never looks at the field and
+    decodes it; the engine must not turn the declaration into an allocation (it is bounded by what the block headers allow: exact for
+    raw and RLE blocks) — same bytes as the oracle, and a following honest submit still works."""
+    body = bytearray()
+    want = bytearray()
+    n = 500000
+    for i in range(n):
+        data = b"abc" if i % 1000 == 999 else b""
+        body += (((len(data) << 3) | (1 if i == n - 1 else 0)).to_bytes(3, "little")) + data      # raw block: last | type 0 << 1 | size << 3
+        want += data
+    # magic, descriptor 0xC0 (8-byte Frame_Content_Size, window descriptor present), window descriptor 0 (1 KiB), FCS = 60 GiB
+    z = bytes.fromhex("28b52ffd") + bytes([0xC0, 0x00]) + (60 << 30).to_bytes(8, "little") + bytes(body)
+    ost, oout = oracle.FrameDecoder().decode_all(z, len(want) + 16)
+    assert ost == 0 and oout == bytes(want)
+    assert ctx.decode_all(z, len(want) + 16) == bytes(want)
+    spack, sman = read_pack("synthetic.pack"), read_manifest("synthetic.json")
+    assert _sha(ctx.decode_all(spack["text_1m_l3.zst"], sman["text_1m_l3.zst"]["size"])) == sman["text_1m_l3.zst"]["sha256"]
+
+
 def test_output_sized_in_advance_and_frames_that_lie(ctx, monkeypatch):
     """Every frame declares its content size: the engine sizes the output before the run and enqueues the LZ77 stages behind the scan
     without waiting for the host. Frame_Content_Size is never checked by FrameDecoder::decode_all (frame_decoder.rs:541-577), so a

@@ -51,3 +51,35 @@ def test_small_random_soak():
             assert emu.decode_all_verdict(m) == ost, (bi, it, ost)
             nerr += 1 if ost else 0
     assert nerr > 80
+
+
+def _trailing_cases():
+    """a valid frame, then a frame header and a first block header the walk stops at: the trailing frame holds NO block"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import zgdata
+    packs = read_pack("decodecorpus.pack")
+    good_ck = packs["z000033.zst"]                                      # the corpus frames carry a content checksum ...
+    good_nock = zgdata.zstd_compress(zgdata.text_like(300000, seed=5), checksum=False)  # ... this one has none
+    cases = []
+    for good in (good_ck, good_nock):
+        for other in (good_ck, good_nock):
+            hdr_len = 4 + 1 + (0 if (other[4] >> 5) & 1 else 1) + (0, 1, 2, 4)[other[4] & 3] + ((1 if (other[4] >> 5) & 1 else 0), 2, 4, 8)[other[4] >> 6]
+            hdr = other[:hdr_len]
+            cases.append(good + hdr)                                  # truncated behind the frame header
+            cases.append(good + hdr + b"\x05")                        # ... inside the block header
+            cases.append(good + hdr + bytes([0x06 | 1, 0, 0]))        # reserved block type (3), last block
+            cases.append(good + hdr + (((200000 << 3) | 4 | 1).to_bytes(3, "little")))   # compressed block of 200000 bytes: too large
+            cases.append(good + hdr + (((100 << 3) | 4).to_bytes(3, "little")) + b"xyz")   # body truncated
+            cases.append(good + hdr[:hdr_len - 1])                     # the frame header itself truncated
+    return cases
+
+
+def test_trailing_frame_without_a_block():
+    n = 0
+    for m in _trailing_cases():
+        ost, _ = oracle.FrameDecoder().decode_all(m, 1 << 25)
+        assert ost != 0
+        assert emu.decode_all_verdict(m) == ost, (n, ost, emu.decode_all_verdict(m))
+        n += 1
+    assert n == 24

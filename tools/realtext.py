@@ -1,9 +1,13 @@
 """A real-text corpus from files that are part of this image (no network: enwik9 cannot be fetched): source code and documentation
-under the Python site-packages and the system / ROCm include directories, concatenated in sorted path order until `want` bytes are
-reached. The GPU box runs the same image, so the same bytes come out there; tools/realtext_manifest.json holds the file count, the byte
-count and the sha256 of the concatenation as built here, and load() says whether what it built matches it.
+under the Python site-packages and the system / ROCm include directories, concatenated in sorted path order.
 
-usage: python tools/realtext.py [--write-manifest]"""
+Deterministic across boxes (round 5): the boxes of this pool do not hold the same site-packages (round 4: 393 MB on the builder's GPU boxes,
+475 MB on the driver's — twelve packages of the offline wheelhouse exist on one and not on the other). tools/realtext_manifest.json therefore
+lists the TOP-LEVEL DIRECTORIES that go in, each with its file count, byte count and a sha256 prefix, as found both in the build container
+and on a GPU box (tools/dev/call2.sh census, round 5): load() walks exactly those, skips one whose files differ and says so
+(info["skipped"]: name and reason), and reports whether the concatenation is the manifest's ("match") or not ("differs").
+
+usage: python tools/realtext.py [--write-manifest [census.json ...]]   (census: only directories that every given census also holds)"""
 import hashlib
 import json
 import os
@@ -15,55 +19,87 @@ MANIFEST = os.path.join(os.path.dirname(os.path.abspath(__file__)), "realtext_ma
 WANT = 512 << 20
 
 
-def files(want=WANT):
-    out, tot = [], 0
+def census():
+    """{root/top-level-entry: [(path, size) ...]} of every candidate file, paths sorted"""
+    out = {}
     for root in ROOTS:
-        cand = []
         for dp, dn, fn in os.walk(root):
             dn.sort()
             for f in sorted(fn):
-                if f.endswith(EXTS):
-                    p = os.path.join(dp, f)
-                    if os.path.islink(p):
-                        continue
-                    try:
-                        s = os.path.getsize(p)
-                    except OSError:
-                        continue
-                    if 1024 < s < (8 << 20):
-                        cand.append((p, s))
-        for p, s in sorted(cand):
-            out.append(p)
-            tot += s
-            if tot >= want:
-                return out
+                if not f.endswith(EXTS):
+                    continue
+                p = os.path.join(dp, f)
+                if os.path.islink(p):
+                    continue
+                try:
+                    s = os.path.getsize(p)
+                except OSError:
+                    continue
+                if 1024 < s < (8 << 20):
+                    rel = os.path.relpath(p, root).split(os.sep)
+                    out.setdefault(root + "/" + (rel[0] if len(rel) > 1 else "."), []).append((p, s))
     return out
 
 
-def load(want=WANT):
-    """returns (bytes, info). info: files, bytes, sha256, manifest ("match" / "differs" / "absent")"""
-    parts = []
-    tot = 0
-    flist = files(want)
-    for p in flist:
+def dir_digest(files):
+    h = hashlib.sha256()
+    n = tot = 0
+    for p, _ in files:
         try:
             b = open(p, "rb").read()
         except OSError:
             continue
-        parts.append(b)
-        tot += len(b)
-    data = b"".join(parts)[:want]
-    info = {"files": len(flist), "bytes": len(data), "sha256": hashlib.sha256(data).hexdigest(), "roots": ROOTS}
+        h.update(b); n += 1; tot += len(b)
+    return [n, tot, h.hexdigest()[:16]]
+
+
+def load(want=WANT):
+    """returns (bytes, info). info: files, bytes, sha256, manifest ("match" / "differs" / "absent"), skipped [(directory, reason) ...]"""
     try:
-        m = json.load(open(MANIFEST))
-        info["manifest"] = "match" if (m["sha256"] == info["sha256"] and m["bytes"] == info["bytes"]) else "differs"
+        man = json.load(open(MANIFEST))
     except Exception:
-        info["manifest"] = "absent"
+        man = None
+    cen = census()
+    keys = sorted(cen, key=lambda k: (ROOTS.index(k[:k.rindex("/")]) if k[:k.rindex("/")] in ROOTS else 99, k))
+    parts, skipped, nfiles = [], [], 0
+    for k in (keys if man is None else [k for k in man["dirs"]]):
+        if k not in cen:
+            skipped.append((k, "missing on this box"))
+            continue
+        fl = cen[k]                                   # (walk order: a directory's files, then its subdirectories, names sorted)
+        bs = []
+        for p, _ in fl:
+            try:
+                bs.append(open(p, "rb").read())
+            except OSError:
+                pass
+        if man is not None:
+            h = hashlib.sha256()
+            for b in bs:
+                h.update(b)
+            if [len(bs), sum(len(b) for b in bs), h.hexdigest()[:16]] != man["dirs"][k]:
+                skipped.append((k, "its files differ from the manifest's"))
+                continue
+        parts.extend(bs)
+        nfiles += len(bs)
+    data = b"".join(parts)[:want]
+    info = {"files": nfiles, "bytes": len(data), "sha256": hashlib.sha256(data).hexdigest(), "roots": ROOTS, "skipped": skipped}
+    info["manifest"] = "absent" if man is None else ("match" if (man["sha256"] == info["sha256"] and man["bytes"] == info["bytes"]) else "differs")
     return data, info
 
 
 if __name__ == "__main__":
-    data, info = load()
-    print(json.dumps(info))
     if "--write-manifest" in sys.argv:
-        json.dump({k: info[k] for k in ("files", "bytes", "sha256", "roots")}, open(MANIFEST, "w"), indent=1)
+        cen = census()
+        others = [json.load(open(a)) for a in sys.argv[sys.argv.index("--write-manifest") + 1:]]
+        dirs = {}
+        keys = sorted(cen, key=lambda k: (ROOTS.index(k[:k.rindex("/")]), k))
+        for k in keys:
+            d = dir_digest(cen[k])
+            if all(o.get(k) == d for o in others):
+                dirs[k] = d
+        json.dump({"dirs": dirs, "bytes": 0, "sha256": "", "files": 0, "roots": ROOTS}, open(MANIFEST, "w"), indent=0)
+        data, info = load()
+        json.dump({"dirs": dirs, "bytes": info["bytes"], "sha256": info["sha256"], "files": info["files"], "roots": ROOTS}, open(MANIFEST, "w"), indent=0)
+    data, info = load()
+    print(json.dumps({k: v for k, v in info.items() if k != "skipped"}), "skipped:", info["skipped"][:5])

@@ -485,13 +485,18 @@ int Batch::run() {
   d.dst_cap_pre = 0;
   // ... and the declared sizes are possible at all: a block regenerates at most 128 KiB on this path, and Frame_Content_Size is a field
   // the reference never believes (a corrupted one must not become a 600 GB allocation: the sizes are then taken from the scan)
-  if (!fs && all_declared && !eng->no_presize_ && declared_total <= (uint64_t)bb.blocks.size() * kMaxBlockSize) {
-    int st = 0;
-    if ((st = sc->d_dst.reserve(kOutFront + declared_total + 64)) || (st = sc->d_og.reserve(declared_total * 4 + 64))) return st;
-    d.dst = sc->d_dst.as<uint8_t>() + kOutFront; d.dst_cap = declared_total;
-    d.og = sc->d_og.as<uint32_t>(); d.og_words = og_words = declared_total;
-    d.dst_cap_pre = declared_total ? declared_total : 1;   // (0 means "not sized in advance")
-    presized = true;
+  // (bb.out_bound: what the host already knows the blocks can produce at most — exact for raw and RLE blocks, 128 KiB per compressed block.
+  //  A declared size beyond it is a lie whatever else is true — 500,000 empty raw blocks behind an FCS of 64 GiB must not become a 320 GiB
+  //  allocation — and a reserve that fails all the same is no error either: the reference never looks at the field, so the
+  //  submit falls back to sizes taken from the scan.)
+  // (not with ramped units, a measurement switch: their sweep chain polls flags that the flatten of a no-op run never raises — ADVICE r4)
+  if (!fs && all_declared && !eng->no_presize_ && declared_total <= bb.out_bound && !bb.ramped) {
+    if (sc->d_dst.reserve(kOutFront + declared_total + 64) == 0 && sc->d_og.reserve(declared_total * 4 + 64) == 0) {
+      d.dst = sc->d_dst.as<uint8_t>() + kOutFront; d.dst_cap = declared_total;
+      d.og = sc->d_og.as<uint32_t>(); d.og_words = og_words = declared_total;
+      d.dst_cap_pre = declared_total ? declared_total : 1;   // (0 means "not sized in advance")
+      presized = true;
+    }
   }
   ZG_HIP(hipEventRecord(ev[0], s));
   ZG_HIP(hipMemsetAsync(d.status, 0, 3 * ((size_t)d.nblocks * 4 + 16), s));
@@ -726,13 +731,22 @@ int Batch::sync() {
   }
   // a frame that failed in the execution stage (zg_k_flatten / zg_k_exact / zg_k_lz) still carries the size of all its blocks:
   // what it produced ends with its last good block, as for the entropy errors zg_k_scan trims itself
-  for (uint32_t f = 0; f < dev.nframes; f++) {
-    ZgFrameOut& fo = frame_out[f];
-    const ZgFrame& fr = bb.frames[f];
-    if (!fo.status || fo.good_blocks >= fr.nblocks) continue;
-    ZgBlockPos p;
-    ZG_HIP(hipMemcpy(&p, dev.pos + fr.first_block + fo.good_blocks, sizeof p, hipMemcpyDeviceToHost));
-    if (p.out_base < fo.out_size) fo.out_size = p.out_base;
+  // (host-side only: total_out and the device copy of frame_out keep the untrimmed sizes. One copy per failed frame while they are few; a
+  //  submit of many corrupt frames fetches the block positions once instead of paying a round trip per frame — ADVICE r4)
+  {
+    uint32_t nfail = 0;
+    for (uint32_t f = 0; f < dev.nframes; f++) nfail += frame_out[f].status && frame_out[f].good_blocks < bb.frames[f].nblocks;
+    std::vector<ZgBlockPos> all_pos;
+    if (nfail > 8) { all_pos.resize(dev.nblocks); ZG_HIP(hipMemcpy(all_pos.data(), dev.pos, (size_t)dev.nblocks * sizeof(ZgBlockPos), hipMemcpyDeviceToHost)); }
+    for (uint32_t f = 0; f < dev.nframes && nfail; f++) {
+      ZgFrameOut& fo = frame_out[f];
+      const ZgFrame& fr = bb.frames[f];
+      if (!fo.status || fo.good_blocks >= fr.nblocks) continue;
+      ZgBlockPos p;
+      if (!all_pos.empty()) p = all_pos[fr.first_block + fo.good_blocks];
+      else ZG_HIP(hipMemcpy(&p, dev.pos + fr.first_block + fo.good_blocks, sizeof p, hipMemcpyDeviceToHost));
+      if (p.out_base < fo.out_size) fo.out_size = p.out_base;
+    }
   }
   hipEvent_t* ev = sc->ev;
   for (int i = 0; i < ZG_T_TOTAL; i++) {
