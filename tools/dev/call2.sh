@@ -1,27 +1,11 @@
 #!/bin/bash
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/c9
+OUT=$ROOT/gpurun_out/c10
 mkdir -p $OUT; cd $ROOT; export TMPDIR=/tmp
-python - > $OUT/realtext_dirs.json <<'PY'
-import os, sys, json, hashlib
-sys.path.insert(0, "tools")
-import realtext
-res = {}
-for root in realtext.ROOTS:
-    for dp, dn, fn in os.walk(root):
-        dn.sort()
-        for f in sorted(fn):
-            if f.endswith(realtext.EXTS):
-                p = os.path.join(dp, f)
-                if os.path.islink(p): continue
-                try: s = os.path.getsize(p)
-                except OSError: continue
-                if 1024 < s < (8 << 20):
-                    rel = os.path.relpath(p, root).split(os.sep)
-                    key = root + "/" + (rel[0] if len(rel) > 1 else ".")
-                    h = res.setdefault(key, [0, 0, hashlib.sha256()])
-                    h[0] += 1; h[1] += s; h[2].update(open(p, "rb").read())
-print(json.dumps({k: [v[0], v[1], v[2].hexdigest()[:16]] for k, v in res.items()}))
-PY
-( timeout 900 python -m pytest tests -x -q -m gpu -k "trailing_frame or lies_by_gigabytes or inorder_fallback or ramped or sized_in_advance" ) > $OUT/tests.log 2>&1
-tail -5 $OUT/tests.log
+( ZGPU_SEQ_PACKED=1 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu ) > $OUT/tests_packed.log 2>&1
+tail -3 $OUT/tests_packed.log
+cd /tmp
+timeout 600 python $ROOT/tools/dev/variants.py 2147483648 blocks -- ZGPU_SEQ_PACKED=0 ZGPU_SEQ_PACKED=1 > $OUT/blocks.log 2>&1
+timeout 600 python $ROOT/tools/dev/variants.py 4294967296 many -- ZGPU_SEQ_PACKED=0 ZGPU_SEQ_PACKED=1 > $OUT/many.log 2>&1
+timeout 600 python $ROOT/tools/dev/variants.py 1000000000 text -- ZGPU_SEQ_PACKED=0 ZGPU_SEQ_PACKED=1 > $OUT/text.log 2>&1
+cat $OUT/blocks.log $OUT/many.log $OUT/text.log | cut -c1-330

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""rocprofv3 outputs of tools/dev/profile.sh (gpurun_out/prof/<workload>/...) -> the summaries kept under profiles/r04/.
+"""rocprofv3 outputs of tools/dev/profile.sh (gpurun_out/prof/<workload>/...) -> the summaries kept under profiles/r05/.
 
   --reduce W..  (on the GPU box) condense the counter CSVs into gpurun_out/prof/pmc_reduced.json: per workload and kernel the summed
                 counter and the number of launches; the SQ-counter CSVs are cut down to the engine's kernels (one row per launch
                 and counter: the raw evidence kept under profiles/). The bulky traces stay behind.
-  (default)     (here) write profiles/r04/: per workload <w>_kernel_stats.csv, <w>_bench_under_rocprof.json and <w>_pmc.json: HBM bytes
+  (default)     (here) write profiles/r05/: per workload <w>_kernel_stats.csv, <w>_bench_under_rocprof.json and <w>_pmc.json: HBM bytes
                 per pass per kernel, raw and calibrated PER ACCESS PATTERN. On gfx950 FETCH_SIZE reports half of a wide coalesced
                 read (MI355X_MICROARCH.md, HBM section); what it reports for the engine's other patterns is measured by the
                 calibration kernels (zg_k_calib_*): the factor applied to a kernel is that of the pattern its reads are made of.
@@ -12,7 +12,7 @@
 import collections, csv, glob, hashlib, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 P = os.path.join(ROOT, "gpurun_out", "prof")
-OUT = os.path.join(ROOT, "profiles", "r04")
+OUT = os.path.join(ROOT, "profiles", "r05")
 CSRC = os.path.join(ROOT, "zstd-rs_amd", "csrc")
 
 
@@ -66,7 +66,7 @@ def reduce(workloads):
 
 
 # which calibration pattern a kernel's reads are (mostly) made of; its writes are 4 or 16 B per lane coalesced
-READ_PATTERN = {"zg_k_sweep": "mixed_sweep", "zg_k_flatten": "mixed_flat", "zg_k_seqpost": "copy16", "zg_k_seq": "copy16", "zg_k_huf": "copy16",
+READ_PATTERN = {"zg_k_sweep": "mixed_sweep", "zg_k_flatten": "mixed_flat", "zg_k_flatten4": "mixed_flat", "zg_k_seqpost": "copy16", "zg_k_seq": "copy16", "zg_k_huf": "copy16",
                 "zg_k_ftab": "copy16", "zg_k_tables": "copy16", "zg_k_scan": "copy4", "zg_k_lit": "copy16"}
 
 
@@ -95,8 +95,16 @@ def main():
         ks = os.path.join(P, w + "_kernel_stats.csv")
         if os.path.exists(ks):
             shutil.copy(ks, os.path.join(OUT, w + "_kernel_stats.csv"))
-        for f in glob.glob(os.path.join(P, w + "_sq*.csv")):
-            shutil.copy(f, os.path.join(OUT, os.path.basename(f)))
+        # SQ counters: per kernel and counter the sum over the run's launches and the number of launches (the raw per-launch CSVs of round 4
+        # were 40,000 lines of build-specific numbers in git: ADVICE r4 — tools/dev/profile.sh regenerates them on demand under gpurun_out/)
+        sq = {}
+        for f in sorted(glob.glob(os.path.join(P, w + "_sq*.csv"))):
+            for r in csv.DictReader(open(f)):
+                e = sq.setdefault(r["Kernel_Name"], {}).setdefault(r["Counter_Name"], [0.0, 0])
+                e[0] += float(r["Counter_Value"]); e[1] += 1
+        if sq:
+            json.dump({"kernels_sha256": sha, "workload": w, "note": "rocprofv3 --pmc SQ_* passes of bench.py --workload %s --steps 1 --warmup 1 (three passes of counters): "
+                       "[sum over the run's launches, launches]" % w, "counters": sq}, open(os.path.join(OUT, w + "_sq_summary.json"), "w"), indent=0)
         lines = [l for l in open(os.path.join(P, w, "stats.log")) if l.startswith('{"metric"')]
         if not lines:
             print("no bench line for", w)
@@ -114,7 +122,7 @@ def main():
                          "pointer-mode units, 4 B per byte; flatten: sequence records, ~1.2 B per byte of a unit with sequences) with gathers: "
                          "the wide part is corrected analytically, the rest keeps the gather factor.",
                "kernels": {}}
-        once = [n for k, (v, n) in rw["fetch"].items() if k.split("<")[0] in ("zg_k_scan", "zg_k_flatten", "zg_k_seq", "zg_k_ftab")]
+        once = [n for k, (v, n) in rw["fetch"].items() if k.split("<")[0] in ("zg_k_scan", "zg_k_seq", "zg_k_ftab")]
         npass = min(once) if once else 4
         total = 0.0
         for k in sorted(set(rw["fetch"]) | set(rw["write"])):

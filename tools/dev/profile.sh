@@ -4,7 +4,7 @@
 #   <w>/fetch, <w>/write  HBM byte counters, separate passes (FETCH_SIZE and WRITE_SIZE do not fit one)
 # plus, once: a calibration of the byte counters on kernels with known traffic per access pattern (zg_k_calib_*), and for the
 # first workload the SQ counters of the two LZ77 kernels (raw CSVs, one row per launch).
-# Writes under gpurun_out/prof; tools/dev/pmc_summary.py turns that into profiles/r04/.
+# Writes under gpurun_out/prof; tools/dev/pmc_summary.py turns that into profiles/r05/.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof

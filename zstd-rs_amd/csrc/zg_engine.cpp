@@ -98,6 +98,7 @@ Tuning Tuning::from_env() {
   t.no_exact = getenv("ZGPU_DEBUG_NO_EXACT") != nullptr;
   t.no_presize = is0("ZGPU_PRESIZE");
   { uint32_t v = 0; if (num("ZGPU_FLAT4", &v, false)) t.flat4 = (int)v; }
+  { uint32_t v = 0; if (num("ZGPU_SEQ_PACKED", &v, false)) t.seq_packed = (int)v; }
   { const char* e = getenv("ZGPU_FLAT_T"); t.flat_shape = (e && atoi(e) == 512) ? 1 : 0; }   // "512": 512 threads x 8 KiB tiles, two workgroups per CU; else the default
   num("ZGPU_SWEEP_MODE", &t.sweep.mode, false);
   num("ZGPU_SWEEP_NB", &t.sweep.nbatch, true);
@@ -533,7 +534,10 @@ int Batch::run() {
   if (!lit_direct) zg_launch_huf(d, s2);
   ZG_HIP(hipEventRecord(sc->ev_huf[1], s2));
   ZG_HIP(hipEventRecord(ev[2], s));
-  zg_launch_seq(d, s);
+  // (more blocks with sequences than chains the device runs at once — CUs x 32 —: the kernel is then bound by chains per unit of time, not by
+  //  the length of one chain, and the packed-entry form holds half as many again per CU)
+  const int seq_pk = eng->tn_.seq_packed;
+  zg_launch_seq(d, s, seq_pk < 0 ? d.nseq_blocks > (uint32_t)eng->cus_ * 32u : seq_pk != 0);
   ZG_HIP(hipEventRecord(ev[3], s));
   zg_launch_seqpost(d, s);
   ZG_HIP(hipStreamWaitEvent(s, sc->ev_huf[1], 0));

@@ -102,6 +102,8 @@ struct Tuning {
                                    // CU, round 4's form); 1 / 4 / 6: by zg_k_flatten4 with 1024 / 512 / 256 threads and 8 / 4 / 2 KiB tiles (2 / 4 / 8
                                    // workgroups per CU); 2, 3, 5, 7: other shapes (measurement)
   int flat_shape = 0;              // ZGPU_FLAT_T=512 -> 1
+  int seq_packed = -1;             // ZGPU_SEQ_PACKED: zg_k_seq's table entries — -1 (default): packed (16 bits, three workgroups per CU) when the submit has more
+                                   // blocks with sequences than one round holds, else unpacked; 0 / 1: never / always
   ZgSweepTuning sweep;             // ZGPU_SWEEP_MODE / _NB / _GROUP / _HEAD_LDS
   static Tuning from_env();
 };

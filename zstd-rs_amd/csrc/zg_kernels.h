@@ -23,7 +23,7 @@ struct ZgSweepTuning { uint32_t mode = 0, nbatch = 1, group = 16, head_lds = 52u
 
 void zg_launch_tables(const ZgBatchDev& d, hipStream_t s, int part);   // part 0: Huffman trees, part 1: FSE tables
 void zg_launch_huf(const ZgBatchDev& d, hipStream_t s);
-void zg_launch_seq(const ZgBatchDev& d, hipStream_t s);
+void zg_launch_seq(const ZgBatchDev& d, hipStream_t s, bool packed);   // packed: 16-bit table entries, three workgroups per CU (submits of more blocks than one round holds)
 void zg_launch_seqpost(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_merge(const ZgBatchDev& d, hipStream_t s);
 void zg_launch_litfix(const ZgBatchDev& d, hipStream_t s);   // ZG_FLAG_LIT_DIRECT: literal verdicts found after the scan -> block and frame statuses

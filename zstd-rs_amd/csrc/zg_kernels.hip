@@ -603,10 +603,17 @@ __device__ __forceinline__ void zg_seq_window(ZgSeqChain& c, const uint8_t* stor
 }
 // One step of the chain. FAST: no checks (see above). Otherwise `act`, `left`, `cnt` are maintained and a finished or
 // failed block keeps its state.
-template <bool FAST>
+// PK (round 5): ONE 16-bit entry per state instead of a u16 and a u8 — [9:0] (baseline << 1) | (1 << state bits): a baseline is a multiple of
+// 2^(state bits), so the lowest set bit says how many there are; [15:10] all bits the symbol takes. Four instructions more in the step and
+// a third less LDS per block: three workgroups per CU instead of two. The kernel lasts as long as ONE chain when all blocks of the submit are
+// resident at once (the 7630 blocks of the 1e9-byte frame: the unpacked form), and as long as blocks x chain / resident chains when they
+// are not (65536 single-block frames, 128 x 64 MiB frames: eight rounds -> 5.3: the packed form). zg_launch_seq picks.
+#define ZG_SEQ_PK(bl, nb, all) ((uint16_t)((((uint32_t)(bl) << 1) | (1u << (nb))) | ((uint32_t)(all) << 10)))
+template <bool FAST, bool PK>
 __device__ __forceinline__ void zg_seq_step(ZgSeqChain& c, const uint16_t* tab, const uint8_t* xtab, const uint8_t* store4, uint16_t* rec,
                                             int32_t rbits, bool& act, uint32_t& left, uint32_t& cnt) {
-  const uint32_t nb0 = c.e & 15u;
+  const uint32_t nb0 = PK ? (uint32_t)__builtin_ctz(c.e) : c.e & 15u;
+  if (PK) c.s = c.e >> 10;
   uint32_t nb = nb0, pk = c.s | (nb0 << 8);          // pk: [7:0] all bits this lane's symbol takes, [15:8] its state bits
   if (!FAST) { const bool last = left == 1u; nb = last ? 0u : nb0; pk = last ? c.s - nb0 : pk; }   // no state update after the last sequence (:203)
   // quad prefix sums, lanes in stream order from the low end: OF state, ML state, LL state (the extra bits above them are skipped as one count)
@@ -620,11 +627,11 @@ __device__ __forceinline__ void zg_seq_step(ZgSeqChain& c, const uint16_t* tab, 
   const uint32_t a0 = up ? c.w2 : c.w0, a1 = up ? c.w3 : c.w1, a2 = up ? c.w3 : c.w2;
   const uint32_t d0 = odd ? a1 : a0, d1 = odd ? a2 : a1;
   const uint32_t bits = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(d1, d0, rel), 0u, nb);
-  const uint32_t st2 = (c.e >> 4) + bits;
+  const uint32_t st2 = PK ? ((c.e & 0x3FFu) >> 1) + bits - ((1u << nb0) >> 1) : (c.e >> 4) + bits;
   if (FAST) {
     *rec = (uint16_t)c.st;
     c.pr = q; c.st = st2;
-    c.e = tab[st2]; c.s = xtab[st2];
+    c.e = tab[st2]; if (!PK) c.s = xtab[st2];
     zg_seq_window(c, store4);
     __builtin_amdgcn_sched_barrier(0);
   } else {
@@ -635,7 +642,7 @@ __device__ __forceinline__ void zg_seq_step(ZgSeqChain& c, const uint16_t* tab, 
     left -= ok ? 1u : 0u;                             // stops at the sequence that ran out of bits
     act = ok && left != 0u;
     ZgSeqChain n = c;
-    n.pr = q; n.st = st2; n.e = tab[st2]; n.s = xtab[st2];
+    n.pr = q; n.st = st2; n.e = tab[st2]; if (!PK) n.s = xtab[st2];
     zg_seq_window(n, store4);
     __builtin_amdgcn_sched_barrier(0);
     if (was) { c.pr = n.pr; c.wlo = n.wlo; c.w0 = n.w0; c.w1 = n.w1; c.w2 = n.w2; c.w3 = n.w3; }
@@ -643,9 +650,10 @@ __device__ __forceinline__ void zg_seq_step(ZgSeqChain& c, const uint16_t* tab, 
   }
 }
 
+template <bool PK>
 __global__ void __launch_bounds__(128) zg_k_seq(ZgBatchDev d) {
   __shared__ uint16_t s_tab[ZG_SEQ_G][ZG_FSE_SLOT_U32 + 2];   // + the one-entry dummy table of the spare lane
-  __shared__ uint8_t s_xb[ZG_SEQ_G][ZG_FSE_SLOT_U32 + 4];
+  __shared__ uint8_t s_xb[PK ? 1 : ZG_SEQ_G][PK ? 4 : ZG_FSE_SLOT_U32 + 4];
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[ZG_SEQ_G][ZG_SEQ_RSTORE];
   __shared__ __attribute__((aligned(16))) uint2 s_out[2][ZG_SEQ_G][ZG_SEQ_CH];   // records, 4 x u16: states {OF, ML, LL, 0}; one buffer per phase parity
   __shared__ int32_t s_pos[2][ZG_SEQ_G];            // decoder -> mover, per phase parity: the block's position after the phase,
@@ -679,14 +687,15 @@ __global__ void __launch_bounds__(128) zg_k_seq(ZgBatchDev d) {
           const uint32_t i = t + 128 * j;
           if (i < (1u << lg)) {
             const uint32_t nb = ZG_FSE_NB(v[j]);
-            s_tab[g][offs[k] + i] = (uint16_t)((ZG_FSE_BL(v[j]) << 4) | nb);
-            s_xb[g][offs[k] + i] = (uint8_t)(nb + (k == 1 ? ZG_FSE_SYM(v[j]) : v[j] >> 26));   // OF: the code is the number of extra bits
+            const uint32_t all = nb + (k == 1 ? ZG_FSE_SYM(v[j]) : v[j] >> 26);                // OF: the code is the number of extra bits
+            if (PK) s_tab[g][offs[k] + i] = ZG_SEQ_PK(ZG_FSE_BL(v[j]), nb, all);
+            else { s_tab[g][offs[k] + i] = (uint16_t)((ZG_FSE_BL(v[j]) << 4) | nb); s_xb[g][offs[k] + i] = (uint8_t)all; }
           }
         }
       }
       if (t == 0) s_log[g][k] = (uint8_t)lg;
     }
-    if (t == 0) { s_ok[g] = ok ? 1 : 0; s_tab[g][ZG_FSE_SLOT_U32] = 0; s_xb[g][ZG_FSE_SLOT_U32] = 0; }
+    if (t == 0) { s_ok[g] = ok ? 1 : 0; s_tab[g][ZG_FSE_SLOT_U32] = PK ? ZG_SEQ_PK(0, 0, 0) : 0; if (!PK) s_xb[g][ZG_FSE_SLOT_U32] = 0; }
   }
   __syncthreads();
   // ---- per-lane setup: four lanes per block in either wave. Decoder: lane role 0 follows the OF chain, 1 the ML chain,
@@ -700,7 +709,7 @@ __global__ void __launch_bounds__(128) zg_k_seq(ZgBatchDev d) {
   uint64_t bsA = 0, floorA = 0, lo = 0, dstp = 0;
   const uint32_t toff = role == 0u ? ZG_FSE_OF_OFF : role == 1u ? ZG_FSE_ML_OFF : role == 2u ? ZG_FSE_LL_OFF : ZG_FSE_SLOT_U32;
   const uint16_t* tab = &s_tab[g][toff];
-  const uint8_t* xtab = &s_xb[g][toff];
+  const uint8_t* xtab = PK ? &s_xb[0][0] : &s_xb[g][toff];
   uint8_t* const store = s_ring[g];
   const uint8_t* const store4 = store + 4;
   int32_t P = 0;
@@ -757,7 +766,7 @@ __global__ void __launch_bounds__(128) zg_k_seq(ZgBatchDev d) {
     const uint32_t lg = role == 0u ? of_log : role == 1u ? ml_log : role == 2u ? ll_log : 0u;
     const int32_t q = P - (int32_t)(role == 2u ? ll_log : role == 0u ? ll_log + of_log : ll_log + of_log + ml_log);
     c.st = (q >= 0 && role != 3u) ? zg_ring_bits(store, q + rbits, lg) : 0u;
-    c.e = tab[c.st]; c.s = xtab[c.st];
+    c.e = tab[c.st]; c.s = PK ? 0u : xtab[c.st];
     P -= (int32_t)(ll_log + of_log + ml_log);
     if (owner && !mover) d.seq_out[b].pad = (uint32_t)P;   // where the first sequence starts: zg_k_seqpost rebuilds the positions from the bit counts
     left = nseq;
@@ -780,12 +789,12 @@ __global__ void __launch_bounds__(128) zg_k_seq(ZgBatchDev d) {
       uint32_t cnt = 0;
       if (act && left > ZG_SEQ_CH) {
 #pragma unroll
-        for (int k = 0; k < ZG_SEQ_CH; k++) zg_seq_step<true>(c, tab, xtab, store4, out_base + 4 * k, rbits, act, left, cnt);
+        for (int k = 0; k < ZG_SEQ_CH; k++) zg_seq_step<true, PK>(c, tab, xtab, store4, out_base + 4 * k, rbits, act, left, cnt);
         cnt = ZG_SEQ_CH; left -= ZG_SEQ_CH;
         if (c.pr < rbits) act = false;                             // ran out of bits with sequences left (:209-211)
       } else if (act) {
 #pragma unroll
-        for (int k = 0; k < ZG_SEQ_CH; k++) zg_seq_step<false>(c, tab, xtab, store4, out_base, rbits, act, left, cnt);
+        for (int k = 0; k < ZG_SEQ_CH; k++) zg_seq_step<false, PK>(c, tab, xtab, store4, out_base, rbits, act, left, cnt);
       }
       P = c.pr - rbits;
       const bool more = __any(act);
@@ -1659,8 +1668,11 @@ void zg_launch_huf(const ZgBatchDev& d, hipStream_t s) {
   hipLaunchKernelGGL(zg_k_huf, dim3(d.nhuf_groups), dim3(ZG_HUF_T), 0, s, d);
   hipLaunchKernelGGL(zg_k_huf_uneven, dim3(d.nblocks), dim3(64), 0, s, d);
 }
-void zg_launch_seq(const ZgBatchDev& d, hipStream_t s) {
-  if (d.nseq_blocks) hipLaunchKernelGGL(zg_k_seq, dim3((d.nseq_blocks + ZG_SEQ_G - 1) / ZG_SEQ_G), dim3(128), 0, s, d);
+// packed: the 16-bit-entry form (three workgroups per CU): for submits with more blocks than the device holds chains at once
+void zg_launch_seq(const ZgBatchDev& d, hipStream_t s, bool packed) {
+  if (!d.nseq_blocks) return;
+  if (packed) hipLaunchKernelGGL(zg_k_seq<true>, dim3((d.nseq_blocks + ZG_SEQ_G - 1) / ZG_SEQ_G), dim3(128), 0, s, d);
+  else hipLaunchKernelGGL(zg_k_seq<false>, dim3((d.nseq_blocks + ZG_SEQ_G - 1) / ZG_SEQ_G), dim3(128), 0, s, d);
 }
 // The literals chain (Huffman tree descriptions, zg_k_huf) ran beside the sequences chain on a second stream: fold its
 // errors into the block status. The literals section is decoded first (block_decoder.rs:131-150), so its errors —
