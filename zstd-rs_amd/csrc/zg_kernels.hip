@@ -1389,7 +1389,7 @@ __global__ void __launch_bounds__(256) zg_k_swprep(ZgBatchDev d, uint32_t n) {
 // OGM (timing experiments only, ZGPU_SWEEP_MODE 5..8: wrong results): how many bytes of scratch a group reads — 5: 8, 6: 4, 8: 12,
 // 7: 8 and then 8 more at an address that depends on the first (what a directory + entries format would cost a step)
 template <int OGM>
-__global__ void __launch_bounds__(ZG_SW_T) __attribute__((amdgpu_waves_per_eu(2, 3))) zg_k_sweep(ZgBatchDev d, uint32_t list_off, uint32_t nbatch, uint32_t dbgmode, uint32_t part) {
+__device__ __forceinline__ void zg_sweep_body(const ZgBatchDev& d, uint32_t list_off, uint32_t nbatch, uint32_t dbgmode, uint32_t part) {
   if (d.overlap_epoch) {
     // the flatten may still be at this unit (it runs beside the chain): one lane polls the unit's flag. A step that finds it set
     // — the usual case: units finish in frame order, ahead of the chain — reads data that was released before this launch began;
@@ -1493,6 +1493,14 @@ __global__ void __launch_bounds__(ZG_SW_T) __attribute__((amdgpu_waves_per_eu(2,
     if (e) out[x] = out[(int64_t)x - (int64_t)e];
   }
 }
+// the steps of a chain, and the heads beside them: at most three waves per SIMD (a step is a short launch that should find free slots, and
+// the heads must not fill the CUs)
+template <int OGM>
+__global__ void __launch_bounds__(ZG_SW_T) __attribute__((amdgpu_waves_per_eu(2, 3))) zg_k_sweep(ZgBatchDev d, uint32_t list_off, uint32_t nbatch, uint32_t dbgmode, uint32_t part) {
+  zg_sweep_body<OGM>(d, list_off, nbatch, dbgmode, part);
+}
+// (round 5, measured on 64 x 64 MiB frames whose sweep is ONE step of 64 units: eight waves per SIMD instead of three change nothing,
+//  10.18 ms either way; four batches per workgroup, software-pipelined, do: 8.95 ms — zg_launch_sweep)
 
 // after the last sweep step: an execution error found by zg_k_flatten becomes the frame's status
 __global__ void __launch_bounds__(256) zg_k_fin(ZgBatchDev d) {
@@ -1810,7 +1818,9 @@ bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* step
   uint32_t dbgmode = tn.mode;                                 // timing experiments only (ZGPU_SWEEP_MODE)
   void (*kern)(ZgBatchDev, uint32_t, uint32_t, uint32_t, uint32_t) = zg_k_sweep<0>;
   if (dbgmode >= 5u) { kern = dbgmode == 5u ? zg_k_sweep<5> : dbgmode == 6u ? zg_k_sweep<6> : dbgmode == 7u ? zg_k_sweep<7> : zg_k_sweep<8>; dbgmode = 0u; }
-  const uint32_t nbatch = tn.nbatch ? tn.nbatch : 1u;          // batches per workgroup (more than one did not pay)
+  // batches per workgroup, software-pipelined (the scratch words of batch i + 1 are requested behind the gathers of batch i): in a chain of
+  // steps more than one did not pay (a step is over when its slowest workgroup is); a sweep that is ONE large launch gains 12 % with four
+  const uint32_t nbatch = tn.nbatch ? tn.nbatch : (nsteps == 1 ? 4u : 1u);
   constexpr uint32_t BB = 4u * ZG_SW_T * ZG_SW_B;             // bytes per batch
   uint32_t n = 0;
   bool contiguous = true;
