@@ -104,6 +104,7 @@ Tuning Tuning::from_env() {
   num("ZGPU_SWEEP_NB", &t.sweep.nbatch, true);
   num("ZGPU_SWEEP_GROUP", &t.sweep.group, true);
   num("ZGPU_SWEEP_HEAD_LDS", &t.sweep.head_lds, false);
+  num("ZGPU_SWEEP_HEAD_NB", &t.sweep.head_nbatch, true);
   return t;
 }
 

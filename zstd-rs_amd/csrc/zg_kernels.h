@@ -19,7 +19,7 @@ struct ZgSweepStep { uint32_t list_off, nunits, slices, pad; };
 // measurement switches of the sweep (tools/dev/README.md): read from the environment ONCE, when an engine is created (zg::Tuning) —
 // mode: ZGPU_SWEEP_MODE (timing experiments: wrong results), nbatch: batches per workgroup, group: steps whose heads share a launch,
 // head_lds: unused LDS a head workgroup asks for (keeps the heads to a few workgroups per CU)
-struct ZgSweepTuning { uint32_t mode = 0, nbatch = 0, group = 16, head_lds = 52u * 1024u; };   // nbatch 0: chosen by zg_launch_sweep
+struct ZgSweepTuning { uint32_t mode = 0, nbatch = 0, group = 16, head_lds = 52u * 1024u, head_nbatch = 0; };   // nbatch 0: chosen by zg_launch_sweep
 
 void zg_launch_tables(const ZgBatchDev& d, hipStream_t s, int part);   // part 0: Huffman trees, part 1: FSE tables
 void zg_launch_huf(const ZgBatchDev& d, hipStream_t s);

@@ -1849,7 +1849,8 @@ bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* step
       e++;
       // (the heads are bulk work beside a chain of short launches: an unused LDS allocation keeps them to a few workgroups per
       //  CU, so that a tail step always finds free wave slots instead of waiting for head workgroups to retire)
-      hipLaunchKernelGGL(kern, dim3((slices + nbatch - 1) / nbatch, units), dim3(ZG_SW_T), head_lds, s2, d, steps[g0].list_off, nbatch, dbgmode, 2u);
+      const uint32_t hnb = tn.head_nbatch ? tn.head_nbatch : 1u;
+      hipLaunchKernelGGL(kern, dim3((slices + hnb - 1) / hnb, units), dim3(ZG_SW_T), head_lds, s2, d, steps[g0].list_off, hnb, dbgmode, 2u);
       g0 = g1;
     };
     auto need = [&]() { return (int64_t)(g0 + gs < nsteps ? g0 + gs : nsteps) - 2; };   // the last tail step the next group of heads waits for
