@@ -1,16 +1,16 @@
 #!/bin/bash
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/c14
-mkdir -p $OUT; cd $ROOT; export TMPDIR=/tmp
-( time timeout 900 python -m pytest tests -x -q -m gpu ) > $OUT/tests.log 2>&1
-tail -4 $OUT/tests.log
-( time timeout 1500 python bench.py ) > $OUT/bench.log 2> $OUT/bench.err
-tail -c 600 $OUT/bench.err
+cd $ROOT
+( time bash tools/dev/profile.sh blocks4b ) > gpurun_out/profile_4b.log 2>&1
+tail -5 gpurun_out/profile_4b.log | cut -c1-300
 python - <<'PY'
-import json
-l=[x for x in open("gpurun_out/c14/bench.log") if x.startswith('{"metric"')]
-d=json.loads(l[-1])
-print("headline", d["value"], d["kernel_ms"], d["roofline"]["frac"])
-print("e2e", d.get("e2e_GBps"), "cpu", {k:v for k,v in d.get("cpu_baseline",{}).items() if "GBps" in k or k in ("value","all_cores")})
-for w,o in d.get("other_workloads",{}).items(): print(w, o["GBps"], o["kernel_ms"], o["host_prepare_s"])
+import csv, collections, glob
+for k in (1,2,3):
+    f = "gpurun_out/prof/blocks4b_sq%d.csv" % k
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"]][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(r["Kernel_Name"], r["Counter_Name"])] += 1
+    for kn in acc:
+        if "flatten" in kn or "seqpost" in kn or kn.startswith("zg_k_seq") or "huf" in kn:
+            print(k, kn[:40], {c: int(v / cnt[(kn, c)]) for c, v in acc[kn].items()})
 PY
