@@ -67,10 +67,11 @@ enum zgpu_status {
    *  - offsets >= 2^30 (offset codes 30, 31) while >= 1 GiB of the frame is held undrained (FrameDecoder::decode_blocks(All) on a
    *    frame beyond 1 GiB that nobody reads from): ZGPU_E_UNSUPPORTED. With less than 1 GiB held — always the case in decode_all
    *    and the streaming decoder — such an offset fails in the reference too, and with the same error here;
-   *  - a block that regenerates >= 2^31 bytes: ZGPU_E_UNSUPPORTED;
-   *  - a match that starts in the dictionary and continues BEHIND bytes the caller has drained (needs a dictionary, a
-   *    total_output_counter kept small by raw / RLE blocks, and an offset beyond the window): ZGPU_E_UNSUPPORTED — the reference
-   *    splices the dictionary's tail with the oldest byte it still holds (decode_buffer.rs:159-163).
+   *  - a block that regenerates >= 2^31 bytes: ZGPU_E_UNSUPPORTED.
+   * (Rounds 2-4 listed a third case here: a match that starts in the dictionary and continues BEHIND bytes the caller has drained — the
+   *  reference splices the dictionary's tail with the oldest byte it still holds, decode_buffer.rs:159-163. Since round 5 the device
+   *  window of a frame with a dictionary is laid out like the reference's buffer, [dictionary content][undrained bytes], and the match
+   *  yields the reference's bytes.)
    * Blocks regenerating more than 128 KiB (beyond Block_Maximum_Size) are decoded, by the in-order kernel, and fail with the
    * reference's own error leaf (the exact buffer bookkeeping of zg_exact.h covers them since round 4). */
   ZGPU_E_UNSUPPORTED = 80,

@@ -166,3 +166,40 @@ def test_many_sequences_per_block_with_dictionary(ctx):
         seen.add(st)
     assert seen == {0, 52, 53}, seen
     d.close()
+
+
+def test_dictionary_spliced_behind_drained_bytes(ctx):
+    """a dictionary, three raw blocks (not counted: total_output_counter stays below the window), a collect() that drains down to the
+    window, then a match that starts in front of what is left: the reference copies the dictionary's tail and goes on with the OLDEST byte
+    it still holds (decode_buffer.rs:159-163) — not with the drained byte that once stood in front of it. Bytes and verdicts as the oracle's,
+    through the FrameDecoder mirror; the same frame without the drain takes the drained byte (both are checked)."""
+    import zgpu
+    raw = read_pack("dict_tests.pack")["dictionary"]
+    d = zgpu.FrameDecoder(ctx)
+    did = d.add_dict(raw)
+    seen = set()
+    for off_extra in (1, 2, 3, 4, 50, 40000, 200000):
+        for drain in (True, False):
+            for tail_blocks in ([seq_block(K + off_extra, last=True)],
+                                [seq_block(K + off_extra), raw_block(1000, 9), seq_block(K + 7 + 1000 + off_extra, last=True)]):
+                z = frame(*([raw_block(K, 1), raw_block(K, 2), raw_block(K, 3)] + tail_blocks))
+                o = oracle.FrameDecoder()
+                assert o.add_dict(raw) == did
+                st, c, _, _ = d.reset(z)
+                ost, oc, _, _ = o.init(z)
+                assert (st, c) == (ost, oc) and d.force_dict(did) == o.force_dict(did) == 0
+                got, want = b"", b""
+                used = oused = 0
+                if drain:
+                    st, used, fin = d.decode_blocks(z[c:], zgpu.STRAT_UPTO_BLOCKS, 3)
+                    ost, oused, ofin = o.decode_blocks(z[c:], oracle.STRAT_UPTO_BLOCKS, 3)
+                    assert (st, used, fin) == (ost, oused, ofin)
+                    got, want = d.collect(), o.collect()
+                    assert got == want and len(got) == 2 * K
+                st, u2, fin = d.decode_blocks(z[c + used:], zgpu.STRAT_ALL)
+                ost, ou2, ofin = o.decode_blocks(z[c + oused:], oracle.STRAT_ALL)
+                assert (st, fin) == (ost, ofin), (off_extra, drain, st, ost)
+                seen.add(ost)
+                assert d.collect() == o.collect(), (off_extra, drain)
+    assert 0 in seen and 53 in seen
+    d.close()

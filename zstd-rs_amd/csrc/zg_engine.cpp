@@ -258,10 +258,28 @@ void FrameState::reset() {
   base = 0; have = 0; produced = 0; counted = 0; hist[0] = 1; hist[1] = 4; hist[2] = 8;
   logs[0] = logs[1] = logs[2] = logs[3] = 0; huf_maxbits = 0; carry_mask = 0; window_size = 0;
 }
-void FrameState::release() { d_out.release(); d_fse.release(); d_huf.release(); }
+void FrameState::release() { d_out.release(); d_fse.release(); d_huf.release(); d_tmp.release(); }
 
 int FrameState::make_room(uint64_t extra, uint64_t keep, hipStream_t s) {
   if (keep > have) keep = have;
+  // With a dictionary in front, the window is kept the way the reference keeps it: DecodeBuffer holds the undrained bytes and nothing older,
+  // and a match that starts in front of them is served from the dictionary's tail and then from the OLDEST undrained byte
+  // (repeat_from_dict, decode_buffer.rs:144-179) — bytes that have been drained are not in between. So they are not in between here either:
+  // [dictionary content][undrained bytes], and every kernel's copy "offset bytes back" lands where the reference's does. (Only such a
+  // non-conforming match can tell the difference; a conforming one stays inside the window, which is never drained.)
+  if (base && keep < have && d_out.p) {
+    uint8_t* dst = out_ptr() + base;
+    const uint8_t* src = dst + (have - keep);
+    hipError_t e = hipSuccess;
+    if (keep && have - keep >= keep) e = hipMemcpyAsync(dst, src, keep, hipMemcpyDeviceToDevice, s);   // the ranges do not overlap
+    else if (keep) {
+      if (d_tmp.reserve(keep)) return ZG_NOMEM;
+      e = hipMemcpyAsync(d_tmp.p, src, keep, hipMemcpyDeviceToDevice, s);
+      if (e == hipSuccess) e = hipMemcpyAsync(dst, d_tmp.p, keep, hipMemcpyDeviceToDevice, s);
+    }
+    if (e != hipSuccess) return ZG_HIP_ERROR;
+    have = keep;
+  }
   const uint64_t need = kOutFront + base + have + extra + 64;
   if (d_out.p && need <= d_out.cap) return 0;
   // rebuild: [dictionary][the last `keep` frame bytes] move to a new buffer with room to grow; what the caller has drained

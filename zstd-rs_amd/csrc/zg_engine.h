@@ -48,6 +48,7 @@ struct FrameState {
   uint64_t counted = 0;          // DecodeBuffer::total_output_counter so far (decode_buffer.rs:16): decides between the two "offset too far" errors
   DevBuf d_fse;                  // carried FSE tables, one arena slot (ZG_FSE_SLOT_U32 packed entries)
   DevBuf d_huf;                  // carried Huffman table (ZG_HUF_SLOT_U16 entries)
+  DevBuf d_tmp;                  // make_room: staging for the undrained bytes when they are moved down over themselves
   uint8_t logs[4] = {0, 0, 0, 0};// accuracy logs LL, OF, ML of the carried FSE tables
   uint8_t huf_maxbits = 0;
   uint32_t carry_mask = 0;       // bit 0 Huffman, 1 LL, 2 OF, 3 ML: which tables exist

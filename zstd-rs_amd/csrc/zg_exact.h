@@ -50,7 +50,6 @@ ZX_DEV void zg_exact_frame(const ZgBatchDev& d, const uint32_t f, const uint32_t
   uint64_t buf = fr.prior_reach;         // DecodeBuffer::len(): undrained bytes
   uint64_t cnt = fr.prior_counted;       // total_output_counter
   uint64_t round0 = buf;                 // decode_blocks' buffer_size_before (frame_decoder.rs:321-323)
-  uint64_t produced = 0;                 // bytes of this submit in front of the block
   for (uint32_t i = 0; i < nwalk; i++) {
     const uint32_t b = fr.first_block + i;
     const ZgBlock blk = d.blocks[b];
@@ -107,8 +106,10 @@ ZX_DEV void zg_exact_frame(const ZgBatchDev& d, const uint32_t f, const uint32_t
           uint32_t st = 0;
           if (c > fr.window_size) st = ZG_EXE_OFFSET_TOO_BIG;                       // :173-178
           else if (need > fr.dict_len) st = ZG_EXE_DICT_TOO_SMALL;                  // :152-157
-          else if (at < fr.prior_out + produced + m0) st = ZG_UNSUPPORTED;          // the reference would splice dictionary bytes behind drained ones: not modelled (needs a dictionary,
-                                                                                    // a counter that raw / RLE blocks kept small, and an offset beyond the window)
+          // (at < prior_out + produced + m0 — bytes of the frame have been drained, and the match starts in front of what is left: the
+          //  reference then splices the dictionary's tail with the OLDEST byte it still holds, decode_buffer.rs:159-163. Since round 5 the
+          //  engine's window is laid out exactly like that when a dictionary is in front — [dictionary content][undrained bytes], the drained
+          //  ones dropped: FrameState::make_room — so the copy with the sequence's own offset yields the reference's bytes: no verdict here)
           if (st) zx_min_lds64(&L.bad, ((unsigned long long)j << 8) | st);
         }
         dict_only += all;
@@ -127,7 +128,7 @@ ZX_DEV void zg_exact_frame(const ZgBatchDev& d, const uint32_t f, const uint32_t
         return;
       }
     }
-    buf += size; produced += size;
+    buf += size;
     if (blk.btype == ZG_BT_COMPRESSED) cnt += size - dict_only;
     if (drain_rule == ZG_DRAIN_DECODE_ALL && buf - round0 >= (1u << 20)) {   // UptoBytes(1 MiB) is reached after this block (:364-375); read() then drains
       if (buf > fr.window_size) buf = fr.window_size;                        // can_drain_to_window_size (decode_buffer.rs:182-188)

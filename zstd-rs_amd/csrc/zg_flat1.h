@@ -94,7 +94,11 @@ ZX_DEV void zg_flat1_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat1Lds<T, 
     // (once the caller has drained bytes the dictionary is out of reach: DecodeBuffer holds nothing older than what is undrained, and
     //  total_output_counter has passed window_size by then — repeat_from_dict, decode_buffer.rs:144-179, answers OffsetTooBig)
     const ZgFrame& frr = d.frames[un.frame];
-    const uint64_t reach = p.out_base + frr.prior_reach + (frr.prior_reach == frr.prior_out ? frr.dict_len : 0ull);
+    // (round 5: with a dictionary in front the device window is [dictionary content][undrained bytes] whatever has been drained — the
+    //  reference's DecodeBuffer + dict_content, FrameState::make_room —, so the dictionary is in reach of the copy as long as the reference
+    //  would serve it; whether it still WOULD, total_output_counter <= window_size, is zg_k_exact's verdict: it runs for every frame with a
+    //  dictionary)
+    const uint64_t reach = p.out_base + frr.prior_reach + frr.dict_len;
     const bool reach_all = reach >= 0x80000000ull;
     const uint32_t reach32 = (uint32_t)reach;
     if (no_scratch) {
