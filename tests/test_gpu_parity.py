@@ -146,6 +146,40 @@ def test_kernel_intermediates_match_oracle(ctx, name):
     b.close()
 
 
+def test_packed_sequence_tables(monkeypatch):
+    """zg_k_seq's packed form (16-bit table entries, three workgroups per CU: what a submit of more blocks than one round holds gets,
+    round 5) forced onto small inputs: every sequence of corpus frames against the oracle's, and the verdicts of corrupted sequence
+    sections (the careful form of the step, a stream that runs out of bits, bits left over) like the unpacked form's"""
+    import random
+    import zgpu
+    monkeypatch.setenv("ZGPU_SEQ_PACKED", "1")
+    c = zgpu.Context(0)
+    pack = read_pack("decodecorpus.pack")
+    for name in ("z000000.zst", "z000033.zst", "z000059.zst", "z000088.zst", "z000012.zst"):
+        test_kernel_intermediates_match_oracle(c, name)
+    monkeypatch.setenv("ZGPU_SEQ_PACKED", "0")
+    c0 = zgpu.Context(0)
+    rng = random.Random(55)
+    nerr = 0
+    for name in ("z000033.zst", "z000059.zst", "z000047.zst"):
+        base = pack[name]
+        for it in range(40):
+            m = bytearray(base)
+            i = rng.randrange(12, len(m)); m[i] ^= 1 << rng.randrange(8)
+            m = bytes(m)
+            ost, oout = oracle.FrameDecoder().decode_all(m, 1 << 24)
+            res = []
+            for cx in (c, c0):
+                try:
+                    res.append((0, cx.decode_all(m, 1 << 24)))
+                except zgpu.ZgpuError as e:
+                    res.append((e.status, None))
+            assert res[0] == res[1] and res[0][0] == ost and (ost or res[0][1] == oout), (name, it, ost, res[0][0], res[1][0])
+            nerr += 1 if ost else 0
+    assert nerr > 30
+    c.close(); c0.close()
+
+
 def test_synthetic_fixtures(ctx):
     """real libzstd streams (committed fixtures): text L1/L3/L19, iso-like, mixed"""
     pack, man = read_pack("synthetic.pack"), read_manifest("synthetic.json")

@@ -90,11 +90,16 @@ def test_640_multi_block_frames(ctx):
     os.environ["ZGPU_UNIT_BLOCKS"] = "2"       # 3 units (sweep steps) per frame
     try:
         import zgpu
-        c = zgpu.Context(0)
-        _check_batch(c, zs, plains, oracle_on=(7,))
-        c.close()
+        # the direct units (every frame's first) by the kernel of the pointer-mode units, and — what a submit of thousands of frames gets by
+        # itself — by zg_k_flatten4 on the second stream BESIDE the pointer-mode units' kernel, in its small and its large shape
+        for flat4 in ("0", "6", "1"):
+            os.environ["ZGPU_FLAT4"] = flat4
+            c = zgpu.Context(0)
+            _check_batch(c, zs, plains, oracle_on=(7,) if flat4 == "0" else ())
+            c.close()
     finally:
         del os.environ["ZGPU_UNIT_BLOCKS"]
+        os.environ.pop("ZGPU_FLAT4", None)
 
 
 def test_iso_like_256mib_frame(ctx):
