@@ -333,6 +333,15 @@ int zgemu_block(void* h, uint32_t b, uint32_t* info /*[12]*/) {
   info[11] = e->pos[b].active;
   return 0;
 }
+// the sequence bitstream of a block (after the table descriptions): pointer into the harness's copy of the input + its length
+// (tools/dev/seq_sync.py: can a second decoder started mid-stream fall onto the true chain?)
+const uint8_t* zgemu_block_seq_bits(void* h, uint32_t b, uint32_t* len) {
+  EmuBatch* e = (EmuBatch*)h;
+  const ZgBlock& k = e->bb.blocks[b];
+  const uint32_t off = e->aux[b].seq_bits_off;
+  *len = off <= k.src_len ? k.src_len - off : 0u;
+  return e->src + k.src_off + off;
+}
 const uint8_t* zgemu_block_literals(void* h, uint32_t b) { EmuBatch* e = (EmuBatch*)h; return e->lit.data() + e->bb.blocks[b].lit_base; }
 const EmuSeq* zgemu_block_sequences(void* h, uint32_t b) { EmuBatch* e = (EmuBatch*)h; return e->seq.data() + e->bb.blocks[b].seq_base; }
 void zgemu_block_hist(void* h, uint32_t b, uint32_t* out3) { EmuBatch* e = (EmuBatch*)h; memcpy(out3, e->pos[b].hist_init, 12); }
