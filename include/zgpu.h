@@ -153,6 +153,8 @@ typedef struct {
  * *out is valid unless the status is ZGPU_E_NOMEM / ZGPU_E_HIP. */
 int zgpu_batch_prepare(zgpu_ctx*, const uint8_t* src, size_t len, zgpu_batch** out);
 int zgpu_batch_run(zgpu_batch*);                                     /* enqueue the kernels (async on the ctx stream) */
+/* (*total_out = the bytes of all frames as the block walk sized them: a frame that FAILED keeps its place — its out_size in
+ * zgpu_batch_frame_info ends with its last good block, the frames behind it stay where they are, total_out is not shrunk.) */
 int zgpu_batch_sync(zgpu_batch*, uint64_t* total_out, uint32_t* first_bad_frame /* UINT32_MAX if none */, uint32_t* its_status);
 uint32_t zgpu_batch_num_frames(const zgpu_batch*);
 uint32_t zgpu_batch_num_blocks(const zgpu_batch*);
