@@ -221,3 +221,36 @@ def test_device_output_view(ctx):
     ptr, n = f.device_output()
     assert ptr and n == read_manifest("synthetic.json")["text_1m_l3.zst"]["size"]
     f.close()
+
+
+def test_dictionary_spliced_behind_drained_bytes(ctx):
+    """the thin boundary's side of tests/test_gpu_exact.py::test_dictionary_spliced_behind_drained_bytes: the caller reads (drains) what three
+    raw blocks produced down to the window, then submits a block whose match starts in front of what is left — the dictionary's tail, then
+    the oldest byte still held (decode_buffer.rs:159-163). Same bytes as the oracle's FrameDecoder driven the same way."""
+    import zgpu
+    from test_exact_cpu import K, frame, raw_block, seq_block
+    raw = read_pack("dict_tests.pack")["dictionary"]
+    did = ctx.add_dict(raw)
+    for off_extra in (1, 2, 3, 50):
+        z = frame(raw_block(K, 1), raw_block(K, 2), raw_block(K, 3), seq_block(K + off_extra, last=True))
+        o = oracle.FrameDecoder()
+        assert o.add_dict(raw) == did
+        st, c, _, _ = o.init(z)
+        assert st == 0 and o.force_dict(did) == 0
+        st, used, fin = o.decode_blocks(z[c:], oracle.STRAT_UPTO_BLOCKS, 3)
+        want = o.collect()
+        st, _, fin = o.decode_blocks(z[c + used:], oracle.STRAT_ALL)
+        assert st == 0 and fin
+        want += o.collect()
+        hl, window, fcs, _, _ = parse_frame_header(z)
+        blocks, end = walk_blocks(z, hl)
+        f = zgpu.BlockFrame(ctx, window, fcs, did)
+        f.submit(z, blocks[:3])
+        assert f.sync() == (None, 0)
+        got = f.read(f.available(False), False)
+        assert len(got) == 2 * K                      # drained down to the window
+        f.submit(z, blocks[3:])
+        assert f.sync() == (None, 0)
+        got += f.read(f.available(True), True)
+        f.close()
+        assert got == want, off_extra

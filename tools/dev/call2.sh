@@ -1,6 +1,6 @@
 #!/bin/bash
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/c17
+OUT=$ROOT/gpurun_out/c19
 mkdir -p $OUT; cd $ROOT; export TMPDIR=/tmp
-( time timeout 900 python -m pytest tests -x -q -m gpu -k "packed_sequence or 640_multi" ) > $OUT/tests.log 2>&1
-tail -15 $OUT/tests.log
+( timeout 900 python -m pytest tests/test_gpu_thin_boundary.py -x -q -m gpu ) > $OUT/tests.log 2>&1
+tail -12 $OUT/tests.log
