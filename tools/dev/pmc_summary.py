@@ -100,11 +100,13 @@ def main():
         sq = {}
         for f in sorted(glob.glob(os.path.join(P, w + "_sq*.csv"))):
             for r in csv.DictReader(open(f)):
-                e = sq.setdefault(r["Kernel_Name"], {}).setdefault(r["Counter_Name"], [0.0, 0])
-                e[0] += float(r["Counter_Value"]); e[1] += 1
+                if not kname(r["Kernel_Name"]).startswith("zg_k_"):
+                    continue
+                e = sq.setdefault(kname(r["Kernel_Name"]), {}).setdefault(r["Counter_Name"], [0, 0])
+                e[0] += int(float(r["Counter_Value"])); e[1] += 1
         if sq:
             json.dump({"kernels_sha256": sha, "workload": w, "note": "rocprofv3 --pmc SQ_* passes of bench.py --workload %s --steps 1 --warmup 1 (three passes of counters): "
-                       "[sum over the run's launches, launches]" % w, "counters": sq}, open(os.path.join(OUT, w + "_sq_summary.json"), "w"), indent=0)
+                       "[sum over the run's launches, launches]" % w, "counters": sq}, open(os.path.join(OUT, w + "_sq_summary.json"), "w"))
         lines = [l for l in open(os.path.join(P, w, "stats.log")) if l.startswith('{"metric"')]
         if not lines:
             print("no bench line for", w)
