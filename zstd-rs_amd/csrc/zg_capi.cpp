@@ -641,7 +641,7 @@ int zgpu_decoder_checksum_from_data(const zgpu_decoder* d, uint32_t* out) {
 uint32_t zgpu_decoder_calculated_checksum(const zgpu_decoder* d) { return (uint32_t)d->hash.digest(); }
 // device memory the frame holds right now: window (dictionary + undrained and recent bytes) + carried tables. Stays bounded by
 // the window size however long the frame is (FrameState::make_room).
-uint64_t zgpu_decoder_device_bytes(const zgpu_decoder* d) { return d ? (uint64_t)(d->fs.d_out.cap + d->fs.d_fse.cap + d->fs.d_huf.cap) : 0; }
+uint64_t zgpu_decoder_device_bytes(const zgpu_decoder* d) { return d ? (uint64_t)(d->fs.d_out.cap + d->fs.d_fse.cap + d->fs.d_huf.cap + d->fs.d_tmp.cap) : 0; }
 
 }  // extern "C"
 
