@@ -1,5 +1,6 @@
 // zg_host_parse.cpp — see zg_host_parse.h.
 #include "zg_host_parse.h"
+#include <math.h>
 #include <string.h>
 
 namespace zg {
@@ -245,6 +246,23 @@ void BatchBuilder::finish() {
   if (ub == 0) {
     const uint32_t slots = flat_slots ? flat_slots : 1;
     ub = (nb + slots - 1) / slots;
+    // (round 5) ... but no larger than the submit needs. The flatten lasts as long as its largest unit (~137 us per block of text), the sweep
+    // as many steps as the longest frame has units (~10 us each): units of sqrt(0.0745 x blocks of the longest frame) blocks balance the two,
+    // and only the blocks that HAVE sequences (in frames that are swept at all) need a workgroup. Twelve Silesia-sized frames, a third of
+    // them literal-heavy: 1617 blocks / 256 = 7 blocks per unit left half of the CUs without a unit; 5 (the balance for its 316-block
+    // text frame, and still one round of workgroups for its 935 blocks with sequences): flatten 0.97 -> 0.65 ms, 64 -> 70 GB/s. One long
+    // frame (7630 blocks -> 30) and submits of many frames (-> 256) are bound by the workgroups the device holds, as before.
+    uint64_t nbs_all = 0, nbs_longest = 0;
+    for (const ZgFrame& fr : frames) {
+      uint64_t nsq = 0, nbs = 0;
+      for (uint32_t i = 0; i < fr.nblocks; i++) { const ZgBlock& bk = blocks[fr.first_block + i]; if (bk.btype == ZG_BT_COMPRESSED && bk.nseq) { nbs++; nsq += bk.nseq; } }
+      if (sparse_max && nsq <= sparse_max && (uint64_t)fr.nblocks * sparse_per_block >= nsq) continue;   // (zg_k_sparse finishes it: no units to speak of)
+      nbs_all += nbs;
+      if (nbs > nbs_longest) nbs_longest = nbs;
+    }
+    const uint32_t bal = (uint32_t)(sqrt(0.0745 * (double)nbs_longest) + 0.5);
+    const uint32_t need = (uint32_t)((nbs_all + slots - 1) / slots);
+    if (bal < ub) ub = bal > need ? bal : (need < ub ? need : ub);
     if (ub < 4) ub = 4;
     if (ub > 256) ub = 256;   // unit-relative positions stay far below 2^30
   }
@@ -277,7 +295,9 @@ void BatchBuilder::finish() {
     // measured in round 4: 1.55 against 1.19 MB/ms per workgroup), and the units of a submit are flattened side by side — so the
     // first unit gets ~1.3 shares of the frame's blocks and the others one each: they finish together, and less of the frame goes
     // through the scratch and the sweep.
-    const bool direct_frame = unit_blocks == 0 && !ramp && direct_units && !fr.fixed_base && !fr.sparse && nun >= 2 && nun <= direct_max_units;
+    // (round 5: only where units are large — with units of a few blocks the share rounds to 1.4 - 1.5 and the direct unit becomes the longest
+    //  of the submit: twelve Silesia-sized frames in units of 5 blocks, flatten 0.82 ms with the share, 0.65 ms without)
+    const bool direct_frame = unit_blocks == 0 && !ramp && direct_units && !fr.fixed_base && !fr.sparse && nun >= 2 && nun <= direct_max_units && ubf >= 16;
     uint32_t first_take = 0, rest_take = 0;
     if (direct_frame) {
       first_take = (uint32_t)(((uint64_t)fr.nblocks * direct_share10 + (10ull * (nun - 1) + direct_share10) - 1) / (10ull * (nun - 1) + direct_share10));
