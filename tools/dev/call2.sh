@@ -1,5 +1,5 @@
 #!/bin/bash
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-cd $ROOT
-bash tools/dev/profile.sh silesia12 > gpurun_out/profile_silesia.log 2>&1
-tail -3 gpurun_out/profile_silesia.log | cut -c1-300
+cd $ROOT; mkdir -p gpurun_out/c24
+( time timeout 1500 python bench.py ) > gpurun_out/c24/bench.log 2> gpurun_out/c24/bench.err
+tail -3 gpurun_out/c24/bench.err
