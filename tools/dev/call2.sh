@@ -1,5 +1,6 @@
 #!/bin/bash
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-cd $ROOT; mkdir -p gpurun_out/c24
-( time timeout 1500 python bench.py ) > gpurun_out/c24/bench.log 2> gpurun_out/c24/bench.err
-tail -3 gpurun_out/c24/bench.err
+OUT=$ROOT/gpurun_out/c25
+mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+timeout 600 python $ROOT/tools/dev/variants.py 1000000000 text -- "" ZGPU_SWEEP_HEAD_LDS=81920 ZGPU_SWEEP_HEAD_LDS=110000 ZGPU_SWEEP_HEAD_LDS=30000 ZGPU_SWEEP_HEAD_LDS=81920,ZGPU_SWEEP_GROUP=32 ZGPU_SWEEP_HEAD_LDS=81920,ZGPU_SWEEP_GROUP=8 > $OUT/text.log 2>&1
+cat $OUT/text.log | cut -c1-330
