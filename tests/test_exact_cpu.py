@@ -284,3 +284,24 @@ def test_dictionary_spliced_behind_drained_bytes():
                 assert want == (0 if off_extra <= dict_len else 53)
             else:
                 assert want == 52
+
+
+def test_dictionary_splice_behind_a_drain_inside_one_submit_is_refused():
+    """decode_all on a frame with a dictionary is ONE submit, and the drain rule (rounds of 1 MiB, frame_decoder.rs:560-563) then
+    drops bytes INSIDE it which the device keeps in place. A match that starts in the dictionary (counter kept small by raw blocks) and
+    continues behind such a drain would copy the drained bytes instead of the dictionary's tail + the oldest held byte: the kernel must
+    say ZG_UNSUPPORTED (80) there, never 0. Without a drain inside the submit the splice is served (status 0), as before."""
+    raw = read_pack("dict_tests.pack")["dictionary"]
+    dict_len = len(raw)      # an upper bound is enough here: the offsets below need only a few dictionary bytes
+    for nraw, held, want in ((9, 2 * K, 80), (3, 3 * K, 0)):      # 9 raw blocks: drained to the window after the eighth, one more on top
+        z = frame(*([raw_block(K, i) for i in range(nraw)] + [seq_block(held + 4 + 10, last=True)]))   # starts ten bytes inside the dictionary
+        e = emu.EmuBatch(z)
+        assert e.parse_status == 0
+        got = e.exact(drain_rule=1, dict_len=dict_len)[0][0]
+        if want == 0:
+            # three raw blocks: nothing drained yet (384 KiB < 1 MiB): dictionary tail + the frame's first bytes, all where the device has them
+            assert got == 0
+        else:
+            assert got == 80, got
+        # decode_blocks(All): no drain inside the run, every byte in reach
+        assert e.exact(drain_rule=0, dict_len=dict_len)[0][0] == 0

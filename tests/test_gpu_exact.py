@@ -203,3 +203,28 @@ def test_dictionary_spliced_behind_drained_bytes(ctx):
                 assert d.collect() == o.collect(), (off_extra, drain)
     assert 0 in seen and 53 in seen
     d.close()
+
+
+def test_dictionary_splice_behind_a_drain_inside_decode_all(ctx):
+    """decode_all on a frame that names a dictionary is ONE submit (decode_all_per_frame -> decode_blocks(All) with the drain
+    rule of decode_all). With fewer than 1 MiB in front nothing is drained inside it and the splice yields the oracle's bytes; with a
+    drain inside the submit the device still holds the drained bytes in place, and the engine must refuse (ZGPU_E_UNSUPPORTED, listed in
+    include/zgpu.h) rather than return bytes the reference would not."""
+    import zgpu
+    raw = read_pack("dict_tests.pack")["dictionary"]
+    did = ctx.add_dict(raw)
+    hdr = bytes([0x28, 0xB5, 0x2F, 0xFD, 0x03, (17 - 10) << 3]) + did.to_bytes(4, "little")
+    for nraw, held in ((3, 3 * K), (9, 2 * K)):
+        z = hdr + b"".join([raw_block(K, i) for i in range(nraw)] + [seq_block(held + 4 + 10, last=True)])
+        o = oracle.FrameDecoder()
+        assert o.add_dict(raw) == did
+        ost, oout = o.decode_all(z, 1 << 26)
+        assert ost == 0
+        try:
+            out, st = ctx.decode_all(z, 1 << 26), 0
+        except zgpu.ZgpuError as e:
+            out, st = None, e.status
+        if nraw == 3:
+            assert st == 0 and out == oout
+        else:
+            assert st == 80, st

@@ -50,6 +50,7 @@ ZX_DEV void zg_exact_frame(const ZgBatchDev& d, const uint32_t f, const uint32_t
   uint64_t buf = fr.prior_reach;         // DecodeBuffer::len(): undrained bytes
   uint64_t cnt = fr.prior_counted;       // total_output_counter
   uint64_t round0 = buf;                 // decode_blocks' buffer_size_before (frame_decoder.rs:321-323)
+  bool cut_here = false;                 // the drain rule has dropped bytes INSIDE this submit (the device still holds them in place)
   for (uint32_t i = 0; i < nwalk; i++) {
     const uint32_t b = fr.first_block + i;
     const ZgBlock blk = d.blocks[b];
@@ -109,7 +110,12 @@ ZX_DEV void zg_exact_frame(const ZgBatchDev& d, const uint32_t f, const uint32_t
           // (at < prior_out + produced + m0 — bytes of the frame have been drained, and the match starts in front of what is left: the
           //  reference then splices the dictionary's tail with the OLDEST byte it still holds, decode_buffer.rs:159-163. Since round 5 the
           //  engine's window is laid out exactly like that when a dictionary is in front — [dictionary content][undrained bytes], the drained
-          //  ones dropped: FrameState::make_room — so the copy with the sequence's own offset yields the reference's bytes: no verdict here)
+          //  ones dropped: FrameState::make_room — so the copy with the sequence's own offset yields the reference's bytes: no verdict here.
+          //  That holds for drains BETWEEN submits. A drain the rule models inside this submit — decode_all's rounds of 1 MiB — leaves the
+          //  drained bytes in place on the device, where the copy would read them instead of the dictionary's tail: the one splice the
+          //  engine cannot serve, ADVICE r5. It needs a dictionary, more than 1 MiB of uncounted raw / RLE output in ONE decode_all frame
+          //  and an offset beyond the window)
+          else if (cut_here) st = ZG_UNSUPPORTED;
           if (st) zx_min_lds64(&L.bad, ((unsigned long long)j << 8) | st);
         }
         dict_only += all;
@@ -131,7 +137,7 @@ ZX_DEV void zg_exact_frame(const ZgBatchDev& d, const uint32_t f, const uint32_t
     buf += size;
     if (blk.btype == ZG_BT_COMPRESSED) cnt += size - dict_only;
     if (drain_rule == ZG_DRAIN_DECODE_ALL && buf - round0 >= (1u << 20)) {   // UptoBytes(1 MiB) is reached after this block (:364-375); read() then drains
-      if (buf > fr.window_size) buf = fr.window_size;                        // can_drain_to_window_size (decode_buffer.rs:182-188)
+      if (buf > fr.window_size) { buf = fr.window_size; cut_here = true; }   // can_drain_to_window_size (decode_buffer.rs:182-188)
       round0 = buf;
     }
   }
