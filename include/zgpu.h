@@ -197,6 +197,11 @@ int zgpu_batch_debug_scratch(zgpu_batch*, int what, uint64_t off, void* dst, uin
 /* diagnostics: runs kernels with known traffic per access pattern (16 B/lane copy, 4 B/lane copy, random 4- and 8-byte
  * reads) to calibrate the profiler's HBM byte counters */
 int zgpu_debug_calibrate(zgpu_ctx*, uint64_t bytes);
+/* diagnostics: the measurement / test switches the context's engine took when it was created. The product library reads NO environment
+ * variable (every value is its default, out[0] = 0); libzgpu_dev.so (built with -DZG_DEV_SWITCHES, loaded by tests and tools/dev only) reads
+ * the ZGPU_* variables of tools/dev/README.md once, at zgpu_ctx_create. out[0] development build, [1] ZGPU_UNIT_BLOCKS, [2] ZGPU_SEQ_PACKED,
+ * [3] ZGPU_FLAT4, [4] ZGPU_RAMP, [5] ZGPU_SWEEP_W, [6] ZGPU_FLAT_T shape, [7] ZGPU_FORCE_INORDER. Returns how many were written. */
+int zgpu_debug_tuning(const zgpu_ctx*, uint32_t* out, int n);
 int zgpu_batch_fse_slot(zgpu_batch*, uint32_t slot, uint32_t* entries /* 1280 */, uint8_t logs[4]);
 int zgpu_batch_huf_slot(zgpu_batch*, uint32_t slot, uint16_t* entries /* 2048 */, int* max_bits);
 
@@ -228,6 +233,10 @@ uint64_t zgpu_decoder_bytes_read_from_source(const zgpu_decoder*);   /* :273 */
 uint64_t zgpu_decoder_content_size(const zgpu_decoder*);             /* :246 */
 int zgpu_decoder_checksum_from_data(const zgpu_decoder*, uint32_t* out); /* :254 — returns 1 if present */
 uint32_t zgpu_decoder_calculated_checksum(const zgpu_decoder*);      /* :263-270 XXH64 seed 0, low 32 bits */
+void zgpu_decoder_set_hash(zgpu_decoder*, int on);                    /* ruzstd's `hash` cargo feature (default on): 0 = no XXH64 of the bytes handed out */
+/* decode_blocks(UptoBytes(n)) decodes at least `bytes` per call (what UptoBytes(max(n, bytes)) gives in the reference): one submit lasts
+ * as long as one block's sequence chain whatever it holds, so small requests are served from large submits. 0 (default): exactly n. */
+void zgpu_decoder_set_read_ahead(zgpu_decoder*, uint64_t bytes);
 uint64_t zgpu_decoder_device_bytes(const zgpu_decoder*);             /* device memory the frame holds now (window + carried tables): bounded by the window, not by the frame */
 
 /* ---- the thin boundary: host-parsed block tables -----------------------------------------------------------------------
@@ -266,14 +275,51 @@ int zgpu_device_output(zgpu_frame*, const void** dptr, size_t* len);   /* the fr
 uint32_t zgpu_frame_checksum(const zgpu_frame*);         /* XXH64 (seed 0) of the bytes read so far, low 32 bits (frame_decoder.rs:263-270) */
 uint64_t zgpu_frame_blocks_decoded(const zgpu_frame*);   /* frame_decoder.rs:297 */
 
-/* ---- StreamingDecoder mirror (ruzstd/src/decoding/streaming_decoder.rs:40-156): io::Read over one frame ---------------- */
+/* ---- StreamingDecoder mirror (ruzstd/src/decoding/streaming_decoder.rs:40-156): io::Read over one frame ----------------
+ * The reference decodes lazily — read(buf) runs decode_blocks(UptoBytes(missing)) until buf.len() bytes can be collected (:134-150),
+ * one block per call for the 8 KiB reader std::io::copy is (cli/src/main.rs:142-144). A GPU submit lasts as long as one block's sequence
+ * chain whatever it holds, so this mirror READS AHEAD: it pulls whole runs of blocks from the source, decodes run k + 1 while run k
+ * travels to a pinned host ring and the reader drains run k - 1 (zg_stream.h), bounded by a budget whatever the frame's length.
+ * What io::Read shows stays the reference's:
+ *   - the same bytes; read() returns cap bytes unless the frame ends first, 0 at the end of the frame;
+ *   - an error of block b surfaces in the read() call in which the reference would have decoded b (a run decoded ahead is only taken
+ *     when no block of it failed and no sequence set an offset beyond the window — else it is dropped and the stream continues block
+ *     by block from the state the reference would be in);
+ *   - nothing behind the frame's last block (+ checksum) is taken from the source.
+ * What differs, because blocks are decoded before the reader asks: the source is consumed earlier (by whole runs), and
+ * zgpu_decoder_blocks_decoded / zgpu_decoder_bytes_read_from_source of the decoder behind the stream count what has been decoded, which
+ * runs ahead of what read() has returned. zgpu_stream_opts.read_ahead_bytes = 1 switches all of that off (the reference's schedule). */
 typedef struct zgpu_streaming zgpu_streaming;
 typedef size_t (*zgpu_read_fn)(void* user, uint8_t* dst, size_t n);   /* io::Read::read of the source: 0 = end of input */
+typedef struct {
+  uint64_t read_ahead_bytes;   /* plaintext that may be decoded ahead of the reader = size of the pinned host ring. 0: default (512 MiB, and
+                                  never less than the frame's window + 2 MiB); 1: no read-ahead at all */
+  uint32_t no_checksum;        /* 1: ruzstd built without its `hash` feature — no XXH64 of the bytes handed out (one core hashes ~10-20 GB/s:
+                                  with the checksum on, a hasher thread keeps it off the reader's path, but it bounds the stream) */
+  uint32_t copy_threads;       /* helper threads that copy reads of 4 MiB and more out of the ring. 0: default (3); 0xFFFFFFFF: none */
+  uint64_t pipe_after_bytes;   /* a frame is decoded on the caller's thread (runs of 8, 32, 128 ... blocks) until this much is decoded, or
+                                  its header declares more than this; then a worker thread takes over. 0: default (32 MiB) */
+  uint32_t first_run_blocks;   /* 0: default (8) */
+  uint32_t pad;
+} zgpu_stream_opts;
 int zgpu_streaming_create(zgpu_ctx*, zgpu_read_fn read, void* user, zgpu_streaming** out);   /* new (:51-58): reads the frame header */
+int zgpu_streaming_create_ex(zgpu_ctx*, zgpu_read_fn read, void* user, const zgpu_stream_opts* opts_or_null, zgpu_streaming** out);
+/* the source is memory (Rust: StreamingDecoder<&[u8], _>, what the reference's benches and fuzz targets use): blocks are uploaded from where
+ * they lie, nothing is copied on the host. src must stay valid until the stream is destroyed; pinned memory is DMA'd directly. */
+int zgpu_streaming_create_slice(zgpu_ctx*, const uint8_t* src, size_t len, const zgpu_stream_opts* opts_or_null, zgpu_streaming** out);
+size_t zgpu_streaming_source_position(const zgpu_streaming*);   /* slice sources: bytes of src taken so far (runs ahead of the reader) */
 void zgpu_streaming_destroy(zgpu_streaming*);
-zgpu_decoder* zgpu_streaming_decoder(zgpu_streaming*);               /* get_ref / into_frame_decoder (:66-85) */
-/* read (:119-155): whole blocks are pulled from the source as needed; *n = bytes written to dst (0 = end of frame) */
+/* get_ref (:66-85): the decoder behind the stream, for its accessors (is_finished, the checksums, the counters). While the stream owns it,
+ * do not call its decode_* / collect / read functions. */
+zgpu_decoder* zgpu_streaming_decoder(zgpu_streaming*);
+/* read (:119-155): *n = bytes written to dst (0 = end of frame) */
 int zgpu_streaming_read(zgpu_streaming*, uint8_t* dst, size_t cap, size_t* n);
+/* std::io::copy(&mut decoder, &mut writer) with a buffer of buf_size bytes (the reference's CLI: 8 KiB, cli/src/main.rs:142-144);
+ * write == NULL is io::sink(). *total = bytes copied. */
+int zgpu_streaming_copy(zgpu_streaming*, size_t buf_size, zgpu_write_fn write, void* user, uint64_t* total);
+/* diagnostics: out[0] mode now (0 runs on the caller's thread, 1 worker thread + ring, 2 block by block), [1] runs decoded ahead and
+ * taken, [2] runs decoded ahead and dropped, [3] host bytes held (buffer + ring). Returns how many were written. */
+int zgpu_streaming_stats(const zgpu_streaming*, uint64_t* out, int n);
 
 #ifdef __cplusplus
 }

@@ -153,12 +153,12 @@ def test_packed_sequence_tables(monkeypatch):
     import random
     import zgpu
     monkeypatch.setenv("ZGPU_SEQ_PACKED", "1")
-    c = zgpu.Context(0)
+    c = zgpu.Context(0, dev=True)
     pack = read_pack("decodecorpus.pack")
     for name in ("z000000.zst", "z000033.zst", "z000059.zst", "z000088.zst", "z000012.zst"):
         test_kernel_intermediates_match_oracle(c, name)
     monkeypatch.setenv("ZGPU_SEQ_PACKED", "0")
-    c0 = zgpu.Context(0)
+    c0 = zgpu.Context(0, dev=True)
     rng = random.Random(55)
     nerr = 0
     for name in ("z000033.zst", "z000059.zst", "z000047.zst"):
@@ -402,7 +402,7 @@ def test_inorder_fallback_path(monkeypatch):
     its switches once, when it is created: the context comes after the switch)"""
     import zgpu
     monkeypatch.setenv("ZGPU_FORCE_INORDER", "1")
-    ctx = zgpu.Context(0)
+    ctx = zgpu.Context(0, dev=True)
     pack, man = read_pack("decodecorpus.pack"), read_manifest("decodecorpus.json")
     for name in sorted(man)[::9]:
         assert _sha(ctx.decode_all(pack[name], man[name]["size"])) == man[name]["sha256"], name
@@ -546,7 +546,7 @@ def test_dense_sequences_cut_tiles(ctx):
         for flat_t in ("512", "1024"):
             os.environ["ZGPU_FLAT_T"] = flat_t
             try:
-                c = zgpu.Context(0)
+                c = zgpu.Context(0, dev=True)
                 out = c.decode_all(z, len(data))
                 c.close()
             finally:
@@ -567,7 +567,7 @@ def test_corpus_other_shapes(env):
     for k, v in env.items():
         os.environ[k] = v
     try:
-        c = zgpu.Context(0)
+        c = zgpu.Context(0, dev=True)
         b = c.prepare(blob)
         b.run()
         b.sync()
@@ -605,7 +605,7 @@ def test_flat_scratch_matches_model(monkeypatch):
             monkeypatch.setenv("ZGPU_UNIT_BLOCKS", ub)
         else:
             monkeypatch.delenv("ZGPU_UNIT_BLOCKS", raising=False)
-        c = zgpu.Context(0)
+        c = zgpu.Context(0, dev=True)
         for ci, z in enumerate(cases):
             b = c.prepare(z)
             b.run()
@@ -788,7 +788,7 @@ def _run_batch(z, env):
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
-        c = zgpu.Context(0)
+        c = zgpu.Context(0, dev=True)
         b = c.prepare(z)
         assert b.parse_status == 0
         b.run(); b.sync()
@@ -906,7 +906,7 @@ def test_output_sized_in_advance_and_frames_that_lie(ctx, monkeypatch):
         assert ost == 0 and oout == want, name
         assert ctx.decode_all(blob, len(want) + 16) == want, name
     monkeypatch.setenv("ZGPU_PRESIZE", "0")
-    c2 = zgpu.Context(0)
+    c2 = zgpu.Context(0, dev=True)
     for name, blob in cases.items():
         assert c2.decode_all(blob, len(want) + 16) == want, name
     c2.close()

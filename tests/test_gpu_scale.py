@@ -94,7 +94,7 @@ def test_640_multi_block_frames(ctx):
         # itself — by zg_k_flatten4 on the second stream BESIDE the pointer-mode units' kernel, in its small and its large shape
         for flat4 in ("0", "6", "1"):
             os.environ["ZGPU_FLAT4"] = flat4
-            c = zgpu.Context(0)
+            c = zgpu.Context(0, dev=True)
             _check_batch(c, zs, plains, oracle_on=(7,) if flat4 == "0" else ())
             c.close()
     finally:
@@ -139,7 +139,7 @@ def test_ramped_units_chain_beside_flatten(ctx, monkeypatch):
     import zgpu
     for ramp in ("50", "90"):
         monkeypatch.setenv("ZGPU_RAMP", ramp)    # (read when the engine is created: a context per setting)
-        c = zgpu.Context(0)
+        c = zgpu.Context(0, dev=True)
         _check_batch(c, [z], [plain])
         c.close()
     monkeypatch.delenv("ZGPU_RAMP")
@@ -291,7 +291,7 @@ def test_pool_decode_all_places_jobs_around_a_lying_content_size(ctx, monkeypatc
         assert (z[4] >> 6) == 2 and not (z[4] >> 5) & 1 and not z[4] & 3, "expected a 4-byte FCS behind a window descriptor"
         fcs = int.from_bytes(z[6:10], "little") + delta
         return z[:6] + fcs.to_bytes(4, "little") + z[10:]
-    pool = zgpu.Pool(devices=[0])
+    pool = zgpu.Pool(devices=[0], dev=True)
     for which, delta in ((0, -100000), (0, +100000), (2, -70000), (4, -5)):
         blob = b"".join(lie(z, delta) if k == which else z for k, z in enumerate(zs))
         out = pool.decode_all(blob, len(want) + (1 << 20))

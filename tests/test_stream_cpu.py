@@ -1,0 +1,350 @@
+"""The host side of the streaming decoder (zstd-rs_amd/csrc/zg_stream.h) on the CPU: source handling, runs decoded ahead on the caller's
+thread and by the worker thread, the ring, the hasher, the fall back to the reference's block-by-block schedule — against a table-driven
+stand-in for the engine (tests/emu/zg_emu_stream.cpp) and a model of what ruzstd's StreamingDecoder::read does with the same blocks
+(streaming_decoder.rs:119-155 over FrameDecoder::decode_blocks / read, frame_decoder.rs:309-377,615-627).
+
+What must hold for EVERY sequence of read sizes: the same bytes, the same return value of every read() call, an error in the same call
+(and the same error), the XXH64 of what was handed out, nothing taken from the source behind the frame's end, and nothing the stand-in
+objects to (it checks that each run it is given is exactly the next blocks' bytes and that the window stays in reach)."""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import pytest
+import xxhash
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+K = 128 << 10
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        d = os.path.join(HERE, "emu")
+        subprocess.check_call(["make", "-C", d, "-s"])
+        L = C.CDLL(os.environ.get("ZG_EMU_STREAM_LIB") or os.path.join(d, "libzg_emu_stream.so"))   # (ZG_EMU_STREAM_LIB: the ThreadSanitizer build, `make -C tests/emu tsan`)
+        L.zgemu_stream_new.restype = C.c_void_p
+        L.zgemu_stream_new.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_char_p, C.c_uint32,
+                                       C.c_uint64, C.c_int, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_uint64, C.c_int, C.c_size_t]
+        L.zgemu_stream_free.argtypes = [C.c_void_p]
+        L.zgemu_stream_read.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.zgemu_stream_checksum.argtypes = [C.c_void_p]
+        L.zgemu_stream_checksum.restype = C.c_uint32
+        L.zgemu_stream_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        _LIB = L
+    return _LIB
+
+
+E_HDR, E_BODY, E_CS, E_RESERVED = 9, 10, 11, 20
+
+
+class Frame:
+    """blocks (raw / RLE: the stand-in does not decode, sizes are all that matter) + what the table says about each"""
+
+    def __init__(self, rng, nblocks, window, has_checksum, max_block=K, small=False):
+        self.window, self.has_checksum = window, has_checksum
+        self.src, self.plain, self.out = bytearray(), bytearray(), []
+        for i in range(nblocks):
+            last = i == nblocks - 1
+            kind = rng.randrange(3)
+            n = rng.randrange(0, 2000) if small else rng.choice([max_block, max_block, rng.randrange(1, max_block + 1), rng.randrange(0, 300)])
+            if kind == 0:                                                    # RLE block
+                b = rng.randrange(256)
+                self.src += ((n << 3) | (1 << 1) | (1 if last else 0)).to_bytes(3, "little") + bytes([b])
+                self.plain += bytes([b]) * n
+            else:                                                            # raw block
+                body = rng.randbytes(min(n, 64)) * (n // 64 + 1)
+                body = body[:n]
+                self.src += ((n << 3) | (1 if last else 0)).to_bytes(3, "little") + body
+                self.plain += body
+            self.out.append(n)
+        self.nblocks = nblocks
+        self.checksum = rng.randrange(1 << 32)
+        self.frame_end = len(self.src) + (4 if has_checksum else 0)
+        if has_checksum:
+            self.src += self.checksum.to_bytes(4, "little")
+        self.status = [0] * nblocks
+        self.far = [0] * nblocks
+        self.src_len = len(self.src)                                         # what the source yields (tests cut it, or append junk)
+
+    def block_end(self, i):
+        p = 0
+        for k in range(i + 1):
+            p += 3 + (1 if (self.src[p] >> 1) & 3 == 1 else self.out[k])
+        return p
+
+
+def model(fr, reads, trailing_junk=False):
+    """ruzstd's StreamingDecoder::read over this frame: [(n, data) or ('err', status)] per read() call. The decoder is lazy: a block is
+    decoded when can_collect() < buf.len() (streaming_decoder.rs:134-150)."""
+    src_avail = fr.src_len
+    pos = 0                       # source position
+    nb = 0                        # blocks decoded
+    buf_len = 0                   # DecodeBuffer::len()
+    out_pos = 0                   # bytes handed out
+    frame_finished = False
+    have_cs = False
+    res = []
+
+    def is_finished():
+        return frame_finished and (have_cs or not fr.has_checksum)
+
+    def can_collect():
+        if is_finished():
+            return buf_len
+        return buf_len - fr.window if buf_len > fr.window else 0
+
+    for cap in reads:
+        if is_finished() and can_collect() == 0:
+            res.append((0, b""))
+            continue
+        err = 0
+        while can_collect() < cap and not is_finished():
+            need = cap - can_collect()
+            before = buf_len
+            # decode_blocks(UptoBytes(need)) (frame_decoder.rs:319-375)
+            while True:
+                if src_avail - pos < 3:
+                    err = E_HDR
+                    break
+                h = int.from_bytes(fr.src[pos:pos + 3], "little")
+                btype, size, last = (h >> 1) & 3, h >> 3, h & 1
+                if btype == 3:
+                    err = E_RESERVED
+                    break
+                body = 1 if btype == 1 else size
+                if src_avail - pos - 3 < body:
+                    err = E_BODY
+                    break
+                if nb < fr.nblocks and fr.status[nb]:
+                    err = fr.status[nb]
+                    break
+                pos += 3 + body
+                buf_len += fr.out[nb]
+                nb += 1
+                if last:
+                    frame_finished = True
+                    if fr.has_checksum:
+                        if src_avail - pos < 4:
+                            pos = src_avail
+                            err = E_CS
+                            break
+                        pos += 4
+                        have_cs = True
+                    break
+                if buf_len - before >= need:
+                    break
+            if err:
+                break
+        if err:
+            res.append(("err", err))
+            continue
+        n = min(cap, can_collect())
+        res.append((n, bytes(fr.plain[out_pos:out_pos + n])))
+        out_pos += n
+        buf_len -= n
+    return res, pos
+
+
+def run_stream(fr, reads, read_ahead=0, pipe_after=0, first_run=0, copy_threads=2, hash_on=True, max_run_src=0, callback=False, chunk=0,
+               content_size=0):
+    L = lib()
+    out = (C.c_uint32 * fr.nblocks)(*fr.out)
+    st = (C.c_uint32 * fr.nblocks)(*fr.status)
+    far = bytes(fr.far)
+    h = L.zgemu_stream_new(bytes(fr.src[:fr.src_len]), fr.src_len, bytes(fr.plain), len(fr.plain), out, st, far, fr.nblocks, fr.window,
+                           1 if fr.has_checksum else 0, fr.checksum, content_size, read_ahead, pipe_after, first_run, copy_threads,
+                           1 if hash_on else 0, max_run_src, 1 if callback else 0, chunk)
+    assert h
+    res = []
+    handed = bytearray()
+    stats = (C.c_uint64 * 16)()
+    try:
+        for cap in reads:
+            buf = C.create_string_buffer(max(cap, 1))
+            n = C.c_size_t()
+            e = L.zgemu_stream_read(h, buf, cap, C.byref(n))
+            if e:
+                res.append(("err", e))
+                break                                      # (what a caller does after an error is its own business: the stream is over)
+            else:
+                res.append((n.value, buf.raw[:n.value]))
+                handed += buf.raw[:n.value]
+        cs = L.zgemu_stream_checksum(h)
+        L.zgemu_stream_stats(h, stats)
+    finally:
+        L.zgemu_stream_free(h)
+    keys = ["mode", "runs", "dropped", "be_runs", "commits", "discards", "rebases", "src_taken", "objections", "finished", "blocks", "bytes_read",
+            "has_cs", "cs", "pipe_begins", "callbacks"]
+    return res, bytes(handed), cs, dict(zip(keys, [int(x) for x in stats]))
+
+
+def check(fr, reads, **kw):
+    want, ref_pos = model(fr, reads)
+    got, handed, cs, stats = run_stream(fr, reads, **kw)
+    assert stats["objections"] == 0, stats
+    for i, (w, g) in enumerate(zip(want, got)):
+        if w[0] == "err":
+            assert g == w, (i, reads[i], g[:1], w, stats)
+            # (what a caller does after an error is its own business: the comparison ends with the first one)
+            got = got[:i + 1]; want = want[:i + 1]
+            break
+        assert g[0] == w[0], (i, reads[i], g[0], w[0], stats)
+        assert g[1] == w[1], (i, reads[i], "bytes differ", stats)
+    if kw.get("hash_on", True) and not any(w[0] == "err" for w in want):
+        assert cs == (xxhash.xxh64(handed).intdigest() & 0xFFFFFFFF)
+    assert stats["src_taken"] <= fr.frame_end, (stats, fr.frame_end)          # nothing behind the frame's end is taken from the source
+    return want, stats
+
+
+def read_pattern(rng, total, style):
+    reads = []
+    done = 0
+    while done <= total + 3 * K and len(reads) < 4000:
+        if style == "small":
+            c = rng.choice([1, 100, 8192, 8192, 8192, 65536])
+        elif style == "mixed":
+            c = rng.choice([0, 1, 8192, K, K + 1, 3 * K, 1 << 20, 5 << 20])
+        elif style == "big":
+            c = rng.choice([1 << 20, 4 << 20, 9 << 20, 33 << 20])
+        else:
+            c = style
+        reads.append(c)
+        done += c
+    return reads + [8192, 1]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_clean_frames_every_mode_matches_the_reference_schedule(seed):
+    rng = random.Random(1000 + seed)
+    for case in range(6):
+        nblocks = rng.choice([1, 2, 7, 40, 150])
+        window = rng.choice([1024, K, 2 * K, 1 << 20])
+        fr = Frame(rng, nblocks, window, has_checksum=rng.random() < 0.7, small=(case == 0))
+        style = rng.choice(["small", "mixed", "big"]) if len(fr.plain) < (6 << 20) or case % 2 else rng.choice(["mixed", "big"])
+        reads = read_pattern(rng, len(fr.plain), style)
+        # the reference's own schedule, runs on the caller's thread only, the worker thread early (a small ring: many wraps), and the defaults
+        for kw in (dict(read_ahead=1), dict(pipe_after=1 << 40), dict(pipe_after=256 << 10, read_ahead=(8 << 20) + window, first_run=2),
+                   dict(pipe_after=1, read_ahead=(3 << 20) + window, max_run_src=1 << 20), dict()):
+            for callback in (False, True):
+                want, stats = check(fr, reads, callback=callback, chunk=rng.choice([0, 1000, 70000]), hash_on=rng.random() < 0.8,
+                                    content_size=len(fr.plain) if rng.random() < 0.5 else 0, **kw)
+                assert stats["dropped"] == 0 and stats["rebases"] == 0
+                if kw.get("read_ahead") == 1:
+                    assert stats["mode"] == 2 and stats["runs"] == 0
+                assert want[-1] == (0, b"") and stats["finished"] == 1
+                assert stats["blocks"] == fr.nblocks and stats["bytes_read"] == fr.frame_end
+
+
+def test_worker_thread_really_runs_and_bounds_the_ring():
+    rng = random.Random(5)
+    fr = Frame(rng, 300, 2 * K, True)                        # ~30 MiB
+    reads = read_pattern(rng, len(fr.plain), 8192)
+    want, stats = check(fr, reads, pipe_after=1 << 20, read_ahead=(4 << 20) + 2 * K)
+    assert stats["pipe_begins"] == 1 and stats["mode"] == 1 and stats["runs"] > 5
+    want, stats = check(fr, read_pattern(rng, len(fr.plain), 16 << 20), pipe_after=1, read_ahead=(4 << 20) + 2 * K, content_size=len(fr.plain))
+    assert stats["pipe_begins"] == 1                         # reads larger than the ring are served piece by piece
+    # a frame whose header declares its size goes to the worker at once; a short one never does
+    want, stats = check(fr, reads, content_size=len(fr.plain), pipe_after=1 << 20)
+    assert stats["pipe_begins"] == 1
+    small = Frame(rng, 3, K, True)
+    want, stats = check(small, read_pattern(rng, len(small.plain), 8192))
+    assert stats["pipe_begins"] == 0 and stats["be_runs"] == 1
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_failing_blocks_and_far_offsets_surface_where_the_reference_meets_them(seed):
+    rng = random.Random(2000 + seed)
+    seen_err = 0
+    for case in range(8):
+        nblocks = rng.choice([3, 12, 60, 200])
+        window = rng.choice([1024, K, 4 * K])
+        fr = Frame(rng, nblocks, window, has_checksum=rng.random() < 0.5)
+        bad = rng.randrange(nblocks)
+        kind = rng.choice(["status", "far", "both"])
+        if kind in ("status", "both"):
+            fr.status[bad] = rng.choice([34, 47, 52, 46])
+        if kind in ("far", "both"):
+            for _ in range(rng.choice([1, 3])):
+                fr.far[rng.randrange(nblocks)] = 1
+        reads = read_pattern(rng, len(fr.plain), rng.choice(["small", "mixed", "big", 8192]))
+        for kw in (dict(read_ahead=1), dict(pipe_after=1 << 40), dict(pipe_after=1, read_ahead=(3 << 20) + window), dict(pipe_after=512 << 10, first_run=1)):
+            for callback in (False, True):
+                want, stats = check(fr, reads, callback=callback, chunk=rng.choice([0, 5000]), **kw)
+                if any(w[0] == "err" for w in want):
+                    seen_err += 1
+                if kw.get("read_ahead") != 1 and (any(fr.far) or any(fr.status)):
+                    assert stats["mode"] == 2 or stats["runs"] >= 0       # a dropped run ends in the block-by-block schedule
+                if kind == "far" and kw.get("read_ahead") != 1:
+                    assert want[-1] == (0, b"")                            # a far offset alone is no error: every byte arrives
+    assert seen_err > 10
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_truncated_and_malformed_sources(seed):
+    """the source ends inside a block header, a body or the checksum, or holds a reserved block type: whole blocks in front are decoded
+    (also ahead), the error comes in the read() call that needs the broken block"""
+    rng = random.Random(3000 + seed)
+    for case in range(10):
+        nblocks = rng.choice([2, 9, 50, 120])
+        window = rng.choice([1024, K])
+        fr = Frame(rng, nblocks, window, has_checksum=rng.random() < 0.6)
+        how = rng.choice(["hdr", "body", "cs", "reserved", "junk_behind"])
+        cutb = rng.randrange(nblocks)
+        if how == "hdr":
+            fr.src_len = (fr.block_end(cutb - 1) if cutb else 0) + rng.randrange(0, 3)
+        elif how == "body":
+            lo = (fr.block_end(cutb - 1) if cutb else 0) + 3
+            hi = fr.block_end(cutb)
+            if hi <= lo:
+                continue
+            fr.src_len = rng.randrange(lo, hi)
+        elif how == "cs":
+            if not fr.has_checksum:
+                continue
+            fr.src_len = fr.frame_end - rng.randrange(1, 5)
+        elif how == "reserved":
+            p = fr.block_end(cutb - 1) if cutb else 0
+            fr.src[p] |= 3 << 1
+        else:
+            fr.src += rng.randbytes(1000)                                  # another frame's bytes behind this one: must stay in the source
+            fr.src_len = len(fr.src)
+        if how in ("hdr", "body", "reserved"):
+            nwhole = cutb
+            fr.nblocks_table = nwhole
+        reads = read_pattern(rng, len(fr.plain), rng.choice(["small", "mixed", 8192, "big"]))
+        tfr = fr
+        if how in ("hdr", "body", "reserved"):
+            # the table only describes the whole blocks
+            tfr = Frame.__new__(Frame)
+            tfr.__dict__.update(fr.__dict__)
+            tfr.nblocks = max(cutb, 0)
+            tfr.out, tfr.status, tfr.far = fr.out[:cutb], fr.status[:cutb], fr.far[:cutb]
+            if cutb == 0:
+                continue                                                    # (the stand-in needs at least one whole block)
+            tfr.frame_end = fr.frame_end
+        for kw in (dict(read_ahead=1), dict(pipe_after=1 << 40), dict(pipe_after=1, read_ahead=(3 << 20) + window), dict()):
+            for callback in (False, True):
+                want, ref_pos = model(tfr, reads)
+                got, handed, cs, stats = run_stream(tfr, reads, callback=callback, chunk=rng.choice([0, 3000]), **kw)
+                assert stats["objections"] == 0
+                for i, (w, g) in enumerate(zip(want, got)):
+                    if w[0] == "err":
+                        assert g == w, (how, i, g[:1], w, kw, callback)
+                        break
+                    assert g[0] == w[0] and g[1] == w[1], (how, i, kw, callback)
+                if how == "junk_behind":
+                    assert stats["src_taken"] == fr.frame_end and want[-1] == (0, b"")
+
+
+def test_mode_switch_keeps_what_the_reader_holds_in_reach():
+    """worker thread -> block by block: the reference's buffer holds everything the reader has not drained, and the device must hold it
+    again (rebase) before the stream goes on in LOCKSTEP"""
+    rng = random.Random(9)
+    fr = Frame(rng, 120, K, True)
+    fr.far[100] = 1
+    reads = [8192] * 40 + read_pattern(rng, len(fr.plain), "mixed")
+    want, stats = check(fr, reads, pipe_after=1, read_ahead=(6 << 20) + K)
+    assert stats["dropped"] == 1 and stats["rebases"] == 1 and stats["mode"] == 2 and want[-1] == (0, b"")

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(ROOT, "zstd-rs_amd")); sys.path.insert(0, os.pat
 import zgpu
 from golden_io import read_manifest, read_pack
 pack, man = read_pack("decodecorpus.pack"), read_manifest("decodecorpus.json")
-ctx = zgpu.Context(0)
+ctx = zgpu.Context(0, dev=True)
 for name in sorted(man):
     b = ctx.prepare(pack[name])
     print("FRAME", name, "blocks", b.nblocks, flush=True)

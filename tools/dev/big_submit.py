@@ -10,7 +10,7 @@ zs = [zgdata.zstd_compress(p) for p in plains]
 digests = [hashlib.sha256(p).digest() for p in plains]
 reps = gib * 16 // 16
 blob = b"".join(zs) * reps
-ctx = zgpu.Context(0)
+ctx = zgpu.Context(0, dev=True)
 b = ctx.prepare(blob)
 assert b.parse_status == 0
 for _ in range(2):

@@ -8,7 +8,7 @@ import zgdata, zgpu
 def run(name, frames_plain):
     zs = [zgdata.zstd_compress(p) for p in frames_plain]
     blob = b"".join(zs)
-    ctx = zgpu.Context(0)
+    ctx = zgpu.Context(0, dev=True)
     b = ctx.prepare(blob)
     assert b.parse_status == 0
     for _ in range(2):

@@ -9,7 +9,7 @@ size = int(sys.argv[1]) if len(sys.argv) > 1 else 256 << 20
 d = zgdata.text_like(size); z = zgdata.zstd_compress(d)
 for var in (sys.argv[2:] or ["1024"]):
     os.environ["ZGPU_FLAT_T"] = var
-    c = zgpu.Context(0); b = c.prepare(z)
+    c = zgpu.Context(0, dev=True); b = c.prepare(z)
     for _ in range(2): b.run(); b.sync()
     t = b.debug_timers(); tot = sum(t[:6]) or 1
     names = ["tile setup", "S1a+S1b (records, marks, prefix)", "S1c (walk, gathers issued)", "S2 (pointer jumping)", "S3a (root words, literals out)", "S3b (offsets out) + end"]

@@ -8,7 +8,7 @@ from golden_io import read_manifest, read_pack
 os.environ["ZGPU_DEBUG_NO_SWEEP"] = "1"
 pack, man = read_pack("decodecorpus.pack"), read_manifest("decodecorpus.json")
 names = sys.argv[1:] or sorted(man)
-ctx = zgpu.Context(0)
+ctx = zgpu.Context(0, dev=True)
 nbad = 0
 for name in names:
     z = pack[name]

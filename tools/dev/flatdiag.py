@@ -9,7 +9,7 @@ os.environ["ZGPU_DEBUG_NO_SWEEP"] = "1"
 def run(name, plains, ub, direct="1"):
     os.environ["ZGPU_UNIT_BLOCKS"] = str(ub); os.environ["ZGPU_DIRECT"] = direct
     zs = [zgdata.zstd_compress(p) for p in plains]
-    c = zgpu.Context(0)
+    c = zgpu.Context(0, dev=True)
     b = c.prepare(b"".join(zs)); b.run(); b.sync()
     units = b.units()
     # frames: blocks per frame

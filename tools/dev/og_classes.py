@@ -11,7 +11,7 @@ if len(sys.argv) > 2:
     os.environ["ZGPU_UNIT_BLOCKS"] = sys.argv[2]
 os.environ["ZGPU_DEBUG_NO_SWEEP"] = "1"
 z = zgdata.zstd_compress(zgdata.text_like(size))
-ctx = zgpu.Context(0)
+ctx = zgpu.Context(0, dev=True)
 b = ctx.prepare(z)
 b.run(); b.sync()
 tot = lit = inside = before = runs = full64 = n64 = 0

@@ -6,7 +6,7 @@ import zgpu
 from golden_io import read_manifest, read_pack
 pack, man = read_pack("decodecorpus.pack"), read_manifest("decodecorpus.json")
 name = sys.argv[1] if len(sys.argv) > 1 else sorted(man)[0]
-ctx = zgpu.Context(0)
+ctx = zgpu.Context(0, dev=True)
 b = ctx.prepare(pack[name])
 print("frames", b.nframes, "blocks", b.nblocks, flush=True)
 b.run(); b.sync()

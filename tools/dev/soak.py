@@ -15,7 +15,7 @@ from golden_io import read_pack
 packs, syn = read_pack("decodecorpus.pack"), read_pack("synthetic.pack")
 bases = [packs[n] for n in sorted(packs) if n.endswith(".zst")] + [syn[n] for n in sorted(syn) if n.endswith(".zst") and len(syn[n]) < (1 << 20)]
 rng = random.Random(seed)
-ctx = zgpu.Context(0)
+ctx = zgpu.Context(0, dev=True)
 same_ok = same_err = 0
 diffs = []
 t0 = time.time()

@@ -10,7 +10,7 @@ neng = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 passes = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 plain = zgdata.text_like(size) if kind == "text" else zgdata.iso_like(size)
 z = zgdata.zstd_compress(plain)
-ctxs = [zgpu.Context(0) for _ in range(neng)]
+ctxs = [zgpu.Context(0, dev=True) for _ in range(neng)]
 bs = [c.prepare(z) for c in ctxs]
 for b in bs:
     b.run(); b.sync(); assert b.bad_status == 0

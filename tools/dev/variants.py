@@ -37,7 +37,7 @@ for v in variants:
     sets = [kv.split("=") for kv in v.split(",") if kv]
     for k, val in sets:
         os.environ[k] = val
-    ctx = zgpu.Context(0)
+    ctx = zgpu.Context(0, dev=True)
     b = ctx.prepare(z)
     assert b.parse_status == 0
     acc = {}

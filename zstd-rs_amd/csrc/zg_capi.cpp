@@ -4,28 +4,12 @@
 #include <string.h>
 #include <new>
 #include <vector>
-#include "../../include/zgpu.h"
-#include <map>
+#include "zg_capi_int.h"
 #include "zg_dev.h"
-#include "zg_engine.h"
-#include "zg_xxh64.h"
+#include "zg_stream.h"
 
 using namespace zg;
 
-struct ZgDict {   // Dictionary (decoding/dictionary.rs:12-37), tables in the engine's packed formats
-  uint32_t id = 0;
-  std::vector<uint32_t> fse;   // one FSE arena slot
-  uint8_t logs[4] = {0, 0, 0, 0};
-  std::vector<uint16_t> huf;
-  uint8_t huf_maxbits = 0;
-  uint32_t hist[3] = {1, 4, 8};
-  std::vector<uint8_t> content;
-};
-struct zgpu_ctx {
-  Engine* eng = nullptr;
-  std::map<uint32_t, ZgDict> dicts;   // FrameDecoder::dicts (frame_decoder.rs:82)
-  std::string err;
-};
 struct zgpu_batch {
   zgpu_ctx* ctx = nullptr;
   Batch* b = nullptr;
@@ -232,6 +216,14 @@ int zgpu_debug_calibrate(zgpu_ctx* c, uint64_t bytes) {
   (void)hipFree(a); (void)hipFree(b);
   return e == hipSuccess ? ZGPU_OK : ZGPU_E_HIP;
 }
+int zgpu_debug_tuning(const zgpu_ctx* c, uint32_t* out, int n) {
+  if (!c || !out || n <= 0) return 0;
+  const Tuning& t = c->eng->tuning();
+  const uint32_t v[8] = {t.dev_build ? 1u : 0u, t.unit_blocks, (uint32_t)t.seq_packed, (uint32_t)t.flat4, t.ramp_percent, t.sweep_w, (uint32_t)t.flat_shape, t.force_inorder ? 1u : 0u};
+  const int k = n < 8 ? n : 8;
+  for (int i = 0; i < k; i++) out[i] = v[i];
+  return k;
+}
 int zgpu_batch_fse_slot(zgpu_batch* zb, uint32_t slot, uint32_t* entries, uint8_t logs[4]) {
   std::vector<uint32_t> v;
   int r = zb->b->read_fse_slot(slot, &v, logs);
@@ -380,36 +372,18 @@ extern "C" int zgpu_add_dict(zgpu_ctx* c, const uint8_t* raw, size_t len, uint32
   return ZGPU_OK;
 }
 
-// ---- FrameDecoder mirror (frame_decoder.rs:80-627) ---------------------------------------------------------------------------
-struct zgpu_decoder {
-  zgpu_ctx* ctx = nullptr;
-  bool has_state = false;
-  FrameHeader fh;
-  uint64_t window_size = 0;
-  bool frame_finished = false;
-  uint64_t block_counter = 0, bytes_read = 0;
-  bool has_checksum = false;
-  uint32_t checksum = 0;
-  uint32_t using_dict = 0;
-  FrameState fs;                 // device side of DecoderScratch
-  std::vector<uint8_t> buf;      // decoded, not yet drained bytes (DecodeBuffer, decode_buffer.rs:9-17)
-  size_t head = 0;
-  Xxh64 hash;
-  size_t held() const { return buf.size() - head; }
-  uint32_t drain_rule = ZG_DRAIN_NONE;   // how the surface driving this decoder drains the reference's DecodeBuffer inside one run (zg_exact.h)
-};
-
-static size_t dec_drain(zgpu_decoder* d, size_t n, uint8_t* dst) {  // DecodeBuffer::drain_to decode_buffer.rs:256-314
+// ---- FrameDecoder mirror (frame_decoder.rs:80-627): struct zgpu_decoder is in zg_capi_int.h ------------------------------------
+size_t zg_dec_drain(zgpu_decoder* d, size_t n, uint8_t* dst) {  // DecodeBuffer::drain_to decode_buffer.rs:256-314
   if (!n) return 0;
   if (dst) memcpy(dst, d->buf.data() + d->head, n);
-  d->hash.update(d->buf.data() + d->head, n);
+  if (d->hash_on) d->hash.update(d->buf.data() + d->head, n);
   d->head += n;
   if (d->head == d->buf.size()) { d->buf.clear(); d->head = 0; }
   else if (d->head > (1u << 22) && d->head > d->held()) { d->buf.erase(d->buf.begin(), d->buf.begin() + d->head); d->head = 0; }
   return n;
 }
 
-static int apply_dict(zgpu_decoder* d, const ZgDict& dict) {   // DecoderScratch::init_from_dict scratch.rs:70-78
+int zg_apply_dict(zgpu_decoder* d, const ZgDict& dict) {   // DecoderScratch::init_from_dict scratch.rs:70-78
   // Tables, offset history and dictionary content are replaced, whenever it is called (force_dict may come after blocks
   // were decoded, frame_decoder.rs:229-243): the device window is rebuilt as [new dictionary content][frame bytes so far].
   FrameState& fs = d->fs;
@@ -511,7 +485,7 @@ int zgpu_decoder_init(zgpu_decoder* d, const uint8_t* src, size_t len, size_t* c
   if (h.has_dict_id) {   // :212-219
     auto it = d->ctx->dicts.find(h.dict_id);
     if (it == d->ctx->dicts.end()) return ZGPU_E_DICT_NOT_PROVIDED;
-    return apply_dict(d, it->second);
+    return zg_apply_dict(d, it->second);
   }
   return ZGPU_OK;
 }
@@ -520,7 +494,7 @@ int zgpu_decoder_force_dict(zgpu_decoder* d, uint32_t dict_id) {   // frame_deco
   if (!d->has_state) return ZGPU_E_NOT_INITIALIZED;
   auto it = d->ctx->dicts.find(dict_id);
   if (it == d->ctx->dicts.end()) return ZGPU_E_DICT_NOT_PROVIDED;
-  return apply_dict(d, it->second);
+  return zg_apply_dict(d, it->second);
 }
 
 int zgpu_decoder_decode_blocks(zgpu_decoder* d, const uint8_t* src, size_t len, size_t* consumed, int strat, size_t n, int* frame_finished) {
@@ -537,6 +511,7 @@ int zgpu_decoder_decode_blocks(zgpu_decoder* d, const uint8_t* src, size_t len, 
   } else {
     // UptoBytes(n): stop after the first block that brings the growth to n. A block regenerates at most 128 KiB, so
     // ceil(missing / 128 KiB) blocks can never overshoot that block; repeat until the growth is reached.
+    if (d->read_ahead > n) n = (size_t)d->read_ahead;
     const size_t before = d->buf.size();
     do {
       const size_t growth = d->buf.size() - before;
@@ -555,24 +530,26 @@ int zgpu_decoder_decode_blocks(zgpu_decoder* d, const uint8_t* src, size_t len, 
 
 int zgpu_decoder_is_finished(const zgpu_decoder* d) {
   if (!d->has_state) return 1;
+  if (d->stream) return zg_stream_is_finished(d->stream) ? 1 : 0;
   if (d->fh.content_checksum()) return d->frame_finished && d->has_checksum;
   return d->frame_finished;
 }
 size_t zgpu_decoder_can_collect(const zgpu_decoder* d) {
   if (!d->has_state) return 0;
+  if (d->stream) return zg_stream_can_collect(d->stream);
   if (zgpu_decoder_is_finished(d)) return d->held();
   return d->held() > d->window_size ? d->held() - (size_t)d->window_size : 0;  // decode_buffer.rs:182-188
 }
 size_t zgpu_decoder_collect(zgpu_decoder* d, uint8_t* dst, size_t cap) {
   size_t n = zgpu_decoder_can_collect(d);
   if (n > cap) n = cap;
-  return dec_drain(d, n, dst);
+  return zg_dec_drain(d, n, dst);
 }
 size_t zgpu_decoder_read(zgpu_decoder* d, uint8_t* dst, size_t cap) {
   if (!d->has_state) return 0;
   size_t n = d->frame_finished ? d->held() : (d->held() > d->window_size ? d->held() - (size_t)d->window_size : 0);
   if (n > cap) n = cap;
-  return dec_drain(d, n, dst);
+  return zg_dec_drain(d, n, dst);
 }
 
 int zgpu_decoder_decode_from_to(zgpu_decoder* d, const uint8_t* src, size_t len, uint8_t* dst, size_t cap, size_t* read_out, size_t* written_out) {
@@ -630,15 +607,23 @@ int zgpu_decoder_decode_from_to(zgpu_decoder* d, const uint8_t* src, size_t len,
   return ZGPU_OK;
 }
 
-uint64_t zgpu_decoder_blocks_decoded(const zgpu_decoder* d) { return d->has_state ? d->block_counter : 0; }
-uint64_t zgpu_decoder_bytes_read_from_source(const zgpu_decoder* d) { return d->has_state ? d->bytes_read : 0; }
+// (behind a streaming decoder that reads ahead these two count what has been DECODED, which runs ahead of what the reader was given)
+uint64_t zgpu_decoder_blocks_decoded(const zgpu_decoder* d) { return !d->has_state ? 0 : d->stream ? zg_stream_blocks_decoded(d->stream) : d->block_counter; }
+uint64_t zgpu_decoder_bytes_read_from_source(const zgpu_decoder* d) { return !d->has_state ? 0 : d->stream ? zg_stream_bytes_read(d->stream) : d->bytes_read; }
 uint64_t zgpu_decoder_content_size(const zgpu_decoder* d) { return d->has_state ? d->fh.frame_content_size : 0; }
 int zgpu_decoder_checksum_from_data(const zgpu_decoder* d, uint32_t* out) {
+  if (d->has_state && d->stream) return zg_stream_checksum_from_data(d->stream, out) ? 1 : 0;
   if (!d->has_state || !d->has_checksum) return 0;
   *out = d->checksum;
   return 1;
 }
-uint32_t zgpu_decoder_calculated_checksum(const zgpu_decoder* d) { return (uint32_t)d->hash.digest(); }
+uint32_t zgpu_decoder_calculated_checksum(const zgpu_decoder* d) { return d->stream ? zg_stream_calculated_checksum(d->stream) : (uint32_t)d->hash.digest(); }
+// ruzstd's `hash` cargo feature (default on): without it the decoder keeps no XXH64 of what it hands out (decode_buffer.rs:42,223-227)
+void zgpu_decoder_set_hash(zgpu_decoder* d, int on) { if (d) d->hash_on = on != 0; }
+// decode_blocks(UptoBytes(n)) decodes at least this many bytes per call: a submit costs as long as ONE block's sequence chain whatever it
+// holds, so a caller that asks for 8 KiB at a time (one block per submit) gets the same bytes several hundred times faster by letting the
+// decoder run ahead. What it observes is what UptoBytes(max(n, bytes)) would give in the reference. 0 (default): exactly n.
+void zgpu_decoder_set_read_ahead(zgpu_decoder* d, uint64_t bytes) { if (d) d->read_ahead = bytes; }
 // device memory the frame holds right now: window (dictionary + undrained and recent bytes) + carried tables. Stays bounded by
 // the window size however long the frame is (FrameState::make_room).
 uint64_t zgpu_decoder_device_bytes(const zgpu_decoder* d) { return d ? (uint64_t)(d->fs.d_out.cap + d->fs.d_fse.cap + d->fs.d_huf.cap + d->fs.d_tmp.cap) : 0; }
@@ -706,7 +691,7 @@ int zgpu_frame_begin(zgpu_ctx* c, uint64_t window_size, uint64_t content_size_or
   if (dict_id_or_0) {
     auto it = c->dicts.find(dict_id_or_0);
     if (it == c->dicts.end()) { delete f; return ZGPU_E_DICT_NOT_PROVIDED; }
-    const int st = apply_dict(d, it->second);
+    const int st = zg_apply_dict(d, it->second);
     if (st) { d->fs.release(); delete f; return st; }
   }
   *out = f;
@@ -776,7 +761,7 @@ int zgpu_read(zgpu_frame* f, uint8_t* dst, size_t cap, int frame_finished, size_
   if (st) return st;
   size_t k = zgpu_available(f, frame_finished);
   if (k > cap) k = cap;
-  *n = dec_drain(&f->dec, k, dst);
+  *n = zg_dec_drain(&f->dec, k, dst);
   return ZGPU_OK;
 }
 
@@ -795,15 +780,7 @@ uint64_t zgpu_frame_blocks_decoded(const zgpu_frame* f) { return f ? f->dec.bloc
 
 }  // extern "C"
 
-// ---- collect_to_writer (frame_decoder.rs:395-407) and StreamingDecoder (streaming_decoder.rs:40-156) -------------------------
-struct zgpu_streaming {
-  zgpu_decoder* dec = nullptr;
-  bool owns_dec = false;
-  zgpu_read_fn read = nullptr;
-  void* user = nullptr;
-  std::vector<uint8_t> stage;
-};
-
+// ---- collect_to_writer (frame_decoder.rs:395-407); the StreamingDecoder mirror is in zg_stream.cpp --------------------------------
 extern "C" {
 
 int zgpu_decoder_collect_to_writer(zgpu_decoder* d, zgpu_write_fn write, void* user, size_t* written) {
@@ -814,94 +791,11 @@ int zgpu_decoder_collect_to_writer(zgpu_decoder* d, zgpu_write_fn write, void* u
     const size_t chunk = n - done < (1u << 20) ? n - done : (1u << 20);
     const size_t w = write(user, d->buf.data() + d->head, chunk);
     if (w > chunk) return ZGPU_E_BAD_ARG;
-    dec_drain(d, w, nullptr);
+    zg_dec_drain(d, w, nullptr);
     done += w;
     if (w < chunk) break;
   }
   if (written) *written = done;
-  return ZGPU_OK;
-}
-
-static size_t read_full(zgpu_streaming* s, uint8_t* dst, size_t n) {
-  size_t got = 0;
-  while (got < n) {
-    const size_t r = s->read(s->user, dst + got, n - got);
-    if (r == 0) break;
-    got += r;
-  }
-  return got;
-}
-
-int zgpu_streaming_create(zgpu_ctx* c, zgpu_read_fn read, void* user, zgpu_streaming** out) {
-  // StreamingDecoder::new (streaming_decoder.rs:51-58): reads the frame header from the source
-  if (!c || !read || !out) return ZGPU_E_BAD_ARG;
-  zgpu_streaming* s = new (std::nothrow) zgpu_streaming();
-  if (!s) return ZGPU_E_NOMEM;
-  s->read = read; s->user = user;
-  int st = zgpu_decoder_create(c, &s->dec);
-  if (st) { delete s; return st; }
-  s->owns_dec = true;
-  uint8_t head[18];
-  size_t have = read_full(s, head, 5);
-  if (have == 5 && head[0] == 0x28 && head[1] == 0xB5 && head[2] == 0x2F && head[3] == 0xFD) {
-    const unsigned desc = head[4], single = (desc >> 5) & 1;
-    static const unsigned kDid[4] = {0, 1, 2, 4}, kFcs[4] = {0, 2, 4, 8};
-    const unsigned extra = (single ? 0 : 1) + kDid[desc & 3] + ((desc >> 6) == 0 ? (single ? 1 : 0) : kFcs[desc >> 6]);
-    have += read_full(s, head + 5, extra);
-  } else if (have == 5) have += read_full(s, head + 5, 3);   // a skippable frame's 8-byte header
-  size_t used = 0;
-  uint32_t sm = 0, sl = 0;
-  st = zgpu_decoder_init(s->dec, head, have, &used, &sm, &sl);
-  if (st) { zgpu_decoder_destroy(s->dec); delete s; return st; }
-  *out = s;
-  return ZGPU_OK;
-}
-void zgpu_streaming_destroy(zgpu_streaming* s) {
-  if (!s) return;
-  if (s->owns_dec) zgpu_decoder_destroy(s->dec);
-  delete s;
-}
-zgpu_decoder* zgpu_streaming_decoder(zgpu_streaming* s) { return s ? s->dec : nullptr; }   // get_ref / into_frame_decoder (:66-85)
-
-int zgpu_streaming_read(zgpu_streaming* s, uint8_t* dst, size_t cap, size_t* n_out) {
-  // impl Read for StreamingDecoder (streaming_decoder.rs:119-155)
-  if (!s || !n_out) return ZGPU_E_BAD_ARG;
-  *n_out = 0;
-  zgpu_decoder* d = s->dec;
-  if (zgpu_decoder_is_finished(d) && zgpu_decoder_can_collect(d) == 0) return ZGPU_OK;      // :125-130
-  while (zgpu_decoder_can_collect(d) < cap && !zgpu_decoder_is_finished(d)) {                 // :134-150
-    const size_t need = cap - zgpu_decoder_can_collect(d);
-    // UptoBytes(need) never stops before ceil(need / 128 KiB) blocks: read that many whole blocks and hand them over as one run
-    uint32_t m = (uint32_t)((need + kMaxBlockSize - 1) / kMaxBlockSize);
-    if (m == 0) m = 1;
-    s->stage.clear();
-    for (uint32_t k = 0; k < m; k++) {
-      uint8_t hdr[3];
-      const size_t h = read_full(s, hdr, 3);
-      s->stage.insert(s->stage.end(), hdr, hdr + h);
-      if (h < 3) break;
-      BlockHeader bh;
-      if (read_block_header(hdr, &bh)) break;                 // the decoder reports the error
-      const size_t at = s->stage.size();
-      s->stage.resize(at + bh.content_size);
-      const size_t b = read_full(s, s->stage.data() + at, bh.content_size);
-      s->stage.resize(at + b);
-      if (b < bh.content_size) break;
-      if (bh.last) {
-        if (d->fh.content_checksum()) {
-          uint8_t cs[4];
-          const size_t c4 = read_full(s, cs, 4);
-          s->stage.insert(s->stage.end(), cs, cs + c4);
-        }
-        break;
-      }
-    }
-    size_t used = 0;
-    int fin = 0;
-    const int st = zgpu_decoder_decode_blocks(d, s->stage.data(), s->stage.size(), &used, ZGPU_STRAT_UPTO_BLOCKS, m, &fin);
-    if (st) return st;
-  }
-  *n_out = zgpu_decoder_read(d, dst, cap);
   return ZGPU_OK;
 }
 

@@ -80,7 +80,10 @@ int Engine::fail(hipError_t e, const char* what) {
 
 Tuning Tuning::from_env() {
   Tuning t;
-  auto num = [](const char* name, uint32_t* v, bool positive) { const char* e = getenv(name); if (e && (!positive || atoi(e) > 0)) *v = (uint32_t)atoi(e); return e != nullptr; };
+#ifdef ZG_DEV_SWITCHES   // the development build only (libzgpu_dev.so): the product library never looks at the environment
+  t.dev_build = true;
+  // (a negative value is ignored, not wrapped into a huge unsigned one: ADVICE r5)
+  auto num = [](const char* name, uint32_t* v, bool positive) { const char* e = getenv(name); if (e && atoi(e) >= (positive ? 1 : 0)) *v = (uint32_t)atoi(e); return e != nullptr && atoi(e) >= 0; };
   auto is0 = [](const char* name) { const char* e = getenv(name); return e && e[0] == '0'; };
   num("ZGPU_UNIT_BLOCKS", &t.unit_blocks, true);
   t.direct = !is0("ZGPU_DIRECT");
@@ -105,6 +108,7 @@ Tuning Tuning::from_env() {
   num("ZGPU_SWEEP_GROUP", &t.sweep.group, true);
   num("ZGPU_SWEEP_HEAD_LDS", &t.sweep.head_lds, false);
   num("ZGPU_SWEEP_HEAD_NB", &t.sweep.head_nbatch, true);
+#endif
   return t;
 }
 
@@ -282,6 +286,23 @@ int FrameState::make_room(uint64_t extra, uint64_t keep, hipStream_t s) {
   }
   const uint64_t need = kOutFront + base + have + extra + 64;
   if (d_out.p && need <= d_out.cap) return 0;
+  // In place: the buffer is large enough for what must stay plus the new bytes once the dropped ones are gone (a streaming decoder that
+  // reads ahead reserves its window once, reserve_window, and then only ever gets here: no allocation on the submit path). The kept tail
+  // moves to the front — through the staging buffer when the two ranges overlap.
+  if (d_out.p && !base && kOutFront + keep + extra + 64 <= d_out.cap) {
+    uint8_t* dst = out_ptr();
+    const uint8_t* src = dst + (have - keep);
+    hipError_t e = hipSuccess;
+    if (keep && have - keep >= keep) e = hipMemcpyAsync(dst, src, keep, hipMemcpyDeviceToDevice, s);
+    else if (keep) {
+      if (d_tmp.reserve(keep)) return ZG_NOMEM;
+      e = hipMemcpyAsync(d_tmp.p, src, keep, hipMemcpyDeviceToDevice, s);
+      if (e == hipSuccess) e = hipMemcpyAsync(dst, d_tmp.p, keep, hipMemcpyDeviceToDevice, s);
+    }
+    if (e != hipSuccess) return ZG_HIP_ERROR;
+    have = keep;
+    return 0;
+  }
   // rebuild: [dictionary][the last `keep` frame bytes] move to a new buffer with room to grow; what the caller has drained
   // and no match can reach any more (decode_buffer.rs:182-219) is dropped here, so the device window stays bounded
   const uint64_t live = base + keep;
@@ -300,6 +321,24 @@ int FrameState::make_room(uint64_t extra, uint64_t keep, hipStream_t s) {
   }
   d_out.p = np; d_out.cap = ncap;
   have = keep;
+  return 0;
+}
+
+// Room for `payload` bytes behind the front pad ([dictionary][frame bytes]), what exists is kept: a streaming decoder that reads ahead
+// reserves the window + two runs once, so that make_room never allocates while a run's plaintext is still travelling to the host.
+int FrameState::reserve_window(uint64_t payload, hipStream_t s) {
+  const uint64_t ncap = kOutFront + payload + 64;
+  if (d_out.p && d_out.cap >= ncap) return 0;
+  void* np = nullptr;
+  if (hipMalloc(&np, ncap) != hipSuccess) { (void)hipGetLastError(); return ZG_NOMEM; }
+  if (d_out.p) {
+    hipError_t e = hipSuccess;
+    if (base + have) e = hipMemcpyAsync((uint8_t*)np + kOutFront, out_ptr(), base + have, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { (void)hipFree(np); return ZG_HIP_ERROR; }
+    (void)hipFree(d_out.p);
+  }
+  d_out.p = np; d_out.cap = ncap;
   return 0;
 }
 

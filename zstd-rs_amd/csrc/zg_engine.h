@@ -57,6 +57,13 @@ struct FrameState {
   // Make room for `extra` more frame bytes. `keep` = frame bytes that must stay reachable (what the caller still holds
   // undrained: DecodeBuffer semantics, decode_buffer.rs:79-111,182-219); older bytes are dropped when the buffer is rebuilt.
   int make_room(uint64_t extra, uint64_t keep, hipStream_t s);
+  int reserve_window(uint64_t payload, hipStream_t s);
+  // would make_room(extra, keep) move or reallocate what the buffer holds? (a download of earlier bytes must not be in flight then)
+  bool room_moves(uint64_t extra, uint64_t keep) const {
+    if (keep > have) keep = have;
+    if (base && keep < have && d_out.p) return true;
+    return !d_out.p || kOutFront + base + have + extra + 64 > d_out.cap;
+  }
   void reset();
   void release();
 };
@@ -78,10 +85,13 @@ struct Scratch {
   void release_but_output();
 };
 
-// Measurement and test switches (the ZGPU_* environment variables of tools/dev/README.md). They are read ONCE, when an engine is
-// created: nothing on the submit path (prepare / run / sync, zg_launch_sweep) calls getenv. A test that wants a switch sets it before it
-// creates its context.
+// Measurement and test switches (the ZGPU_* environment variables of tools/dev/README.md). The PRODUCT library (libzgpu.so) reads none of
+// them: an environment variable must not be able to make a drop-in decoder slower, let alone wrong. The development build (make dev ->
+// libzgpu_dev.so, -DZG_DEV_SWITCHES; what the tests that force a path and tools/dev load) reads them ONCE, when an engine is created:
+// nothing on the submit path (prepare / run / sync, zg_launch_sweep) calls getenv. A test that wants a switch sets it before it creates
+// its (development) context; a switch set afterwards is ignored (zgpu_debug_tuning shows what an engine took).
 struct Tuning {
+  bool dev_build = false;          // libzgpu_dev.so (-DZG_DEV_SWITCHES): the only build in which any of the switches below is read
   uint32_t unit_blocks = 0;        // ZGPU_UNIT_BLOCKS: blocks per flatten unit (0: chosen by BatchBuilder::finish)
   bool direct = true;              // ZGPU_DIRECT=0: no direct units
   uint32_t ramp_percent = 0;       // ZGPU_RAMP
@@ -192,6 +202,7 @@ class Engine {
   hipStream_t download_stream() const { return stream3_; }   // D2H of a finished submit while the next one runs (zgpu_pool_decode_all): nothing else uses it then
   int device() const { return device_; }
   int compute_units() const { return cus_; }
+  const Tuning& tuning() const { return tn_; }
   std::string last_error;
 
  private:

@@ -52,7 +52,7 @@ ZX_DEV void zg_flat1_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat1Lds<T, 
   const bool no_scratch = d.frames[un.frame].sparse != 0u;
   // (timing experiments, ZGPU_FLAT_MODE: bit 0 drops the scratch stores, bit 1 the cross-tile scratch gathers — wrong results, what is
   //  left is what the kernel costs without that traffic)
-  const uint32_t fdbg = ((d.flags >> 4) & 3u) | ((d.flags >> 5) & 4u);   // (bit 2, flag bit 7: S3b without the literal bytes' loads and stores)
+  const uint32_t fdbg = ZG_DEVSW(((d.flags >> 4) & 3u) | ((d.flags >> 5) & 4u));   // (bit 2, flag bit 7: S3b without the literal bytes' loads and stores)
   if (t == 0) { L.err = 0; L.bad = ~0ull; }
   uint32_t unit_size = 0;
 #if defined(ZG_PROFILE_FLAT) && defined(__HIPCC__)   // per-phase cycle counters (tools/dev/flat_phases.py); costs registers, off in the product build

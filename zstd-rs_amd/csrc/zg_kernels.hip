@@ -1335,7 +1335,7 @@ __global__ void __launch_bounds__(T, 4) zg_k_flatten(ZgBatchDev d, uint32_t both
   // handed to its sweep step here — descriptor, then everything this workgroup wrote made visible to the whole device (release),
   // then the flag the step polls. (Producer recipe of the hardware guide: plain stores -> workgroup barrier -> one lane's
   // agent-scope release -> vmcnt(0) -> relaxed agent-scope flag store.)
-  if (d.overlap_epoch) {
+  if (ZG_DEVSW(d.overlap_epoch)) {
     __syncthreads();
     if (threadIdx.x == 0) {
       const uint32_t de = d.units[ui].desc;
@@ -1389,8 +1389,9 @@ __global__ void __launch_bounds__(256) zg_k_swprep(ZgBatchDev d, uint32_t n) {
 // OGM (timing experiments only, ZGPU_SWEEP_MODE 5..8: wrong results): how many bytes of scratch a group reads — 5: 8, 6: 4, 8: 12,
 // 7: 8 and then 8 more at an address that depends on the first (what a directory + entries format would cost a step)
 template <int OGM>
-__device__ __forceinline__ void zg_sweep_body(const ZgBatchDev& d, uint32_t list_off, uint32_t nbatch, uint32_t dbgmode, uint32_t part) {
-  if (d.overlap_epoch) {
+__device__ __forceinline__ void zg_sweep_body(const ZgBatchDev& d, uint32_t list_off, uint32_t nbatch, uint32_t dbgmode_arg, uint32_t part) {
+  const uint32_t dbgmode = ZG_DEVSW(dbgmode_arg);             // (the product build: constant 0, the timing modes below fold away)
+  if (ZG_DEVSW(d.overlap_epoch)) {
     // the flatten may still be at this unit (it runs beside the chain): one lane polls the unit's flag. A step that finds it set
     // — the usual case: units finish in frame order, ahead of the chain — reads data that was released before this launch began;
     // one that had to wait acquires (consumer recipe of the hardware guide). The wait is bounded: the flatten does not depend
@@ -1817,7 +1818,11 @@ bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* step
                      uint32_t unit_bytes, uint32_t window_max, uint32_t window_min, const ZgSweepTuning& tn) {
   uint32_t dbgmode = tn.mode;                                 // timing experiments only (ZGPU_SWEEP_MODE)
   void (*kern)(ZgBatchDev, uint32_t, uint32_t, uint32_t, uint32_t) = zg_k_sweep<0>;
+#ifdef ZG_DEV_SWITCHES
   if (dbgmode >= 5u) { kern = dbgmode == 5u ? zg_k_sweep<5> : dbgmode == 6u ? zg_k_sweep<6> : dbgmode == 7u ? zg_k_sweep<7> : zg_k_sweep<8>; dbgmode = 0u; }
+#else
+  dbgmode = 0u;
+#endif
   // batches per workgroup, software-pipelined (the scratch words of batch i + 1 are requested behind the gathers of batch i): in a chain of
   // steps more than one did not pay (a step is over when its slowest workgroup is); a sweep that is ONE large launch gains 12 % with four
   const uint32_t nbatch = tn.nbatch ? tn.nbatch : (nsteps == 1 ? 4u : 1u);

@@ -126,9 +126,11 @@ static int pool_build(const int* devices, int n, zgpu_pool** out) {
     p->eng2.push_back(e2);
   }
   p->gpu_wall_ms.assign(p->eng.size(), 0.f);
+#ifdef ZG_DEV_SWITCHES   // (the development build only, like zg::Tuning)
   { const char* e = getenv("ZGPU_POOL_JOBS"); if (e && atoi(e) > 0) p->tn_pool_jobs = (uint32_t)atoi(e); }
   { const char* e = getenv("ZGPU_DA_SPLIT"); if (e && atoi(e) > 0) p->tn_da_split = (uint32_t)atoi(e); }
   { const char* e = getenv("ZGPU_DA_FLOOR_MB"); if (e && atoi(e) > 0) p->tn_da_floor_mb = (uint32_t)atoi(e); }
+#endif
   p->start_workers(2u * (uint32_t)p->eng.size());   // workers [0, n): the GPUs' first engines; [n, 2n): their second ones (decode_all only)
   *out = p;
   return ZGPU_OK;

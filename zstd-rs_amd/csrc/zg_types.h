@@ -217,6 +217,15 @@ struct __attribute__((aligned(16))) ZxU4 { uint32_t x, y, z, w; };
 #define ZG_RAW_ML(r) (((r) >> 8) & 511u)
 #define ZG_RAW_LL(r) (((r) >> 17) & 511u)
 
+// Measurement switches that change bytes or verdicts (timing modes that drop a cost, the ramped chain beside the flatten) exist only in
+// the development build (make dev -> libzgpu_dev.so, -DZG_DEV_SWITCHES): in the product library the expressions that read them are the
+// constant 0 and the code behind them is not compiled.
+#ifdef ZG_DEV_SWITCHES
+#define ZG_DEVSW(x) (x)
+#else
+#define ZG_DEVSW(x) 0u
+#endif
+
 // The Huffman literals are decoded AFTER the position scan (literal-heavy submits, chosen by the host): the literals of a block
 // without sequences go straight to the block's place in the output instead of through the arena and zg_k_lit's copy.
 #define ZG_FLAG_LIT_DIRECT 0x40u

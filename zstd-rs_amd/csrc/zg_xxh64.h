@@ -21,7 +21,12 @@ class Xxh64 {
       for (int i = 0; i < 4; i++) v_[i] = round(v_[i], rd(mem_ + 8 * i));
       p += fill; n_ = 0;
     }
-    while (p + 32 <= end) { for (int i = 0; i < 4; i++) v_[i] = round(v_[i], rd(p + 8 * i)); p += 32; }
+    {  // the four lanes in locals: the stripe loop keeps them in registers (as members they are stored and reloaded every stripe,
+       // a byte pointer may alias them) — the streaming decoder's hasher thread runs at this loop's speed
+      uint64_t a = v_[0], b = v_[1], c = v_[2], d = v_[3];
+      while (p + 32 <= end) { a = round(a, rd(p)); b = round(b, rd(p + 8)); c = round(c, rd(p + 16)); d = round(d, rd(p + 24)); p += 32; }
+      v_[0] = a; v_[1] = b; v_[2] = c; v_[3] = d;
+    }
     if (p < end) { memcpy(mem_, p, (size_t)(end - p)); n_ = (unsigned)(end - p); }
   }
   uint64_t digest() const {

@@ -8,7 +8,11 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ZGPU_LIB") or os.path.join(HERE, "libzgpu.so")   # ZGPU_LIB: a profiling build (tools/dev)
+# the development build (-DZG_DEV_SWITCHES): the only library that reads the ZGPU_* measurement / test switches. Tests that force a path
+# and tools/dev ask for it explicitly (Context(dev=True)); the product library ignores the environment.
+DEV_LIB_PATH = os.path.join(HERE, "libzgpu_dev.so")
 _LIB = None
+_DEV_LIB = None
 
 STRAT_ALL, STRAT_UPTO_BLOCKS, STRAT_UPTO_BYTES = 0, 1, 2
 E_SKIP_FRAME = 1
@@ -59,20 +63,30 @@ EXPORTS = [
     "zgpu_streaming_destroy", "zgpu_streaming_decoder", "zgpu_streaming_read", "zgpu_pool_create", "zgpu_pool_create_on", "zgpu_pool_destroy",
     "zgpu_pool_num_gpus", "zgpu_pool_decode_all", "zgpu_pool_plan", "zgpu_pool_stage", "zgpu_pool_run", "zgpu_pool_frame", "zgpu_pool_read", "zgpu_pool_timings", "zgpu_pool_plan_stats",
     "zgpu_frame_begin", "zgpu_frame_end", "zgpu_blocks_submit", "zgpu_sync", "zgpu_available", "zgpu_read", "zgpu_device_output",
-    "zgpu_frame_checksum", "zgpu_frame_blocks_decoded", "zgpu_decoder_device_bytes",
+    "zgpu_frame_checksum", "zgpu_frame_blocks_decoded", "zgpu_decoder_device_bytes", "zgpu_debug_tuning",
 ]
 WRITE_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
 READ_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
 
 
-def load_library():
-    """Load libzgpu.so and declare the prototypes. Does not touch the GPU."""
-    global _LIB
+def load_library(dev=False):
+    """Load libzgpu.so (dev=True: libzgpu_dev.so) and declare the prototypes. Does not touch the GPU."""
+    global _LIB, _DEV_LIB
+    if dev:
+        if _DEV_LIB is None:
+            if not os.path.exists(DEV_LIB_PATH):
+                raise RuntimeError("libzgpu_dev.so is not built (run __graft_entry__.build())")
+            _DEV_LIB = _declare(C.CDLL(DEV_LIB_PATH))
+        return _DEV_LIB
     if _LIB is not None:
         return _LIB
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libzgpu.so is not built (run __graft_entry__.build()); there is no CPU fallback")
-    L = C.CDLL(LIB_PATH)
+    _LIB = _declare(C.CDLL(LIB_PATH))
+    return _LIB
+
+
+def _declare(L):
     vp, sz, u8p = C.c_void_p, C.c_size_t, C.c_char_p
     P = C.POINTER
     L.zgpu_ctx_create.argtypes = [C.c_int, P(vp)]
@@ -167,7 +181,7 @@ def load_library():
     L.zgpu_pool_read.argtypes = [vp, C.c_uint32, vp, sz, P(sz)]
     L.zgpu_pool_timings.argtypes = [vp, C.c_uint32, P(C.c_float), C.c_int, P(C.c_uint64), P(C.c_uint64), P(C.c_uint32), P(C.c_uint32)]
     L.zgpu_pool_plan_stats.argtypes = [vp, C.c_uint32, P(C.c_uint64), C.c_int]
-    _LIB = L
+    L.zgpu_debug_tuning.argtypes = [vp, P(C.c_uint32), C.c_int]
     return L
 
 
@@ -181,8 +195,8 @@ class ZgpuError(Exception):
 class Context:
     """One engine per GPU (zgpu_ctx)."""
 
-    def __init__(self, device=0):
-        self.L = load_library()
+    def __init__(self, device=0, dev=False):
+        self.L = load_library(dev)
         h = C.c_void_p()
         st = self.L.zgpu_ctx_create(device, C.byref(h))
         if st:
@@ -195,6 +209,17 @@ class Context:
             self.h = None
 
     __del__ = close
+
+    def tuning(self):
+        """the switches this context's engine took when it was created (zgpu_debug_tuning): all defaults in the product library"""
+        a = (C.c_uint32 * 8)()
+        n = self.L.zgpu_debug_tuning(self.h, a, 8)
+        keys = ["dev_build", "unit_blocks", "seq_packed", "flat4", "ramp_percent", "sweep_w", "flat_shape", "force_inorder"]
+        d = dict(zip(keys[:n], [int(x) for x in a][:n]))
+        for k in ("seq_packed", "flat4"):
+            if d.get(k, 0) >= 1 << 31:
+                d[k] -= 1 << 32
+        return d
 
     def set_max_window_size(self, n):
         self.L.zgpu_set_max_window_size(self.h, n)
@@ -481,8 +506,8 @@ def plan(costs, n_workers):
 class Pool:
     """Frames over the GPUs of one node through the library's work queue (zgpu_pool): one worker thread + engine per GPU."""
 
-    def __init__(self, n_gpus=0, devices=None):
-        self.L = load_library()
+    def __init__(self, n_gpus=0, devices=None, dev=False):
+        self.L = load_library(dev)
         h = C.c_void_p()
         if devices is not None:
             arr = (C.c_int * len(devices))(*devices)
