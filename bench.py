@@ -12,6 +12,9 @@ generation and compression stay in seconds), every frame's output is compared wi
   enwik9like  configs[1]  enwik9.zst as ONE frame per GPU. $ZGPU_DATA/enwik9 (1e9 bytes) is compressed with libzstd -3 when
               present; else the stand-in text_like(1e9 B, seed 0xE9 + gpu, V=14000) | libzstd -3 (ratio 3.19, 7630 blocks).
               N > 1: every GPU decodes its own frame (a single frame does not shard: replicas, weak scaling).
+  realtext1g  the same real text stretched to 1e9 bytes (its 4 MiB pieces in seeded permutations, tools/realtext.py load_tiled: no match reaches
+              a piece's earlier copy through a 2 MiB window) as ONE frame: real-text statistics at enwik9's size. $ZGPU_DATA/enwik9 replaces
+              the stand-in of `enwik9like` when it exists; this workload is the real-data line when it does not.
   realtext    a real-text single frame per GPU: source code and documentation found in this image (tools/realtext.py: 393 MB from the
               directories listed in tools/realtext_manifest.json — the ones every box of the pool holds with the same bytes; a directory
               that differs is skipped and named) | libzstd -3: what the stand-in is a stand-in for.
@@ -45,7 +48,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 SILESIA_SIZES = [51220480, 41458703, 33553445, 21606400, 10192446, 10085684, 9970564, 8474240, 7251944, 6627202, 6152192, 5345280]
 KERNELS = ("tables", "huf", "seq", "seqpost", "scan", "lit", "flat", "sweep", "lz")
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r05")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r06")
 KERNEL_SOURCES = ("zg_kernels.hip", "zg_flat1.h", "zg_flat4.h", "zg_huf.h", "zg_exact.h", "zg_dev.h", "zg_types.h")   # what the device code is built from
 
 
@@ -79,6 +82,12 @@ def build_workload(name, gpu, size, small=False):
         return ("real text found in this image (%d files, %d B, sha256 %s.., manifest %s%s) | libzstd %s -3, one frame per GPU"
                 % (info["files"], info["bytes"], info["sha256"][:16], info["manifest"],
                    "".join("; skipped %s: %s" % (k, why) for k, why in info["skipped"][:4]), zgdata.zstd_version())), [plain], 1, False, "file"
+    if name == "realtext1g":
+        import realtext
+        plain, info = realtext.load_tiled(1000000000)
+        return ("real text found in this image stretched to %d B (%.2f passes over %d B in 4 MiB pieces, seeded permutations; sha256 %s.., corpus manifest %s) "
+                "| libzstd %s -3, one frame per GPU" % (info["tiled_bytes"], info["passes"], info["bytes"], info["tiled_sha256"][:16], info["manifest"],
+                                                       zgdata.zstd_version())), [plain], 1, False, "file"
     if name == "silesia12":
         sdir = os.path.join(data_dir, "silesia") if data_dir else None
         if sdir and os.path.isdir(sdir) and len(os.listdir(sdir)) >= 12:
@@ -142,13 +151,16 @@ def cpu_baseline(zs, plain_len, cores):
                 t.join()
         return go
 
-    def runs(fn, n=3):
+    def runs(fn, n=5):
         out = []
         for _ in range(n):
             t0 = time.perf_counter()
             fn()
             out.append(time.perf_counter() - t0)
         return out
+
+    def med(ts):
+        return sorted(ts)[len(ts) // 2]
 
     one = C.create_string_buffer(plain_len)
     t_o1, t_z1 = runs(lambda: oracle_one(one)), runs(lambda: zstd_one(one))
@@ -157,20 +169,24 @@ def cpu_baseline(zs, plain_len, cores):
     # ... and on every core the box has ("N = nproc, state N"; decode_all.rs:6-11 is the reference's own bench loop)
     allc = os.cpu_count() or cores
     if allc > cores:
-        t_oa, t_za = runs(threaded(oracle_one, allc)), runs(threaded(zstd_one, allc))
+        t_oa, t_za = runs(threaded(oracle_one, allc), 3), runs(threaded(zstd_one, allc), 3)
     else:
         t_oa, t_za = t_on, t_zn
-    return {"value": round(gb / min(t_o1), 4), "unit": "GB/s", "cores": 1, "kind": "port",
-            "sample": "%d-byte frame of the same workload through the oracle's decode_all (FrameDecoder::decode_all semantics), best of 3" % plain_len,
-            "oracle_nt_GBps": round(cores * gb / min(t_on), 4), "nt_cores": cores,
-            "libzstd_1t_GBps": round(gb / min(t_z1), 4), "libzstd_nt_GBps": round(cores * gb / min(t_zn), 4),
-            "libzstd_nt_GBps_runs": [round(cores * gb / t, 2) for t in t_zn], "oracle_nt_GBps_runs": [round(cores * gb / t, 2) for t in t_on],
-            "all_cores": allc, "oracle_all_GBps": round(allc * gb / min(t_oa), 4), "oracle_all_GBps_runs": [round(allc * gb / t, 2) for t in t_oa],
-            "libzstd_all_GBps": round(allc * gb / min(t_za), 4), "libzstd_all_GBps_runs": [round(allc * gb / t, 2) for t in t_za],
+    rate = lambda k, ts: [round(k * gb / t, 2) for t in ts]
+    # every figure is the MEDIAN of its runs (five; three on all cores), all runs listed: the multi-thread legs spread by 2-3 x between runs
+    # and boxes (unpinned threads that each fault in a fresh 64 MiB buffer) — they are context, not a baseline to divide by
+    return {"value": round(gb / med(t_o1), 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": "%d-byte frame of the same workload through the oracle's decode_all (FrameDecoder::decode_all semantics), median of 5 runs" % plain_len,
+            "runs_GBps": rate(1, t_o1),
+            "oracle_nt_GBps": round(cores * gb / med(t_on), 4), "nt_cores": cores, "oracle_nt_GBps_runs": rate(cores, t_on),
+            "libzstd_1t_GBps": round(gb / med(t_z1), 4), "libzstd_1t_GBps_runs": rate(1, t_z1),
+            "libzstd_nt_GBps": round(cores * gb / med(t_zn), 4), "libzstd_nt_GBps_runs": rate(cores, t_zn),
+            "all_cores": allc, "oracle_all_GBps": round(allc * gb / med(t_oa), 4), "oracle_all_GBps_runs": rate(allc, t_oa),
+            "libzstd_all_GBps": round(allc * gb / med(t_za), 4), "libzstd_all_GBps_runs": rate(allc, t_za),
             "libzstd_version": zgdata.zstd_version(), "host_cores_available": os.cpu_count(),
-            "note": "nt = one frame per thread on nt_cores threads, all = the same on every core of the box (all_cores threads; all three runs listed: "
-                    "the spread between runs and boxes is large); "
-                    "ruzstd itself is not buildable here (no rustc/cargo)"}
+            "note": "medians; nt = one frame per thread on nt_cores threads, all = the same on every hardware thread of the box (threads not pinned: the "
+                    "multi-thread figures are context only, their runs are listed); ruzstd itself is not buildable here (no rustc/cargo): "
+                    "the oracle is its C port"}
 
 
 def check_frames(pool, plains, repeat, first=0):
@@ -210,15 +226,19 @@ def roofline(kern, A, workload, pass_ms=None, njobs=1, plaintext_bytes=None, pla
     try:   # HBM bytes from the committed rocprofv3 PMC passes; refused when the kernels or the workload differ from what they were taken on
         pm = json.load(open(os.path.join(PROFILE_DIR, "%s_pmc.json" % workload)))
         if pm.get("kernels_sha256") != kernels_sha256():
-            traffic_src = "profiles/r05/%s_pmc.json is stale for this build: not reported" % workload
+            traffic_src = "profiles/r06/%s_pmc.json is stale for this build: not reported" % workload
         elif plaintext_bytes is not None and pm.get("plaintext_bytes") != plaintext_bytes:
-            traffic_src = "profiles/r05/%s_pmc.json was taken on %s plaintext bytes, this run decodes %s: not reported" % (workload, pm.get("plaintext_bytes"), plaintext_bytes)
+            traffic_src = "profiles/r06/%s_pmc.json was taken on %s plaintext bytes, this run decodes %s: not reported" % (workload, pm.get("plaintext_bytes"), plaintext_bytes)
         else:
             traffic = pm["pipeline_hbm_bytes_per_pass"]
-            traffic_src = "profiles/r05/%s_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per-kernel calibration; all kernels of one pass)" % workload
+            traffic_src = "profiles/r06/%s_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per-kernel calibration; all kernels of one pass)" % workload
     except Exception:
         pass
+    # the same time against the bytes the counters saw: how far the HBM is really loaded (frac counts only C + D, SURVEY 8d: the gap between
+    # the two is the pipeline's own traffic — scratch words, sequence records, gathers)
+    frac_traffic = round(traffic / (t_pipe / 1e3) / 1e9 / HBM_PEAK_GBS, 6) if (traffic and t_pipe > 0) else None
     return {"bound": "hbm", "achieved": round(pipe, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pipe / HBM_PEAK_GBS, 6),
+            "frac_of_traffic": frac_traffic,
             "scope": "whole pipeline of one pass on one GPU: (C + D) / t_pass (SURVEY 8d); t_pass = sum of the kernels of the pass (one job) "
                      "or the time the GPU's two engines took for their jobs (several jobs in flight: kernels of different jobs overlap)",
             "jobs_in_flight": njobs, "t_pass_ms": round(t_pipe, 4),
@@ -287,12 +307,81 @@ def e2e_rate(device, zs_list, plain_total):
     return plain_total / t / 1e9, hashlib.sha256(dst.numpy().tobytes()).digest()
 
 
+def stream_rates(device, z, plain):
+    """The io::Read surface (zgpu_streaming_*: StreamingDecoder::read with read-ahead, zg_stream.h) on ONE frame, host to host: the
+    compressed frame lies in pinned host memory, std::io::copy-style loops with caller buffers of 8 KiB (the reference CLI's), 1 MiB and
+    64 MiB drain it (zgpu_streaming_copy into a sink: every byte is copied into the caller's buffer and dropped), with the content
+    checksum computed (ruzstd's default `hash` feature) and without; and the whole frame read into one pinned buffer of its size
+    (e2e_single_frame). Source walk + H2D + kernels + D2H + the reader's copy, best of 3 after one warm-up (the pinned ring of the
+    first stream is kept by the library). Parity: byte counts, calculated == stored checksum, sha256 of the single-buffer read."""
+    import torch
+    import zgpu
+    ctx = zgpu.Context(device)
+    src = torch.frombuffer(bytearray(z), dtype=torch.uint8).pin_memory()
+    dst = torch.empty(len(plain), dtype=torch.uint8).pin_memory()
+    want_sha = hashlib.sha256(plain).digest()
+
+    def one_copy(buf, checksum, callback=False):
+        if callback:
+            s = zgpu.CStreamingDecoder(ctx, _PinnedReader(src), checksum=checksum)
+        else:
+            s = zgpu.CStreamingDecoder(ctx, data=(src.data_ptr(), len(z)), checksum=checksum)
+        t0 = time.perf_counter()
+        n = s.copy_to_sink(buf)
+        dt = time.perf_counter() - t0
+        assert n == len(plain) and s.is_finished() and s.stats()["dropped"] == 0, (n, s.stats())
+        if checksum:
+            assert s.get_calculated_checksum() == s.get_checksum_from_data()
+        s.close()
+        return dt
+
+    def one_read(checksum):
+        s = zgpu.CStreamingDecoder(ctx, data=(src.data_ptr(), len(z)), checksum=checksum)
+        t0 = time.perf_counter()
+        n = s.read_into(dst.data_ptr(), len(plain))
+        dt = time.perf_counter() - t0
+        assert n == len(plain)
+        assert s.read_into(dst.data_ptr(), 16) == 0 and s.is_finished()
+        s.close()
+        return dt
+    one_copy(1 << 20, True)                              # warm-up: the ring, the engine's buffers
+    gb = len(plain) / 1e9
+    out = {"stream_GBps": {}, "stream_nohash_GBps": {}}
+    for label, buf in (("8KiB", 8192), ("1MiB", 1 << 20), ("64MiB", 64 << 20)):
+        out["stream_GBps"][label] = round(gb / min(one_copy(buf, True) for _ in range(3)), 3)
+        out["stream_nohash_GBps"][label] = round(gb / min(one_copy(buf, False) for _ in range(3)), 3)
+    out["stream_callback_GBps"] = {"1MiB": round(gb / min(one_copy(1 << 20, True, True) for _ in range(2)), 3)}
+    t = min(one_read(False) for _ in range(3))
+    assert hashlib.sha256(dst.numpy().tobytes()).digest() == want_sha, "stream output differs"
+    out["e2e_single_frame_GBps"] = round(gb / t, 3)
+    out["e2e_single_frame_hash_GBps"] = round(gb / min(one_read(True) for _ in range(2)), 3)
+    out["stream_note"] = ("zgpu_streaming_* (StreamingDecoder::read with read-ahead) on the %d-byte frame, compressed bytes in pinned host memory (slice source; "
+                          "stream_callback: an io::Read callback that copies from it), zgpu_streaming_copy with caller buffers of 8 KiB / 1 MiB / 64 MiB into a sink; "
+                          "stream_GBps with the XXH64 of ruzstd's default `hash` feature (hasher thread), stream_nohash without; e2e_single_frame: one read() of "
+                          "the whole frame into a pinned buffer. Walk + H2D + kernels + D2H + the reader's copy; best of 3; one GPU" % len(plain))
+    ctx.close()
+    return out
+
+
+class _PinnedReader:
+    """an io::Read-like source over pinned memory (a torch uint8 tensor): read(n) -> bytes"""
+
+    def __init__(self, t):
+        self.t, self.pos, self.n = t, 0, t.numel()
+
+    def read(self, n):
+        k = min(n, self.n - self.pos)
+        b = C.string_at(self.t.data_ptr() + self.pos, k)
+        self.pos += k
+        return b
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="enwik9like", choices=["enwik9like", "realtext", "silesia12", "blocks", "blocks4b", "iso"])
+    ap.add_argument("--workload", default="enwik9like", choices=["enwik9like", "realtext", "realtext1g", "silesia12", "blocks", "blocks4b", "iso"])
     ap.add_argument("--size", type=int, default=int(os.environ.get("ZGPU_BENCH_SIZE", 1000000000)), help="plaintext bytes per GPU (enwik9like)")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="lower bound of the timed region (passes per step are raised to reach it)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -416,6 +505,8 @@ def main():
             out["e2e_GBps"] = round(rate, 3)
             out["e2e_note"] = ("C ABI zgpu_pool_decode_all on %d frames (%d B of plaintext): pinned host buffer in, pinned host buffer out; host walk + H2D "
                                "+ kernels + D2H with the jobs of two engines overlapped, best of 3; per GPU" % (len(ez), sum(len(p) for p in ep)))
+        if not args.no_e2e and args.workload == "enwik9like" and len(staged_z) == 1:
+            out.update(stream_rates(local_rank, staged_z[0], staged_p[0]))
         if not args.no_cpu:
             # bounded CPU sample of the same workload: one frame of at most 64 MiB of plaintext
             n = min(len(staged_p[0]), 64 << 20)
@@ -425,7 +516,7 @@ def main():
             # the other BASELINE.json configurations on this GPU, at one GPU's share of their size (parity gate on every frame first):
             # context for the headline, not part of `value`
             del staged_p, staged_z, per_gpu, zs_gpu
-            out["other_workloads"] = {w: other_workload(w, local_rank, args.min_seconds) for w in ("silesia12", "blocks", "blocks4b", "iso", "realtext")}
+            out["other_workloads"] = {w: other_workload(w, local_rank, args.min_seconds) for w in ("realtext1g", "silesia12", "blocks", "blocks4b", "iso", "realtext")}
         print(json.dumps(out), flush=True)
     if pool is not None:
         pool.close()

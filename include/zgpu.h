@@ -296,7 +296,7 @@ typedef struct {
                                   never less than the frame's window + 2 MiB); 1: no read-ahead at all */
   uint32_t no_checksum;        /* 1: ruzstd built without its `hash` feature — no XXH64 of the bytes handed out (one core hashes ~10-20 GB/s:
                                   with the checksum on, a hasher thread keeps it off the reader's path, but it bounds the stream) */
-  uint32_t copy_threads;       /* helper threads that copy reads of 4 MiB and more out of the ring. 0: default (3); 0xFFFFFFFF: none */
+  uint32_t copy_threads;       /* helper threads that copy reads of 512 KiB and more out of the ring. 0: default (3); 0xFFFFFFFF: none */
   uint64_t pipe_after_bytes;   /* a frame is decoded on the caller's thread (runs of 8, 32, 128 ... blocks) until this much is decoded, or
                                   its header declares more than this; then a worker thread takes over. 0: default (32 MiB) */
   uint32_t first_run_blocks;   /* 0: default (8) */
@@ -318,7 +318,9 @@ int zgpu_streaming_read(zgpu_streaming*, uint8_t* dst, size_t cap, size_t* n);
  * write == NULL is io::sink(). *total = bytes copied. */
 int zgpu_streaming_copy(zgpu_streaming*, size_t buf_size, zgpu_write_fn write, void* user, uint64_t* total);
 /* diagnostics: out[0] mode now (0 runs on the caller's thread, 1 worker thread + ring, 2 block by block), [1] runs decoded ahead and
- * taken, [2] runs decoded ahead and dropped, [3] host bytes held (buffer + ring). Returns how many were written. */
+ * taken, [2] runs decoded ahead and dropped, [3] host bytes held (buffer + ring); [4..11] microseconds — worker thread: waiting for a run
+ * from the reader, decoding (parse + upload + kernels), waiting for the previous run's download, commit, waiting for room in the ring; reader:
+ * waiting for bytes, copying reads of 1 MiB and more out of the ring, taking runs from the source. Returns how many were written. */
 int zgpu_streaming_stats(const zgpu_streaming*, uint64_t* out, int n);
 
 #ifdef __cplusplus

@@ -49,3 +49,25 @@ def test_fails_loudly_without_gpu():
     with pytest.raises(zgpu.ZgpuError) as e:
         zgpu.Context()
     assert e.value.status == zgpu.E_HIP
+
+
+def test_product_library_has_no_measurement_switches():
+    """an environment variable must not be able to make the drop-in decoder slower, let alone wrong. The product library
+    (libzgpu.so) reads no ZGPU_* variable and calls getenv nowhere; the switches — timing modes that return wrong bytes, the ramped sweep
+    chain, unit sizes — exist only in libzgpu_dev.so (-DZG_DEV_SWITCHES), which the tests that force a path and tools/dev load."""
+    _built()
+    dev = os.path.join(ROOT, "zstd-rs_amd", "libzgpu_dev.so")
+    assert os.path.exists(dev)
+    names = ("ZGPU_FLAT_MODE", "ZGPU_SWEEP_MODE", "ZGPU_DEBUG_NO_SWEEP", "ZGPU_DEBUG_NO_EXACT", "ZGPU_RAMP", "ZGPU_UNIT_BLOCKS", "ZGPU_SEQ_PACKED",
+             "ZGPU_FORCE_INORDER", "ZGPU_POOL_JOBS", "ZGPU_DA_SPLIT")
+    rel = open(LIB, "rb").read()
+    devb = open(dev, "rb").read()
+    for n in names:
+        assert n.encode() not in rel, n
+        assert n.encode() in devb, n
+    assert b"ZGPU_" not in rel.replace(b"ZGPU_E_", b"")          # no other switch either
+    und = subprocess.check_output(["nm", "-D", "--undefined-only", LIB]).decode()
+    assert "getenv" not in und
+    assert "getenv" in subprocess.check_output(["nm", "-D", "--undefined-only", dev]).decode()
+    # the timing variants of the sweep kernel are not even compiled into the product
+    assert b"zg_k_sweepILi5" not in rel and b"zg_k_sweepILi5" in devb

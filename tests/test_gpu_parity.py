@@ -719,15 +719,16 @@ def test_force_dict_at_any_time_matches_oracle(ctx):
 
 
 def test_streaming_window_stays_bounded(ctx):
-    """StreamingDecoder over a 192 MiB frame with 4 MiB reads: linear time and a device window that does not grow with the
-    frame (bytes the caller has drained are dropped when the window buffer is rebuilt, decode_buffer.rs:182-219)"""
+    """StreamingDecoder over a 192 MiB frame with 4 MiB reads, WITHOUT read-ahead (the reference's block-by-block schedule): linear time
+    and a device window that does not grow with the frame (bytes the caller has drained are dropped when the window buffer is rebuilt,
+    decode_buffer.rs:182-219). With read-ahead the bound is the budget: tests/test_gpu_stream.py."""
     import io
     import time
     import zgdata
     import zgpu
     plain = zgdata.text_like(192 << 20, seed=0x5D)
     z = zgdata.zstd_compress(plain)
-    s = zgpu.CStreamingDecoder(ctx, io.BytesIO(z))
+    s = zgpu.CStreamingDecoder(ctx, io.BytesIO(z), read_ahead=zgpu.NO_READ_AHEAD)
     h = hashlib.sha256()
     marks, done, dev = [], 0, []
     t0 = time.perf_counter()

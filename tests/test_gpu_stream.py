@@ -1,0 +1,253 @@
+"""The io::Read surface with read-ahead on the GPU (zgpu_streaming_*, zstd-rs_amd/csrc/zg_stream.h / zg_stream.cpp) against the oracle's
+FrameDecoder driven by the reference's own read loop (StreamingDecoder::read, streaming_decoder.rs:119-155): for every sequence of read
+sizes the same bytes, the same return value of every read() call, an error in the same call and with the same leaf, the same checksums.
+Fixtures: the reference's decode corpus and dictionary fixtures, mutated corpus frames, hand-made frames whose offsets reach beyond the
+window (what the reference does with those depends on what its caller has drained: the read-ahead must fall back to its schedule)."""
+import hashlib
+import io
+import os
+import random
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "zstd-rs_amd"))
+import oracle
+from golden_io import read_manifest, read_pack
+from test_exact_cpu import K, frame, lit_block, raw_block, seq_block
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import zgpu
+    c = zgpu.Context(0)
+    yield c
+    c.close()
+
+
+def oracle_reads(z, reads, dict_raw=None):
+    """ruzstd's StreamingDecoder::read over the oracle's FrameDecoder: [(n, bytes)] per call, ('err', status) ends the list"""
+    o = oracle.FrameDecoder()
+    if dict_raw is not None:
+        o.add_dict(dict_raw)
+    st, pos, _, _ = o.init(z)
+    if st:
+        return [("init", st)], o
+    res = []
+    for cap in reads:
+        if o.is_finished() and o.can_collect() == 0:
+            res.append((0, b""))
+            continue
+        err = 0
+        while o.can_collect() < cap and not o.is_finished():
+            st, used, fin = o.decode_blocks(z[pos:pos + (8 << 20) + cap], oracle.STRAT_UPTO_BYTES, cap - o.can_collect())
+            pos += used
+            if st:
+                err = st
+                break
+        if err:
+            res.append(("err", err))
+            break
+        d = o.read(cap)
+        res.append((len(d), d))
+    return res, o
+
+
+def zgpu_reads(ctx, z, reads, callback, **kw):
+    import zgpu
+    try:
+        s = zgpu.CStreamingDecoder(ctx, io.BytesIO(z), **kw) if callback else zgpu.CStreamingDecoder(ctx, data=z, **kw)
+    except zgpu.ZgpuError as e:
+        return [("init", e.status)], None
+    res = []
+    for cap in reads:
+        try:
+            d = s.read(cap)
+        except zgpu.ZgpuError as e:
+            res.append(("err", e.status))
+            break
+        res.append((len(d), d))
+    return res, s
+
+
+MODES = [dict(), dict(read_ahead=1), dict(pipe_after=1, read_ahead=4 << 20), dict(pipe_after=1 << 40, first_run_blocks=1)]
+
+
+def patterns(rng, total):
+    yield [total + 100, 10]
+    yield [8192] * (total // 8192 + 3)
+    r, done = [], 0
+    while done < total + 1000:
+        c = rng.choice([0, 1, 7, 4096, 8192, 65536, K, K + 1, 1 << 20, 3 << 20])
+        r.append(c)
+        done += c
+    yield r + [5, 5]
+
+
+def same(want, got, what):
+    assert len(got) == len(want), (what, len(got), len(want), got[-1][:1], want[-1][:1])
+    for i, (w, g) in enumerate(zip(want, got)):
+        assert g[0] == w[0], (what, i, g[0], w[0])
+        assert g[1] == w[1], (what, i, "bytes / status differ", g[1] if isinstance(g[1], int) else len(g[1]), w[1] if isinstance(w[1], int) else len(w[1]))
+
+
+def test_corpus_through_every_mode(ctx):
+    pack, man = read_pack("decodecorpus.pack"), read_manifest("decodecorpus.json")
+    rng = random.Random(61)
+    names = sorted(man)
+    for k, name in enumerate(names):
+        z = pack[name]
+        size = man[name]["size"]
+        pats = list(patterns(rng, size))
+        pat = pats[k % 3]
+        want, o = oracle_reads(z, pat)
+        assert want[-1] == (0, b"") or size == 0
+        for mi, kw in enumerate(MODES):
+            if k % 4 != mi and k % 9:           # every frame through one mode, every ninth through all
+                continue
+            for callback in (False, True):
+                got, s = zgpu_reads(ctx, z + b"bytes of the next frame", pat, callback, **kw)
+                same(want, got, (name, kw, callback))
+                assert s.is_finished() and s.get_calculated_checksum() == o.calculated_checksum() == s.get_checksum_from_data()
+                assert s.blocks_decoded() == o.blocks_decoded() and s.bytes_read_from_source() == o.bytes_read_from_source() == len(z)
+                if not callback:
+                    assert s.source_position() == len(z)             # nothing behind the frame is taken from the source
+                if kw.get("read_ahead") == 1:
+                    assert s.stats()["mode"] == 2 and s.stats()["runs"] == 0
+                s.close()
+
+
+def test_dictionary_frames(ctx):
+    pack, man = read_pack("dict_tests.pack"), read_manifest("dict_tests.json")
+    raw = pack["dictionary"]
+    ctx.add_dict(raw)
+    rng = random.Random(62)
+    names = sorted(n for n in man if n.endswith(".zst"))[::6]
+    for k, name in enumerate(names):
+        z = pack[name]
+        pat = list(patterns(rng, man[name]["size"]))[k % 3]
+        want, o = oracle_reads(z, pat, raw)
+        for kw in (MODES[k % 4], MODES[(k + 1) % 4]):
+            got, s = zgpu_reads(ctx, z, pat, k % 2 == 0, **kw)
+            same(want, got, (name, kw))
+            assert s.get_calculated_checksum() == o.calculated_checksum()
+            s.close()
+
+
+def test_mutated_frames_fail_in_the_same_read_call(ctx):
+    """one to three bit flips per frame: the same bytes in front of the defect, the error in the same read() call, the same leaf —
+    whether the defect is met block by block or inside a run that was decoded ahead (and then dropped)"""
+    pack, man = read_pack("decodecorpus.pack"), read_manifest("decodecorpus.json")
+    rng = random.Random(63)
+    names = sorted(man)
+    nerr = nok = 0
+    leaves = set()
+    for it in range(140):
+        name = names[rng.randrange(len(names))]
+        m = bytearray(pack[name])
+        for _ in range(rng.choice([1, 1, 2, 3])):
+            i = rng.randrange(4, len(m))
+            m[i] ^= 1 << rng.randrange(8)
+        z = bytes(m)
+        pat = list(patterns(rng, man[name]["size"]))[it % 3]
+        want, o = oracle_reads(z, pat)
+        if want[-1][0] in ("err", "init"):
+            nerr += 1
+            leaves.add(want[-1][1])
+        else:
+            nok += 1
+        for kw in (MODES[it % 4], MODES[0]):
+            got, s = zgpu_reads(ctx, z, pat, it % 2 == 1, **kw)
+            same(want, got, (name, it, kw))
+            if s:
+                s.close()
+    assert nerr > 40 and nok > 10 and len(leaves) >= 5, (nerr, nok, leaves)
+
+
+def test_offsets_beyond_the_window_follow_the_readers_drains(ctx):
+    """A match that reaches beyond the window is served by the reference as long as its caller has not drained the bytes (decode_buffer.rs:
+    79-111): with 8 KiB reads they are gone, with one large read they are still there. A run decoded ahead cannot know — it is dropped, and
+    the block-by-block schedule decides like the oracle for both readers."""
+    import zgpu
+    blocks = [raw_block(K, i) for i in range(12)] + [seq_block(6 * K)] + [raw_block(K, 40 + i) for i in range(6)] + [lit_block(100, last=True)]
+    z = frame(*blocks)
+    seen = set()
+    for pat in ([8192] * 400, [20 * K] * 3, [K] * 30, [3 * K, 9 * K, 9 * K, 9 * K]):
+        want, o = oracle_reads(z, pat)
+        seen.add(want[-1][0])
+        for kw in MODES:
+            for callback in (False, True):
+                got, s = zgpu_reads(ctx, z, pat, callback, **kw)
+                same(want, got, (pat[0], kw, callback))
+                if kw.get("read_ahead") != 1:
+                    assert s.stats()["dropped"] >= 1 and s.stats()["mode"] == 2
+                s.close()
+    assert seen == {"err", 0}, seen
+
+
+def test_long_frame_goes_through_the_worker_thread(ctx):
+    """192 MiB of text, 8 KiB reads (std::io::copy's buffer): the worker thread decodes runs ahead into the ring; the device window and the
+    host ring stay bounded; plaintext, checksum and counters as the generator's / the frame's"""
+    import zgdata
+    import zgpu
+    n = 192 << 20
+    data = zgdata.text_like(n, seed=0x57A)
+    z = zgdata.zstd_compress(data)
+    want = hashlib.sha256(data).hexdigest()
+    for kw, cap in ((dict(read_ahead=64 << 20), 8192), (dict(), 1 << 20), (dict(read_ahead=48 << 20, checksum=False), 40 << 20)):
+        for callback in (True, False):
+            s = zgpu.CStreamingDecoder(ctx, io.BytesIO(z + b"tail") if callback else None, data=None if callback else z + b"tail", **kw)
+            h = hashlib.sha256()
+            total = 0
+            peak = 0
+            while True:
+                d = s.read(cap)
+                if not d:
+                    break
+                assert len(d) == cap or total + len(d) == n
+                h.update(d)
+                total += len(d)
+                if total % (32 << 20) < cap:
+                    peak = max(peak, s.device_bytes())
+            st = s.stats()
+            assert total == n and h.hexdigest() == want, (kw, cap, callback)
+            assert st["mode"] == 1 and st["runs"] >= 2 and st["dropped"] == 0, st
+            assert s.is_finished() and s.get_checksum_from_data() is not None
+            if kw.get("checksum", True):
+                assert s.get_calculated_checksum() == s.get_checksum_from_data()
+            assert st["host_bytes"] <= kw.get("read_ahead", 512 << 20) + (4 << 20)
+            assert peak < (3 * kw.get("read_ahead", 512 << 20)) // 2 + (64 << 20), peak      # the window + two runs, not the frame
+            if not callback:
+                assert s.source_position() == len(z)
+            s.close()
+
+
+def test_io_copy_and_the_frame_decoders_read_ahead(ctx):
+    import zgdata
+    import zgpu
+    data = zgdata.text_like(40 << 20, seed=0x10C)
+    z = zgdata.zstd_compress(data)
+    for bs in (8192, 1 << 20):
+        s = zgpu.CStreamingDecoder(ctx, data=z)
+        assert s.copy_to_sink(bs) == len(data)
+        assert s.is_finished() and s.get_calculated_checksum() == s.get_checksum_from_data()
+        s.close()
+    # FrameDecoder::decode_blocks(UptoBytes(n)) with a read-ahead of 8 MiB: what UptoBytes(8 MiB) gives, asked for in 8 KiB pieces
+    d = zgpu.FrameDecoder(ctx)
+    d.set_read_ahead(8 << 20)
+    st, c, _, _ = d.reset(z)
+    assert st == 0
+    pos, out, calls = c, [], 0
+    while not d.is_finished():
+        st, used, fin = d.decode_blocks(z[pos:pos + (12 << 20)], zgpu.STRAT_UPTO_BYTES, 8192)
+        assert st == 0
+        pos += used
+        calls += 1
+        out.append(d.collect())
+    out.append(d.collect())
+    assert b"".join(out) == data and calls <= 8, calls
+    d.close()

@@ -88,6 +88,27 @@ def load(want=WANT):
     return data, info
 
 
+def load_tiled(target=1000000000, chunk=4 << 20, seed=0xE9):
+    """the corpus stretched to `target` bytes: the first pass in its own order, every further pass with its 4 MiB pieces in a seeded
+    permutation. A piece meets its earlier copy hundreds of MB back — far beyond the 2 MiB window of `zstd -3` — so the tiling adds no
+    match the compressor can use: per byte this is the corpus's own statistics, at enwik9's size. Returns (bytes, info)."""
+    import random
+    data, info = load()
+    pieces = [data[i:i + chunk] for i in range(0, len(data), chunk)]
+    out, n, rng = [data], len(data), random.Random(seed)
+    while n < target:
+        order = list(range(len(pieces)))
+        rng.shuffle(order)
+        for i in order:
+            out.append(pieces[i]); n += len(pieces[i])
+            if n >= target:
+                break
+    big = b"".join(out)[:target]
+    info = dict(info)
+    info.update({"tiled_bytes": len(big), "tiled_sha256": hashlib.sha256(big).hexdigest(), "passes": round(len(big) / max(len(data), 1), 2)})
+    return big, info
+
+
 if __name__ == "__main__":
     if "--write-manifest" in sys.argv:
         cen = census()

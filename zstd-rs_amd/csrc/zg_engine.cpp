@@ -132,6 +132,7 @@ int Engine::create(int device, Engine** out) {
   if (hipStreamCreateWithPriority(&e->stream_, hipStreamNonBlocking, prio_hi) != hipSuccess) { delete e; return ZG_HIP_ERROR; }
   if (hipStreamCreateWithPriority(&e->stream2_, hipStreamNonBlocking, prio_lo) != hipSuccess) { delete e; return ZG_HIP_ERROR; }
   if (hipStreamCreateWithPriority(&e->stream3_, hipStreamNonBlocking, prio_hi) != hipSuccess) { delete e; return ZG_HIP_ERROR; }
+  if (hipStreamCreateWithPriority(&e->stream4_, hipStreamNonBlocking, prio_lo) != hipSuccess) { delete e; return ZG_HIP_ERROR; }
   *out = e;
   return ZG_OK;
 }
@@ -141,6 +142,7 @@ Engine::~Engine() {
   if (stream_) (void)hipStreamDestroy(stream_);
   if (stream2_) (void)hipStreamDestroy(stream2_);
   if (stream3_) (void)hipStreamDestroy(stream3_);
+  if (stream4_) (void)hipStreamDestroy(stream4_);
 }
 Scratch* Engine::acquire() {
   if (!free_.empty()) { Scratch* s = free_.back(); free_.pop_back(); return s; }
@@ -473,7 +475,12 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   // ... and 64 bytes in front for the 16-byte windows of the sequence decoder
   if ((st = sc->d_src.reserve(len + 128))) { delete b; return st; }
   (void)hipMemsetAsync(sc->d_src.p, 0, 64, stream_);
-  if (len && hipMemcpyAsync((uint8_t*)sc->d_src.p + 64, src, len, hipMemcpyHostToDevice, stream_) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
+  if (len && preup.dev && preup.host == src && preup.len == len) {
+    // the bytes are on the device already (brought there beside the submit in front): a device-to-device copy behind that upload
+    if (hipStreamWaitEvent(stream_, preup.done, 0) != hipSuccess ||
+        hipMemcpyAsync((uint8_t*)sc->d_src.p + 64, preup.dev, len, hipMemcpyDeviceToDevice, stream_) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
+  } else if (len && hipMemcpyAsync((uint8_t*)sc->d_src.p + 64, src, len, hipMemcpyHostToDevice, stream_) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
+  preup = PreUpload();
   (void)hipMemsetAsync((uint8_t*)sc->d_src.p + 64 + len, 0, 64, stream_);
   const uint32_t nslots = bb.nslots();
   if ((st = up(sc->d_blocks, bb.blocks.data(), nb * sizeof(ZgBlock))) || (st = up(sc->d_frames, bb.frames.data(), nf * sizeof(ZgFrame))) ||

@@ -199,7 +199,12 @@ class Engine {
   int prepare_blocks(const uint8_t* src, size_t len, const HostBlock* hb, size_t n, FrameState* fs, uint64_t keep, Batch** out);
   hipStream_t stream() const { return stream_; }
   hipStream_t copy_stream() const { return stream2_; }
-  hipStream_t download_stream() const { return stream3_; }   // D2H of a finished submit while the next one runs (zgpu_pool_decode_all): nothing else uses it then
+  hipStream_t download_stream() const { return stream3_; }
+  hipStream_t upload_stream() const { return stream4_; }     // H2D of a run's bytes ahead of its prepare (the streaming decoder's worker): nothing else uses it
+  // A caller that has brought the NEXT submit's compressed bytes to the device already (asynchronously, on upload_stream(), while the submit in
+  // front was running) says so here: upload() then takes them from there (a device-to-device copy behind the event) instead of from the host.
+  struct PreUpload { const uint8_t* host = nullptr; size_t len = 0; const void* dev = nullptr; hipEvent_t done = nullptr; };
+  PreUpload preup;   // D2H of a finished submit while the next one runs (zgpu_pool_decode_all): nothing else uses it then
   int device() const { return device_; }
   int compute_units() const { return cus_; }
   const Tuning& tuning() const { return tn_; }
@@ -212,7 +217,7 @@ class Engine {
   Tuning tn_;                    // the ZGPU_* switches as they were when the engine was created
   bool no_presize_ = false;      // (ZGPU_PRESIZE=0: measurement / tests) never size the output before the run
   int flat_shape_ = 0;           // zg_k_flatten shape: 0 = 1024 threads x 16 KiB tiles (one workgroup per CU), 1 = 512 x 8 KiB (two)
-  hipStream_t stream_ = nullptr, stream2_ = nullptr, stream3_ = nullptr;   // stream3_: the flatten, when the sweep chain runs beside it
+  hipStream_t stream_ = nullptr, stream2_ = nullptr, stream3_ = nullptr, stream4_ = nullptr;   // stream3_: the flatten, when the sweep chain runs beside it
   std::vector<Scratch*> free_;   // finished submits' buffers, for reuse
   Scratch* acquire();
   void recycle(Scratch* s);

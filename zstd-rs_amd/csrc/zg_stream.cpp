@@ -3,6 +3,7 @@
 // and the zgpu_streaming_* entry points of include/zgpu.h.
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -55,23 +56,72 @@ struct PinnedCache {
 };
 PinnedCache g_pinned;
 
+// Engines of streaming decoders that are not in use. A stream whose worker thread decodes ahead has an engine of its own (streams, scratch
+// buffers sized to its runs); the next stream on the same device takes it over instead of allocating all of that again. Process-wide (a
+// stream may outlive the context it was made from), at most two per device.
+struct IdleEngines {
+  std::mutex mu;
+  std::vector<Engine*> v;
+  Engine* take(int device) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (size_t i = 0; i < v.size(); i++) if (v[i]->device() == device) { Engine* e = v[i]; v.erase(v.begin() + i); return e; }
+    return nullptr;
+  }
+  void give(Engine* e) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      size_t same = 0;
+      for (Engine* x : v) same += x->device() == e->device();
+      if (same < 2) { v.push_back(e); return; }
+    }
+    delete e;
+  }
+};
+IdleEngines g_idle_engines;
+
 class GpuStreamBackend : public StreamBackend {
  public:
   explicit GpuStreamBackend(zgpu_decoder* d) : d_(d), eng_(d->ctx->eng) {}
-  ~GpuStreamBackend() override { delete b_; delete own_; }
+  ~GpuStreamBackend() override {
+    delete b_;
+    if (own_) {
+      (void)hipSetDevice(own_->device());
+      (void)hipStreamSynchronize(own_->upload_stream());
+      own_->preup = Engine::PreUpload();
+      g_idle_engines.give(own_);
+    }
+    for (auto& e : pre_ev_) if (e) (void)hipEventDestroy(e);
+    for (auto& b : pre_) b.release();
+  }
 
   int run(const uint8_t* src, size_t len, uint32_t nblocks, uint64_t keep, StreamRun* out) override {
     delete b_; b_ = nullptr;
     FrameState* fs = &d_->fs;
-    // the plaintext of the run in front may still be on its way to the host: nothing may move under it
-    if (fetching_ && fs->room_moves((uint64_t)nblocks * kMaxBlockSize, keep)) { const int w = fetch_wait(); if (w) return w; }
+    // the plaintext of the run in front may still be on its way to the host: nothing may move under it. A move is harmless when the
+    // buffer is compacted in place and both what moves (the kept tail, to the front) and what this run will write behind it stay in
+    // FRONT of the bytes that are being fetched — the window is reserved for three runs, so that is the usual case.
+    const uint64_t bound = (uint64_t)nblocks * kMaxBlockSize;
+    if (fetching_ && fs->room_moves(bound, keep)) {
+      const uint64_t k2 = keep < fs->have ? keep : fs->have;
+      const bool inplace = fs->d_out.p && !fs->base && kOutFront + k2 + bound + 64 <= fs->d_out.cap;
+      const bool safe = inplace && k2 + bound <= committed_base_ && fs->have - k2 >= k2;
+      if (!safe) { const int w = fetch_wait(); if (w) return w; }
+    }
+    eng_->preup = (pre_next_.host == src && pre_next_.len == len) ? pre_next_ : Engine::PreUpload();
+    pre_next_ = Engine::PreUpload();
     size_t used = 0;
+    const auto t0 = std::chrono::steady_clock::now();
     int st = eng_->prepare_run(src, len, fs, d_->fh.content_checksum(), nblocks, keep, &b_, &used);
     if (st) { b_ = nullptr; return st; }
     const size_t nb = b_->bb.blocks.size();
     if (nb == 0) { const int ps = b_->parse_status; delete b_; b_ = nullptr; return ps ? ps : ZGPU_E_INTERNAL; }
     b_->drain_rule = d_->drain_rule;
+    const auto t1 = std::chrono::steady_clock::now();
     if ((st = b_->run()) || (st = b_->sync())) { delete b_; b_ = nullptr; return st; }
+    const auto t2 = std::chrono::steady_clock::now();
+    us_prepare += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count();
+    us_kernels += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(t2 - t1).count();
+    for (int i = 0; i < ZG_T_COUNT; i++) kus[i] += (uint64_t)(b_->ms[i] * 1000.f);
     if (b_->frame_out.empty()) { delete b_; b_ = nullptr; return ZGPU_E_INTERNAL; }
     const ZgFrameOut fo = b_->frame_out[0];          // (a failed frame: out_size ends with its last good block, Batch::sync)
     out->nblocks = (uint32_t)nb;
@@ -122,11 +172,25 @@ class GpuStreamBackend : public StreamBackend {
     fs.have = n;
     return ZGPU_OK;
   }
+  // bring the NEXT run's compressed bytes to the device while the current run is decoded (worker thread, its own DMA stream)
+  void prefetch(const uint8_t* src, size_t len) override {
+    if (!own_ || eng_ != own_ || !len || pre_next_.host == src) return;
+    const int i = pre_i_ ^= 1;
+    if (hipSetDevice(eng_->device()) != hipSuccess) return;
+    if (!pre_ev_[i] && hipEventCreateWithFlags(&pre_ev_[i], hipEventDisableTiming) != hipSuccess) { pre_ev_[i] = nullptr; return; }
+    if (pre_[i].reserve(len)) return;                 // (no memory: the run is uploaded the plain way)
+    if (hipMemcpyAsync(pre_[i].p, src, len, hipMemcpyHostToDevice, eng_->upload_stream()) != hipSuccess ||
+        hipEventRecord(pre_ev_[i], eng_->upload_stream()) != hipSuccess) { (void)hipGetLastError(); return; }
+    pre_next_.host = src; pre_next_.len = len; pre_next_.dev = pre_[i].p; pre_next_.done = pre_ev_[i];
+  }
   int pipe_begin(uint64_t window_bytes) override {
     // the worker thread gets an engine of its own (streams, scratch pool): the context's engine stays with the caller's thread
     if (!own_) {
-      const int st = Engine::create(d_->ctx->eng->device(), &own_);
-      if (st) { own_ = nullptr; return st; }
+      own_ = g_idle_engines.take(d_->ctx->eng->device());
+      if (!own_) {
+        const int st = Engine::create(d_->ctx->eng->device(), &own_);
+        if (st) { own_ = nullptr; return st; }
+      }
       own_->max_window = d_->ctx->eng->max_window;
     }
     const int st = d_->fs.reserve_window(d_->fs.base + window_bytes + (1u << 20), d_->ctx->eng->stream());
@@ -134,10 +198,17 @@ class GpuStreamBackend : public StreamBackend {
     eng_ = own_;
     return ZGPU_OK;
   }
-  void pipe_end() override { (void)fetch_wait(); eng_ = d_->ctx->eng; }
+  void pipe_end() override {
+    (void)fetch_wait();
+    if (own_) { (void)hipStreamSynchronize(own_->upload_stream()); own_->preup = Engine::PreUpload(); }
+    pre_next_ = Engine::PreUpload();
+    eng_ = d_->ctx->eng;
+  }
   void thread_init() override { (void)hipSetDevice(eng_->device()); }
   void* host_alloc(size_t n) override { return g_pinned.get(n); }
   void host_free(void* p, size_t) override { g_pinned.put(p); }
+  // diagnostics (zgpu_streaming_stats): host microseconds in prepare (walk + upload) and in run + sync, the kernels' HIP-event times summed over the runs
+  uint64_t us_prepare = 0, us_kernels = 0, kus[ZG_T_COUNT] = {};
 
  private:
   zgpu_decoder* d_;
@@ -146,6 +217,10 @@ class GpuStreamBackend : public StreamBackend {
   Batch* b_ = nullptr;
   uint64_t run_base_ = 0, committed_base_ = 0;
   bool fetching_ = false;
+  DevBuf pre_[2];                       // the next run's compressed bytes, uploaded ahead
+  hipEvent_t pre_ev_[2] = {nullptr, nullptr};
+  int pre_i_ = 0;
+  Engine::PreUpload pre_next_;
 };
 
 }  // namespace
@@ -299,8 +374,11 @@ int zgpu_streaming_copy(zgpu_streaming* s, size_t buf_size, zgpu_write_fn write,
 
 int zgpu_streaming_stats(const zgpu_streaming* s, uint64_t* out, int n) {
   if (!s || !out || n <= 0) return 0;
-  const uint64_t v[4] = {(uint64_t)s->core->mode(), s->core->runs(), s->core->dropped_runs(), s->core->host_bytes()};
-  const int k = n < 4 ? n : 4;
+  uint64_t v[24] = {(uint64_t)s->core->mode(), s->core->runs(), s->core->dropped_runs(), s->core->host_bytes()};
+  for (int i = 0; i < 8; i++) v[4 + i] = s->core->tus[i].load();
+  v[12] = s->be->us_prepare; v[13] = s->be->us_kernels;
+  for (int i = 0; i < ZG_T_COUNT && i < 10; i++) v[14 + i] = s->be->kus[i];
+  const int k = n < 24 ? n : 24;
   for (int i = 0; i < k; i++) out[i] = v[i];
   return k;
 }

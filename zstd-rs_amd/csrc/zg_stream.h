@@ -64,6 +64,7 @@ class StreamBackend {
   // LOCKSTEP after PIPE: the reference's buffer holds everything the reader has not drained, and a (non-conforming) match may reach all
   // of it: make the frame's most recent n bytes (host copy at `held`) reachable on the device again
   virtual int rebase(const uint8_t* held, uint64_t n) = 0;
+  virtual void prefetch(const uint8_t* src, size_t len) {}         // worker thread: the NEXT run's bytes may start travelling to the device now
   virtual int pipe_begin(uint64_t window_bytes) { return 0; }       // the calling thread hands the engine to a worker (own streams, window reserved)
   virtual void pipe_end() {}
   virtual void thread_init() {}                                     // first call on the worker thread
@@ -76,7 +77,7 @@ struct StreamOpts {
   bool hash = true;                 // XXH64 of the drained bytes (ruzstd's `hash` feature, default on)
   uint32_t first_run_blocks = 8;    // INLINE: blocks of the first run; each later one holds four times as many
   uint64_t pipe_after = 32ull << 20;   // INLINE -> PIPE once this many bytes are decoded and the frame goes on (or at once, when the header declares more)
-  uint32_t copy_threads = 3;        // PIPE: helper threads for reads of 4 MiB and more
+  uint32_t copy_threads = 3;        // PIPE: helper threads for reads of 512 KiB and more
   uint64_t max_run_src = 96ull << 20;  // PIPE: source bytes per run at most (size of a staging buffer)
   bool allow_pipe = true;
 };
@@ -238,7 +239,7 @@ class StreamCopyPool {
   }
   void copy(uint8_t* dst, const uint8_t* src, size_t n) {
     const size_t nt = th_.size();
-    if (!nt || n < (4u << 20)) { memcpy(dst, src, n); return; }
+    if (!nt || n < (512u << 10)) { memcpy(dst, src, n); return; }
     const size_t share = ((n / (nt + 1)) + 4095) & ~(size_t)4095;
     size_t off = share < n ? share : n;                 // [0, off) is the caller's
     uint32_t used = 0;
@@ -285,6 +286,15 @@ class StreamCopyPool {
 class StreamCore {
  public:
   enum Mode { INLINE = 0, PIPE = 1, LOCKSTEP = 2 };
+  // where the time goes (microseconds; diagnostics, zgpu_streaming_stats): worker — [0] waiting for a run from the reader, [1] in the
+  // backend's run (parse + upload + kernels), [2] waiting for the previous run's download, [3] commit, [4] waiting for room in the ring;
+  // reader — [5] waiting for bytes, [6] copying out of the ring, [7] taking runs from the source
+  std::atomic<uint64_t> tus[8] = {};
+  struct Tick {
+    std::atomic<uint64_t>* a; std::chrono::steady_clock::time_point t0;
+    explicit Tick(std::atomic<uint64_t>* x) : a(x), t0(std::chrono::steady_clock::now()) {}
+    ~Tick() { a->fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed); }
+  };
   StreamSrc src;
   // the frame (set by the owner before the first read)
   uint64_t window = 0;
@@ -536,7 +546,7 @@ class StreamCore {
         s.cap = scap;
       }
     }
-    int st = be_->pipe_begin(window + 2 * run_bytes_);
+    int st = be_->pipe_begin(window + 3 * run_bytes_);   // (three runs: the device window is compacted without waiting for the run that is being fetched)
     if (st) { free_pipe_memory(); return st; }
     // what the inline runs left undrained becomes the ring's first content: one source of bytes from here on
     const size_t h = held_buf();
@@ -568,7 +578,7 @@ class StreamCore {
       {
         std::lock_guard<std::mutex> lk(mu_);
         if (stopping_ || pstate_.load(std::memory_order_relaxed) != P_RUNNING) return;
-        if (jobs_.size() + (worker_busy_ ? 1u : 0u) >= 2u) return;
+        if (jobs_.size() + (worker_busy_ ? 1u : 0u) >= 3u) return;   // the one being decoded, the one whose bytes travel to the device, one more
         if (src.ended || src_stop_) return;
         if (!src.is_slice()) {
           for (size_t i = 0; i < stages_.size(); i++) if (!stages_[i].busy) { sb = (int)i; break; }
@@ -578,8 +588,9 @@ class StreamCore {
       }
       StreamStage st;
       if (sb >= 0) { st.own = stages_[sb].p; st.own_cap = stages_[sb].cap; }
+      Tick tk(&tus[7]);
       src.pull(pipe_ramp_ < run_blocks_ ? pipe_ramp_ : run_blocks_, (size_t)o_.max_run_src, true, &st, nullptr);
-      if (pipe_ramp_ < run_blocks_) pipe_ramp_ *= 4;      // the first runs are short (the first read returns soon), the later ones as long as the budget allows
+      if (pipe_ramp_ < run_blocks_) pipe_ramp_ *= 8;      // the first runs are short (the first read returns soon), the later ones as long as the budget allows
       if (st.stop) src_stop_ = true;                    // what cannot be read whole stays in the source: LOCKSTEP meets it when its turn comes
       std::lock_guard<std::mutex> lk(mu_);
       if (stopping_ || pstate_.load(std::memory_order_relaxed) != P_RUNNING) {
@@ -602,7 +613,7 @@ class StreamCore {
       if (no_more_jobs_) return;
     }
   }
-  uint32_t pipe_ramp_ = 64;
+  uint32_t pipe_ramp_ = 256;
   bool src_stop_ = false;          // the source could not yield the next whole block (its error waits for LOCKSTEP)
   bool no_more_jobs_ = false;      // (under mu_) the reader will queue nothing more
 
@@ -612,9 +623,12 @@ class StreamCore {
   }
   // worker: bring the committed run's n bytes into the ring (waits for room; returns early when the reader wants to stop)
   int fetch_to_ring(uint64_t n, bool wait_done) {
-    while (ring_free() < n) {
-      { std::lock_guard<std::mutex> lk(mu_); if (stop_req_) return ZG_OK; }
-      std::this_thread::sleep_for(std::chrono::microseconds(40));
+    if (ring_free() < n) {
+      Tick tk(&tus[4]);
+      while (ring_free() < n) {
+        { std::lock_guard<std::mutex> lk(mu_); if (stop_req_) return ZG_OK; }
+        std::this_thread::sleep_for(std::chrono::microseconds(40));
+      }
     }
     const uint64_t w = reserved_ % ring_cap_;
     const uint64_t first = n < ring_cap_ - w ? n : ring_cap_ - w;
@@ -646,7 +660,10 @@ class StreamCore {
     be_->thread_init();
     for (;;) {
       Job job;
+      const uint8_t* next_p = nullptr;
+      size_t next_len = 0;
       {
+        Tick tk(&tus[0]);
         std::unique_lock<std::mutex> lk(mu_);
         cv_worker_.wait(lk, [&]() { return stop_req_ || !jobs_.empty() || no_more_jobs_; });
         if (stop_req_) break;
@@ -658,10 +675,14 @@ class StreamCore {
         }
         job = jobs_.front(); jobs_.pop_front();
         worker_busy_ = true;
+        if (!jobs_.empty()) { next_p = jobs_.front().p; next_len = jobs_.front().len; }
       }
+      if (next_p) be_->prefetch(next_p, next_len);
       StreamRun r;
-      int e = be_->run(job.p, job.len, job.nblocks, window, &r);
-      const int e2 = land_fetch();              // the run in front travelled to the ring meanwhile
+      int e;
+      { Tick tk(&tus[1]); e = be_->run(job.p, job.len, job.nblocks, window, &r); }
+      int e2;
+      { Tick tk(&tus[2]); e2 = land_fetch(); }  // the run in front travelled to the ring meanwhile
       if (!e) e = e2;
       if (e) { be_->discard(); give_back(job, 0); set_pstate(P_FAILED, e); return; }
       if (!clean(r, job.nblocks)) {
@@ -673,7 +694,8 @@ class StreamCore {
         set_pstate(e ? P_FAILED : P_STOPPED, e);
         return;
       }
-      if ((e = be_->commit())) { set_pstate(P_FAILED, e); return; }
+      { Tick tk(&tus[3]); e = be_->commit(); }
+      if (e) { set_pstate(P_FAILED, e); return; }
       account(r, job.len, job.nblocks, true);
       runs_++;
       e = fetch_to_ring(r.out_size, false);
@@ -737,8 +759,8 @@ class StreamCore {
     const uint64_t w = t % ring_cap_;
     const uint64_t first = n < ring_cap_ - w ? n : ring_cap_ - w;
     if (dst) {
-      pool_.copy(dst, ring_ + w, first);
-      if (n > first) pool_.copy(dst + first, ring_, n - first);
+      if (n >= (1u << 20)) { Tick tk(&tus[6]); pool_.copy(dst, ring_ + w, first); if (n > first) pool_.copy(dst + first, ring_, n - first); }
+      else { memcpy(dst, ring_ + w, first); if (n > first) memcpy(dst + first, ring_, n - first); }
     }
     tail_.store(t + n, std::memory_order_release);
   }
@@ -770,6 +792,7 @@ class StreamCore {
       }
       if (ps == P_RUNNING) {
         produce_jobs();
+        Tick tk(&tus[5]);
         std::unique_lock<std::mutex> lk(mu_);
         const uint64_t seen = pub_.load(std::memory_order_relaxed);
         cv_reader_.wait_for(lk, std::chrono::milliseconds(2), [&]() { return pub_.load(std::memory_order_relaxed) != seen || pstate_.load(std::memory_order_relaxed) != P_RUNNING; });

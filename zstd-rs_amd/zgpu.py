@@ -50,6 +50,14 @@ class Block(C.Structure):
                 ("pad", C.c_uint8 * 6)]
 
 
+class StreamOpts(C.Structure):
+    """zgpu_stream_opts (include/zgpu.h)"""
+    _fields_ = [("read_ahead_bytes", C.c_uint64), ("no_checksum", C.c_uint32), ("copy_threads", C.c_uint32), ("pipe_after_bytes", C.c_uint64),
+                ("first_run_blocks", C.c_uint32), ("pad", C.c_uint32)]
+
+
+NO_READ_AHEAD = 1
+
 EXPORTS = [
     "zgpu_ctx_create", "zgpu_ctx_destroy", "zgpu_set_max_window_size", "zgpu_max_window_size", "zgpu_last_error", "zgpu_status_name",
     "zgpu_decode_all", "zgpu_batch_prepare", "zgpu_batch_run", "zgpu_batch_sync", "zgpu_batch_num_frames", "zgpu_batch_num_blocks",
@@ -64,6 +72,8 @@ EXPORTS = [
     "zgpu_pool_num_gpus", "zgpu_pool_decode_all", "zgpu_pool_plan", "zgpu_pool_stage", "zgpu_pool_run", "zgpu_pool_frame", "zgpu_pool_read", "zgpu_pool_timings", "zgpu_pool_plan_stats",
     "zgpu_frame_begin", "zgpu_frame_end", "zgpu_blocks_submit", "zgpu_sync", "zgpu_available", "zgpu_read", "zgpu_device_output",
     "zgpu_frame_checksum", "zgpu_frame_blocks_decoded", "zgpu_decoder_device_bytes", "zgpu_debug_tuning",
+    "zgpu_streaming_create_ex", "zgpu_streaming_create_slice", "zgpu_streaming_source_position", "zgpu_streaming_copy", "zgpu_streaming_stats",
+    "zgpu_decoder_set_hash", "zgpu_decoder_set_read_ahead",
 ]
 WRITE_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
 READ_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
@@ -182,6 +192,16 @@ def _declare(L):
     L.zgpu_pool_timings.argtypes = [vp, C.c_uint32, P(C.c_float), C.c_int, P(C.c_uint64), P(C.c_uint64), P(C.c_uint32), P(C.c_uint32)]
     L.zgpu_pool_plan_stats.argtypes = [vp, C.c_uint32, P(C.c_uint64), C.c_int]
     L.zgpu_debug_tuning.argtypes = [vp, P(C.c_uint32), C.c_int]
+    L.zgpu_streaming_create_ex.argtypes = [vp, READ_FN, vp, P(StreamOpts), P(vp)]
+    L.zgpu_streaming_create_slice.argtypes = [vp, vp, sz, P(StreamOpts), P(vp)]
+    L.zgpu_streaming_source_position.argtypes = [vp]
+    L.zgpu_streaming_source_position.restype = sz
+    L.zgpu_streaming_copy.argtypes = [vp, sz, vp, vp, P(C.c_uint64)]
+    L.zgpu_streaming_stats.argtypes = [vp, P(C.c_uint64), C.c_int]
+    L.zgpu_decoder_set_hash.argtypes = [vp, C.c_int]
+    L.zgpu_decoder_set_read_ahead.argtypes = [vp, C.c_uint64]
+    for f in ("zgpu_decoder_is_finished", "zgpu_decoder_checksum_from_data"):
+        getattr(L, f).argtypes = [vp] if f.endswith("finished") else [vp, P(C.c_uint32)]
     return L
 
 
@@ -460,6 +480,12 @@ class FrameDecoder:
     def is_finished(self):
         return bool(self.L.zgpu_decoder_is_finished(self.h))
 
+    def set_hash(self, on):
+        self.L.zgpu_decoder_set_hash(self.h, 1 if on else 0)
+
+    def set_read_ahead(self, n):
+        self.L.zgpu_decoder_set_read_ahead(self.h, n)
+
     def blocks_decoded(self):
         return self.L.zgpu_decoder_blocks_decoded(self.h)
 
@@ -590,18 +616,31 @@ class Pool:
 
 
 class CStreamingDecoder:
-    """zgpu_streaming (the C-ABI mirror of StreamingDecoder, streaming_decoder.rs:40-156) over a Python file-like source"""
+    """zgpu_streaming (the C-ABI mirror of StreamingDecoder, streaming_decoder.rs:40-156) over a Python file-like source, or over
+    bytes / a numpy array (source=None, data=...: zgpu_streaming_create_slice, nothing is copied on the host).
+    read_ahead: bytes decoded ahead of the reader at most (ring size); NO_READ_AHEAD: the reference's block-by-block schedule."""
 
-    def __init__(self, ctx, source):
-        self.L, self.source = ctx.L, source
-
-        def rd(_user, dst, n):
-            b = source.read(n)
-            C.memmove(dst, b, len(b))
-            return len(b)
-        self._cb = READ_FN(rd)
+    def __init__(self, ctx, source=None, data=None, read_ahead=0, checksum=True, pipe_after=0, first_run_blocks=0, copy_threads=0):
+        self.L, self.source, self.ctx = ctx.L, source, ctx      # (the context must outlive the stream)
+        o = StreamOpts(read_ahead, 0 if checksum else 1, copy_threads, pipe_after, first_run_blocks, 0)
         h = C.c_void_p()
-        st = self.L.zgpu_streaming_create(ctx.h, self._cb, None, C.byref(h))
+        if source is not None:
+            def rd(_user, dst, n):
+                b = source.read(n)
+                C.memmove(dst, b, len(b))
+                return len(b)
+            self._cb = READ_FN(rd)
+            st = self.L.zgpu_streaming_create_ex(ctx.h, self._cb, None, C.byref(o), C.byref(h))
+        else:
+            self._keep = data
+            if isinstance(data, (bytes, bytearray)):
+                self._buf = (C.c_char * len(data)).from_buffer_copy(data) if isinstance(data, bytes) else (C.c_char * len(data)).from_buffer(data)
+                ptr, n = C.addressof(self._buf), len(data)
+            elif isinstance(data, tuple):                  # (address, length): e.g. pinned memory of a torch tensor
+                ptr, n = data
+            else:                                          # numpy array
+                ptr, n = data.ctypes.data, data.nbytes
+            st = self.L.zgpu_streaming_create_slice(ctx.h, ptr, n, C.byref(o), C.byref(h))
         if st:
             raise ZgpuError(st)
         self.h = h
@@ -614,11 +653,56 @@ class CStreamingDecoder:
             raise ZgpuError(st)
         return buf.raw[:got.value]
 
-    def device_bytes(self):
-        """device memory the frame holds right now (zgpu_decoder_device_bytes of the decoder behind the stream)"""
+    def read_into(self, addr, n):
+        """read(&mut buf[..n]) into memory the caller owns; returns the byte count"""
+        got = C.c_size_t()
+        st = self.L.zgpu_streaming_read(self.h, addr, n, C.byref(got))
+        if st:
+            raise ZgpuError(st)
+        return got.value
+
+    def copy_to_sink(self, buf_size):
+        """std::io::copy(&mut decoder, &mut io::sink()) with a buffer of buf_size bytes; returns the bytes copied"""
+        total = C.c_uint64()
+        st = self.L.zgpu_streaming_copy(self.h, buf_size, None, None, C.byref(total))
+        if st:
+            raise ZgpuError(st)
+        return total.value
+
+    def _dec(self):
         self.L.zgpu_streaming_decoder.restype = C.c_void_p
         self.L.zgpu_streaming_decoder.argtypes = [C.c_void_p]
-        return self.L.zgpu_decoder_device_bytes(self.L.zgpu_streaming_decoder(self.h))
+        return self.L.zgpu_streaming_decoder(self.h)
+
+    def device_bytes(self):
+        """device memory the frame holds right now (zgpu_decoder_device_bytes of the decoder behind the stream)"""
+        return self.L.zgpu_decoder_device_bytes(self._dec())
+
+    def is_finished(self):
+        return bool(self.L.zgpu_decoder_is_finished(self._dec()))
+
+    def get_calculated_checksum(self):
+        return self.L.zgpu_decoder_calculated_checksum(self._dec())
+
+    def get_checksum_from_data(self):
+        v = C.c_uint32()
+        return v.value if self.L.zgpu_decoder_checksum_from_data(self._dec(), C.byref(v)) else None
+
+    def blocks_decoded(self):
+        return self.L.zgpu_decoder_blocks_decoded(self._dec())
+
+    def bytes_read_from_source(self):
+        return self.L.zgpu_decoder_bytes_read_from_source(self._dec())
+
+    def source_position(self):
+        return self.L.zgpu_streaming_source_position(self.h)
+
+    def stats(self):
+        a = (C.c_uint64 * 24)()
+        self.L.zgpu_streaming_stats(self.h, a, 24)
+        return dict(zip(["mode", "runs", "dropped", "host_bytes", "us_worker_idle", "us_run", "us_land", "us_commit", "us_ring_full", "us_reader_wait",
+                         "us_reader_copy", "us_pull", "us_prepare", "us_kernels", "k_tables", "k_huf", "k_seq", "k_seqpost", "k_scan", "k_lit", "k_flat",
+                         "k_sweep", "k_lz", "k_total"], [int(x) for x in a]))
 
     def close(self):
         if getattr(self, "h", None):
