@@ -44,7 +44,30 @@ class TableBackend : public StreamBackend {
   uint64_t last_reason = 0;
   void obj(uint64_t why) { bad_src++; last_reason = why; }
 
-  int run(const uint8_t* src, size_t len, uint32_t nblocks, uint64_t keep, StreamRun* o) override {
+  // prepare / launch / wait like the engine's backend: one run may be prepared while another is "on the device"
+  const uint8_t* p_src = nullptr; size_t p_len = 0; uint32_t p_nblocks = 0; bool have_prep = false;
+  StreamRun cur;
+  bool launched = false;
+  int prepare(const uint8_t* src, size_t len, uint32_t nblocks) override {
+    if (have_prep) obj(7);
+    p_src = src; p_len = len; p_nblocks = nblocks; have_prep = true;
+    return ZG_OK;
+  }
+  void drop_prepared() override { have_prep = false; }
+  int launch(uint64_t keep) override {
+    if (!have_prep) { obj(8); return ZG_INTERNAL; }
+    have_prep = false;
+    const int e = run_now(p_src, p_len, p_nblocks, keep, &cur);
+    launched = e == ZG_OK;
+    return e;
+  }
+  int wait(StreamRun* o) override {
+    if (!launched) { obj(9); return ZG_INTERNAL; }
+    launched = false;
+    *o = cur;
+    return ZG_OK;
+  }
+  int run_now(const uint8_t* src, size_t len, uint32_t nblocks, uint64_t keep, StreamRun* o) {
     nruns++;
     if (have_run) obj(1);                                               // a run must be committed or dropped before the next one
     if (next + nblocks > t->out.size() || nblocks == 0) { obj(2); return ZG_INTERNAL; }
@@ -68,6 +91,7 @@ class TableBackend : public StreamBackend {
     have_run = true; run_blocks = nblocks; run_good = o->good_blocks; run_out = o->out_size;
     return ZG_OK;
   }
+
   int commit() override {
     if (!have_run) { obj(5); return ZG_INTERNAL; }
     have_run = false; ncommits++;
@@ -168,3 +192,28 @@ void zgemu_stream_stats(void* hp, uint64_t* out) {
 }
 
 }  // extern "C"
+
+// StreamCopyPool on its own: every size around the share boundaries with 1..4 helpers; returns the number of sizes that copied wrong
+extern "C" int zgemu_pool_selftest(uint32_t seed) {
+  int bad = 0;
+  std::vector<uint8_t> src(12u << 20), dst(12u << 20);
+  uint32_t x = seed * 2654435761u + 1u;
+  for (auto& b : src) { x = x * 1664525u + 1013904223u; b = (uint8_t)(x >> 24); }
+  for (uint32_t nt = 1; nt <= 4; nt++) {
+    StreamCopyPool pool;
+    pool.start(nt);
+    for (uint32_t k = 0; k < 160; k++) {
+      x = x * 1664525u + 1013904223u;
+      const size_t unit = (size_t)((x >> 8) % 600 + 128) * 4096;            // a page-aligned share ...
+      for (int d = -2; d <= 2; d++) {                                       // ... times (nt + 1), and a few bytes around it
+        const size_t n = unit * (nt + 1) + (size_t)(d + 2);
+        if (n > src.size()) continue;
+        memset(dst.data(), 0, n);
+        pool.copy(dst.data(), src.data(), n);
+        if (memcmp(dst.data(), src.data(), n) != 0) bad++;
+      }
+    }
+    pool.stop();
+  }
+  return bad;
+}

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""rocprofv3 outputs of tools/dev/profile.sh (gpurun_out/prof/<workload>/...) -> the summaries kept under profiles/r05/.
+"""rocprofv3 outputs of tools/dev/profile.sh (gpurun_out/prof/<workload>/...) -> the summaries kept under profiles/r06/.
 
   --reduce W..  (on the GPU box) condense the counter CSVs into gpurun_out/prof/pmc_reduced.json: per workload and kernel the summed
                 counter and the number of launches; the SQ-counter CSVs are cut down to the engine's kernels (one row per launch
                 and counter: the raw evidence kept under profiles/). The bulky traces stay behind.
-  (default)     (here) write profiles/r05/: per workload <w>_kernel_stats.csv, <w>_bench_under_rocprof.json and <w>_pmc.json: HBM bytes
+  (default)     (here) write profiles/r06/: per workload <w>_kernel_stats.csv, <w>_bench_under_rocprof.json and <w>_pmc.json: HBM bytes
                 per pass per kernel, raw and calibrated PER ACCESS PATTERN. On gfx950 FETCH_SIZE reports half of a wide coalesced
                 read (MI355X_MICROARCH.md, HBM section); what it reports for the engine's other patterns is measured by the
                 calibration kernels (zg_k_calib_*): the factor applied to a kernel is that of the pattern its reads are made of.
@@ -12,7 +12,7 @@
 import collections, csv, glob, hashlib, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 P = os.path.join(ROOT, "gpurun_out", "prof")
-OUT = os.path.join(ROOT, "profiles", "r05")
+OUT = os.path.join(ROOT, "profiles", "r06")
 CSRC = os.path.join(ROOT, "zstd-rs_amd", "csrc")
 
 

@@ -4,13 +4,13 @@
 #   <w>/fetch, <w>/write  HBM byte counters, separate passes (FETCH_SIZE and WRITE_SIZE do not fit one)
 # plus, once: a calibration of the byte counters on kernels with known traffic per access pattern (zg_k_calib_*), and for the
 # first workload the SQ counters of the two LZ77 kernels (raw CSVs, one row per launch).
-# Writes under gpurun_out/prof; tools/dev/pmc_summary.py turns that into profiles/r05/.
+# Writes under gpurun_out/prof; tools/dev/pmc_summary.py turns that into profiles/r06/.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-WL=${*:-"enwik9like blocks blocks4b iso silesia12 realtext"}
+WL=${*:-"enwik9like realtext1g blocks blocks4b iso silesia12 realtext"}
 B="--no-cpu --no-e2e --no-other --min-seconds 0"
 first=1
 for w in $WL; do

@@ -44,6 +44,7 @@ int Scratch::init_events() {
     if (hipEventCreate(&e) != hipSuccess) return ZG_HIP_ERROR;
   if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return ZG_HIP_ERROR;
   if (hipEventCreateWithFlags(&ev_fork3, hipEventDisableTiming) != hipSuccess) return ZG_HIP_ERROR;
+  if (hipEventCreateWithFlags(&ev_up, hipEventDisableTiming) != hipSuccess) return ZG_HIP_ERROR;
   for (auto& e : ev_sw)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return ZG_HIP_ERROR;
   for (auto& e : ev_flat)
@@ -66,6 +67,7 @@ void Scratch::release() {
     if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
   if (ev_fork3) { (void)hipEventDestroy(ev_fork3); ev_fork3 = nullptr; }
+  if (ev_up) { (void)hipEventDestroy(ev_up); ev_up = nullptr; }
   for (auto& e : ev_sw)
     if (e) { (void)hipEventDestroy(e); e = nullptr; }
   for (auto& e : ev_flat)
@@ -256,6 +258,7 @@ Batch::~Batch() {
   if (sc && eng) {
     (void)hipSetDevice(eng->device_);
     (void)hipStreamSynchronize(eng->stream_); (void)hipStreamSynchronize(eng->stream2_); (void)hipStreamSynchronize(eng->stream3_);
+    if (wait_upload) (void)hipStreamSynchronize(eng->stream4_);   // (prepared beside another submit and never run)
     eng->recycle(sc);
   }
 }
@@ -398,18 +401,22 @@ int Engine::prepare(const uint8_t* src, size_t len, Batch** out) {
   return upload(b, src, len, out);
 }
 
-int Engine::prepare_run(const uint8_t* src, size_t len, FrameState* fs, bool has_checksum, uint32_t max_blocks, uint64_t keep, Batch** out, size_t* consumed) {
+int Engine::prepare_run(const uint8_t* src, size_t len, FrameState* fs, bool has_checksum, uint32_t max_blocks, uint64_t keep, Batch** out, size_t* consumed,
+                        bool side, const uint32_t* carry_mask_now) {
   Batch* b = new Batch();
   b->eng = this;
   b->fs = fs;
   b->keep_bytes = keep;
-  b->parse_status = parse_block_run(src, len, fs->window_size, has_checksum, fs->hist, fs->carry_mask, max_blocks, &b->bb, &b->info, consumed,
+  // (carry_mask_now: the run in front has not been folded into fs yet — its caller says which tables will exist when this one starts; the
+  //  offset history is taken when the run is launched, Batch::run)
+  b->carry_mask_in = carry_mask_now ? *carry_mask_now : fs->carry_mask;
+  b->parse_status = parse_block_run(src, len, fs->window_size, has_checksum, fs->hist, b->carry_mask_in, max_blocks, &b->bb, &b->info, consumed,
                                     &b->saw_last_block);
   b->src_len = *consumed;
   b->bb.frames[0].fixed_base = 1;   // where its bytes go is decided in run(), when the size of the run is known
   int st;
   if ((st = fs->d_fse.reserve(ZG_FSE_SLOT_U32 * 4)) || (st = fs->d_huf.reserve(ZG_HUF_SLOT_U16 * 2))) { delete b; return st; }   // the tables it will carry on
-  return upload(b, src, *consumed, out);
+  return upload(b, src, *consumed, out, side);
 }
 
 int Engine::prepare_blocks(const uint8_t* src, size_t len, const HostBlock* hb, size_t n, FrameState* fs, uint64_t keep, Batch** out) {
@@ -446,9 +453,12 @@ int Engine::prepare_blocks(const uint8_t* src, size_t len, const HostBlock* hb, 
   return upload(b, src, len, out);
 }
 
-int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
+int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out, bool side) {
   Engine* eng = this;
   ZG_HIP(hipSetDevice(device_));
+  // side: the submit in front is still running on the main stream — everything this one brings to the device travels on the upload stream
+  // beside it, and its run() waits for the event instead of the host waiting here
+  hipStream_t us = side ? stream4_ : stream_;
   // a frame-layer error after some good frames: the good frames are still uploaded (callers such as the
   // FrameDecoder mirror may want them); decode_all reports parse_status.
   const Tuning& tn = tn_;                                      // (measurement / test switches, read when the engine was created)
@@ -467,21 +477,16 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   auto up = [&](DevBuf& d, const void* h, size_t bytes) -> int {
     int st = d.reserve(bytes ? bytes : 16);
     if (st) return st;
-    if (bytes && hipMemcpyAsync(d.p, h, bytes, hipMemcpyHostToDevice, stream_) != hipSuccess) return ZG_HIP_ERROR;
+    if (bytes && hipMemcpyAsync(d.p, h, bytes, hipMemcpyHostToDevice, us) != hipSuccess) return ZG_HIP_ERROR;
     return 0;
   };
   int st = 0;
   // compressed bytes, padded so that 8-byte bit-window loads near the end stay inside the allocation
   // ... and 64 bytes in front for the 16-byte windows of the sequence decoder
   if ((st = sc->d_src.reserve(len + 128))) { delete b; return st; }
-  (void)hipMemsetAsync(sc->d_src.p, 0, 64, stream_);
-  if (len && preup.dev && preup.host == src && preup.len == len) {
-    // the bytes are on the device already (brought there beside the submit in front): a device-to-device copy behind that upload
-    if (hipStreamWaitEvent(stream_, preup.done, 0) != hipSuccess ||
-        hipMemcpyAsync((uint8_t*)sc->d_src.p + 64, preup.dev, len, hipMemcpyDeviceToDevice, stream_) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
-  } else if (len && hipMemcpyAsync((uint8_t*)sc->d_src.p + 64, src, len, hipMemcpyHostToDevice, stream_) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
-  preup = PreUpload();
-  (void)hipMemsetAsync((uint8_t*)sc->d_src.p + 64 + len, 0, 64, stream_);
+  (void)hipMemsetAsync(sc->d_src.p, 0, 64, us);
+  if (len && hipMemcpyAsync((uint8_t*)sc->d_src.p + 64, src, len, hipMemcpyHostToDevice, us) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
+  (void)hipMemsetAsync((uint8_t*)sc->d_src.p + 64 + len, 0, 64, us);
   const uint32_t nslots = bb.nslots();
   if ((st = up(sc->d_blocks, bb.blocks.data(), nb * sizeof(ZgBlock))) || (st = up(sc->d_frames, bb.frames.data(), nf * sizeof(ZgFrame))) ||
       (st = up(sc->d_seqblocks, bb.seq_blocks.data(), bb.seq_blocks.size() * 4)) ||
@@ -535,7 +540,10 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out) {
   d.flags |= (uint32_t)flat_shape_ << 2;
   d.flags |= ((tn.flat_mode & 3u) << 4) | ((tn.flat_mode & 4u) << 5);   // (timing experiments) zg_k_flatten without scratch stores / gathers
   d.sweep_window = tn.sweep_w;
-  if (hipStreamSynchronize(stream_) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
+  if (side) {
+    if (hipEventRecord(sc->ev_up, us) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
+    b->wait_upload = true;
+  } else if (hipStreamSynchronize(stream_) != hipSuccess) { delete b; return ZG_HIP_ERROR; }
   *out = b;
   return ZG_OK;
 }
@@ -564,7 +572,15 @@ int Batch::run() {
       presized = true;
     }
   }
+  if (wait_upload) { ZG_HIP(hipStreamWaitEvent(s, sc->ev_up, 0)); wait_upload = false; }
   ZG_HIP(hipEventRecord(ev[0], s));
+  if (fs) {
+    // a continued frame: the offset history is the one the run in front has left (that run may have been folded into fs after this one
+    // was prepared: the streaming decoder prepares run k + 1 while run k is on the GPU)
+    ZgFrame& fr0 = bb.frames[0];
+    fr0.hist_init[0] = fs->hist[0]; fr0.hist_init[1] = fs->hist[1]; fr0.hist_init[2] = fs->hist[2];
+    ZG_HIP(hipMemcpyAsync((void*)d.frames, bb.frames.data(), sizeof(ZgFrame), hipMemcpyHostToDevice, s));
+  }
   ZG_HIP(hipMemsetAsync(d.status, 0, 3 * ((size_t)d.nblocks * 4 + 16), s));
   ZG_HIP(hipMemsetAsync(d.huf_maxbits, 0, d.nhuf_slots + 16, s));
   ZG_HIP(hipMemsetAsync(d.slot_log, 0, (size_t)d.nslots * 4, s));
@@ -828,6 +844,19 @@ int Batch::sync() {
   if (hipEventElapsedTime(&m, ev[0], ev[ZG_T_TOTAL]) == hipSuccess) ms[ZG_T_TOTAL] = m;
   synced = true;
   return ZG_OK;
+}
+
+// which tables exist once this run has been folded into the frame's state (what commit() will leave in FrameState::carry_mask): the
+// streaming decoder prepares the NEXT run while this one is still on the GPU
+uint32_t Batch::carry_mask_after() const {
+  uint32_t m = carry_mask_in;
+  if (bb.frames.empty()) return m;
+  const Lineage fl = bb.final_lineage();
+  const int32_t sl[3] = {fl.ll, fl.of, fl.ml};
+  const int32_t carry = (int32_t)bb.frames[0].carry_slot;
+  for (int k = 0; k < 3; k++) if (sl[k] >= 0 && sl[k] != carry) m |= 2u << k;
+  if (fl.huf >= 0 && fl.huf != (int32_t)bb.frames[0].carry_huf_slot) m |= 1u;
+  return m;
 }
 
 int Batch::commit(FrameState* st) {

@@ -76,6 +76,7 @@ struct Scratch {
   DevBuf d_src, d_blocks, d_frames, d_aux, d_slot_log, d_fse, d_huf, d_hufmax, d_status, d_lit, d_seq, d_seqout, d_pos, d_frameout,
       d_dst, d_seqblocks, d_hufitems, d_hufgroups, d_totals, d_og, d_units, d_unitinfo, d_stepunits, d_swdesc, d_dbg, d_raw, d_unitlist;
   hipEvent_t ev[ZG_T_COUNT + 1] = {};
+  hipEvent_t ev_up = nullptr;                     // a submit prepared beside another one: its uploads are done (Engine::upload side)
   hipEvent_t ev_huf[2] = {}, ev_fork = nullptr, ev_fork3 = nullptr;   // zg_k_huf runs on the engine's second stream beside zg_k_seq
   hipEvent_t ev_sw[80] = {};                      // split sweep: heads on the second stream (zg_launch_sweep)
   hipEvent_t ev_flat[2] = {};                     // the direct units' flatten on the second stream beside the pointer-mode units' (zg_launch_flat)
@@ -146,6 +147,9 @@ class Batch {
   int run();
   // streaming submits: after sync(), fold this run into the frame's carried state (tables, history, produced bytes)
   int commit(FrameState* fs);
+  uint32_t carry_mask_in = 0;            // streaming runs: the tables that existed when the run was parsed
+  uint32_t carry_mask_after() const;
+  bool wait_upload = false;              // prepared with side uploads: run() waits for them on the device
   bool saw_last_block = false;           // the run ended with the frame's last block
   int sync();                            // wait, download per-frame results, compute timings
   int size_output();                     // after the scan: read the frames' sizes, size output + flatten scratch exactly (one host round trip)
@@ -192,7 +196,10 @@ class Engine {
   // header itself). *consumed = bytes of the run (block headers, bodies, checksum).
   // max_blocks: 0 = up to the last block of the frame. fs carries the frame's state across calls; keep = frame bytes
   // that must stay reachable (FrameState::make_room).
-  int prepare_run(const uint8_t* src, size_t len, FrameState* fs, bool has_checksum, uint32_t max_blocks, uint64_t keep, Batch** out, size_t* consumed);
+  // side: the run in front (of the same frame) is still on the GPU — this run's bytes and tables travel on the upload stream beside it and its run()
+  // waits for them; carry_mask_now: the tables that will exist when it starts (Batch::carry_mask_after of the run in front), fs->carry_mask if null
+  int prepare_run(const uint8_t* src, size_t len, FrameState* fs, bool has_checksum, uint32_t max_blocks, uint64_t keep, Batch** out, size_t* consumed,
+                  bool side = false, const uint32_t* carry_mask_now = nullptr);
   // Same for blocks whose 3-byte headers the CALLER parsed (the thin boundary: ruzstd keeps read_block_header,
   // block_decoder.rs:201-247): hb[i] describes Block_Content i inside src. The run ends with the first block marked last.
   struct HostBlock { uint64_t src_off; uint32_t src_len; uint32_t raw_rle_size; uint8_t type; uint8_t last; };
@@ -200,11 +207,8 @@ class Engine {
   hipStream_t stream() const { return stream_; }
   hipStream_t copy_stream() const { return stream2_; }
   hipStream_t download_stream() const { return stream3_; }
-  hipStream_t upload_stream() const { return stream4_; }     // H2D of a run's bytes ahead of its prepare (the streaming decoder's worker): nothing else uses it
-  // A caller that has brought the NEXT submit's compressed bytes to the device already (asynchronously, on upload_stream(), while the submit in
-  // front was running) says so here: upload() then takes them from there (a device-to-device copy behind the event) instead of from the host.
-  struct PreUpload { const uint8_t* host = nullptr; size_t len = 0; const void* dev = nullptr; hipEvent_t done = nullptr; };
-  PreUpload preup;   // D2H of a finished submit while the next one runs (zgpu_pool_decode_all): nothing else uses it then
+  hipStream_t upload_stream() const { return stream4_; }     // uploads of a run that is prepared while the run in front is on the GPU (prepare_run side = true)
+   // D2H of a finished submit while the next one runs (zgpu_pool_decode_all): nothing else uses it then
   int device() const { return device_; }
   int compute_units() const { return cus_; }
   const Tuning& tuning() const { return tn_; }
@@ -222,7 +226,7 @@ class Engine {
   Scratch* acquire();
   void recycle(Scratch* s);
   int fail(hipError_t e, const char* what);
-  int upload(Batch* b, const uint8_t* src, size_t len, Batch** out);
+  int upload(Batch* b, const uint8_t* src, size_t len, Batch** out, bool side = false);
 };
 
 // Host-only walk of concatenated frames into a BatchBuilder (no GPU involved; unit-tested on CPU).

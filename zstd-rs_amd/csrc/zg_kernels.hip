@@ -1104,7 +1104,10 @@ __global__ void __launch_bounds__(ZG_SP_T, 4) zg_k_seqpost(ZgBatchDev d) {
 // ------------------------------------------------------------------------------------------------------------
 // ZG_SCAN_T threads per frame: 1024 for frames of many blocks, one wave for a submit of short frames (16384 single-block frames:
 // 16384 workgroups of 1024 threads that hold one block each took 0.69 ms)
-template <int ZG_SCAN_T>
+// Round 6: ZG_SCAN_I consecutive blocks per thread (8 in the 1024-thread form: the 7630 blocks of the 1e9-byte frame are ONE pass — their
+// loads are requested together, a thread composes its own blocks serially, one wave scan, one cross-wave step — where eight passes of one
+// block per thread, each with its own memory round trip and four barriers, took 0.10 ms).
+template <int ZG_SCAN_T, int ZG_SCAN_I>
 __global__ void __launch_bounds__(ZG_SCAN_T) zg_k_scan(ZgBatchDev d) {
   __shared__ uint64_t s_size[ZG_SCAN_T / 64];
   __shared__ ZgHistMap s_map[ZG_SCAN_T / 64];
@@ -1119,35 +1122,48 @@ __global__ void __launch_bounds__(ZG_SCAN_T) zg_k_scan(ZgBatchDev d) {
   __shared__ unsigned long long s_counted;   // output of the good compressed blocks (what DecodeBuffer counts, decode_buffer.rs:74-77,108)
   uint64_t my_counted = 0;
   if (t == 0) { s_slow = 0; s_counted = 0; }
-  for (uint32_t c0 = 0; c0 < fr.nblocks; c0 += ZG_SCAN_T) {
-    uint32_t i = c0 + t;
-    bool have = i < fr.nblocks;
-    uint32_t b = fr.first_block + i;
-    uint64_t size = 0;
-    ZgHistMap m = zg_map_identity();
-    uint32_t st = 0;
+  constexpr uint32_t CH = ZG_SCAN_T * ZG_SCAN_I;
+  for (uint32_t c0 = 0; c0 < fr.nblocks; c0 += CH) {
+    uint64_t size[ZG_SCAN_I];
+    ZgHistMap m[ZG_SCAN_I];
+    uint32_t st[ZG_SCAN_I];
+    bool comp[ZG_SCAN_I];
     if (t == 0) { s_bad = 0xFFFFFFFFu; s_badst = 0; }
     __syncthreads();
-    if (have) {
-      const ZgBlock* blk = &d.blocks[b];
-      st = blk->host_status ? blk->host_status : d.status[b];
-      if (blk->btype != ZG_BT_COMPRESSED) size = blk->regen_size;
-      else if (blk->nseq == 0) size = blk->regen_size;
-      else {
-        const ZgBlockSeqOut so = d.seq_out[b];
-        size = (uint64_t)blk->regen_size + so.sum_ml;
-        if (size > ZG_FLAT_MAX) s_slow = 1;
-        m.s[0] = so.hist_end[0]; m.s[1] = so.hist_end[1]; m.s[2] = so.hist_end[2];
+#pragma unroll
+    for (int j = 0; j < ZG_SCAN_I; j++) {
+      const uint32_t i = c0 + t * ZG_SCAN_I + (uint32_t)j;
+      size[j] = 0; m[j] = zg_map_identity(); st[j] = 0; comp[j] = false;
+      if (i < fr.nblocks) {
+        const uint32_t b = fr.first_block + i;
+        const ZgBlock* blk = &d.blocks[b];
+        st[j] = blk->host_status ? blk->host_status : d.status[b];
+        comp[j] = blk->btype == ZG_BT_COMPRESSED;
+        if (!comp[j] || blk->nseq == 0) size[j] = blk->regen_size;
+        else {
+          const ZgBlockSeqOut so = d.seq_out[b];
+          size[j] = (uint64_t)blk->regen_size + so.sum_ml;
+          if (size[j] > ZG_FLAT_MAX) s_slow = 1;
+          m[j].s[0] = so.hist_end[0]; m[j].s[1] = so.hist_end[1]; m[j].s[2] = so.hist_end[2];
+        }
+        if (st[j]) atomicMin(&s_bad, t * ZG_SCAN_I + (uint32_t)j);
       }
-      if (st) atomicMin(&s_bad, t);
     }
     __syncthreads();
     const uint32_t bad = s_bad;
-    if (t >= bad) { size = 0; m = zg_map_identity(); }  // the failing block and everything after it produce nothing
-    if (have && d.blocks[b].btype == ZG_BT_COMPRESSED) my_counted += size;
-    // inclusive scans over the chunk: inside the wave with shuffles, across the waves through LDS
-    uint64_t isz = size;
-    ZgHistMap im = m;
+    // the failing block and everything after it produce nothing; the thread's own blocks are composed serially
+    uint64_t tsum = 0;
+    ZgHistMap tmapl = zg_map_identity();
+#pragma unroll
+    for (int j = 0; j < ZG_SCAN_I; j++) {
+      if (t * ZG_SCAN_I + (uint32_t)j >= bad) { size[j] = 0; m[j] = zg_map_identity(); }
+      if (comp[j]) my_counted += size[j];
+      tsum += size[j];
+      tmapl = zg_map_compose(tmapl, m[j]);
+    }
+    // inclusive scans over the threads of the chunk: inside the wave with shuffles, across the waves through LDS
+    uint64_t isz = tsum;
+    ZgHistMap im = tmapl;
     {
       const uint32_t lane = t & 63;
 #pragma unroll
@@ -1166,21 +1182,29 @@ __global__ void __launch_bounds__(ZG_SCAN_T) zg_k_scan(ZgBatchDev d) {
       if (w < (t >> 6)) { wsz += s_size[w]; wmap = zg_map_compose(wmap, s_map[w]); }
       tsz += s_size[w]; tmap = zg_map_compose(tmap, s_map[w]);
     }
-    // history before a block: everything before the chunk, the earlier waves, the earlier lanes of its wave
+    // history before a thread's first block: everything before the chunk, the earlier waves, the earlier lanes of its wave
     ZgHistMap prev;
     prev.s[0] = __shfl_up(im.s[0], 1, 64); prev.s[1] = __shfl_up(im.s[1], 1, 64); prev.s[2] = __shfl_up(im.s[2], 1, 64);
     if ((t & 63) == 0) prev = zg_map_identity();
-    if (have) {
-      const uint64_t excl = carry_size + wsz + isz - size;                       // sizes before this block
-      const ZgHistMap pre = zg_map_compose(zg_map_compose(carry_map, wmap), prev);
-      ZgBlockPos p;
-      p.out_base = excl;
-      p.hist_init[0] = zg_sym_resolve(pre.s[0], fr.hist_init);
-      p.hist_init[1] = zg_sym_resolve(pre.s[1], fr.hist_init);
-      p.hist_init[2] = zg_sym_resolve(pre.s[2], fr.hist_init);
-      p.active = t < bad ? 1u : 0u;
-      d.pos[b] = p;
-      if (t == bad) s_badst = st;
+    {
+      uint64_t excl = carry_size + wsz + isz - tsum;                             // sizes before the thread's first block
+      ZgHistMap pre = zg_map_compose(zg_map_compose(carry_map, wmap), prev);
+#pragma unroll
+      for (int j = 0; j < ZG_SCAN_I; j++) {
+        const uint32_t li = t * ZG_SCAN_I + (uint32_t)j, i = c0 + li;
+        if (i < fr.nblocks) {
+          ZgBlockPos p;
+          p.out_base = excl;
+          p.hist_init[0] = zg_sym_resolve(pre.s[0], fr.hist_init);
+          p.hist_init[1] = zg_sym_resolve(pre.s[1], fr.hist_init);
+          p.hist_init[2] = zg_sym_resolve(pre.s[2], fr.hist_init);
+          p.active = li < bad ? 1u : 0u;
+          d.pos[fr.first_block + i] = p;
+          if (li == bad) s_badst = st[j];
+        }
+        excl += size[j];
+        pre = zg_map_compose(pre, m[j]);
+      }
     }
     __syncthreads();
     if (bad != 0xFFFFFFFFu) {  // sizes / maps of blocks from the failing one on are zero / identity
@@ -1189,7 +1213,7 @@ __global__ void __launch_bounds__(ZG_SCAN_T) zg_k_scan(ZgBatchDev d) {
       carry_size += tsz;
       carry_map = zg_map_compose(carry_map, tmap);
       // blocks after this chunk are inactive
-      for (uint32_t j = c0 + ZG_SCAN_T + t; j < fr.nblocks; j += ZG_SCAN_T) d.pos[fr.first_block + j].active = 0;
+      for (uint32_t j = c0 + CH + t; j < fr.nblocks; j += ZG_SCAN_T) d.pos[fr.first_block + j].active = 0;
       break;
     }
     carry_size += tsz;
@@ -1209,6 +1233,11 @@ __global__ void __launch_bounds__(ZG_SCAN_T) zg_k_scan(ZgBatchDev d) {
     fo.fast = (s_slow || (d.flags & 1u)) ? 0u : 1u;
     fo.err_packed = 0xFFFFFFFFu;
     fo.og_base = 0;
+    if (d.nframes == 1u) {   // a submit of ONE frame needs no scan over the frames (zg_k_scanf is not launched): its place and the totals, here
+      fo.out_base = fr.fixed_base ? fr.out_base_fixed : 0ull;
+      const uint64_t tot = fr.fixed_base ? 0ull : carry_size;
+      d.totals[0] = (uint32_t)tot; d.totals[1] = (uint32_t)(tot >> 32); d.totals[2] = (d.dst_cap_pre && tot > d.dst_cap_pre) ? 1u : 0u;
+    }
     d.frame_out[f] = fo;
   }
 }
@@ -1732,9 +1761,10 @@ void zg_launch_seqpost(const ZgBatchDev& d, hipStream_t s) {
   if (d.nseq_blocks) hipLaunchKernelGGL(zg_k_seqpost, dim3(d.nseq_blocks), dim3(ZG_SP_T), 0, s, d);
 }
 void zg_launch_scan(const ZgBatchDev& d, hipStream_t s, uint32_t max_frame_blocks) {
-  if (max_frame_blocks <= 64u) hipLaunchKernelGGL((zg_k_scan<64>), dim3(d.nframes), dim3(64), 0, s, d);
-  else hipLaunchKernelGGL((zg_k_scan<1024>), dim3(d.nframes), dim3(1024), 0, s, d);
-  hipLaunchKernelGGL(zg_k_scanf, dim3(1), dim3(1024), 0, s, d);
+  if (max_frame_blocks <= 64u) hipLaunchKernelGGL((zg_k_scan<64, 1>), dim3(d.nframes), dim3(64), 0, s, d);
+  else if (max_frame_blocks <= 1024u) hipLaunchKernelGGL((zg_k_scan<1024, 1>), dim3(d.nframes), dim3(1024), 0, s, d);
+  else hipLaunchKernelGGL((zg_k_scan<1024, 8>), dim3(d.nframes), dim3(1024), 0, s, d);
+  if (d.nframes != 1u) hipLaunchKernelGGL(zg_k_scanf, dim3(1), dim3(1024), 0, s, d);
 }
 void zg_launch_lit(const ZgBatchDev& d, hipStream_t s) {
   if (d.nblocks) hipLaunchKernelGGL(zg_k_lit, dim3(d.nblocks), dim3(256), 0, s, d);

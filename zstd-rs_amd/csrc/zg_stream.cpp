@@ -83,46 +83,56 @@ class GpuStreamBackend : public StreamBackend {
  public:
   explicit GpuStreamBackend(zgpu_decoder* d) : d_(d), eng_(d->ctx->eng) {}
   ~GpuStreamBackend() override {
+    delete nb_;
     delete b_;
-    if (own_) {
-      (void)hipSetDevice(own_->device());
-      (void)hipStreamSynchronize(own_->upload_stream());
-      own_->preup = Engine::PreUpload();
-      g_idle_engines.give(own_);
-    }
-    for (auto& e : pre_ev_) if (e) (void)hipEventDestroy(e);
-    for (auto& b : pre_) b.release();
+    if (own_) g_idle_engines.give(own_);
   }
 
-  int run(const uint8_t* src, size_t len, uint32_t nblocks, uint64_t keep, StreamRun* out) override {
-    delete b_; b_ = nullptr;
+  // host walk + plan + uploads of the NEXT run. While a run is on the GPU everything travels on the upload stream beside it
+  // (Engine::prepare_run side = true) and the tables that will exist are the ones that run leaves behind.
+  int prepare(const uint8_t* src, size_t len, uint32_t nblocks) override {
+    delete nb_; nb_ = nullptr;
+    FrameState* fs = &d_->fs;
+    size_t used = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    const bool side = b_ != nullptr;
+    const uint32_t mask = side ? b_->carry_mask_after() : fs->carry_mask;
+    int st = eng_->prepare_run(src, len, fs, d_->fh.content_checksum(), nblocks, 0, &nb_, &used, side, &mask);
+    if (st) { nb_ = nullptr; return st; }
+    if (nb_->bb.blocks.empty()) { const int ps = nb_->parse_status; delete nb_; nb_ = nullptr; return ps ? ps : ZGPU_E_INTERNAL; }
+    us_prepare += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+    return ZGPU_OK;
+  }
+  // the prepared run goes to the GPU (the run in front has been committed or dropped)
+  int launch(uint64_t keep) override {
+    if (!nb_ || b_) return ZGPU_E_INTERNAL;
     FrameState* fs = &d_->fs;
     // the plaintext of the run in front may still be on its way to the host: nothing may move under it. A move is harmless when the
     // buffer is compacted in place and both what moves (the kept tail, to the front) and what this run will write behind it stay in
     // FRONT of the bytes that are being fetched — the window is reserved for three runs, so that is the usual case.
-    const uint64_t bound = (uint64_t)nblocks * kMaxBlockSize;
+    const uint64_t bound = (uint64_t)nb_->bb.blocks.size() * kMaxBlockSize;
     if (fetching_ && fs->room_moves(bound, keep)) {
       const uint64_t k2 = keep < fs->have ? keep : fs->have;
       const bool inplace = fs->d_out.p && !fs->base && kOutFront + k2 + bound + 64 <= fs->d_out.cap;
       const bool safe = inplace && k2 + bound <= committed_base_ && fs->have - k2 >= k2;
       if (!safe) { const int w = fetch_wait(); if (w) return w; }
     }
-    eng_->preup = (pre_next_.host == src && pre_next_.len == len) ? pre_next_ : Engine::PreUpload();
-    pre_next_ = Engine::PreUpload();
-    size_t used = 0;
-    const auto t0 = std::chrono::steady_clock::now();
-    int st = eng_->prepare_run(src, len, fs, d_->fh.content_checksum(), nblocks, keep, &b_, &used);
-    if (st) { b_ = nullptr; return st; }
-    const size_t nb = b_->bb.blocks.size();
-    if (nb == 0) { const int ps = b_->parse_status; delete b_; b_ = nullptr; return ps ? ps : ZGPU_E_INTERNAL; }
+    b_ = nb_; nb_ = nullptr;
+    b_->keep_bytes = keep;
     b_->drain_rule = d_->drain_rule;
-    const auto t1 = std::chrono::steady_clock::now();
-    if ((st = b_->run()) || (st = b_->sync())) { delete b_; b_ = nullptr; return st; }
-    const auto t2 = std::chrono::steady_clock::now();
-    us_prepare += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count();
-    us_kernels += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(t2 - t1).count();
+    t_launch_ = std::chrono::steady_clock::now();
+    const int st = b_->run();
+    if (st) { delete b_; b_ = nullptr; }
+    return st;
+  }
+  int wait(StreamRun* out) override {
+    if (!b_) return ZGPU_E_INTERNAL;
+    int st = b_->sync();
+    if (st) { delete b_; b_ = nullptr; return st; }
+    us_kernels += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_launch_).count();
     for (int i = 0; i < ZG_T_COUNT; i++) kus[i] += (uint64_t)(b_->ms[i] * 1000.f);
     if (b_->frame_out.empty()) { delete b_; b_ = nullptr; return ZGPU_E_INTERNAL; }
+    const size_t nb = b_->bb.blocks.size();
     const ZgFrameOut fo = b_->frame_out[0];          // (a failed frame: out_size ends with its last good block, Batch::sync)
     out->nblocks = (uint32_t)nb;
     // a block's own verdict (the kernels', or what the host found in its section headers); frame-layer trouble — a truncated block, a
@@ -137,6 +147,7 @@ class GpuStreamBackend : public StreamBackend {
     run_base_ = fo.out_base;
     return ZGPU_OK;
   }
+  void drop_prepared() override { delete nb_; nb_ = nullptr; }
   int commit() override {
     if (!b_) return ZGPU_E_INTERNAL;
     const int st = b_->commit(&d_->fs);
@@ -172,17 +183,6 @@ class GpuStreamBackend : public StreamBackend {
     fs.have = n;
     return ZGPU_OK;
   }
-  // bring the NEXT run's compressed bytes to the device while the current run is decoded (worker thread, its own DMA stream)
-  void prefetch(const uint8_t* src, size_t len) override {
-    if (!own_ || eng_ != own_ || !len || pre_next_.host == src) return;
-    const int i = pre_i_ ^= 1;
-    if (hipSetDevice(eng_->device()) != hipSuccess) return;
-    if (!pre_ev_[i] && hipEventCreateWithFlags(&pre_ev_[i], hipEventDisableTiming) != hipSuccess) { pre_ev_[i] = nullptr; return; }
-    if (pre_[i].reserve(len)) return;                 // (no memory: the run is uploaded the plain way)
-    if (hipMemcpyAsync(pre_[i].p, src, len, hipMemcpyHostToDevice, eng_->upload_stream()) != hipSuccess ||
-        hipEventRecord(pre_ev_[i], eng_->upload_stream()) != hipSuccess) { (void)hipGetLastError(); return; }
-    pre_next_.host = src; pre_next_.len = len; pre_next_.dev = pre_[i].p; pre_next_.done = pre_ev_[i];
-  }
   int pipe_begin(uint64_t window_bytes) override {
     // the worker thread gets an engine of its own (streams, scratch pool): the context's engine stays with the caller's thread
     if (!own_) {
@@ -200,8 +200,7 @@ class GpuStreamBackend : public StreamBackend {
   }
   void pipe_end() override {
     (void)fetch_wait();
-    if (own_) { (void)hipStreamSynchronize(own_->upload_stream()); own_->preup = Engine::PreUpload(); }
-    pre_next_ = Engine::PreUpload();
+    delete nb_; nb_ = nullptr;
     eng_ = d_->ctx->eng;
   }
   void thread_init() override { (void)hipSetDevice(eng_->device()); }
@@ -217,10 +216,8 @@ class GpuStreamBackend : public StreamBackend {
   Batch* b_ = nullptr;
   uint64_t run_base_ = 0, committed_base_ = 0;
   bool fetching_ = false;
-  DevBuf pre_[2];                       // the next run's compressed bytes, uploaded ahead
-  hipEvent_t pre_ev_[2] = {nullptr, nullptr};
-  int pre_i_ = 0;
-  Engine::PreUpload pre_next_;
+  Batch* nb_ = nullptr;                 // the run that is prepared (parsed, uploaded) and not launched yet
+  std::chrono::steady_clock::time_point t_launch_;
 };
 
 }  // namespace

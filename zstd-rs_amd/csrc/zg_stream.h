@@ -53,10 +53,23 @@ struct StreamRun {             // what the host learns about one run of blocks
 class StreamBackend {
  public:
   virtual ~StreamBackend() {}
-  // Decode `nblocks` whole blocks of the frame: src starts at a block header and holds them completely (+ the Content_Checksum behind
-  // the last block of a frame that has one, when `len` reaches that far). keep: frame bytes in front of the run that must stay in
-  // reach on the device. Synchronous: the verdicts are known on return. Nothing is folded into the frame's state yet.
-  virtual int run(const uint8_t* src, size_t len, uint32_t nblocks, uint64_t keep, StreamRun* out) = 0;
+  // A run = `nblocks` whole blocks of the frame: src starts at a block header and holds them completely (+ the Content_Checksum behind
+  // the last block of a frame that has one, when `len` reaches that far). Three steps, so that the host work of run k + 1 overlaps the
+  // device work of run k:
+  //   prepare  host walk, plan, uploads. May be called while the run in front is still on the device (before its wait()).
+  //   launch   the prepared run goes to the device; the run in front has been committed or dropped. keep: frame bytes in front of the
+  //            run that must stay in reach on the device.
+  //   wait     its verdicts. Nothing is folded into the frame's state yet (commit / discard).
+  virtual int prepare(const uint8_t* src, size_t len, uint32_t nblocks) = 0;
+  virtual int launch(uint64_t keep) = 0;
+  virtual int wait(StreamRun* out) = 0;
+  virtual void drop_prepared() = 0;
+  int run(const uint8_t* src, size_t len, uint32_t nblocks, uint64_t keep, StreamRun* out) {
+    int e = prepare(src, len, nblocks);
+    if (!e) e = launch(keep);
+    if (!e) e = wait(out);
+    return e;
+  }
   virtual int commit() = 0;                                         // fold the last run into the frame's state (DecoderScratch after decode_block_content)
   virtual void discard() = 0;                                       // drop it instead
   virtual int fetch(uint8_t* dst, uint64_t off, uint64_t n) = 0;    // plaintext [off, off + n) of the last COMMITTED run -> host memory, asynchronous
@@ -64,7 +77,6 @@ class StreamBackend {
   // LOCKSTEP after PIPE: the reference's buffer holds everything the reader has not drained, and a (non-conforming) match may reach all
   // of it: make the frame's most recent n bytes (host copy at `held`) reachable on the device again
   virtual int rebase(const uint8_t* held, uint64_t n) = 0;
-  virtual void prefetch(const uint8_t* src, size_t len) {}         // worker thread: the NEXT run's bytes may start travelling to the device now
   virtual int pipe_begin(uint64_t window_bytes) { return 0; }       // the calling thread hands the engine to a worker (own streams, window reserved)
   virtual void pipe_end() {}
   virtual void thread_init() {}                                     // first call on the worker thread
@@ -240,7 +252,7 @@ class StreamCopyPool {
   void copy(uint8_t* dst, const uint8_t* src, size_t n) {
     const size_t nt = th_.size();
     if (!nt || n < (512u << 10)) { memcpy(dst, src, n); return; }
-    const size_t share = ((n / (nt + 1)) + 4095) & ~(size_t)4095;
+    const size_t share = (((n + nt) / (nt + 1)) + 4095) & ~(size_t)4095;   // ceil(n / (nt + 1)), page-aligned: (nt + 1) shares cover n
     size_t off = share < n ? share : n;                 // [0, off) is the caller's
     uint32_t used = 0;
     {
@@ -508,7 +520,7 @@ class StreamCore {
   std::mutex mu_;
   std::condition_variable cv_worker_, cv_reader_;
   std::deque<Job> jobs_;
-  bool worker_busy_ = false;               // (under mu_) a job has been taken and is not judged yet
+  uint32_t taken_ = 0;                     // (under mu_) runs the worker has taken from the queue and not judged yet (at most two)
   bool stopping_ = false;                  // (under mu_) the worker has handed its jobs back: nothing may be queued any more
   std::atomic<int> pstate_{P_RUNNING};
   int pipe_err_ = 0;
@@ -555,7 +567,7 @@ class StreamCore {
     pub_.store(h, std::memory_order_relaxed); tail_.store(0, std::memory_order_relaxed); hashed_.store(0, std::memory_order_relaxed);
     reserved_ = h;
     pstate_.store(P_RUNNING, std::memory_order_relaxed);
-    stop_req_ = false; hash_stop_.store(false); pipe_err_ = 0; worker_busy_ = false; stopping_ = false;
+    stop_req_ = false; hash_stop_.store(false); pipe_err_ = 0; taken_ = 0; stopping_ = false;
     hasher_on_ = o_.hash;
     mode_ = PIPE;
     pipe_up_ = true;
@@ -578,7 +590,7 @@ class StreamCore {
       {
         std::lock_guard<std::mutex> lk(mu_);
         if (stopping_ || pstate_.load(std::memory_order_relaxed) != P_RUNNING) return;
-        if (jobs_.size() + (worker_busy_ ? 1u : 0u) >= 3u) return;   // the one being decoded, the one whose bytes travel to the device, one more
+        if (jobs_.size() + taken_ >= 3u) return;   // the one being decoded, the one that is prepared beside it, one more
         if (src.ended || src_stop_) return;
         if (!src.is_slice()) {
           for (size_t i = 0; i < stages_.size(); i++) if (!stages_[i].busy) { sb = (int)i; break; }
@@ -656,78 +668,103 @@ class StreamCore {
     cv_reader_.notify_all();
   }
 
+  // take the next queued run; block: wait for one (false: only if it is there). 0 = got one, 1 = none (now / ever), 2 = asked to stop
+  int take_job(Job* job, bool block) {
+    Tick tk(&tus[0]);
+    std::unique_lock<std::mutex> lk(mu_);
+    if (block) cv_worker_.wait(lk, [&]() { return stop_req_ || !jobs_.empty() || no_more_jobs_; });
+    if (stop_req_) return 2;
+    if (jobs_.empty()) return 1;
+    *job = jobs_.front(); jobs_.pop_front();
+    taken_++;
+    return 0;
+  }
   void worker_main() {
     be_->thread_init();
+    Job cur, nxt;
+    bool have_nxt = false, nxt_ready = false;
+    int e = ZG_OK;
+    {
+      const int g = take_job(&cur, true);
+      if (g == 2) return;
+      if (g == 1) { set_pstate(P_STOPPED, 0); return; }     // the source ran dry in front of the frame's end before a single run
+      { Tick tk(&tus[1]); e = be_->prepare(cur.p, cur.len, cur.nblocks); if (!e) e = be_->launch(window); }
+      if (e) { give_back(&cur, nullptr, 0); set_pstate(P_FAILED, e); return; }
+    }
     for (;;) {
-      Job job;
-      const uint8_t* next_p = nullptr;
-      size_t next_len = 0;
-      {
-        Tick tk(&tus[0]);
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_worker_.wait(lk, [&]() { return stop_req_ || !jobs_.empty() || no_more_jobs_; });
-        if (stop_req_) break;
-        if (jobs_.empty()) {                      // nothing more will come: the source ran dry in front of the frame's end
-          lk.unlock();
-          const int e = land_fetch();
-          set_pstate(e ? P_FAILED : P_STOPPED, e);
-          return;
-        }
-        job = jobs_.front(); jobs_.pop_front();
-        worker_busy_ = true;
-        if (!jobs_.empty()) { next_p = jobs_.front().p; next_len = jobs_.front().len; }
+      // run `cur` is on the device: meanwhile the next one is taken from the queue, walked and uploaded
+      if (!have_nxt && take_job(&nxt, false) == 0) have_nxt = true;
+      if (have_nxt && !nxt_ready) {
+        Tick tk(&tus[1]);
+        e = be_->prepare(nxt.p, nxt.len, nxt.nblocks);
+        if (e) { StreamRun dummy; (void)be_->wait(&dummy); be_->discard(); give_back(&cur, &nxt, 0); set_pstate(P_FAILED, e); return; }
+        nxt_ready = true;
       }
-      if (next_p) be_->prefetch(next_p, next_len);
       StreamRun r;
-      int e;
-      { Tick tk(&tus[1]); e = be_->run(job.p, job.len, job.nblocks, window, &r); }
+      { Tick tk(&tus[1]); e = be_->wait(&r); }
       int e2;
       { Tick tk(&tus[2]); e2 = land_fetch(); }  // the run in front travelled to the ring meanwhile
       if (!e) e = e2;
-      if (e) { be_->discard(); give_back(job, 0); set_pstate(P_FAILED, e); return; }
-      if (!clean(r, job.nblocks)) {
+      if (e) { be_->discard(); be_->drop_prepared(); give_back(&cur, have_nxt ? &nxt : nullptr, 0); set_pstate(P_FAILED, e); return; }
+      if (!clean(r, cur.nblocks)) {
         be_->discard();
+        be_->drop_prepared();
         dropped_++;
         size_t used = 0;
-        e = salvage(job.p, job.len, r, &used, true);
-        give_back(job, used);
+        e = salvage(cur.p, cur.len, r, &used, true);
+        give_back(&cur, have_nxt ? &nxt : nullptr, used);
         set_pstate(e ? P_FAILED : P_STOPPED, e);
         return;
       }
       { Tick tk(&tus[3]); e = be_->commit(); }
-      if (e) { set_pstate(P_FAILED, e); return; }
-      account(r, job.len, job.nblocks, true);
+      if (e) { be_->drop_prepared(); set_pstate(P_FAILED, e); return; }
+      account(r, cur.len, cur.nblocks, true);
       runs_++;
       e = fetch_to_ring(r.out_size, false);
       {
         std::lock_guard<std::mutex> lk(mu_);
-        if (job.stage >= 0) stages_[job.stage].busy = false;
-        worker_busy_ = false;
+        if (cur.stage >= 0) stages_[cur.stage].busy = false;
+        taken_--;
       }
-      if (e) { set_pstate(P_FAILED, e); return; }
-      if (r.saw_last || job.stop) {
+      if (e) { be_->drop_prepared(); set_pstate(P_FAILED, e); return; }
+      if (r.saw_last || cur.stop) {
         e = land_fetch();
         if (!e) publish_fin();
         set_pstate(e ? P_FAILED : (r.saw_last ? P_DONE : P_STOPPED), e);
         return;
       }
+      if (!have_nxt) {
+        const int g = take_job(&nxt, true);
+        if (g == 2) break;
+        if (g == 1) { e = land_fetch(); set_pstate(e ? P_FAILED : P_STOPPED, e); return; }   // nothing more will come: the source ran dry in front of the frame's end
+        have_nxt = true;
+      }
+      if (!nxt_ready) {
+        Tick tk(&tus[1]);
+        e = be_->prepare(nxt.p, nxt.len, nxt.nblocks);
+      }
+      if (!e) { Tick tk(&tus[1]); e = be_->launch(window); }
+      if (e) { be_->drop_prepared(); give_back(&nxt, nullptr, 0); set_pstate(P_FAILED, e); return; }
+      cur = nxt; have_nxt = false; nxt_ready = false;
     }
     (void)land_fetch();
   }
-  // the dropped job's bytes behind `used`, and every job queued behind it, go back to the source (in order)
-  void give_back(const Job& job, size_t used) {
+  // the dropped run's bytes behind `used`, the run that was taken behind it (if any) and every run still queued go back to the source, in order
+  void give_back(const Job* job, const Job* next, size_t used) {
     std::lock_guard<std::mutex> lk(mu_);
     stopping_ = true;                       // (in the same critical section: a run the reader is taking from the source right now is not queued any more)
     if (src.is_slice()) {
-      size_t back = job.len - used;
+      size_t back = job->len - used;
+      if (next) back += next->len;
       for (const Job& j : jobs_) back += j.len;
       leftover_slice_back_ = back;
     } else {
-      leftover_.assign(job.p + used, job.p + job.len);
+      leftover_.assign(job->p + used, job->p + job->len);
+      if (next) leftover_.insert(leftover_.end(), next->p, next->p + next->len);
       for (const Job& j : jobs_) leftover_.insert(leftover_.end(), j.p, j.p + j.len);
     }
     jobs_.clear();
-    worker_busy_ = false;
+    taken_ = 0;
   }
 
   void hasher_main() {
