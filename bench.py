@@ -52,6 +52,29 @@ PROFILE_DIR = os.path.join(ROOT, "profiles", "r06")
 KERNEL_SOURCES = ("zg_kernels.hip", "zg_flat1.h", "zg_flat4.h", "zg_huf.h", "zg_exact.h", "zg_dev.h", "zg_types.h")   # what the device code is built from
 
 
+def pin_to_gpu_node(idx):
+    """Run this process on the CPUs of the NUMA node the GPU hangs off (sysfs local_cpulist of its PCI function): pinned host buffers are then
+    allocated next to the GPU and the host-to-host figures (e2e, stream) stop depending on where the scheduler happened to put the process
+    (27 vs 40 GB/s between two runs of round 6). Returns (description, the affinity to restore for the CPU-baseline legs)."""
+    try:
+        import torch
+        before = os.sched_getaffinity(0)
+        pr = torch.cuda.get_device_properties(idx)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        txt = open("/sys/bus/pci/devices/%s/local_cpulist" % bdf).read().strip()
+        cpus = set()
+        for part in txt.split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= before
+        if not cpus:
+            return "unchanged (empty local_cpulist)", before
+        os.sched_setaffinity(0, cpus)
+        return "GPU %d at %s: CPUs %s" % (idx, bdf, txt), before
+    except Exception as e:   # no sysfs entry, no permission ...: run where the scheduler puts us
+        return "unchanged (%s)" % type(e).__name__, None
+
+
 def pmap(fn, items):
     """fn over items on host threads (the generators and libzstd are C behind ctypes: the GIL is released while they run), results in
     order: eight GPUs' worth of frames are generated and compressed side by side instead of one after the other"""
@@ -329,11 +352,15 @@ def stream_rates(device, z, plain):
         t0 = time.perf_counter()
         n = s.copy_to_sink(buf)
         dt = time.perf_counter() - t0
-        assert n == len(plain) and s.is_finished() and s.stats()["dropped"] == 0, (n, s.stats())
+        st = s.stats()
+        assert n == len(plain) and s.is_finished() and st["dropped"] == 0, (n, st)
         if checksum:
             assert s.get_calculated_checksum() == s.get_checksum_from_data()
         s.close()
+        last_stats.clear(); last_stats.update(st)
         return dt
+
+    last_stats = {}
 
     def one_read(checksum):
         s = zgpu.CStreamingDecoder(ctx, data=(src.data_ptr(), len(z)), checksum=checksum)
@@ -350,6 +377,11 @@ def stream_rates(device, z, plain):
     for label, buf in (("8KiB", 8192), ("1MiB", 1 << 20), ("64MiB", 64 << 20)):
         out["stream_GBps"][label] = round(gb / min(one_copy(buf, True) for _ in range(3)), 3)
         out["stream_nohash_GBps"][label] = round(gb / min(one_copy(buf, False) for _ in range(3)), 3)
+    # where the 64 MiB loop's time went (zgpu_streaming_stats of its last run; ms): the worker thread's host prepare + kernels per run, the reader
+    out["stream_breakdown_ms"] = {k[3:]: round(v / 1e3, 2) for k, v in last_stats.items() if k.startswith("us_")}
+    out["stream_breakdown_ms"].update({"runs": last_stats.get("runs"), "kernels_total": round(last_stats.get("k_total", 0) / 1e3, 2),
+                                       "k_seq": round(last_stats.get("k_seq", 0) / 1e3, 2), "k_flat": round(last_stats.get("k_flat", 0) / 1e3, 2),
+                                       "k_sweep": round(last_stats.get("k_sweep", 0) / 1e3, 2)})
     out["stream_callback_GBps"] = {"1MiB": round(gb / min(one_copy(1 << 20, True, True) for _ in range(2)), 3)}
     t = min(one_read(False) for _ in range(3))
     assert hashlib.sha256(dst.numpy().tobytes()).digest() == want_sha, "stream output differs"
@@ -398,6 +430,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
+    affinity_note, affinity_before = pin_to_gpu_node(local_rank) if args.gpus == 1 or world > 1 else ("unchanged (one process drives several GPUs)", None)
 
     import zgdata
     import zgpu
@@ -481,7 +514,7 @@ def main():
                                        "passes (one zgpu_pool_run each), >= %.1f s" % args.min_seconds,
                        "queue": ("one process, zgpu_pool_create(%d): LPT order, one worker thread + engine per GPU; GPUs used: %s" % (args.gpus, sorted(used_gpus)))
                                 if world == 1 else "one process per GPU (torch.distributed.run); frames -> ranks by zgpu_dist.shard_frames (the queue's LPT rule)",
-                       "gpus_requested": args.gpus, "host_prepare_s": round(prep_s, 3)},
+                       "gpus_requested": args.gpus, "host_prepare_s": round(prep_s, 3), "host_affinity": affinity_note},
             "roofline": roofline(kern, C0 + D0, args.workload, per_gpu_busy[0], pool.last_njobs, D0, pool.plan_stats(0)),
             "read_GBps": round(C0 / (kern["total"] / 1e3) / 1e9, 3) if kern["total"] > 0 else 0.0,
             "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
@@ -508,6 +541,8 @@ def main():
         if not args.no_e2e and args.workload == "enwik9like" and len(staged_z) == 1:
             out.update(stream_rates(local_rank, staged_z[0], staged_p[0]))
         if not args.no_cpu:
+            if affinity_before:
+                os.sched_setaffinity(0, affinity_before)         # the CPU legs use every core of the box
             # bounded CPU sample of the same workload: one frame of at most 64 MiB of plaintext
             n = min(len(staged_p[0]), 64 << 20)
             zc = staged_z[0] if n == len(staged_p[0]) else zgdata.zstd_compress(staged_p[0][:n], level=3)

@@ -171,10 +171,6 @@ int zgemu_flat4(void* h, int shape, uint8_t* dst_out, uint32_t* unit_mode) {
       if (shape == 0) run_unit<256, 4096, 2>(d, u);
       else if (shape == 1) run_unit<512, 8192, 2>(d, u);
       else if (shape == 2) run_unit<1024, 16384, 2>(d, u);
-      else if (shape == 3) run_unit<1024, 8192, 1>(d, u);
-      else if (shape == 4) run_unit<512, 4096, 1>(d, u);
-      else if (shape == 5) run_unit<256, 2048, 1>(d, u);
-      else if (shape == 6) run_unit<512, 2048, 1>(d, u);
       else if (shape == 3) run_unit<1024, 8192, 1>(d, u);      // zg_k_flatten4's default shape (two workgroups per CU)
       else if (shape == 4) run_unit<512, 4096, 1>(d, u);
       else if (shape == 5) run_unit<256, 2048, 1>(d, u);

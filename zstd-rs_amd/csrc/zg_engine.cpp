@@ -135,6 +135,7 @@ int Engine::create(int device, Engine** out) {
   if (hipStreamCreateWithPriority(&e->stream2_, hipStreamNonBlocking, prio_lo) != hipSuccess) { delete e; return ZG_HIP_ERROR; }
   if (hipStreamCreateWithPriority(&e->stream3_, hipStreamNonBlocking, prio_hi) != hipSuccess) { delete e; return ZG_HIP_ERROR; }
   if (hipStreamCreateWithPriority(&e->stream4_, hipStreamNonBlocking, prio_lo) != hipSuccess) { delete e; return ZG_HIP_ERROR; }
+  if (hipStreamCreateWithPriority(&e->stream5_, hipStreamNonBlocking, prio_hi) != hipSuccess) { delete e; return ZG_HIP_ERROR; }
   *out = e;
   return ZG_OK;
 }
@@ -145,6 +146,7 @@ Engine::~Engine() {
   if (stream2_) (void)hipStreamDestroy(stream2_);
   if (stream3_) (void)hipStreamDestroy(stream3_);
   if (stream4_) (void)hipStreamDestroy(stream4_);
+  if (stream5_) (void)hipStreamDestroy(stream5_);
 }
 Scratch* Engine::acquire() {
   if (!free_.empty()) { Scratch* s = free_.back(); free_.pop_back(); return s; }
@@ -259,6 +261,7 @@ Batch::~Batch() {
     (void)hipSetDevice(eng->device_);
     (void)hipStreamSynchronize(eng->stream_); (void)hipStreamSynchronize(eng->stream2_); (void)hipStreamSynchronize(eng->stream3_);
     if (wait_upload) (void)hipStreamSynchronize(eng->stream4_);   // (prepared beside another submit and never run)
+    (void)hipStreamSynchronize(eng->stream5_);                      // (the second half of a download)
     eng->recycle(sc);
   }
 }
@@ -469,6 +472,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out, bool s
   b->bb.flat_slots = (uint32_t)cus_ * (flat_shape_ == 0 ? 1u : 2u);   // zg_k_flatten: workgroups the device holds at once
   b->bb.chain_slots = (uint32_t)cus_ * 32u;                            // zg_k_seq: blocks whose chains run at once
   if (tn.lit_direct == 0) b->bb.lit_direct_allowed = false;
+  b->bb.seq_packed_force = tn.seq_packed;
   if (tn.direct_share10) b->bb.direct_share10 = tn.direct_share10;   // (measurement) tenths
   b->bb.finish();
   BatchBuilder& bb = b->bb;
@@ -565,12 +569,14 @@ int Batch::run() {
   //  submit falls back to sizes taken from the scan.)
   // (not with ramped units, a measurement switch: their sweep chain polls flags that the flatten of a no-op run never raises — ADVICE r4)
   if (!fs && all_declared && !eng->no_presize_ && declared_total <= bb.out_bound && !bb.ramped) {
-    if (sc->d_dst.reserve(kOutFront + declared_total + 64) == 0 && sc->d_og.reserve(declared_total * 4 + 64) == 0) {
+    // (the scratch first: it is four times the output. When either reserve fails nothing of the attempt stays allocated — the sizes taken
+    //  from the scan may well fit where the declared ones did not: ADVICE r5)
+    if (sc->d_og.reserve(declared_total * 4 + 64) == 0 && sc->d_dst.reserve(kOutFront + declared_total + 64) == 0) {
       d.dst = sc->d_dst.as<uint8_t>() + kOutFront; d.dst_cap = declared_total;
       d.og = sc->d_og.as<uint32_t>(); d.og_words = og_words = declared_total;
       d.dst_cap_pre = declared_total ? declared_total : 1;   // (0 means "not sized in advance")
       presized = true;
-    }
+    } else { sc->d_og.release(); sc->d_dst.release(); }
   }
   if (wait_upload) { ZG_HIP(hipStreamWaitEvent(s, sc->ev_up, 0)); wait_upload = false; }
   ZG_HIP(hipEventRecord(ev[0], s));
@@ -617,8 +623,7 @@ int Batch::run() {
   ZG_HIP(hipEventRecord(ev[2], s));
   // (more blocks with sequences than chains the device runs at once — CUs x 32 —: the kernel is then bound by chains per unit of time, not by
   //  the length of one chain, and the packed-entry form holds half as many again per CU)
-  const int seq_pk = eng->tn_.seq_packed;
-  zg_launch_seq(d, s, seq_pk < 0 ? d.nseq_blocks > (uint32_t)eng->cus_ * 32u : seq_pk != 0);
+  zg_launch_seq(d, s, bb.seq_packed);   // (BatchBuilder::finish decided: more blocks with sequences than one round holds -> the packed form)
   ZG_HIP(hipEventRecord(ev[3], s));
   zg_launch_seqpost(d, s);
   ZG_HIP(hipStreamWaitEvent(s, sc->ev_huf[1], 0));

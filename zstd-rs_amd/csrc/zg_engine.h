@@ -207,6 +207,7 @@ class Engine {
   hipStream_t stream() const { return stream_; }
   hipStream_t copy_stream() const { return stream2_; }
   hipStream_t download_stream() const { return stream3_; }
+  hipStream_t download_stream2() const { return stream5_; }  // the second half of a large download (two copy engines instead of one: zg_stream.cpp)
   hipStream_t upload_stream() const { return stream4_; }     // uploads of a run that is prepared while the run in front is on the GPU (prepare_run side = true)
    // D2H of a finished submit while the next one runs (zgpu_pool_decode_all): nothing else uses it then
   int device() const { return device_; }
@@ -221,7 +222,7 @@ class Engine {
   Tuning tn_;                    // the ZGPU_* switches as they were when the engine was created
   bool no_presize_ = false;      // (ZGPU_PRESIZE=0: measurement / tests) never size the output before the run
   int flat_shape_ = 0;           // zg_k_flatten shape: 0 = 1024 threads x 16 KiB tiles (one workgroup per CU), 1 = 512 x 8 KiB (two)
-  hipStream_t stream_ = nullptr, stream2_ = nullptr, stream3_ = nullptr, stream4_ = nullptr;   // stream3_: the flatten, when the sweep chain runs beside it
+  hipStream_t stream_ = nullptr, stream2_ = nullptr, stream3_ = nullptr, stream4_ = nullptr, stream5_ = nullptr;   // stream3_: the flatten, when the sweep chain runs beside it
   std::vector<Scratch*> free_;   // finished submits' buffers, for reuse
   Scratch* acquire();
   void recycle(Scratch* s);

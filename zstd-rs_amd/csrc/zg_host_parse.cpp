@@ -368,8 +368,10 @@ void BatchBuilder::finish() {
       if (b.nseq) { nsb++; if (b.nseq > max_nseq) max_nseq = b.nseq; }
       else if (b.lit_type >= ZG_LT_COMPRESSED) huf_noseq += b.regen_size;
     }
-    // (more blocks than one round holds: zg_k_seq runs in its packed-entry form, half as many chains again per CU)
-    const uint64_t slots = chain_slots ? (nsb > chain_slots ? chain_slots + chain_slots / 2 : chain_slots) : 1;
+    // (more blocks than one round holds: zg_k_seq runs in its packed-entry form, half as many chains again per CU. Decided HERE, once — the
+    //  launch, Batch::run, takes the same flag: ADVICE r5)
+    seq_packed = seq_packed_force < 0 ? (chain_slots && nsb > chain_slots) : seq_packed_force != 0;
+    const uint64_t slots = chain_slots ? (seq_packed ? chain_slots + chain_slots / 2 : chain_slots) : 1;
     const uint64_t rounds = (nsb + slots - 1) / slots;
     const double gain_us = (double)huf_noseq / 2.5e6, loss_us = 0.12 * (double)max_nseq * (double)(rounds ? rounds : 1);
     lit_direct = lit_direct_allowed && gain_us > 1.5 * loss_us + 20.0;

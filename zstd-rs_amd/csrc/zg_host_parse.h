@@ -86,6 +86,8 @@ class BatchBuilder {
   bool lit_direct = false;
   bool lit_direct_allowed = true;   // (ZGPU_LIT_DIRECT=0: measurement / tests)
   uint32_t chain_slots = 8192;      // sequence chains the device runs at once (engine: CUs x 32)
+  int seq_packed_force = -1;        // (ZGPU_SEQ_PACKED, development build) 0 / 1: never / always the packed form of zg_k_seq
+  bool seq_packed = false;          // finish(): zg_k_seq runs in its packed-entry form (more blocks with sequences than one round holds)
 
   // Start a frame. carry: lineage handed in by a dictionary or an earlier submit (slots are resolved in finish()).
   // carry_mask: bit 0 Huffman, bit 1 LL, bit 2 OF, bit 3 ML — tables that already exist when the frame (or this run of

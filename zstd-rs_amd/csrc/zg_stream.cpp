@@ -159,14 +159,26 @@ class GpuStreamBackend : public StreamBackend {
   int fetch(uint8_t* dst, uint64_t off, uint64_t n) override {
     if (!n) return ZGPU_OK;
     if (hipSetDevice(eng_->device()) != hipSuccess) return ZGPU_E_HIP;
-    if (hipMemcpyAsync(dst, d_->fs.out_ptr() + committed_base_ + off, n, hipMemcpyDeviceToHost, eng_->download_stream()) != hipSuccess) return ZGPU_E_HIP;
+    // A large download goes out as two halves on two streams. One copy engine moves ~28 GB/s over PCIe, and whether the runtime gives a
+    // single large copy one engine or more depends on what else the process has done on the device (measured: 45 GB/s in a fresh process,
+    // 28 once torch or another engine had run anything — tools/dev/stream_probe2.py); two copies get an engine each whatever ran before
+    // (38 GB/s in every case; timing the first download and splitting only when it was slow was tried: too noisy to decide on).
+    const uint8_t* src = d_->fs.out_ptr() + committed_base_ + off;
+    const uint64_t h = n >= (8u << 20) ? (n / 2 + 4095) & ~4095ull : n;
+    if (hipMemcpyAsync(dst, src, h, hipMemcpyDeviceToHost, eng_->download_stream()) != hipSuccess) return ZGPU_E_HIP;
     fetching_ = true;
+    if (n > h) {
+      if (hipMemcpyAsync(dst + h, src + h, n - h, hipMemcpyDeviceToHost, eng_->download_stream2()) != hipSuccess) return ZGPU_E_HIP;
+      fetching2_ = true;
+    }
     return ZGPU_OK;
   }
   int fetch_wait() override {
     if (!fetching_) return ZGPU_OK;
     fetching_ = false;
-    return hipStreamSynchronize(eng_->download_stream()) == hipSuccess ? ZGPU_OK : ZGPU_E_HIP;
+    hipError_t e = hipStreamSynchronize(eng_->download_stream());
+    if (fetching2_) { fetching2_ = false; const hipError_t e2 = hipStreamSynchronize(eng_->download_stream2()); if (e == hipSuccess) e = e2; }
+    return e == hipSuccess ? ZGPU_OK : ZGPU_E_HIP;
   }
   int rebase(const uint8_t* held, uint64_t n) override {
     FrameState& fs = d_->fs;
@@ -215,7 +227,7 @@ class GpuStreamBackend : public StreamBackend {
   Engine* own_ = nullptr;
   Batch* b_ = nullptr;
   uint64_t run_base_ = 0, committed_base_ = 0;
-  bool fetching_ = false;
+  bool fetching_ = false, fetching2_ = false;
   Batch* nb_ = nullptr;                 // the run that is prepared (parsed, uploaded) and not launched yet
   std::chrono::steady_clock::time_point t_launch_;
 };
