@@ -138,7 +138,12 @@ int zgpu_pool_plan_stats(const zgpu_pool*, uint32_t g, uint64_t* out, int n);
 int zgpu_pool_frame(zgpu_pool*, uint32_t i, int* gpu, uint64_t* out_size, uint32_t* status);
 int zgpu_pool_read(zgpu_pool*, uint32_t i, uint8_t* dst, size_t cap, size_t* written);
 
-/* ---- staged form of the same path, for device-resident runs (bench / roofline) ---------------------------- */
+/* ---- staged form of the same path, for device-resident runs (bench / roofline) ----------------------------
+ * (No content checksum on this surface: the reference feeds XXH64 as bytes are DRAINED (decode_buffer.rs:223-227,290,301) and output that
+ *  stays in HBM is never drained. XXH64 is serial in 32-byte stripes — one 1 GB frame is 31 M dependent steps, ~0.5 s on a GPU lane against
+ *  ~50 ms on a host core — so the checksum is computed where the bytes reach the host: zgpu_decoder_* / zgpu_frame_* / zgpu_streaming_*. A caller
+ *  of zgpu_batch_* / zgpu_pool_stage that wants it reads the frame back (zgpu_batch_read) and hashes, or compares zgpu_frame_info.checksum,
+ *  the value stored in the frame, with its own.) */
 typedef struct {
   uint64_t src_begin, src_end;   /* byte range of the frame in the input */
   uint64_t window_size;          /* FrameHeader::window_size  frame.rs:116-139 */

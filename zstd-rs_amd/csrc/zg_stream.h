@@ -637,9 +637,11 @@ class StreamCore {
   int fetch_to_ring(uint64_t n, bool wait_done) {
     if (ring_free() < n) {
       Tick tk(&tus[4]);
+      uint32_t nap = 40;                                    // (a reader that has gone away for a while must not cost a core: back off to 1 ms)
       while (ring_free() < n) {
         { std::lock_guard<std::mutex> lk(mu_); if (stop_req_) return ZG_OK; }
-        std::this_thread::sleep_for(std::chrono::microseconds(40));
+        std::this_thread::sleep_for(std::chrono::microseconds(nap));
+        if (nap < 1000) nap *= 2;
       }
     }
     const uint64_t w = reserved_ % ring_cap_;
@@ -769,6 +771,7 @@ class StreamCore {
 
   void hasher_main() {
     uint64_t h = 0;
+    uint32_t nap = 30;
     for (;;) {
       const uint64_t t = tail_.load(std::memory_order_acquire);
       if (h < t) {
@@ -780,13 +783,15 @@ class StreamCore {
         if (n > first) hash_.update(ring_, n - first);
         h += n;
         hashed_.store(h, std::memory_order_release);
+        nap = 30;
         continue;
       }
       if (hash_stop_.load(std::memory_order_acquire)) {
         if (h == tail_.load(std::memory_order_acquire)) return;
         continue;
       }
-      std::this_thread::sleep_for(std::chrono::microseconds(30));
+      std::this_thread::sleep_for(std::chrono::microseconds(nap));
+      if (nap < 500) nap *= 2;
     }
   }
 
