@@ -251,3 +251,36 @@ def test_io_copy_and_the_frame_decoders_read_ahead(ctx):
     out.append(d.collect())
     assert b"".join(out) == data and calls <= 8, calls
     d.close()
+
+
+def test_large_windows_and_unknown_sizes(ctx):
+    """frames whose window is larger than the read-ahead budget (the ring then holds the window + two short runs), a frame without
+    Frame_Content_Size (the stream starts on the caller's thread and hands over to the worker after 32 MiB), both against the generator's
+    plaintext and the stored checksum; the repetitive text makes matches reach far back into the 32 MiB window"""
+    import zgdata
+    import zgpu
+    rng = random.Random(64)
+    base = zgdata.text_like(6 << 20, seed=0x71)
+    data = b"".join(base[rng.randrange(0, 5 << 20):][: 1 << 20] for _ in range(72))          # 72 MiB: pieces of 6 MiB of text, repeated
+    want = hashlib.sha256(data).hexdigest()
+    for z, kw, cap in ((zgdata.zstd_compress(data, window_log=25), dict(read_ahead=16 << 20), 1 << 20),
+                       (zgdata.zstd_compress(data, window_log=25), dict(), 8192),
+                       (zgdata.zstd_compress(data, content_size=False), dict(read_ahead=24 << 20), 3 << 20),
+                       (zgdata.zstd_compress(data, window_log=25, content_size=False), dict(read_ahead=1), 5 << 20)):
+        for callback in (False, True):
+            s = zgpu.CStreamingDecoder(ctx, io.BytesIO(z) if callback else None, data=None if callback else z, **kw)
+            h = hashlib.sha256()
+            total = 0
+            while True:
+                d = s.read(cap)
+                if not d:
+                    break
+                assert len(d) == cap or total + len(d) == len(data)
+                h.update(d)
+                total += len(d)
+            st = s.stats()
+            assert total == len(data) and h.hexdigest() == want, (kw, cap, callback, st)
+            assert s.is_finished() and s.get_calculated_checksum() == s.get_checksum_from_data()
+            # (the frame without a declared size is 576 blocks: runs of 8, 32, 128 and then 512 blocks finish it on the caller's thread)
+            assert st["dropped"] == 0 and st["mode"] == (2 if kw.get("read_ahead") == 1 else 1 if z[4] >> 6 else 0), st
+            s.close()
