@@ -898,8 +898,13 @@ int Batch::read_output(uint64_t off, uint8_t* dst, uint64_t n) {
   if (ran && !synced) { const int st = sync(); if (st) return st; }   // (sync() may still have to repeat the sweep)
   if (off + n > dev.dst_cap) return ZG_BAD_ARG;
   if (n) {   // on the engine's second stream (idle once the run is synced): several engines' downloads and uploads overlap
-    ZG_HIP(hipMemcpyAsync(dst, dev.dst + off, n, hipMemcpyDeviceToHost, eng->stream2_));
+    // (a large download as two halves on two streams: a single copy may get one copy engine, ~28 GB/s, where two copies get one each — what a
+    //  process has done on the device before decides, LABNOTES round 6)
+    const uint64_t h = n >= (8u << 20) ? (n / 2 + 4095) & ~4095ull : n;
+    ZG_HIP(hipMemcpyAsync(dst, dev.dst + off, h, hipMemcpyDeviceToHost, eng->stream2_));
+    if (n > h) ZG_HIP(hipMemcpyAsync(dst + h, dev.dst + off + h, n - h, hipMemcpyDeviceToHost, eng->stream5_));
     ZG_HIP(hipStreamSynchronize(eng->stream2_));
+    if (n > h) ZG_HIP(hipStreamSynchronize(eng->stream5_));
   }
   return ZG_OK;
 }

@@ -608,10 +608,21 @@ __device__ __forceinline__ void zg_seq_window(ZgSeqChain& c, const uint8_t* stor
 // a third less LDS per block: three workgroups per CU instead of two. The kernel lasts as long as ONE chain when all blocks of the submit are
 // resident at once (the 7630 blocks of the 1e9-byte frame: the unpacked form), and as long as blocks x chain / resident chains when they
 // are not (65536 single-block frames, 128 x 64 MiB frames: eight rounds -> 5.3: the packed form). zg_launch_seq picks.
+// (measurement variant, tools/dev/mkvariant.sh ILV -DZG_SEQ_ILV: the tables of a workgroup's 16 blocks interleaved at 16-byte granularity, so
+//  that block g's look-ups always land in the four LDS banks 4g .. 4g + 3 and never collide with another block's — VERDICT r5 item 2a. A
+//  lane's `tab` / `xtab` are then BYTE bases (block granule + the table's offset), the address of entry i is computed per look-up.)
+#ifdef ZG_SEQ_ILV
+#define ZG_SEQ_ILVA(o) ((((o) >> 4) << 8) | ((o) & 15u))
+#define ZG_SEQ_LD16(tab, i) (*(const uint16_t*)((const uint8_t*)(tab) + ZG_SEQ_ILVA(to2 + 2u * (i))))
+#define ZG_SEQ_LD8(xtab, i) (*((const uint8_t*)(xtab) + ZG_SEQ_ILVA(to1 + (i))))
+#else
+#define ZG_SEQ_LD16(tab, i) ((tab)[i])
+#define ZG_SEQ_LD8(xtab, i) ((xtab)[i])
+#endif
 #define ZG_SEQ_PK(bl, nb, all) ((uint16_t)((((uint32_t)(bl) << 1) | (1u << (nb))) | ((uint32_t)(all) << 10)))
 template <bool FAST, bool PK>
 __device__ __forceinline__ void zg_seq_step(ZgSeqChain& c, const uint16_t* tab, const uint8_t* xtab, const uint8_t* store4, uint16_t* rec,
-                                            int32_t rbits, bool& act, uint32_t& left, uint32_t& cnt) {
+                                            int32_t rbits, bool& act, uint32_t& left, uint32_t& cnt, const uint32_t to2 = 0, const uint32_t to1 = 0) {
   const uint32_t nb0 = PK ? (uint32_t)__builtin_ctz(c.e) : c.e & 15u;
   if (PK) c.s = c.e >> 10;
   uint32_t nb = nb0, pk = c.s | (nb0 << 8);          // pk: [7:0] all bits this lane's symbol takes, [15:8] its state bits
@@ -631,7 +642,7 @@ __device__ __forceinline__ void zg_seq_step(ZgSeqChain& c, const uint16_t* tab, 
   if (FAST) {
     *rec = (uint16_t)c.st;
     c.pr = q; c.st = st2;
-    c.e = tab[st2]; if (!PK) c.s = xtab[st2];
+    c.e = ZG_SEQ_LD16(tab, st2); if (!PK) c.s = ZG_SEQ_LD8(xtab, st2);
     zg_seq_window(c, store4);
     __builtin_amdgcn_sched_barrier(0);
   } else {
@@ -642,7 +653,7 @@ __device__ __forceinline__ void zg_seq_step(ZgSeqChain& c, const uint16_t* tab, 
     left -= ok ? 1u : 0u;                             // stops at the sequence that ran out of bits
     act = ok && left != 0u;
     ZgSeqChain n = c;
-    n.pr = q; n.st = st2; n.e = tab[st2]; if (!PK) n.s = xtab[st2];
+    n.pr = q; n.st = st2; n.e = ZG_SEQ_LD16(tab, st2); if (!PK) n.s = ZG_SEQ_LD8(xtab, st2);
     zg_seq_window(n, store4);
     __builtin_amdgcn_sched_barrier(0);
     if (was) { c.pr = n.pr; c.wlo = n.wlo; c.w0 = n.w0; c.w1 = n.w1; c.w2 = n.w2; c.w3 = n.w3; }
@@ -652,8 +663,17 @@ __device__ __forceinline__ void zg_seq_step(ZgSeqChain& c, const uint16_t* tab, 
 
 template <bool PK>
 __global__ void __launch_bounds__(128) zg_k_seq(ZgBatchDev d) {
+#ifdef ZG_SEQ_ILV
+  __shared__ __attribute__((aligned(16))) uint8_t s_tabi[((ZG_FSE_SLOT_U32 + 2) * 2 + 15) / 16 * 256];
+  __shared__ __attribute__((aligned(16))) uint8_t s_xbi[PK ? 16 : (ZG_FSE_SLOT_U32 + 4 + 15) / 16 * 256];
+#define ZG_SEQ_ST16(g, i, v) (*(uint16_t*)(s_tabi + (ZG_SEQ_ILVA(2u * (i)) | ((g) << 4))) = (v))
+#define ZG_SEQ_ST8(g, i, v) (s_xbi[ZG_SEQ_ILVA((uint32_t)(i)) | ((g) << 4)] = (v))
+#else
   __shared__ uint16_t s_tab[ZG_SEQ_G][ZG_FSE_SLOT_U32 + 2];   // + the one-entry dummy table of the spare lane
   __shared__ uint8_t s_xb[PK ? 1 : ZG_SEQ_G][PK ? 4 : ZG_FSE_SLOT_U32 + 4];
+#define ZG_SEQ_ST16(g, i, v) (s_tab[g][i] = (v))
+#define ZG_SEQ_ST8(g, i, v) (s_xb[g][i] = (v))
+#endif
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[ZG_SEQ_G][ZG_SEQ_RSTORE];
   __shared__ __attribute__((aligned(16))) uint2 s_out[2][ZG_SEQ_G][ZG_SEQ_CH];   // records, 4 x u16: states {OF, ML, LL, 0}; one buffer per phase parity
   __shared__ int32_t s_pos[2][ZG_SEQ_G];            // decoder -> mover, per phase parity: the block's position after the phase,
@@ -688,14 +708,14 @@ __global__ void __launch_bounds__(128) zg_k_seq(ZgBatchDev d) {
           if (i < (1u << lg)) {
             const uint32_t nb = ZG_FSE_NB(v[j]);
             const uint32_t all = nb + (k == 1 ? ZG_FSE_SYM(v[j]) : v[j] >> 26);                // OF: the code is the number of extra bits
-            if (PK) s_tab[g][offs[k] + i] = ZG_SEQ_PK(ZG_FSE_BL(v[j]), nb, all);
-            else { s_tab[g][offs[k] + i] = (uint16_t)((ZG_FSE_BL(v[j]) << 4) | nb); s_xb[g][offs[k] + i] = (uint8_t)all; }
+            if (PK) ZG_SEQ_ST16(g, offs[k] + i, ZG_SEQ_PK(ZG_FSE_BL(v[j]), nb, all));
+            else { ZG_SEQ_ST16(g, offs[k] + i, (uint16_t)((ZG_FSE_BL(v[j]) << 4) | nb)); ZG_SEQ_ST8(g, offs[k] + i, (uint8_t)all); }
           }
         }
       }
       if (t == 0) s_log[g][k] = (uint8_t)lg;
     }
-    if (t == 0) { s_ok[g] = ok ? 1 : 0; s_tab[g][ZG_FSE_SLOT_U32] = PK ? ZG_SEQ_PK(0, 0, 0) : 0; if (!PK) s_xb[g][ZG_FSE_SLOT_U32] = 0; }
+    if (t == 0) { s_ok[g] = ok ? 1 : 0; ZG_SEQ_ST16(g, ZG_FSE_SLOT_U32, PK ? ZG_SEQ_PK(0, 0, 0) : 0); if (!PK) ZG_SEQ_ST8(g, ZG_FSE_SLOT_U32, 0); }
   }
   __syncthreads();
   // ---- per-lane setup: four lanes per block in either wave. Decoder: lane role 0 follows the OF chain, 1 the ML chain,
@@ -708,8 +728,15 @@ __global__ void __launch_bounds__(128) zg_k_seq(ZgBatchDev d) {
   int32_t rbits = 0;
   uint64_t bsA = 0, floorA = 0, lo = 0, dstp = 0;
   const uint32_t toff = role == 0u ? ZG_FSE_OF_OFF : role == 1u ? ZG_FSE_ML_OFF : role == 2u ? ZG_FSE_LL_OFF : ZG_FSE_SLOT_U32;
+#ifdef ZG_SEQ_ILV
+  const uint16_t* tab = (const uint16_t*)(s_tabi + (g << 4));
+  const uint8_t* xtab = PK ? s_xbi : s_xbi + (g << 4);
+  const uint32_t to2 = toff * 2u, to1 = toff;
+#else
   const uint16_t* tab = &s_tab[g][toff];
   const uint8_t* xtab = PK ? &s_xb[0][0] : &s_xb[g][toff];
+  const uint32_t to2 = 0, to1 = 0;
+#endif
   uint8_t* const store = s_ring[g];
   const uint8_t* const store4 = store + 4;
   int32_t P = 0;
@@ -766,7 +793,7 @@ __global__ void __launch_bounds__(128) zg_k_seq(ZgBatchDev d) {
     const uint32_t lg = role == 0u ? of_log : role == 1u ? ml_log : role == 2u ? ll_log : 0u;
     const int32_t q = P - (int32_t)(role == 2u ? ll_log : role == 0u ? ll_log + of_log : ll_log + of_log + ml_log);
     c.st = (q >= 0 && role != 3u) ? zg_ring_bits(store, q + rbits, lg) : 0u;
-    c.e = tab[c.st]; c.s = PK ? 0u : xtab[c.st];
+    c.e = ZG_SEQ_LD16(tab, c.st); c.s = PK ? 0u : ZG_SEQ_LD8(xtab, c.st);
     P -= (int32_t)(ll_log + of_log + ml_log);
     if (owner && !mover) d.seq_out[b].pad = (uint32_t)P;   // where the first sequence starts: zg_k_seqpost rebuilds the positions from the bit counts
     left = nseq;
@@ -789,12 +816,12 @@ __global__ void __launch_bounds__(128) zg_k_seq(ZgBatchDev d) {
       uint32_t cnt = 0;
       if (act && left > ZG_SEQ_CH) {
 #pragma unroll
-        for (int k = 0; k < ZG_SEQ_CH; k++) zg_seq_step<true, PK>(c, tab, xtab, store4, out_base + 4 * k, rbits, act, left, cnt);
+        for (int k = 0; k < ZG_SEQ_CH; k++) zg_seq_step<true, PK>(c, tab, xtab, store4, out_base + 4 * k, rbits, act, left, cnt, to2, to1);
         cnt = ZG_SEQ_CH; left -= ZG_SEQ_CH;
         if (c.pr < rbits) act = false;                             // ran out of bits with sequences left (:209-211)
       } else if (act) {
 #pragma unroll
-        for (int k = 0; k < ZG_SEQ_CH; k++) zg_seq_step<false, PK>(c, tab, xtab, store4, out_base, rbits, act, left, cnt);
+        for (int k = 0; k < ZG_SEQ_CH; k++) zg_seq_step<false, PK>(c, tab, xtab, store4, out_base, rbits, act, left, cnt, to2, to1);
       }
       P = c.pr - rbits;
       const bool more = __any(act);
