@@ -27,6 +27,10 @@ elif kind in ("many", "isomany"):
         for q in parts:
             h.update(q)
     want = h.digest()
+elif kind == "real":        # the real-text corpus of the image, stretched to `size` (tools/realtext.py load_tiled: bench.py's realtext1g)
+    import realtext
+    plain = realtext.load_tiled(size)[0]
+    z = zgdata.zstd_compress(plain)
 else:
     plain = zgdata.text_like(size) if kind == "text" else zgdata.iso_like(size)
     z = zgdata.zstd_compress(plain)
