@@ -837,7 +837,12 @@ class StreamCore {
         Tick tk(&tus[5]);
         std::unique_lock<std::mutex> lk(mu_);
         const uint64_t seen = pub_.load(std::memory_order_relaxed);
+#ifdef ZG_STREAM_TSAN   // (ThreadSanitizer of this toolchain does not know pthread_cond_clockwait, which wait_for uses: it then reports locks that are not there)
+        cv_reader_.wait_until(lk, std::chrono::system_clock::now() + std::chrono::milliseconds(2),
+                              [&]() { return pub_.load(std::memory_order_relaxed) != seen || pstate_.load(std::memory_order_relaxed) != P_RUNNING; });
+#else
         cv_reader_.wait_for(lk, std::chrono::milliseconds(2), [&]() { return pub_.load(std::memory_order_relaxed) != seen || pstate_.load(std::memory_order_relaxed) != P_RUNNING; });
+#endif
         continue;
       }
       // the worker has stopped in front of the frame's end (a run was dropped, the source ran dry, the engine failed)
