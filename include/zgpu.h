@@ -314,8 +314,8 @@ int zgpu_streaming_create_ex(zgpu_ctx*, zgpu_read_fn read, void* user, const zgp
 int zgpu_streaming_create_slice(zgpu_ctx*, const uint8_t* src, size_t len, const zgpu_stream_opts* opts_or_null, zgpu_streaming** out);
 size_t zgpu_streaming_source_position(const zgpu_streaming*);   /* slice sources: bytes of src taken so far (runs ahead of the reader) */
 void zgpu_streaming_destroy(zgpu_streaming*);
-/* get_ref (:66-85): the decoder behind the stream, for its accessors (is_finished, the checksums, the counters). While the stream owns it,
- * do not call its decode_* / collect / read functions. */
+/* get_ref / get_mut (:66-85): the decoder behind the stream — its accessors (is_finished, the checksums, the counters), can_collect / collect /
+ * read (they hand out what the stream has buffered). decode_blocks / decode_from_to on it return ZGPU_E_BAD_ARG: the stream feeds it. */
 zgpu_decoder* zgpu_streaming_decoder(zgpu_streaming*);
 /* read (:119-155): *n = bytes written to dst (0 = end of frame) */
 int zgpu_streaming_read(zgpu_streaming*, uint8_t* dst, size_t cap, size_t* n);

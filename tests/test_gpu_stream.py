@@ -284,3 +284,35 @@ def test_large_windows_and_unknown_sizes(ctx):
             # (the frame without a declared size is 576 blocks: runs of 8, 32, 128 and then 512 blocks finish it on the caller's thread)
             assert st["dropped"] == 0 and st["mode"] == (2 if kw.get("read_ahead") == 1 else 1 if z[4] >> 6 else 0), st
             s.close()
+
+
+def test_decoder_behind_the_stream(ctx):
+    """get_ref() / get_mut() of the streaming decoder (streaming_decoder.rs:66-85): the FrameDecoder behind it hands out what the stream has
+    buffered (can_collect / collect / read), and refuses to be fed by anyone else"""
+    import ctypes as C
+    import zgdata
+    import zgpu
+    data = zgdata.text_like(12 << 20, seed=0x6E7)
+    z = zgdata.zstd_compress(data)
+    for kw in (dict(), dict(pipe_after=1, read_ahead=6 << 20), dict(read_ahead=1)):
+        s = zgpu.CStreamingDecoder(ctx, data=z, **kw)
+        L, d = s.L, s._dec()
+        got = s.read(1 << 20)
+        assert got == data[:1 << 20]
+        n = L.zgpu_decoder_can_collect(d)
+        buf = C.create_string_buffer(max(n, 1))
+        assert L.zgpu_decoder_collect(d, buf, n) == n
+        got += buf.raw[:n]
+        small = C.create_string_buffer(100)
+        k = L.zgpu_decoder_read(d, small, 100)
+        got += small.raw[:k]
+        assert got == data[:len(got)]
+        used, fin = C.c_size_t(), C.c_int()
+        assert L.zgpu_decoder_decode_blocks(d, z, len(z), C.byref(used), zgpu.STRAT_ALL, 0, C.byref(fin)) == 93      # ZGPU_E_BAD_ARG
+        while True:
+            c = s.read(3 << 20)
+            if not c:
+                break
+            got += c
+        assert got == data and s.get_calculated_checksum() == s.get_checksum_from_data()
+        s.close()

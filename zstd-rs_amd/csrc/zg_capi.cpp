@@ -492,6 +492,7 @@ int zgpu_decoder_init(zgpu_decoder* d, const uint8_t* src, size_t len, size_t* c
 
 int zgpu_decoder_force_dict(zgpu_decoder* d, uint32_t dict_id) {   // frame_decoder.rs:229-243
   if (!d->has_state) return ZGPU_E_NOT_INITIALIZED;
+  if (d->stream && zg_stream_blocks_decoded(d->stream)) return ZGPU_E_BAD_ARG;   // (behind a stream: only before its first read)
   auto it = d->ctx->dicts.find(dict_id);
   if (it == d->ctx->dicts.end()) return ZGPU_E_DICT_NOT_PROVIDED;
   return zg_apply_dict(d, it->second);
@@ -502,6 +503,7 @@ int zgpu_decoder_decode_blocks(zgpu_decoder* d, const uint8_t* src, size_t len, 
   if (consumed) *consumed = 0;
   if (frame_finished) *frame_finished = 0;
   if (!d->has_state) return ZGPU_E_NOT_INITIALIZED;
+  if (d->stream) return ZGPU_E_BAD_ARG;            // the streaming decoder that owns this decoder feeds it (zgpu_streaming_decoder: accessors and read / collect only)
   size_t p = 0;
   int st = ZGPU_OK;
   if (strat == ZGPU_STRAT_ALL || strat == ZGPU_STRAT_UPTO_BLOCKS) {
@@ -543,10 +545,12 @@ size_t zgpu_decoder_can_collect(const zgpu_decoder* d) {
 size_t zgpu_decoder_collect(zgpu_decoder* d, uint8_t* dst, size_t cap) {
   size_t n = zgpu_decoder_can_collect(d);
   if (n > cap) n = cap;
+  if (d->stream) return zg_stream_take(d->stream, dst, n);   // (what is collectable is buffered already: nothing is decoded or pulled from the source)
   return zg_dec_drain(d, n, dst);
 }
 size_t zgpu_decoder_read(zgpu_decoder* d, uint8_t* dst, size_t cap) {
   if (!d->has_state) return 0;
+  if (d->stream) { size_t n = zgpu_decoder_can_collect(d); if (n > cap) n = cap; return zg_stream_take(d->stream, dst, n); }
   size_t n = d->frame_finished ? d->held() : (d->held() > d->window_size ? d->held() - (size_t)d->window_size : 0);
   if (n > cap) n = cap;
   return zg_dec_drain(d, n, dst);
@@ -556,6 +560,7 @@ int zgpu_decoder_decode_from_to(zgpu_decoder* d, const uint8_t* src, size_t len,
   // FrameDecoder::decode_from_to (frame_decoder.rs:439-529): only whole blocks are consumed; the checksum may arrive later
   if (read_out) *read_out = 0;
   if (written_out) *written_out = 0;
+  if (d->stream) return ZGPU_E_BAD_ARG;
   const uint64_t at_start = d->has_state ? d->bytes_read : 0;
   if (!zgpu_decoder_is_finished(d) || !d->has_state) {
     size_t p = 0;

@@ -60,3 +60,4 @@ uint64_t zg_stream_bytes_read(const zg::StreamCore* c);
 bool zg_stream_checksum_from_data(const zg::StreamCore* c, uint32_t* out);
 uint32_t zg_stream_calculated_checksum(zg::StreamCore* c);
 uint64_t zg_stream_host_bytes(const zg::StreamCore* c);
+size_t zg_stream_take(zg::StreamCore* c, uint8_t* dst, size_t n);   // n <= can_collect: bytes that are buffered already

@@ -267,6 +267,7 @@ uint64_t zg_stream_bytes_read(const StreamCore* c) { return c->bytes_read_from_s
 bool zg_stream_checksum_from_data(const StreamCore* c, uint32_t* out) { return c->checksum_from_data(out); }
 uint32_t zg_stream_calculated_checksum(StreamCore* c) { return c->calculated_checksum(); }
 uint64_t zg_stream_host_bytes(const StreamCore* c) { return c->host_bytes(); }
+size_t zg_stream_take(StreamCore* c, uint8_t* dst, size_t n) { size_t got = 0; return (n && c->read(dst, n, &got) == ZGPU_OK) ? got : 0; }
 
 extern "C" {
 
