@@ -538,7 +538,7 @@ def main():
             out["e2e_GBps"] = round(rate, 3)
             out["e2e_note"] = ("C ABI zgpu_pool_decode_all on %d frames (%d B of plaintext): pinned host buffer in, pinned host buffer out; host walk + H2D "
                                "+ kernels + D2H with the jobs of two engines overlapped, best of 3; per GPU" % (len(ez), sum(len(p) for p in ep)))
-        if not args.no_e2e and args.workload == "enwik9like" and len(staged_z) == 1:
+        if not args.no_e2e and n_gpus == 1 and args.workload == "enwik9like" and len(staged_z) == 1:
             out.update(stream_rates(local_rank, staged_z[0], staged_p[0]))
         if not args.no_cpu:
             if affinity_before:
