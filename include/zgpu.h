@@ -322,6 +322,10 @@ int zgpu_streaming_read(zgpu_streaming*, uint8_t* dst, size_t cap, size_t* n);
 /* std::io::copy(&mut decoder, &mut writer) with a buffer of buf_size bytes (the reference's CLI: 8 KiB, cli/src/main.rs:142-144);
  * write == NULL is io::sink(). *total = bytes copied. */
 int zgpu_streaming_copy(zgpu_streaming*, size_t buf_size, zgpu_write_fn write, void* user, uint64_t* total);
+/* A stream that used a worker thread leaves its engine (streams, device buffers sized to its runs; at most two per device) and its pinned ring /
+ * staging memory (at most 3 GiB) to the next stream of the process: allocating them is what a short-lived stream would otherwise spend its time on.
+ * This returns all of that to the runtime (no stream may be in a call meanwhile). */
+void zgpu_release_caches(void);
 /* diagnostics: out[0] mode now (0 runs on the caller's thread, 1 worker thread + ring, 2 block by block), [1] runs decoded ahead and
  * taken, [2] runs decoded ahead and dropped, [3] host bytes held (buffer + ring); [4..11] microseconds — worker thread: waiting for a run
  * from the reader, decoding (parse + upload + kernels), waiting for the previous run's download, commit, waiting for room in the ring; reader:

@@ -316,3 +316,7 @@ def test_decoder_behind_the_stream(ctx):
             got += c
         assert got == data and s.get_calculated_checksum() == s.get_checksum_from_data()
         s.close()
+    ctx.L.zgpu_release_caches()          # the worker engine and the pinned ring the streams above left behind
+    s = zgpu.CStreamingDecoder(ctx, data=z, pipe_after=1, read_ahead=6 << 20)
+    assert s.read(len(data) + 1) == data
+    s.close()

@@ -52,6 +52,11 @@ struct PinnedCache {
     }
     (void)hipHostFree(p);
   }
+  void trim() {
+    std::lock_guard<std::mutex> lk(mu);
+    for (const Blk& b : free_) (void)hipHostFree(b.p);
+    free_.clear(); held = 0;
+  }
   std::vector<Blk> sizes_;   // blocks handed out (their real sizes)
 };
 PinnedCache g_pinned;
@@ -75,6 +80,11 @@ struct IdleEngines {
       if (same < 2) { v.push_back(e); return; }
     }
     delete e;
+  }
+  void trim() {
+    std::vector<Engine*> all;
+    { std::lock_guard<std::mutex> lk(mu); all.swap(v); }
+    for (Engine* e : all) delete e;
   }
 };
 IdleEngines g_idle_engines;
@@ -380,6 +390,13 @@ int zgpu_streaming_copy(zgpu_streaming* s, size_t buf_size, zgpu_write_fn write,
   if (pinned) g_pinned.put(pinned);
   if (total) *total = sum;
   return st;
+}
+
+// what finished streams left behind for the next one — the worker engines with their device buffers (at most two per device), the pinned
+// ring / staging memory (at most 3 GiB) — goes back to the runtime
+void zgpu_release_caches(void) {
+  g_idle_engines.trim();
+  g_pinned.trim();
 }
 
 int zgpu_streaming_stats(const zgpu_streaming* s, uint64_t* out, int n) {

@@ -73,7 +73,7 @@ EXPORTS = [
     "zgpu_frame_begin", "zgpu_frame_end", "zgpu_blocks_submit", "zgpu_sync", "zgpu_available", "zgpu_read", "zgpu_device_output",
     "zgpu_frame_checksum", "zgpu_frame_blocks_decoded", "zgpu_decoder_device_bytes", "zgpu_debug_tuning",
     "zgpu_streaming_create_ex", "zgpu_streaming_create_slice", "zgpu_streaming_source_position", "zgpu_streaming_copy", "zgpu_streaming_stats",
-    "zgpu_decoder_set_hash", "zgpu_decoder_set_read_ahead",
+    "zgpu_decoder_set_hash", "zgpu_decoder_set_read_ahead", "zgpu_release_caches",
 ]
 WRITE_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
 READ_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
