@@ -543,7 +543,7 @@ class StreamCore {
     if (cap < held_buf() + (8ull << 20)) cap = held_buf() + (8ull << 20);
     cap = (cap + 4095) & ~4095ull;
     run_bytes_ = (cap - window) / 2;
-    if (run_bytes_ > (2047ull * kMaxBlockSize)) run_bytes_ = 2047ull * kMaxBlockSize;
+    if (run_bytes_ > (8191ull * kMaxBlockSize)) run_bytes_ = 8191ull * kMaxBlockSize;   // (one round of sequence chains on a 256-CU device)
     run_blocks_ = (uint32_t)(run_bytes_ / kMaxBlockSize);
     if (run_blocks_ == 0) return ZG_NOMEM;
     ring_ = (uint8_t*)be_->host_alloc(cap);
@@ -601,7 +601,7 @@ class StreamCore {
       StreamStage st;
       if (sb >= 0) { st.own = stages_[sb].p; st.own_cap = stages_[sb].cap; }
       Tick tk(&tus[7]);
-      src.pull(pipe_ramp_ < run_blocks_ ? pipe_ramp_ : run_blocks_, (size_t)o_.max_run_src, true, &st, nullptr);
+      src.pull(pipe_ramp_ < run_blocks_ ? pipe_ramp_ : run_blocks_, src.is_slice() ? (size_t)0 : (size_t)o_.max_run_src, true, &st, nullptr);   // (a slice is uploaded from where it lies: only the block count bounds a run)
       if (pipe_ramp_ < run_blocks_) pipe_ramp_ *= 8;      // the first runs are short (the first read returns soon), the later ones as long as the budget allows
       if (st.stop) src_stop_ = true;                    // what cannot be read whole stays in the source: LOCKSTEP meets it when its turn comes
       std::lock_guard<std::mutex> lk(mu_);
