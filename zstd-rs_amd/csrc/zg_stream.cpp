@@ -169,25 +169,29 @@ class GpuStreamBackend : public StreamBackend {
   int fetch(uint8_t* dst, uint64_t off, uint64_t n) override {
     if (!n) return ZGPU_OK;
     if (hipSetDevice(eng_->device()) != hipSuccess) return ZGPU_E_HIP;
-    // A large download goes out as two halves on two streams. One copy engine moves ~28 GB/s over PCIe, and whether the runtime gives a
+    // A large download goes out in pieces on separate streams. One copy engine moves ~28 GB/s over PCIe, and whether the runtime gives a
     // single large copy one engine or more depends on what else the process has done on the device (measured: 45 GB/s in a fresh process,
-    // 28 once torch or another engine had run anything — tools/dev/stream_probe2.py); two copies get an engine each whatever ran before
-    // (38 GB/s in every case; timing the first download and splitting only when it was slow was tried: too noisy to decide on).
+    // 28 once torch or another engine had run anything — tools/dev/stream_probe2.py); separate copies get an engine each whatever ran before
+    // (38 GB/s and more in every case; timing the first download and splitting only when it was slow was tried: too noisy to decide on).
     const uint8_t* src = d_->fs.out_ptr() + committed_base_ + off;
-    const uint64_t h = n >= (8u << 20) ? (n / 2 + 4095) & ~4095ull : n;
-    if (hipMemcpyAsync(dst, src, h, hipMemcpyDeviceToHost, eng_->download_stream()) != hipSuccess) return ZGPU_E_HIP;
-    fetching_ = true;
-    if (n > h) {
-      if (hipMemcpyAsync(dst + h, src + h, n - h, hipMemcpyDeviceToHost, eng_->download_stream2()) != hipSuccess) return ZGPU_E_HIP;
-      fetching2_ = true;
+    // (three pieces: 3.5-3.8 ms of waiting per GB against 4.8 with two; a fourth would have to share a stream with kernels)
+    hipStream_t ss[3] = {eng_->download_stream(), eng_->download_stream2(), eng_->upload_stream()};
+    const int parts = n >= (8u << 20) ? 3 : 1;
+    const uint64_t piece = ((n / parts) + 4095) & ~4095ull;
+    uint64_t o = 0;
+    for (int i = 0; i < parts && o < n; i++) {
+      const uint64_t k = (i == parts - 1 || n - o < piece) ? n - o : piece;
+      if (hipMemcpyAsync(dst + o, src + o, k, hipMemcpyDeviceToHost, ss[i]) != hipSuccess) return ZGPU_E_HIP;
+      o += k;
     }
+    fetching_ = true;
     return ZGPU_OK;
   }
   int fetch_wait() override {
     if (!fetching_) return ZGPU_OK;
     fetching_ = false;
     hipError_t e = hipStreamSynchronize(eng_->download_stream());
-    if (fetching2_) { fetching2_ = false; const hipError_t e2 = hipStreamSynchronize(eng_->download_stream2()); if (e == hipSuccess) e = e2; }
+    for (hipStream_t x : {eng_->download_stream2(), eng_->upload_stream()}) { const hipError_t e2 = hipStreamSynchronize(x); if (e == hipSuccess) e = e2; }
     return e == hipSuccess ? ZGPU_OK : ZGPU_E_HIP;
   }
   int rebase(const uint8_t* held, uint64_t n) override {
@@ -237,7 +241,7 @@ class GpuStreamBackend : public StreamBackend {
   Engine* own_ = nullptr;
   Batch* b_ = nullptr;
   uint64_t run_base_ = 0, committed_base_ = 0;
-  bool fetching_ = false, fetching2_ = false;
+  bool fetching_ = false;
   Batch* nb_ = nullptr;                 // the run that is prepared (parsed, uploaded) and not launched yet
   std::chrono::steady_clock::time_point t_launch_;
 };
