@@ -406,6 +406,7 @@ int zgpu_pool_decode_all(zgpu_pool* p, const uint8_t* src, size_t len, uint8_t* 
       if (!downloading) return;
       if (hipStreamSynchronize(eng->download_stream()) != hipSuccess && !downloading->status) downloading->status = ZGPU_E_HIP;
       if (hipStreamSynchronize(eng->download_stream2()) != hipSuccess && !downloading->status) downloading->status = ZGPU_E_HIP;
+      if (hipStreamSynchronize(eng->upload_stream()) != hipSuccess && !downloading->status) downloading->status = ZGPU_E_HIP;
       delete downloading->batch; downloading->batch = nullptr;
       downloading = nullptr;
     };
@@ -428,11 +429,17 @@ int zgpu_pool_decode_all(zgpu_pool* p, const uint8_t* src, size_t len, uint8_t* 
       if (!j.status) j.out_size = j.batch->total_out;
       if (!j.status && direct_out && j.out_size == j.want_size) {
         land();                            // (at most one download in flight per engine: its buffers are this job's predecessor's)
-        // (two halves on two streams: a single copy may get one copy engine, ~28 GB/s, or more, depending on what the process has done on the
+        // (three pieces on three streams: a single copy may get one copy engine, ~28 GB/s, or more, depending on what the process has done on the
         //  device before; two copies get one each — see GpuStreamBackend::fetch, zg_stream.cpp)
-        const uint64_t h = j.out_size >= (8u << 20) ? (j.out_size / 2 + 4095) & ~4095ull : j.out_size;
-        j.status = j.batch->read_output_async(0, dst + j.out_off, h, eng->download_stream());
-        if (!j.status && j.out_size > h) j.status = j.batch->read_output_async(h, dst + j.out_off + h, j.out_size - h, eng->download_stream2());
+        hipStream_t ds[3] = {eng->download_stream(), eng->download_stream2(), eng->upload_stream()};
+        const int parts = j.out_size >= (8u << 20) ? 3 : 1;
+        const uint64_t piece = ((j.out_size / parts) + 4095) & ~4095ull;
+        uint64_t o = 0;
+        for (int i = 0; i < parts && o < j.out_size && !j.status; i++) {
+          const uint64_t k = (i == parts - 1 || j.out_size - o < piece) ? j.out_size - o : piece;
+          j.status = j.batch->read_output_async(o, dst + j.out_off + o, k, ds[i]);
+          o += k;
+        }
         j.placed = true;
         downloading = &j;
       } else if (j.batch) {
