@@ -320,3 +320,23 @@ def test_decoder_behind_the_stream(ctx):
     s = zgpu.CStreamingDecoder(ctx, data=z, pipe_after=1, read_ahead=6 << 20)
     assert s.read(len(data) + 1) == data
     s.close()
+
+
+def test_fuzz_artifacts_through_the_stream(ctx):
+    """the reference's fuzz artefacts (fuzz_regressions.rs:2-27: must not crash) through every mode of the streaming decoder: what the
+    oracle's read loop does with them — bytes, the failing read() and its error, or an error when the header is read — is what comes back"""
+    pack = read_pack("fuzz_artifacts.pack")
+    rng = random.Random(65)
+    n = 0
+    for name, data in sorted(pack.items()):
+        if not (name.startswith("decode/") or name.startswith("interop/")):
+            continue
+        pat = [rng.choice([1, 100, 8192, K, 1 << 20]) for _ in range(60)]
+        want, o = oracle_reads(data, pat)
+        for kw in MODES:
+            got, s = zgpu_reads(ctx, data, pat, n % 2 == 0, **kw)
+            same(want, got, (name, kw))
+            if s:
+                s.close()
+        n += 1
+    assert n >= 42
