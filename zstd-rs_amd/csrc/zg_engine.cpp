@@ -53,11 +53,11 @@ int Scratch::init_events() {
   return 0;
 }
 void Scratch::release_but_output() {
-  DevBuf* all[] = {&d_src, &d_aux, &d_slot_log, &d_fse, &d_huf, &d_hufmax, &d_lit, &d_seq, &d_og, &d_raw};
+  DevBuf* all[] = {&d_src, &d_aux, &d_fparsed, &d_slot_log, &d_fse, &d_huf, &d_hufmax, &d_lit, &d_seq, &d_og, &d_raw};
   for (DevBuf* b : all) b->release();
 }
 void Scratch::release() {
-  DevBuf* all[] = {&d_src, &d_blocks, &d_frames, &d_aux, &d_slot_log, &d_fse, &d_huf, &d_hufmax, &d_status, &d_lit, &d_seq, &d_seqout, &d_pos,
+  DevBuf* all[] = {&d_src, &d_blocks, &d_frames, &d_aux, &d_fparsed, &d_slot_log, &d_fse, &d_huf, &d_hufmax, &d_status, &d_lit, &d_seq, &d_seqout, &d_pos,
                    &d_frameout, &d_dst, &d_seqblocks, &d_hufitems, &d_hufgroups, &d_totals, &d_og, &d_units, &d_unitinfo, &d_stepunits, &d_swdesc,
                    &d_dbg, &d_raw, &d_unitlist};
   for (DevBuf* b : all) b->release();
@@ -499,7 +499,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out, bool s
       (st = up(sc->d_units, bb.units.data(), bb.units.size() * sizeof(ZgUnit))) ||
       (st = up(sc->d_stepunits, bb.step_units.data(), bb.step_units.size() * 4)) ||
       (st = up(sc->d_unitlist, bb.unit_list.data(), bb.unit_list.size() * 4)) ||
-      (st = sc->d_aux.reserve((size_t)nb * sizeof(ZgBlockAux) + 16)) || (st = sc->d_slot_log.reserve((size_t)nslots * 4)) ||
+      (st = sc->d_aux.reserve((size_t)nb * sizeof(ZgBlockAux) + 16)) || (st = sc->d_fparsed.reserve((size_t)nb * sizeof(ZgFtabParsed) + 16)) || (st = sc->d_slot_log.reserve((size_t)nslots * 4)) ||
       (st = sc->d_fse.reserve((size_t)nslots * ZG_FSE_SLOT_U32 * 4)) || (st = sc->d_huf.reserve((size_t)(bb.nhuf_slots + 1) * ZG_HUF_SLOT_U16 * 2)) ||
       (st = sc->d_hufmax.reserve(bb.nhuf_slots + 16)) || (st = sc->d_status.reserve(7 * ((size_t)nb * 4 + 16))) ||
       (st = sc->d_lit.reserve(bb.lit_bytes + 128)) || (st = sc->d_seq.reserve((bb.seq_count + 2) * sizeof(ZgSeq))) ||
@@ -517,7 +517,7 @@ int Engine::upload(Batch* b, const uint8_t* src, size_t len, Batch** out, bool s
   d.blocks = sc->d_blocks.as<ZgBlock>(); d.nblocks = nb;
   d.frames = sc->d_frames.as<ZgFrame>(); d.nframes = nf;
   d.nslots = nslots; d.nhuf_slots = bb.nhuf_slots;
-  d.aux = sc->d_aux.as<ZgBlockAux>(); d.slot_log = sc->d_slot_log.as<uint8_t>();
+  d.aux = sc->d_aux.as<ZgBlockAux>(); d.ftab_parsed = sc->d_fparsed.as<ZgFtabParsed>(); d.slot_log = sc->d_slot_log.as<uint8_t>();
   d.fse_arena = sc->d_fse.as<uint32_t>(); d.huf_arena = sc->d_huf.as<uint16_t>(); d.huf_maxbits = sc->d_hufmax.as<uint8_t>();
   d.status = sc->d_status.as<uint32_t>(); d.tab_status = d.status + nb + 4; d.lit_status = d.tab_status + nb + 4;
   d.lit_counts = d.lit_status + nb + 4;     // [4 * nblocks], written by zg_k_huf (no reset needed)

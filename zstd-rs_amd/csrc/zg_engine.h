@@ -73,7 +73,7 @@ enum { ZG_T_TABLES = 0, ZG_T_HUF, ZG_T_SEQ, ZG_T_SEQPOST, ZG_T_SCAN, ZG_T_LIT, Z
 // Device buffers and events of one submit in flight. Engines keep finished ones for reuse: a stream of submits (block runs
 // of a streaming decoder, frames pulled from a work queue) allocates once.
 struct Scratch {
-  DevBuf d_src, d_blocks, d_frames, d_aux, d_slot_log, d_fse, d_huf, d_hufmax, d_status, d_lit, d_seq, d_seqout, d_pos, d_frameout,
+  DevBuf d_src, d_blocks, d_frames, d_aux, d_fparsed, d_slot_log, d_fse, d_huf, d_hufmax, d_status, d_lit, d_seq, d_seqout, d_pos, d_frameout,
       d_dst, d_seqblocks, d_hufitems, d_hufgroups, d_totals, d_og, d_units, d_unitinfo, d_stepunits, d_swdesc, d_dbg, d_raw, d_unitlist;
   hipEvent_t ev[ZG_T_COUNT + 1] = {};
   hipEvent_t ev_up = nullptr;                     // a submit prepared beside another one: its uploads are done (Engine::upload side)

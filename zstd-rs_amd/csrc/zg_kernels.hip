@@ -314,7 +314,6 @@ struct ZgFtabLds {
   uint16_t base[64];
   uint8_t symat[512];
   uint8_t xb_ll[36], xb_ml[53];
-  __attribute__((aligned(16))) uint8_t hdr[1024 + 32];   // the section's first KiB (three descriptions are < 300 bytes)
 };
 __device__ __forceinline__ int zg_fse_build_wave(ZgFtabLds& L, int np, int al, int kind, uint32_t* out_g, uint32_t lane) {
   const uint32_t N = 1u << al, mask = N - 1, step = (N >> 1) + (N >> 3) + 3;
@@ -385,6 +384,59 @@ __device__ __forceinline__ int zg_fse_build_wave(ZgFtabLds& L, int np, int al, i
   return ZG_OK;
 }
 
+// zg_k_fparse: the table descriptions of a block's sequences section, ONE LANE PER BLOCK (round 6). read_probabilities is a bit-serial chain
+// with nothing for a wave to share, and zg_k_ftab — one wave per block, lane 0 reading, 64 lanes building — spent 60 % of its instructions
+// on it (15 K wave instructions per block, the kernel is bound by their number). Here 64 blocks are read by one wave at the price of one.
+#define ZG_FP_STAGE 336      // bytes of a section's start a lane stages in LDS (three descriptions are < 300 bytes); a multiple of 16
+__global__ void __launch_bounds__(64) zg_k_fparse(ZgBatchDev d) {
+  // bit reads are dependent loads: each lane brings the start of its section to LDS with 16-byte loads that are all in flight together
+  // (one memory round trip instead of three per symbol), and reads the descriptions there; rows are 340 bytes apart (85 dwords: odd, so
+  // the lanes' rows start in different banks)
+  __shared__ __attribute__((aligned(16))) uint8_t s_hdr[64][ZG_FP_STAGE + 4];
+  const uint32_t lane = threadIdx.x, b = blockIdx.x * 64u + lane;
+  if (b >= d.nblocks) return;
+  const ZgBlock blk = d.blocks[b];
+  if (blk.host_status || blk.btype != ZG_BT_COMPRESSED || blk.nseq == 0) return;
+  ZgFtabParsed* P = &d.ftab_parsed[b];
+  const uint8_t* body = d.src + blk.src_off + blk.seq_off;
+  const uint32_t rem_all = blk.src_len - blk.seq_off;
+  const uint32_t sh = (uint32_t)((uint64_t)body & 3u);
+  const uint32_t lim = rem_all + sh > (uint32_t)ZG_FP_STAGE - 8u ? (uint32_t)ZG_FP_STAGE - 8u - sh : rem_all;   // bytes of the section that are staged
+  {
+    const uint64_t ga = (uint64_t)body & ~3ull;            // (the submit's bytes have 64 bytes of padding behind them: a row may end up to 11 bytes behind the section)
+    uint32_t* row = (uint32_t*)&s_hdr[lane][0];
+    const uint32_t nd = (lim + sh + 3u) >> 2;
+#pragma unroll 4
+    for (uint32_t i = 0; i < nd; i++) row[i] = *(const __attribute__((address_space(1))) uint32_t*)(ga + 4ull * i);
+  }
+  const int modes[3] = {blk.seq_modes >> 6, (blk.seq_modes >> 4) & 3, (blk.seq_modes >> 2) & 3};
+  const int max_log[3] = {9, 8, 9}, max_sym[3] = {35, 31, 52};
+  int st = ZG_OK, k = 0;
+  uint32_t off = 0;
+  auto parse = [&](const uint8_t* pb, uint32_t plim) {   // inlined twice: on the staged bytes, and (a section whose descriptions are longer) on the section itself
+    uint32_t rem = plim;
+    st = ZG_OK; off = 0;
+    for (k = 0; k < 3; k++) {
+      if (modes[k] == ZG_MODE_FSE) {
+        int np = 0, al = 0;
+        uint32_t used = 0;
+        st = zg_fse_read_probs(pb + off, rem, max_log[k], max_sym[k], P->probs[k], &np, &al, &used);
+        if (st) break;
+        for (int i = np; i < 64; i++) P->probs[k][i] = 0;
+        P->np[k] = (uint8_t)np; P->al[k] = (uint8_t)al;
+        off += used; rem -= used;
+      } else if (modes[k] == ZG_MODE_RLE) {
+        if (rem == 0 || pb[off] > max_sym[k]) { st = ZG_SEQ_RLE_BYTE; break; }
+        P->rle[k] = pb[off];
+        off += 1; rem -= 1;
+      }
+    }
+  };
+  parse(&s_hdr[lane][sh], lim);
+  if (st && lim != rem_all) parse(body, rem_all);
+  P->nparsed = (uint8_t)k; P->status = (uint32_t)st; P->done = off;
+}
+
 __global__ void __launch_bounds__(64 * ZG_FT_W) zg_k_ftab(ZgBatchDev d) {
   __shared__ ZgFtabLds s_l[ZG_FT_W];
   const uint32_t t = threadIdx.x, wv = t >> 6, lane = t & 63;
@@ -412,53 +464,34 @@ __global__ void __launch_bounds__(64 * ZG_FT_W) zg_k_ftab(ZgBatchDev d) {
   }
   const ZgBlock blk = d.blocks[b];
   if (blk.host_status || blk.btype != ZG_BT_COMPRESSED) return;
-  const uint8_t* body = d.src + blk.src_off;
   uint32_t seq_bits_off = blk.seq_off;
   uint8_t logs[3] = {0, 0, 0};
   int st = ZG_OK;
   if (blk.nseq > 0) {
-    const uint32_t rem_all = blk.src_len - blk.seq_off;
     uint32_t* slot = d.fse_arena + (uint64_t)b * ZG_FSE_SLOT_U32;
-    // order LL, OF, ML (sequence_section_decoder.rs:305,341,376)
+    // order LL, OF, ML (sequence_section_decoder.rs:305,341,376). The descriptions were read by zg_k_fparse (one lane per block); a table
+    // is built here, by the whole wave, when everything in front of it was fine: the first failing step in section order decides
+    const ZgFtabParsed* P = &d.ftab_parsed[b];
     const int kinds[3] = {ZG_KIND_LL, ZG_KIND_OF, ZG_KIND_ML};
     const int modes[3] = {blk.seq_modes >> 6, (blk.seq_modes >> 4) & 3, (blk.seq_modes >> 2) & 3};
-    const int max_log[3] = {9, 8, 9}, max_sym[3] = {35, 31, 52};
     const uint32_t offs[3] = {ZG_FSE_LL_OFF, ZG_FSE_OF_OFF, ZG_FSE_ML_OFF};
-    // the descriptions are staged in LDS (bit reads are dependent loads): 1 KiB in one go, 16 bytes per lane
-    const uint32_t lim = rem_all > 1000u ? 1000u : rem_all;
-    {
-      const uint64_t ga = (uint64_t)(body + blk.seq_off) & ~3ull;
-      const uint32_t sh = (uint32_t)((uint64_t)(body + blk.seq_off) & 3u);
-      if (16 * lane < lim + 8 + sh) *(zg_v4u*)(L.hdr + 16 * lane) = *(const zg_gv4u*)(ga + 16ull * lane);
-    }
-    const uint8_t* p0 = L.hdr + ((uint64_t)(body + blk.seq_off) & 3u);
-    uint32_t done = 0;
-    auto parse = [&](const uint8_t* pb, uint32_t plim) {   // inlined twice: once on LDS addresses, once on global ones
-      uint32_t off = 0, rem = plim;
-      st = ZG_OK;
-      for (int k = 0; k < 3 && !st; k++) {
-        if (modes[k] == ZG_MODE_FSE) {
-          int np = 0, al = 0, pst = 0;
-          uint32_t used = 0;
-          if (lane == 0) {
-            pst = zg_fse_read_probs(pb + off, rem, max_log[k], max_sym[k], L.probs, &np, &al, &used);
-            for (int i = np; i < 64; i++) L.probs[i] = 0;
-          }
-          zg_wave_publish();
-          st = __shfl(pst, 0, 64); np = __shfl(np, 0, 64); al = __shfl(al, 0, 64); used = (uint32_t)__shfl((int)used, 0, 64);
-          if (!st) st = zg_fse_build_wave(L, np, al, kinds[k], slot + offs[k], lane);
-          if (!st) { logs[k] = (uint8_t)al; off += used; rem -= used; }
-        } else if (modes[k] == ZG_MODE_RLE) {
-          if (rem == 0) st = ZG_SEQ_RLE_BYTE;
-          else if (pb[off] > max_sym[k]) st = ZG_SEQ_RLE_BYTE;
-          else { if (lane == 0) slot[offs[k]] = zg_fse_pack(kinds[k], 0, 0, pb[off]); logs[k] = 0; off += 1; rem -= 1; }
-        }
+    const uint32_t nparsed = P->nparsed;
+    for (int k = 0; k < 3 && !st; k++) {
+      if ((uint32_t)k >= nparsed) { st = (int)P->status; break; }
+      if (modes[k] == ZG_MODE_FSE) {
+        const int np = P->np[k], al = P->al[k];
+        zg_wave_publish();                                   // (the previous table's build still reads L.probs)
+        L.probs[lane] = P->probs[k][lane];
+        zg_wave_publish();
+        st = zg_fse_build_wave(L, np, al, kinds[k], slot + offs[k], lane);
+        if (!st) logs[k] = (uint8_t)al;
+      } else if (modes[k] == ZG_MODE_RLE) {
+        if (lane == 0) slot[offs[k]] = zg_fse_pack(kinds[k], 0, 0, P->rle[k]);
+        logs[k] = 0;
       }
-      done = off;
-    };
-    parse(p0, lim);
-    if (st && lim != rem_all) parse(body + blk.seq_off, rem_all);   // a description longer than the staged part: from the section itself
-    seq_bits_off = blk.seq_off + done;
+    }
+    if (!st && nparsed < 3u) st = (int)P->status;
+    seq_bits_off = blk.seq_off + P->done;
     if (lane == 0) { uint8_t* lg = d.slot_log + (uint64_t)b * 4; lg[0] = logs[0]; lg[1] = logs[1]; lg[2] = logs[2]; lg[3] = 0; }
   }
   if (lane == 0) {
@@ -1157,21 +1190,30 @@ __global__ void __launch_bounds__(ZG_SCAN_T) zg_k_scan(ZgBatchDev d) {
     bool comp[ZG_SCAN_I];
     if (t == 0) { s_bad = 0xFFFFFFFFu; s_badst = 0; }
     __syncthreads();
+    // every load of the thread's blocks is requested before any is used (no load behind a branch on another load's value: one round trip)
+    uint32_t f_host[ZG_SCAN_I], f_stat[ZG_SCAN_I], f_regen[ZG_SCAN_I], f_nseq[ZG_SCAN_I], f_bt[ZG_SCAN_I];
+    ZgBlockSeqOut f_so[ZG_SCAN_I];
+#pragma unroll
+    for (int j = 0; j < ZG_SCAN_I; j++) {
+      const uint32_t i = c0 + t * ZG_SCAN_I + (uint32_t)j;
+      const uint32_t b = fr.first_block + (i < fr.nblocks ? i : fr.nblocks - 1u);     // (clamped: the last block again)
+      const ZgBlock* blk = &d.blocks[b];
+      f_host[j] = blk->host_status; f_regen[j] = blk->regen_size; f_nseq[j] = blk->nseq; f_bt[j] = blk->btype;
+      f_stat[j] = d.status[b];
+      f_so[j] = d.seq_out[b];
+    }
 #pragma unroll
     for (int j = 0; j < ZG_SCAN_I; j++) {
       const uint32_t i = c0 + t * ZG_SCAN_I + (uint32_t)j;
       size[j] = 0; m[j] = zg_map_identity(); st[j] = 0; comp[j] = false;
       if (i < fr.nblocks) {
-        const uint32_t b = fr.first_block + i;
-        const ZgBlock* blk = &d.blocks[b];
-        st[j] = blk->host_status ? blk->host_status : d.status[b];
-        comp[j] = blk->btype == ZG_BT_COMPRESSED;
-        if (!comp[j] || blk->nseq == 0) size[j] = blk->regen_size;
+        st[j] = f_host[j] ? f_host[j] : f_stat[j];
+        comp[j] = f_bt[j] == ZG_BT_COMPRESSED;
+        if (!comp[j] || f_nseq[j] == 0) size[j] = f_regen[j];
         else {
-          const ZgBlockSeqOut so = d.seq_out[b];
-          size[j] = (uint64_t)blk->regen_size + so.sum_ml;
+          size[j] = (uint64_t)f_regen[j] + f_so[j].sum_ml;
           if (size[j] > ZG_FLAT_MAX) s_slow = 1;
-          m[j].s[0] = so.hist_end[0]; m[j].s[1] = so.hist_end[1]; m[j].s[2] = so.hist_end[2];
+          m[j].s[0] = f_so[j].hist_end[0]; m[j].s[1] = f_so[j].hist_end[1]; m[j].s[2] = f_so[j].hist_end[2];
         }
         if (st[j]) atomicMin(&s_bad, t * ZG_SCAN_I + (uint32_t)j);
       }
@@ -1726,7 +1768,10 @@ void zg_launch_calib(const void* src, void* dst, uint64_t bytes, hipStream_t s) 
 void zg_launch_tables(const ZgBatchDev& d, hipStream_t s, int part) {
   uint32_t n = d.nblocks + 1;
   if (part == 0) hipLaunchKernelGGL(zg_k_tables, dim3((n + ZG_HT_W - 1) / ZG_HT_W), dim3(64 * ZG_HT_W), 0, s, d);
-  else hipLaunchKernelGGL(zg_k_ftab, dim3((n + ZG_FT_W - 1) / ZG_FT_W), dim3(64 * ZG_FT_W), 0, s, d);
+  else {
+    hipLaunchKernelGGL(zg_k_fparse, dim3((d.nblocks + 63) / 64), dim3(64), 0, s, d);
+    hipLaunchKernelGGL(zg_k_ftab, dim3((n + ZG_FT_W - 1) / ZG_FT_W), dim3(64 * ZG_FT_W), 0, s, d);
+  }
 }
 void zg_launch_huf(const ZgBatchDev& d, hipStream_t s) {
   if (!d.nhuf_groups) return;

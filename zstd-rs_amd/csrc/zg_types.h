@@ -139,6 +139,18 @@ struct ZgBlockAux {
   uint8_t pad;
 };
 
+// What zg_k_fparse leaves for zg_k_ftab: the three FSE table descriptions of a block's sequences section, read (one LANE per block:
+// read_probabilities is a bit-serial chain, fse_decoder.rs:224-307) but not built yet.
+struct ZgFtabParsed {
+  int16_t probs[3][64];        // LL, OF, ML in section order: the probabilities of an FSE-described table (entries behind np are 0)
+  uint8_t np[3], al[3];        // its symbols and accuracy log
+  uint8_t rle[3];              // the symbol of an RLE-mode table
+  uint8_t nparsed;             // descriptions read without an error: the error of description `nparsed` is `status` (3 and 0 when all are fine)
+  uint8_t pad[2];
+  uint32_t status;
+  uint32_t done;               // bytes the descriptions take (the bitstream starts behind them)
+};
+
 // What the sequence kernel records per block.
 struct ZgBlockSeqOut {
   uint32_t sum_ll;         // Σ literal lengths
@@ -241,6 +253,7 @@ struct ZgBatchDev {
   uint32_t nslots;             // FSE arena slots = nblocks + 1 (predefined) + nframes (carry)
   uint32_t nhuf_slots;         // Huffman arena slots
   ZgBlockAux* aux;             // [nblocks]
+  ZgFtabParsed* ftab_parsed;   // [nblocks] zg_k_fparse -> zg_k_ftab
   uint8_t* slot_log;           // [nslots][4]: accuracy logs LL, OF, ML of the tables held by each FSE slot
   uint32_t* fse_arena;         // [nslots][ZG_FSE_SLOT_U32]
   uint16_t* huf_arena;         // [nhuf_slots][ZG_HUF_SLOT_U16]
