@@ -167,6 +167,7 @@ void* zgemu_stream_new(const uint8_t* src, size_t src_len, const uint8_t* plain,
   if (first_run_blocks) o.first_run_blocks = first_run_blocks;
   o.copy_threads = copy_threads;
   if (max_run_src) o.max_run_src = max_run_src;
+  if (const char* e = getenv("ZGEMU_FAIL_THREAD")) o.test_fail_thread = (uint32_t)atoi(e);
   h->core = new StreamCore(&h->be, o);
   h->core->window = window; h->core->content_size = content_size; h->core->header_bytes = 0;
   h->core->src.has_checksum = has_checksum != 0;

@@ -350,6 +350,18 @@ def test_mode_switch_keeps_what_the_reader_holds_in_reach():
     assert stats["dropped"] == 1 and stats["rebases"] == 1 and stats["mode"] == 2 and want[-1] == (0, b"")
 
 
+@pytest.mark.parametrize("where", [1, 2])
+def test_a_thread_that_cannot_be_started_leaves_the_reference_schedule(where, monkeypatch):
+    """PIPE needs a worker (and a hasher, and helpers): when the system refuses one, nothing unwinds across the boundary; what the ring
+    holds goes back to the decode buffer and the stream goes on block by block (where == 2: the worker is already running by then)"""
+    monkeypatch.setenv("ZGEMU_FAIL_THREAD", str(where))
+    rng = random.Random(21 + where)
+    fr = Frame(rng, 150, K, True)
+    reads = [8192] * 30 + read_pattern(rng, len(fr.plain), "mixed")
+    want, stats = check(fr, reads, pipe_after=1 << 20, read_ahead=(6 << 20) + K)
+    assert stats["pipe_begins"] == 1 and stats["mode"] == 2 and stats["rebases"] == 1 and want[-1] == (0, b"")
+
+
 def test_copy_pool_covers_every_size():
     """the helper threads that copy large reads out of the ring: sizes of (helpers + 1) page-aligned shares plus 0..4 bytes (a floor where a
     ceiling belongs left the last bytes of such a read uncopied — found by the tests above when it was already in the GPU build)"""

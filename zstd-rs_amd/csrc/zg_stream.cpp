@@ -285,7 +285,11 @@ size_t zg_stream_take(StreamCore* c, uint8_t* dst, size_t n) { size_t got = 0; r
 
 extern "C" {
 
+static int streaming_build2(zgpu_ctx* c, zgpu_streaming* s, const zgpu_stream_opts* opts, zgpu_streaming** out);
 static int streaming_build(zgpu_ctx* c, zgpu_streaming* s, const zgpu_stream_opts* opts, zgpu_streaming** out) {
+  try { return streaming_build2(c, s, opts, out); } catch (...) { return ZGPU_E_NOMEM; }
+}
+static int streaming_build2(zgpu_ctx* c, zgpu_streaming* s, const zgpu_stream_opts* opts, zgpu_streaming** out) {
   // StreamingDecoder::new (streaming_decoder.rs:51-58): reads the frame header from the source
   int st = zgpu_decoder_create(c, &s->dec);
   if (st) { delete s; return st; }
@@ -361,7 +365,11 @@ size_t zgpu_streaming_source_position(const zgpu_streaming* s) {
 int zgpu_streaming_read(zgpu_streaming* s, uint8_t* dst, size_t cap, size_t* n_out) {
   // impl Read for StreamingDecoder (streaming_decoder.rs:119-155)
   if (!s || !n_out || (!dst && cap)) return ZGPU_E_BAD_ARG;
-  return s->core->read(dst, cap, n_out);
+  try {
+    return s->core->read(dst, cap, n_out);
+  } catch (...) {          // (an allocation that failed, a thread that could not be started: nothing unwinds across the boundary)
+    return ZGPU_E_NOMEM;
+  }
 }
 
 // std::io::copy(&mut decoder, &mut writer) with a buffer of buf_size bytes (what the reference's CLI does with 8 KiB,
@@ -378,7 +386,7 @@ int zgpu_streaming_copy(zgpu_streaming* s, size_t buf_size, zgpu_write_fn write,
   int st = ZGPU_OK;
   for (;;) {
     size_t n = 0;
-    st = s->core->read(buf, buf_size, &n);
+    try { st = s->core->read(buf, buf_size, &n); } catch (...) { st = ZGPU_E_NOMEM; }
     if (st || n == 0) break;
     if (write) {
       size_t off = 0;

@@ -92,6 +92,7 @@ struct StreamOpts {
   uint32_t copy_threads = 3;        // PIPE: helper threads for reads of 512 KiB and more
   uint64_t max_run_src = 96ull << 20;  // PIPE: source bytes per run at most (size of a staging buffer)
   bool allow_pipe = true;
+  uint32_t test_fail_thread = 0;    // (tests/emu only) 1: starting the first thread of PIPE fails; 2: the worker runs, the next thread fails
 };
 constexpr uint64_t kStreamDefaultReadAhead = 512ull << 20;
 constexpr uint64_t kStreamNoReadAhead = 1;
@@ -571,9 +572,16 @@ class StreamCore {
     hasher_on_ = o_.hash;
     mode_ = PIPE;
     pipe_up_ = true;
-    pool_.start(o_.copy_threads);
-    worker_ = std::thread([this]() { worker_main(); });
-    if (hasher_on_) hasher_ = std::thread([this]() { hasher_main(); });
+    try {
+      if (o_.test_fail_thread == 1) throw std::bad_alloc();
+      pool_.start(o_.copy_threads);
+      worker_ = std::thread([this]() { worker_main(); });
+      if (o_.test_fail_thread == 2) throw std::bad_alloc();
+      if (hasher_on_) hasher_ = std::thread([this]() { hasher_main(); });
+    } catch (...) {                       // a thread could not be started: the reference's schedule from what the ring holds
+      const int st2 = stop_pipe(true);
+      return st2 ? st2 : ZG_OK;
+    }
     produce_jobs();
     return ZG_OK;
   }
