@@ -340,3 +340,41 @@ def test_fuzz_artifacts_through_the_stream(ctx):
                 s.close()
         n += 1
     assert n >= 42
+
+
+def test_streams_interleaved_on_one_context(ctx):
+    """several streams of one context read in turn (every mode, one of them behind an io::Read callback), with decode_all calls of the same
+    context in between: each stream keeps its own device window / worker engine, and the context's engine serves whoever calls"""
+    import zgdata
+    import zgpu
+    rng = random.Random(0x171)
+    frames = []
+    for i, n in enumerate((5 << 20, 9 << 20, 3 << 20, 7 << 20)):
+        data = zgdata.text_like(n + 12345 * i, seed=0x900 + i)
+        frames.append((data, zgdata.zstd_compress(data)))
+    kws = [dict(), dict(pipe_after=1, read_ahead=4 << 20), dict(read_ahead=1), dict(pipe_after=2 << 20, read_ahead=5 << 20, first_run_blocks=2)]
+    streams = []
+    for i, ((data, z), kw) in enumerate(zip(frames, kws)):
+        s = zgpu.CStreamingDecoder(ctx, io.BytesIO(z), **kw) if i == 1 else zgpu.CStreamingDecoder(ctx, data=z, **kw)
+        streams.append([s, data, 0])
+    other = zgdata.text_like(1 << 20, seed=0x9FF)
+    oz = zgdata.zstd_compress(other)
+    live = list(range(len(streams)))
+    step = 0
+    while live:
+        i = rng.choice(live)
+        s, data, pos = streams[i]
+        cap = rng.choice([1, 4096, 8192, K, 300000, 1 << 20, 2 << 20])
+        d = s.read(cap)
+        assert d == data[pos:pos + cap], (i, pos, cap, len(d))
+        streams[i][2] = pos + len(d)
+        if not d:
+            assert pos == len(data) and s.is_finished() and s.get_calculated_checksum() == s.get_checksum_from_data()
+            live.remove(i)
+        step += 1
+        if step % 7 == 0:
+            assert ctx.decode_all(oz, len(other)) == other
+    modes = [s.stats()["mode"] for s, _, _ in streams]
+    assert modes == [0, 1, 2, 1], modes
+    for s, _, _ in streams:
+        s.close()
