@@ -15,3 +15,32 @@ def test_frame_decoder_call_sequences_match_the_oracle():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dev", "soak_api.py"), "600", "11"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "disagreements 0" in r.stdout
+
+
+def test_decode_blocks_goes_on_behind_the_frames_end_like_the_reference():
+    """decode_blocks does not look at frame_finished when it starts (frame_decoder.rs:321-359): a caller that goes on after the last block has
+    its bytes read as further blocks, and every strategy ends with a last block of THAT call, a block count or a growth — not with the flag
+    the earlier call left (found by tools/dev/soak_api.py: UptoBytes stopped after one block)"""
+    sys.path.insert(0, os.path.join(ROOT, "zstd-rs_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    import zgpu
+    from test_exact_cpu import frame, raw_block, rle_block
+    z = frame(raw_block(300, 1), rle_block(50, last=True)) + raw_block(20, 2) + rle_block(7) + raw_block(5, 3, last=True) + rle_block(9, last=True)
+    ctx = zgpu.Context(0)
+    for strat, n in ((oracle.STRAT_UPTO_BYTES, 1000), (oracle.STRAT_UPTO_BYTES, 21), (oracle.STRAT_UPTO_BLOCKS, 2), (oracle.STRAT_ALL, 0)):
+        o, g = oracle.FrameDecoder(), zgpu.FrameDecoder(ctx)
+        a, b = o.init(z), g.init(z)
+        assert a == b and a[0] == 0
+        pos = a[1]
+        a, b = o.decode_blocks(z[pos:], oracle.STRAT_ALL, 0), g.decode_blocks(z[pos:], oracle.STRAT_ALL, 0)
+        assert a == b and a[0] == 0 and a[2]
+        pos += a[1]
+        while pos < len(z):
+            a, b = o.decode_blocks(z[pos:], strat, n), g.decode_blocks(z[pos:], strat, n)
+            assert a == b and a[0] == 0 and a[1] > 0, (strat, n, pos, a, b)
+            pos += a[1]
+            assert (o.can_collect(), o.blocks_decoded(), o.bytes_read_from_source()) == (g.can_collect(), g.blocks_decoded(), g.bytes_read_from_source())
+        assert o.collect() == g.collect()
+        g.close()
+    ctx.close()

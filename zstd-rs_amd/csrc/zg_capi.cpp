@@ -412,8 +412,9 @@ int zg_apply_dict(zgpu_decoder* d, const ZgDict& dict) {   // DecoderScratch::in
 }
 
 // decode up to max_blocks blocks (0 = to the end of the frame) of the current frame from src
-static int decode_run(zgpu_decoder* d, const uint8_t* src, size_t len, uint32_t max_blocks, size_t* consumed) {
+static int decode_run(zgpu_decoder* d, const uint8_t* src, size_t len, uint32_t max_blocks, size_t* consumed, bool* saw_last = nullptr) {
   Engine* eng = d->ctx->eng;
+  if (saw_last) *saw_last = false;
   Batch* b = nullptr;
   size_t used = 0;
   *consumed = 0;
@@ -442,6 +443,7 @@ static int decode_run(zgpu_decoder* d, const uint8_t* src, size_t len, uint32_t 
   int result = fo.status ? (int)fo.status : parse_status;
   if (!result && b->saw_last_block) {
     d->frame_finished = true;
+    if (saw_last) *saw_last = true;
     if (!b->info.empty() && b->info[0].has_checksum) { d->has_checksum = true; d->checksum = b->info[0].checksum; bytes += 4; }
   }
   d->bytes_read += bytes;
@@ -514,16 +516,19 @@ int zgpu_decoder_decode_blocks(zgpu_decoder* d, const uint8_t* src, size_t len, 
     // UptoBytes(n): stop after the first block that brings the growth to n. A block regenerates at most 128 KiB, so
     // ceil(missing / 128 KiB) blocks can never overshoot that block; repeat until the growth is reached.
     if (d->read_ahead > n) n = (size_t)d->read_ahead;
+    // (the loop ends with a last block of THIS call, frame_decoder.rs:347-359: a caller that goes on after the frame's end — the flag is
+    //  already set then — has its bytes read as further blocks by the reference, as many as the strategy asks for: tools/dev/soak_api.py)
     const size_t before = d->buf.size();
+    bool last_now = false;
     do {
       const size_t growth = d->buf.size() - before;
       const size_t missing = n > growth ? n - growth : 0;
       uint32_t m = (uint32_t)((missing + kMaxBlockSize - 1) / kMaxBlockSize);
       if (m == 0) m = 1;
       size_t used = 0;
-      st = decode_run(d, src + p, len - p, m, &used);
+      st = decode_run(d, src + p, len - p, m, &used, &last_now);
       p += used;
-    } while (!st && !d->frame_finished && d->buf.size() - before < n);
+    } while (!st && !last_now && d->buf.size() - before < n);
   }
   if (consumed) *consumed = p;
   if (frame_finished) *frame_finished = d->frame_finished ? 1 : 0;
