@@ -44,3 +44,47 @@ def test_decode_blocks_goes_on_behind_the_frames_end_like_the_reference():
         assert o.collect() == g.collect()
         g.close()
     ctx.close()
+
+
+def test_decoder_state_after_an_error_is_the_references():
+    """what the accessors say after decode_blocks returned an Err (found by the soak once it looked there): the failing block's header is
+    counted when its body failed (frame_decoder.rs:325-341); a last block whose checksum is missing has finished the frame for read(),
+    which hands out everything, but not for is_finished() (:347-357, :284-294, :615-627)"""
+    sys.path.insert(0, os.path.join(ROOT, "zstd-rs_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    import zgpu
+    from test_exact_cpu import WINDOW_LOG, frame, lit_block, raw_block, rle_block, seq_block
+    with_checksum = bytes([0x28, 0xB5, 0x2F, 0xFD, 0x04, (WINDOW_LOG - 10) << 3])
+    cases = [
+        frame(raw_block(300, 1), raw_block(500, 2, last=True))[:-100],                       # the second block's body is cut
+        frame(raw_block(300, 1))[:50],                                                      # the first block's body is cut: no block in the run
+        with_checksum + raw_block(300, 1) + rle_block(4000, last=True) + b"\\x01\\x02",       # two of the checksum's four bytes
+        frame(raw_block(300, 1), bytes([0x06 | 1, 0, 0])),                                  # reserved block type
+        frame(lit_block(200), seq_block(100000, last=True)),                                # an offset beyond everything: sequence execution fails
+    ]
+    ctx = zgpu.Context(0)
+    for i, z in enumerate(cases):
+        for strat, n in ((oracle.STRAT_ALL, 0), (oracle.STRAT_UPTO_BLOCKS, 1), (oracle.STRAT_UPTO_BYTES, 100000)):
+            o, g = oracle.FrameDecoder(), zgpu.FrameDecoder(ctx)
+            a, b = o.init(z), g.init(z)
+            assert a == b and a[0] == 0
+            pos = a[1]
+            err = 0
+            for _ in range(4):
+                a, b = o.decode_blocks(z[pos:], strat, n), g.decode_blocks(z[pos:], strat, n)
+                assert a[0] == b[0], (i, strat, a, b)
+                if a[0]:
+                    err = a[0]
+                    break
+                assert a == b
+                pos += a[1]
+            assert err, (i, strat)
+            sa = (o.is_finished(), o.blocks_decoded(), o.bytes_read_from_source(), o.checksum_from_data())
+            sb = (g.is_finished(), g.blocks_decoded(), g.bytes_read_from_source(), g.get_checksum_from_data())
+            assert sa == sb, (i, strat, err, sa, sb)
+            if not 50 <= err <= 53:                     # (include/zgpu.h, decode_blocks: the one documented difference)
+                assert o.can_collect() == g.can_collect(), (i, strat, err)
+                assert o.read(1 << 20) == g.read(1 << 20), (i, strat, err)
+            g.close()
+    ctx.close()

@@ -20,6 +20,8 @@ names = sorted(k for k in pack if k.endswith(".zst"))
 dnames = sorted(k for k in dpack if k.endswith(".zst"))
 bad = nerr = ncalls = 0
 leaves = {}
+o = g = None
+oracle_default_window = 128 << 20          # DEFAULT_MAX_WINDOW_SIZE, frame_decoder.rs:25
 for it in range(n):
     use_dict = it % 5 == 4
     name = rng.choice(dnames if use_dict else names)
@@ -30,16 +32,54 @@ for it in range(n):
     if rng.random() < 0.1:
         m = m[:rng.randrange(6, len(m))]
     m = bytes(m)
-    o = oracle.FrameDecoder()
-    g = zgpu.FrameDecoder(ctx)
-    if use_dict:
+    # something behind the frame now and then: a skippable frame, a second (mutated or not) corpus frame — a caller that calls init again
+    # where the first frame ended meets them
+    if rng.random() < 0.3:
+        if rng.random() < 0.5:
+            k = rng.randrange(0, 40)
+            m += bytes([0x50 + rng.randrange(16), 0x2A, 0x4D, 0x18]) + k.to_bytes(4, "little") + bytes(rng.randrange(256) for _ in range(k))
+        m += pack[rng.choice(names)] if not use_dict else b""
+    # the decoders live on from input to input (reset() keeps what new() allocated, frame_decoder.rs:200-221), in whatever state the input
+    # in front left them; a new pair every 40 inputs
+    if it % 40 == 0 or o is None:
+        o = oracle.FrameDecoder()
         o.add_dict(raw)
+        if g is not None:
+            g.close()
+        g = zgpu.FrameDecoder(ctx)
+        if rng.random() < 0.3:
+            w = rng.choice([1 << 10, 1 << 17, 1 << 20, 1 << 23])
+            o.set_max_window_size(w)
+            g.set_max_window_size(w)
+        else:
+            g.set_max_window_size(oracle_default_window)
     a, b = o.init(m), g.init(m)
     trace = [("init", a, b)]
     ok = a == b
+    if ok and a[0]:
+        # a header that is rejected leaves the decoder as the frame in front left it (FrameDecoderState::reset fails before it changes anything)
+        sa = (o.can_collect(), o.is_finished(), o.blocks_decoded(), o.bytes_read_from_source(), o.checksum_from_data())
+        sb = (g.can_collect(), g.is_finished(), g.blocks_decoded(), g.bytes_read_from_source(), g.get_checksum_from_data())
+        trace.append(("state after a failed init", sa, sb))
+        ok = sa == sb and o.collect() == g.collect()
     if ok and a[0] == 0:
         pos = a[1]
         for step in range(rng.randrange(4, 60)):
+            if o.is_finished() and o.can_collect() == 0 and pos < len(m) and rng.random() < 0.5:
+                a, b = o.init(m[pos:]), g.init(m[pos:])                  # the next frame, where this one ended
+                trace.append(("init", pos, a, b))
+                if a != b:
+                    ok = False
+                    break
+                if a[0] == oracle.ZOR_SKIP_FRAME:                        # (an Err in the reference too: the caller skips the frame's bytes itself)
+                    pos = min(len(m), pos + a[1] + a[3])
+                    continue
+                if a[0]:
+                    nerr += 1
+                    leaves[a[0]] = leaves.get(a[0], 0) + 1
+                    break
+                pos += a[1]
+                continue
             op = rng.randrange(10)
             if op < 5 and o.is_finished() and rng.random() < 0.9:
                 op = 5 + rng.randrange(5)                      # (decode_blocks on a finished frame: an error; seldom)
@@ -59,6 +99,18 @@ for it in range(n):
                 if a[0]:
                     nerr += 1
                     leaves[a[0]] = leaves.get(a[0], 0) + 1
+                    # the decoder after an Err: its counters, what it still hands out (read() looks at frame_finished, collect() at is_finished())
+                    sa = (o.can_collect(), o.is_finished(), o.blocks_decoded(), o.bytes_read_from_source(), o.checksum_from_data())
+                    sb = (g.can_collect(), g.is_finished(), g.blocks_decoded(), g.bytes_read_from_source(), g.get_checksum_from_data())
+                    ra, rb = o.read(1 << 22), g.read(1 << 22)
+                    trace.append(("after the error", sa, sb, len(ra), len(rb)))
+                    if 50 <= a[0] <= 53:
+                        # sequence execution failed: the reference's buffer also holds what the failing block wrote before it failed
+                        # (include/zgpu.h, decode_blocks): everything else must agree, and what zgpu holds is the front of what the oracle holds
+                        if sa[1:] != sb[1:] or sa[0] < sb[0] or ra[:len(rb)] != rb:
+                            ok = False
+                    elif sa != sb or ra != rb:
+                        ok = False
                     break
             elif op == 5:
                 a, b = o.collect(), g.collect()
@@ -86,7 +138,6 @@ for it in range(n):
             if a != b or o.calculated_checksum() != g.get_calculated_checksum():
                 ok = False
                 trace.append(("tail", len(a), len(b), o.calculated_checksum(), g.get_calculated_checksum()))
-    g.close()
     if not ok:
         bad += 1
         if bad <= 5:

@@ -422,7 +422,11 @@ static int decode_run(zgpu_decoder* d, const uint8_t* src, size_t len, uint32_t 
   if (st) return st;
   const int parse_status = b->parse_status;
   const size_t nb = b->bb.blocks.size();
-  if (nb == 0) { delete b; return parse_status ? parse_status : ZGPU_E_INTERNAL; }
+  if (nb == 0) {
+    if (parse_status == ZG_FAILED_READ_BLOCK_BODY) d->bytes_read += 3;   // (the header of the block whose body is not there was read and counted, :325-328)
+    delete b;
+    return parse_status ? parse_status : ZGPU_E_INTERNAL;
+  }
   b->drain_rule = d->drain_rule;
   if ((st = b->run()) || (st = b->sync())) { delete b; return st; }
   if (b->frame_out.empty()) { delete b; return ZGPU_E_INTERNAL; }
@@ -441,11 +445,16 @@ static int decode_run(zgpu_decoder* d, const uint8_t* src, size_t len, uint32_t 
   for (uint32_t i = 0; i < good && i < nb; i++) bytes += 3 + b->bb.blocks[i].src_len;
   d->block_counter += good;
   int result = fo.status ? (int)fo.status : parse_status;
-  if (!result && b->saw_last_block) {
+  // the last block decoded: the frame counts as finished before the checksum is read (frame_decoder.rs:347-357) — read() hands out
+  // everything from then on, also when the four bytes never come
+  if (!fo.status && b->saw_last_block && (parse_status == 0 || parse_status == ZG_FAILED_READ_CHECKSUM)) {
     d->frame_finished = true;
     if (saw_last) *saw_last = true;
-    if (!b->info.empty() && b->info[0].has_checksum) { d->has_checksum = true; d->checksum = b->info[0].checksum; bytes += 4; }
+    if (!result && !b->info.empty() && b->info[0].has_checksum) { d->has_checksum = true; d->checksum = b->info[0].checksum; bytes += 4; }
   }
+  // a block whose body fails had its header read and counted (:325-341): everything but the three header-level errors
+  if (result && result != ZG_FAILED_READ_BLOCK_HEADER && result != ZG_RESERVED_BLOCK && result != ZG_BLOCK_SIZE_TOO_LARGE && result != ZG_FAILED_READ_CHECKSUM)
+    bytes += 3;
   d->bytes_read += bytes;
   *consumed = bytes;
   delete b;
