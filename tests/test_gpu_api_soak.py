@@ -88,3 +88,37 @@ def test_decoder_state_after_an_error_is_the_references():
                 assert o.read(1 << 20) == g.read(1 << 20), (i, strat, err)
             g.close()
     ctx.close()
+
+
+def test_an_error_in_front_of_the_point_where_the_walk_stops_comes_first_in_every_decode_all():
+    """a frame whose block headers cannot be walked to the end (reserved block type) but which holds a block that fails in FRONT of that
+    point: the reference decodes block by block and meets the block's error first (frame_decoder.rs:319-375). zgpu_decode_all did that
+    since round 4; zgpu_pool_decode_all answered with the walk's error until tools/dev/soak_concat.py compared the two"""
+    sys.path.insert(0, os.path.join(ROOT, "zstd-rs_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    import zgpu
+    from test_exact_cpu import frame, lit_block, raw_block, rle_block, seq_block
+    whole = frame(raw_block(1000, 3), rle_block(77, last=True))
+    reserved = bytes([0x06, 0, 0])
+    bad_body = (((3 << 3) | (2 << 1)).to_bytes(3, "little")) + b"\\xff\\xff\\xff"        # a compressed block of three bytes of nonsense
+    ctx = zgpu.Context(0)
+    pool = zgpu.Pool()
+    for z in (whole + frame(lit_block(200), bad_body, reserved),
+              whole + frame(lit_block(200), seq_block(100000), reserved),               # sequence execution fails in front of the stop
+              whole + frame(lit_block(200), reserved),                                  # nothing fails in front: the walk's error
+              frame(lit_block(100), bad_body)):                                         # ... and a walk that runs out of bytes
+        ost, oout = oracle.FrameDecoder().decode_all(z, 1 << 20)
+        assert ost != 0
+        for fn in (ctx.decode_all, pool.decode_all):
+            with pytest.raises(zgpu.ZgpuError) as e:
+                fn(z, 1 << 20)
+            assert e.value.status == ost, (fn, e.value.status, ost)
+    pool.close()
+    ctx.close()
+
+
+def test_concatenations_through_every_decode_all():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dev", "soak_concat.py"), "300", "12"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "disagreements 0" in r.stdout

@@ -390,6 +390,13 @@ int zgpu_pool_decode_all(zgpu_pool* p, const uint8_t* src, size_t len, uint8_t* 
     else { Job j; j.begin = s.begin; j.end = s.end; jobs.push_back(j); }
     if (!s.skippable) jobs.back().want_size += s.content_size;
   }
+  if (walk) {
+    // the walk stopped inside a frame (or at a header it could not read): what that frame holds in front of the stop is decoded as well —
+    // the reference meets an error in one of THOSE blocks first (zgpu_decode_all; found by tools/dev/soak_concat.py: the pool answered
+    // with the walk's error). A job of its own behind the whole frames: its prepare() stops where this walk did.
+    const uint64_t tail = spans.empty() ? 0 : spans.back().end;
+    if (tail < len) { Job j; j.begin = tail; j.end = len; jobs.push_back(j); }
+  }
   uint64_t want_total = 0;
   for (Job& j : jobs) { j.out_off = want_total; want_total += j.want_size; }
   const bool direct_out = sizes_known && walk == 0 && want_total <= cap;
