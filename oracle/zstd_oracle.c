@@ -1030,6 +1030,52 @@ size_t zor_read(zor_decoder* d, uint8_t* dst, size_t cap) { /* impl Read :615-62
   if (n > cap) n = cap;
   return db_drain_to(&d->scratch.buffer, n, dst);
 }
+int zor_decode_from_to(zor_decoder* d, const uint8_t* src, size_t len, uint8_t* dst, size_t cap, size_t* read_out, size_t* written_out) {
+  /* decode_from_to :439-529: whole blocks only, a header whose body is not all there is "never read"; the checksum may come alone */
+  *read_out = 0; *written_out = 0;
+  const uint64_t at_start = d->has_state ? d->bytes_read_counter : 0;            /* :445-448 */
+  if (!zor_is_finished(d) || !d->has_state) {                                     /* :450 */
+    size_t p = 0;
+    if (!d->has_state) {                                                          /* :453-455 */
+      size_t c = 0; uint32_t sm = 0, sl = 0;
+      int st = zor_init(d, src, len, &c, &sm, &sl);
+      if (st) return st;
+      p = c;
+    }
+    if (fh_checksum_flag(&d->fh) && d->frame_finished && !d->has_checksum) {      /* :465-477 */
+      if (len - p >= 4) { d->check_sum = rd32(src + p); d->has_checksum = 1; d->bytes_read_counter += 4; }
+      *read_out = 4;                                                              /* Ok((4, 0)) whether or not the bytes were there */
+      return ZOR_OK;
+    }
+    for (;;) {
+      if (len - p < 3) break;                                                     /* :481-483 */
+      const uint8_t* hb = src + p;
+      int last = hb[0] & 1; unsigned btype = (hb[0] >> 1) & 3;
+      if (btype == 3) return ZOR_RESERVED_BLOCK;                                  /* :484-486 (read_block_header) */
+      uint32_t bsize = (uint32_t)(hb[0] >> 3) | ((uint32_t)hb[1] << 5) | ((uint32_t)hb[2] << 13);
+      if (bsize > MAX_BLOCK_SIZE) return ZOR_BLOCK_SIZE_TOO_LARGE;
+      uint32_t content_size = btype == 1 ? 1 : bsize;
+      if (len - p - 3 < content_size) break;                                      /* :490-492 */
+      p += 3; d->bytes_read_counter += 3;                                         /* :493 */
+      int st;
+      d->last_block_type = (int)btype;
+      if (btype == 1) st = db_extend_fill(&d->scratch.buffer, src[p], bsize);
+      else if (btype == 0) st = db_extend_raw(&d->scratch.buffer, src + p, bsize);
+      else st = decompress_block(&d->scratch, src + p, content_size);
+      if (btype != 2) { d->scratch.sequences.len = 0; }
+      if (st) return st;                                                          /* :495-501 */
+      p += content_size; d->bytes_read_counter += content_size; d->block_counter++;   /* :502-503 */
+      if (last) {                                                                 /* :505-517 */
+        d->frame_finished = 1;
+        if (fh_checksum_flag(&d->fh) && len - p >= 4) { d->check_sum = rd32(src + p); d->has_checksum = 1; p += 4; d->bytes_read_counter += 4; }
+        break;
+      }
+    }
+  }
+  *written_out = zor_read(d, dst, cap);                                           /* :522 */
+  *read_out = (size_t)(d->bytes_read_counter - at_start);                         /* :523-528 */
+  return ZOR_OK;
+}
 int zor_decode_all(zor_decoder* d, const uint8_t* in, size_t inlen, uint8_t* out, size_t outcap, size_t* written) {
   /* decode_all :541-577 */
   size_t total = 0, p = 0;

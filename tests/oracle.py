@@ -54,6 +54,7 @@ def lib():
     L.zor_read.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.zor_read.restype = C.c_size_t
     L.zor_decode_all.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, szp]
+    L.zor_decode_from_to.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, szp, szp]
     for nm in ("zor_blocks_decoded", "zor_bytes_read_from_source", "zor_content_size", "zor_window_size"):
         getattr(L, nm).argtypes = [C.c_void_p]
         getattr(L, nm).restype = C.c_uint64
@@ -143,6 +144,13 @@ class FrameDecoder:
         buf = C.create_string_buffer(max(cap, 1))
         got = self.L.zor_read(self.h, buf, cap)
         return buf.raw[:got]
+
+    def decode_from_to(self, src, cap):
+        """returns (status, bytes_read, output_bytes) — frame_decoder.rs:439-529"""
+        buf = C.create_string_buffer(max(cap, 1))
+        r, w = C.c_size_t(), C.c_size_t()
+        st = self.L.zor_decode_from_to(self.h, src, len(src), buf, cap, C.byref(r), C.byref(w))
+        return st, r.value, buf.raw[:w.value]
 
     def decode_all(self, src, cap):
         buf = C.create_string_buffer(max(cap, 1))

@@ -59,7 +59,7 @@ def test_decoder_state_after_an_error_is_the_references():
     cases = [
         frame(raw_block(300, 1), raw_block(500, 2, last=True))[:-100],                       # the second block's body is cut
         frame(raw_block(300, 1))[:50],                                                      # the first block's body is cut: no block in the run
-        with_checksum + raw_block(300, 1) + rle_block(4000, last=True) + b"\\x01\\x02",       # two of the checksum's four bytes
+        with_checksum + raw_block(300, 1) + rle_block(4000, last=True) + b"\x01\x02",       # two of the checksum's four bytes
         frame(raw_block(300, 1), bytes([0x06 | 1, 0, 0])),                                  # reserved block type
         frame(lit_block(200), seq_block(100000, last=True)),                                # an offset beyond everything: sequence execution fails
     ]
@@ -101,7 +101,7 @@ def test_an_error_in_front_of_the_point_where_the_walk_stops_comes_first_in_ever
     from test_exact_cpu import frame, lit_block, raw_block, rle_block, seq_block
     whole = frame(raw_block(1000, 3), rle_block(77, last=True))
     reserved = bytes([0x06, 0, 0])
-    bad_body = (((3 << 3) | (2 << 1)).to_bytes(3, "little")) + b"\\xff\\xff\\xff"        # a compressed block of three bytes of nonsense
+    bad_body = (((3 << 3) | (2 << 1)).to_bytes(3, "little")) + b"\xff\xff\xff"        # a compressed block of three bytes of nonsense
     ctx = zgpu.Context(0)
     pool = zgpu.Pool()
     for z in (whole + frame(lit_block(200), bad_body, reserved),
@@ -122,3 +122,48 @@ def test_concatenations_through_every_decode_all():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dev", "soak_concat.py"), "300", "12"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "disagreements 0" in r.stdout
+
+
+def test_decode_from_to_against_the_oracle():
+    """decode_from_to (frame_decoder.rs:439-529) on slices that end anywhere and targets of any size, call by call against the oracle's
+    restatement (pinned on tests/mod.rs:129-230, :382-404 in test_oracle_golden.py); a header that cannot be read behind whole blocks: the
+    blocks are decoded, then that error is the answer (zgpu answered Ok until tools/dev/soak_api.py called this function)"""
+    import random
+    sys.path.insert(0, os.path.join(ROOT, "zstd-rs_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import oracle
+    import zgpu
+    from golden_io import read_pack
+    from test_exact_cpu import frame, raw_block, rle_block
+    ctx = zgpu.Context(0)
+    z = frame(raw_block(300, 1), rle_block(200), bytes([0x06, 0, 0]))               # two whole blocks, then a reserved block type
+    for cap in (0, 100, 1 << 20):
+        o, g = oracle.FrameDecoder(), zgpu.FrameDecoder(ctx)
+        a, b = o.decode_from_to(z, cap), g.decode_from_to(z, cap)
+        assert a[0] == b[0] == 20
+        assert (o.blocks_decoded(), o.bytes_read_from_source(), o.can_collect()) == (g.blocks_decoded(), g.bytes_read_from_source(), g.can_collect())
+        assert o.read(1 << 20) == g.read(1 << 20)
+        g.close()
+    pack = read_pack("decodecorpus.pack")
+    rng = random.Random(0xF70)
+    for name in sorted(k for k in pack if k.endswith(".zst"))[::4]:
+        z = pack[name]
+        o, g = oracle.FrameDecoder(), zgpu.FrameDecoder(ctx)
+        pos = 0
+        for _ in range(200):
+            end = len(z) if rng.random() < 0.3 else min(len(z), pos + rng.choice([0, 2, 3, 7, 1000, 70000, 140000, 300000]))
+            cap = rng.choice([0, 3, 5000, 1 << 22])
+            if pos == 0:
+                end = max(end, min(len(z), 32))             # (the first call reads the frame header: it must be there)
+            a, b = o.decode_from_to(z[pos:end], cap), g.decode_from_to(z[pos:end], cap)
+            assert a == b, (name, pos, end, cap, a[:2], b[:2])
+            assert a[0] == 0
+            pos = min(len(z), pos + a[1])
+            assert (o.is_finished(), o.blocks_decoded(), o.bytes_read_from_source(), o.can_collect()) == \
+                   (g.is_finished(), g.blocks_decoded(), g.bytes_read_from_source(), g.can_collect())
+            if o.is_finished() and o.can_collect() == 0:
+                break
+        assert o.is_finished() and g.is_finished() and o.calculated_checksum() == g.get_calculated_checksum(), name
+        g.close()
+    ctx.close()

@@ -33,6 +33,46 @@ def test_decode_corpus():
         _check(name, pack[name], man[name])
 
 
+def test_decode_from_to_as_the_reference_tests_it():
+    """tests/mod.rs:129-230 (source cut at 50 KiB, then everything but the checksum, then the checksum alone: (4, 0); the byte counter adds
+    up to the file's length) and :382-404 (a three-byte target, the rest through read())"""
+    pack, man = read_pack("decodecorpus.pack"), read_manifest("decodecorpus.json")
+    content = pack["z000088.zst"]
+    d = oracle.FrameDecoder()
+    st, read1, out1 = d.decode_from_to(content[:50 * 1024], 1 << 20)
+    assert st == 0
+    st, read2, out2 = d.decode_from_to(content[read1:len(content) - 4], 1 << 20)
+    assert st == 0 and read1 + read2 == len(content) - 4
+    st, read3, out3 = d.decode_from_to(content[read1 + read2:], 1 << 20)
+    assert (st, read3, out3) == (0, 4, b"")
+    assert read1 + read2 + read3 == len(content)
+    assert hashlib.sha256(out1 + out2).hexdigest() == man["z000088.zst"]["sha256"]
+    assert d.checksum_from_data() == d.calculated_checksum()
+    z = read_pack("test_fixtures.pack")["abc.txt.zst"]
+    d = oracle.FrameDecoder()
+    st, c, _, _ = d.init(z)
+    assert st == 0
+    st, _, out = d.decode_from_to(z[c:], 3)
+    assert st == 0 and out == b"abc" and d.is_finished()
+    assert d.read(3) == b"def"
+    # every corpus file in pieces of every size: the bytes, the counter
+    for name in sorted(man)[:40]:
+        z = pack[name]
+        for piece in (1, 7, 1000, 70000):
+            d = oracle.FrameDecoder()
+            st, pos, _, _ = d.init(z)
+            assert st == 0
+            out, stall = b"", 0
+            while not d.is_finished() and stall < 3:
+                st, r, o = d.decode_from_to(z[pos:pos + piece] if stall == 0 else z[pos:], 1 << 22)
+                assert st == 0, (name, piece)
+                stall = stall + 1 if r == 0 else 0          # (a piece smaller than the next block: hand over everything next time)
+                pos += r
+                out += o
+            out += d.read(1 << 22)
+            assert hashlib.sha256(out).hexdigest() == man[name]["sha256"] and pos == len(z), (name, piece)
+
+
 def test_dict_corpus():
     pack, man = read_pack("dict_tests.pack"), read_manifest("dict_tests.json")
     assert len(man) == 207

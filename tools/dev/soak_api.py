@@ -112,6 +112,25 @@ for it in range(n):
                     elif sa != sb or ra != rb:
                         ok = False
                     break
+            elif op == 5 and rng.random() < 0.5:
+                # decode_from_to (frame_decoder.rs:439-529): whole blocks of a slice that may end anywhere, a target of any size
+                end = len(m) if rng.random() < 0.5 else min(len(m), pos + rng.choice([0, 1, 2, 3, 4, 5, 100, 5000, 140000, 400000]))
+                c = rng.choice([0, 3, 1000, 200000, 1 << 22])
+                a, b = o.decode_from_to(m[pos:end], c), g.decode_from_to(m[pos:end], c)
+                trace.append(("decode_from_to", end - pos, c, a[:2], b[:2], len(a[2]), len(b[2])))
+                if a[0] != b[0] or (a[0] == 0 and a != b):
+                    ok = False
+                    break
+                if a[0]:
+                    nerr += 1
+                    leaves[a[0]] = leaves.get(a[0], 0) + 1
+                    sa = (o.can_collect(), o.is_finished(), o.blocks_decoded(), o.bytes_read_from_source(), o.checksum_from_data())
+                    sb = (g.can_collect(), g.is_finished(), g.blocks_decoded(), g.bytes_read_from_source(), g.get_checksum_from_data())
+                    trace.append(("after the error", sa, sb))
+                    if (sa[1:] != sb[1:] or sa[0] < sb[0]) if 50 <= a[0] <= 53 else sa != sb:
+                        ok = False
+                    break
+                pos = min(len(m), pos + a[1])
             elif op == 5:
                 a, b = o.collect(), g.collect()
                 trace.append(("collect", len(a), len(b)))

@@ -594,10 +594,11 @@ int zgpu_decoder_decode_from_to(zgpu_decoder* d, const uint8_t* src, size_t len,
     size_t q = p;
     uint32_t nblocks = 0;
     bool last = false;
+    int hdr_err = 0;
     while (!last && len - q >= 3) {
       BlockHeader bh;
       int st = read_block_header(src + q, &bh);
-      if (st) { if (nblocks == 0) return st; break; }
+      if (st) { if (nblocks == 0) return st; hdr_err = st; break; }   // (the blocks in front are decoded first, then this is the answer: :484-486)
       if (len - q - 3 < bh.content_size) break;
       q += 3 + bh.content_size;
       nblocks++;
@@ -619,6 +620,7 @@ int zgpu_decoder_decode_from_to(zgpu_decoder* d, const uint8_t* src, size_t len,
       } else st = decode_run(d, src + p, avail, nblocks, &used);
       if (st) return st;
     }
+    if (hdr_err) return hdr_err;
   }
   const size_t w = zgpu_decoder_read(d, dst, cap);
   if (read_out) *read_out = (size_t)(d->bytes_read - at_start);
