@@ -1030,6 +1030,12 @@ size_t zor_read(zor_decoder* d, uint8_t* dst, size_t cap) { /* impl Read :615-62
   if (n > cap) n = cap;
   return db_drain_to(&d->scratch.buffer, n, dst);
 }
+size_t zor_held(const zor_decoder* d, uint8_t* dst, size_t cap) { /* (test accessor, no counterpart: what the decode buffer holds, undrained) */
+  if (!d->has_state) return 0;
+  size_t n = db_len(&d->scratch.buffer); if (n > cap) n = cap;
+  if (dst && n) memcpy(dst, d->scratch.buffer.buf.p + d->scratch.buffer.head, n);
+  return n;
+}
 int zor_decode_from_to(zor_decoder* d, const uint8_t* src, size_t len, uint8_t* dst, size_t cap, size_t* read_out, size_t* written_out) {
   /* decode_from_to :439-529: whole blocks only, a header whose body is not all there is "never read"; the checksum may come alone */
   *read_out = 0; *written_out = 0;

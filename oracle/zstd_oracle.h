@@ -102,6 +102,8 @@ int  zor_decode_blocks(zor_decoder*, const uint8_t* src, size_t len, size_t* con
 size_t zor_can_collect(const zor_decoder*);                   /* frame_decoder.rs:410-424 */
 size_t zor_collect(zor_decoder*, uint8_t* dst, size_t cap);   /* collect(): drain all / drain to window; returns bytes */
 size_t zor_read(zor_decoder*, uint8_t* dst, size_t cap);      /* impl Read  frame_decoder.rs:615-627 */
+/* test accessor without a counterpart in the reference: a copy of what the decode buffer holds (nothing is drained or hashed) */
+size_t zor_held(const zor_decoder*, uint8_t* dst, size_t cap);
 /* decode_from_to (frame_decoder.rs:439-529): *read_out = bytes taken from src, *written_out = bytes drained to dst */
 int  zor_decode_from_to(zor_decoder*, const uint8_t* src, size_t len, uint8_t* dst, size_t cap, size_t* read_out, size_t* written_out);
 int  zor_decode_all(zor_decoder*, const uint8_t* in, size_t inlen, uint8_t* out, size_t outcap,

@@ -54,6 +54,8 @@ def lib():
     L.zor_read.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.zor_read.restype = C.c_size_t
     L.zor_decode_all.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, szp]
+    L.zor_held.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.zor_held.restype = C.c_size_t
     L.zor_decode_from_to.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, szp, szp]
     for nm in ("zor_blocks_decoded", "zor_bytes_read_from_source", "zor_content_size", "zor_window_size"):
         getattr(L, nm).argtypes = [C.c_void_p]
@@ -144,6 +146,13 @@ class FrameDecoder:
         buf = C.create_string_buffer(max(cap, 1))
         got = self.L.zor_read(self.h, buf, cap)
         return buf.raw[:got]
+
+    def held(self, cap=1 << 28):
+        """(test accessor) a copy of everything the decode buffer holds, window included; nothing is drained"""
+        n = self.L.zor_held(self.h, None, cap)
+        buf = C.create_string_buffer(max(n, 1))
+        n = self.L.zor_held(self.h, buf, n)
+        return buf.raw[:n]
 
     def decode_from_to(self, src, cap):
         """returns (status, bytes_read, output_bytes) — frame_decoder.rs:439-529"""

@@ -167,3 +167,41 @@ def test_decode_from_to_against_the_oracle():
         assert o.is_finished() and g.is_finished() and o.calculated_checksum() == g.get_calculated_checksum(), name
         g.close()
     ctx.close()
+
+
+def test_good_blocks_in_front_of_an_execution_error_keep_their_bytes():
+    """a mutated corpus frame (tests/golden/regress, found by tools/dev/soak_batch.py): block 5 fails in sequence execution (a match that
+    starts in front of everything, DictionaryTooSmall), block 4 lies in the same unit. What the frame produced ends with its last good block
+    (include/zgpu.h, zgpu_batch_sync) — and those bytes are the reference's: the sweep used to skip every unit of a frame with such an error,
+    which left the match bytes of the good blocks behind the first unit unresolved"""
+    sys.path.insert(0, os.path.join(ROOT, "zstd-rs_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    import zgpu
+    z = open(os.path.join(ROOT, "tests", "golden", "regress", "exec_error_behind_good_blocks.zst"), "rb").read()
+    o = oracle.FrameDecoder()
+    st, hl, _, _ = o.init(z)
+    assert st == 0
+    ost, _, _ = o.decode_blocks(z[hl:])
+    assert ost == 53 and o.blocks_decoded() == 5
+    want = o.held()[:314443]                                   # (behind them: what block 5 wrote before it failed)
+    ctx = zgpu.Context(0)
+    for src in (z, z + z, z[:6] + z[6:]):                        # alone, and twice in one submit
+        b = zgpu.Batch(ctx, src)
+        b.run()
+        b.sync()
+        for f in range(b.nframes):
+            fi = b.frame_info(f)
+            assert (fi.status, fi.bad_block, fi.out_size) == (53, 5, 314443)
+            assert b.read(fi.out_base, fi.out_size) == want
+        b.close()
+    # the thin boundary: the blocks in front of the failing one are readable
+    from test_gpu_thin_boundary import parse_frame_header, walk_blocks
+    hl2, window, fcs, did, _ = parse_frame_header(z)
+    blocks, _ = walk_blocks(z, hl2)
+    f = zgpu.BlockFrame(ctx, window, fcs, did)
+    f.submit(z, blocks)
+    assert f.sync() == (5, 53)
+    assert f.read(1 << 22, True) == want
+    f.close()
+    ctx.close()

@@ -133,6 +133,7 @@ int zgpu_batch_frame_info(const zgpu_batch* zb, uint32_t f, zgpu_frame_info* o) 
   if (f < b->frame_out.size()) {
     o->out_base = b->frame_out[f].out_base; o->out_size = b->frame_out[f].out_size;
     if (b->frame_out[f].status) { o->status = b->frame_out[f].status; o->bad_block = b->frame_out[f].bad_block; }
+    else if (fi.host_status) o->bad_block = fi.nblocks;   // the walk stopped behind the frame's blocks, all of which decoded: the block it could not read
   }
   return ZGPU_OK;
 }

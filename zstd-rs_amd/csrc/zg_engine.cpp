@@ -557,6 +557,14 @@ int Batch::run() {
   hipStream_t s = eng->stream_;
   ZgBatchDev& d = dev;
   if (d.nframes == 0) { ran = true; total_out = 0; return ZG_OK; }
+  if (d.nblocks == 0) {
+    // frames without a single block (the walk stopped at the first block header of each: parse_status / FrameInfo::host_status say why):
+    // nothing to launch — a grid of zero workgroups is an error to the runtime (tools/dev/soak_batch.py) — and nothing comes out
+    frame_out.assign(d.nframes, ZgFrameOut{});
+    for (ZgFrameOut& fo : frame_out) fo.err_packed = 0xFFFFFFFFu;
+    total_out = 0; ran = false; synced = true;
+    return ZG_OK;
+  }
   hipEvent_t* ev = sc->ev;
   // every frame declares its content size: output and flatten scratch are sized now, and nothing below waits for the host
   presized = false;
@@ -568,13 +576,15 @@ int Batch::run() {
   //  allocation — and a reserve that fails all the same is no error either: the reference never looks at the field, so the
   //  submit falls back to sizes taken from the scan.)
   // (not with ramped units, a measurement switch: their sweep chain polls flags that the flatten of a no-op run never raises — ADVICE r4)
-  if (!fs && all_declared && !eng->no_presize_ && declared_total <= bb.out_bound && !bb.ramped) {
+  // (not for a declared total of 0: the device's "sized in advance" marker is a capacity > 0, and a submit that declares nothing but produces
+  //  one byte kept its promise by that marker while the host's capacity said 0 — zgpu_batch_read refused the byte, tools/dev/soak_batch.py)
+  if (!fs && all_declared && declared_total && !eng->no_presize_ && declared_total <= bb.out_bound && !bb.ramped) {
     // (the scratch first: it is four times the output. When either reserve fails nothing of the attempt stays allocated — the sizes taken
     //  from the scan may well fit where the declared ones did not: ADVICE r5)
     if (sc->d_og.reserve(declared_total * 4 + 64) == 0 && sc->d_dst.reserve(kOutFront + declared_total + 64) == 0) {
       d.dst = sc->d_dst.as<uint8_t>() + kOutFront; d.dst_cap = declared_total;
       d.og = sc->d_og.as<uint32_t>(); d.og_words = og_words = declared_total;
-      d.dst_cap_pre = declared_total ? declared_total : 1;   // (0 means "not sized in advance")
+      d.dst_cap_pre = declared_total;                        // (0 means "not sized in advance")
       presized = true;
     } else { sc->d_og.release(); sc->d_dst.release(); }
   }

@@ -345,6 +345,7 @@ ZX_DEV void zg_flat1_unit(const ZgBatchDev& d, const uint32_t ui, ZgFlat1Lds<T, 
         }
         zx_min_glb(&d.frame_out[un.frame].err_packed, ((b - fr.first_block) << 8) | st);
       }
+      unit_size = bu0;     // the unit ends in front of the block that failed: its scratch is complete up to there, and the sweep resolves the good blocks
       break;
     }
   }

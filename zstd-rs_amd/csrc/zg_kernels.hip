@@ -1409,8 +1409,9 @@ __device__ __forceinline__ ZgSweepDesc zg_sweep_desc(const ZgBatchDev& d, uint32
   sd.size = size;
   const uint32_t w = zg_sweep_window(d, d.frames[un.frame]);
   sd.head = sd.size > w ? (sd.size - w) / (4u * ZG_SW_T * ZG_SW_B) : 0u;
-  // a unit of the frame failed in the flatten: its scratch is incomplete; the frame is reported as failed
-  sd.live = (!d.totals[2] && fo.fast && fo.err_packed == 0xFFFFFFFFu) ? 1u : 0u;
+  // (a frame one of whose units failed in the flatten is swept like any other: a unit's size ends in front of the block that failed —
+  //  zg_flat1_unit — so what the good blocks in front of it copy is resolved, and what lies behind it is nobody's output)
+  sd.live = (!d.totals[2] && fo.fast) ? 1u : 0u;
   sd.pad = 0;
   return sd;
 }
@@ -1854,12 +1855,13 @@ __global__ void __launch_bounds__(64) zg_k_sparse(ZgBatchDev d) {
   const ZgFrame fr = d.frames[f];
   if (!fr.sparse) return;
   const ZgFrameOut fo = d.frame_out[f];
-  if (!fo.fast || fo.err_packed != 0xFFFFFFFFu) return;        // the in-order path has it / zg_k_flatten found a sequence that cannot be executed
+  if (!fo.fast) return;                                        // the in-order path has it
+  const uint32_t stop = fo.err_packed == 0xFFFFFFFFu ? 0xFFFFFFFFu : fo.err_packed >> 8;   // zg_k_flatten found a sequence that cannot be executed: the blocks in front of its block are
   uint8_t* frame_out = d.dst + fo.out_base;
   for (uint32_t e = 0; e < fr.seq_count; e++) {
     const uint32_t b = d.seq_blocks[fr.seq_first + e];
     const ZgBlockPos p = d.pos[b];
-    if (!p.active) break;
+    if (!p.active || b - fr.first_block >= stop) break;
     const ZgBlock* blk = &d.blocks[b];
     const uint32_t nseq = blk->nseq;
     const ZgSeq* sq = d.seq_arena + blk->seq_base;
