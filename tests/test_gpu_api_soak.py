@@ -205,3 +205,31 @@ def test_good_blocks_in_front_of_an_execution_error_keep_their_bytes():
     assert f.read(1 << 22, True) == want
     f.close()
     ctx.close()
+
+
+def test_offset_error_in_front_of_a_sequence_the_post_pass_rejects():
+    """a mutated corpus frame cut behind its second block (tests/golden/regress, found by tools/dev/soak.py seed 41): in that block sequence
+    1708 reaches in front of everything (DictionaryTooSmall) and a sequence behind the first 2048 asks for more literals than are left. The
+    reference executes in order and meets the offset first; zg_k_seqpost rejects the later one, zg_k_exact looks at the sequences in front of
+    it — and was told the rejected sequence's index in its PASS of 2048 instead of in the block, so it stopped short of 1708"""
+    sys.path.insert(0, os.path.join(ROOT, "zstd-rs_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    import zgpu
+    z = open(os.path.join(ROOT, "tests", "golden", "regress", "offset_error_in_front_of_a_rejected_sequence.zst"), "rb").read()
+    ost, _ = oracle.FrameDecoder().decode_all(z, 1 << 22)
+    assert ost == 53
+    ctx = zgpu.Context(0)
+    with pytest.raises(zgpu.ZgpuError) as e:
+        ctx.decode_all(z, 1 << 22)
+    assert e.value.status == ost
+    g = zgpu.FrameDecoder(ctx)
+    st, hl, _, _ = g.init(z)
+    assert st == 0 and g.decode_blocks(z[hl:])[0] == ost and g.blocks_decoded() == 1
+    g.close()
+    s = zgpu.CStreamingDecoder(ctx, data=z)
+    with pytest.raises(zgpu.ZgpuError) as e:
+        s.read(1 << 22)
+    assert e.value.status == ost
+    s.close()
+    ctx.close()

@@ -987,6 +987,7 @@ __global__ void __launch_bounds__(ZG_SP_T, 4) zg_k_seqpost(ZgBatchDev d) {
   ZgHistMap carry = zg_map_identity();
   uint32_t lit_carry = 0, out_carry = 0;
   uint32_t pos_carry = d.seq_out[b].pad;          // bit position where the next pass's first sequence starts (left by zg_k_seq)
+  uint32_t err_i0 = 0;                            // the pass in which a sequence was rejected starts here (s_err holds its index in the pass)
   __syncthreads();
   for (uint32_t i0 = 0; i0 < nseq; i0 += ZG_SP_T * ZG_SP_S) {
     const uint32_t ib = i0 + t * ZG_SP_S;
@@ -1145,13 +1146,15 @@ __global__ void __launch_bounds__(ZG_SP_T, 4) zg_k_seqpost(ZgBatchDev d) {
     if (far) d.totals[3] = 1u;
     carry = tot; lit_carry = totl; out_carry = toto;
     __syncthreads();
-    if (s_err != 0xFFFFFFFFu) break;
+    if (s_err != 0xFFFFFFFFu) { err_i0 = i0; break; }
   }
   if (t == 0) {
     ZgBlockSeqOut so;
     so.sum_ll = lit_carry; so.sum_ml = out_carry - lit_carry;
     so.hist_end[0] = carry.s[0]; so.hist_end[1] = carry.s[1]; so.hist_end[2] = carry.s[2];
-    so.pad = s_err != 0xFFFFFFFFu ? (s_err >> 8) + 1u : 0u;   // 1 + the sequence that cannot be executed (no literals left, offset 0): zg_k_exact looks at the ones in front of it
+    so.pad = s_err != 0xFFFFFFFFu ? err_i0 + (s_err >> 8) + 1u : 0u;   // 1 + the sequence that cannot be executed (no literals left, offset 0): zg_k_exact looks at the ones in front of it
+                                                                       // (its index in the BLOCK: until late in round 6 the pass's start was missing, and a block whose rejected sequence lay behind the
+                                                                       //  first 2048 hid an offset error in front of it from zg_k_exact — tools/dev/soak.py seed 41)
     d.seq_out[b] = so;
     if (s_err != 0xFFFFFFFFu) zg_set_status(d.status, b, (int)(s_err & 0xFFu));
   }
