@@ -14,16 +14,20 @@ ctx = zgpu.Context(0)
 pool = zgpu.Pool()
 pack = read_pack("decodecorpus.pack")
 names = sorted(k for k in pack if k.endswith(".zst") and len(pack[k]) < 300000)
+dpack = read_pack("dict_tests.pack")
+dnames = sorted(k for k in dpack if k.endswith(".zst"))
+ctx.add_dict(dpack["dictionary"])             # (frames that name it go one by one through the FrameDecoder mirror inside zgpu_decode_all; the pool has no dictionaries)
 bad = nerr = 0
 leaves = {}
 for it in range(n):
     m = bytearray()
+    with_dict = it % 4 == 3
     for _ in range(rng.randrange(1, 5)):
         r = rng.random()
         if r < 0.2:
             k = rng.randrange(0, 60)
             m += bytes([0x50 + rng.randrange(16), 0x2A, 0x4D, 0x18]) + k.to_bytes(4, "little") + bytes(rng.randrange(256) for _ in range(k))
-        f = bytearray(pack[rng.choice(names)])
+        f = bytearray(dpack[rng.choice(dnames)] if with_dict and rng.random() < 0.6 else pack[rng.choice(names)])
         if rng.random() < 0.25:
             i = rng.randrange(4, len(f))
             f[i] ^= 1 << rng.randrange(8)
@@ -33,13 +37,17 @@ for it in range(n):
     if rng.random() < 0.1:
         m += bytes(rng.randrange(256) for _ in range(rng.randrange(1, 12)))
     m = bytes(m)
-    ost, oout = oracle.FrameDecoder().decode_all(m, 1 << 25)
+    def ora(cap):
+        o = oracle.FrameDecoder()
+        o.add_dict(dpack["dictionary"])
+        return o.decode_all(m, cap)
+    ost, oout = ora(1 << 25)
     cap = 1 << 25
     if ost == 0 and rng.random() < 0.15:
         cap = max(0, len(oout) - rng.choice([1, 2, 100, 70000]))
-        ost, oout = oracle.FrameDecoder().decode_all(m, cap)
+        ost, oout = ora(cap)
     res = []
-    for what, fn in (("decode_all", lambda: ctx.decode_all(m, cap)), ("pool", lambda: pool.decode_all(m, cap))) + \
+    for what, fn in (("decode_all", lambda: ctx.decode_all(m, cap)),) + ((("pool", lambda: pool.decode_all(m, cap)),) if not with_dict else ()) + \
                     ((("alloc", lambda: ctx.decode_all_to_vec(m)),) if cap == 1 << 25 else ()):
         try:
             out, gst = fn(), 0
