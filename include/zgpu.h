@@ -127,7 +127,11 @@ int zgpu_pool_decode_all(zgpu_pool*, const uint8_t* src, size_t len, uint8_t* ds
  * each job goes to when n_workers workers pull in that order with time proportional to cost; load_out[w] = sum of w's costs. */
 int zgpu_pool_plan(const uint64_t* cost, uint32_t n, uint32_t n_workers, uint32_t* order_out, uint32_t* worker_out, uint64_t* load_out);
 /* device-resident form (bench / roofline): stage n entries (each one frame, or a run of frames) — LPT assignment over the GPUs, one
- * resident submit per GPU — then run passes over them; outputs stay in HBM. */
+ * resident submit per GPU — then run passes over them; outputs stay in HBM. What the HOST reads must be readable in every entry —
+ * frame headers, block headers, whole bodies, the literals / sequences section headers of every block (a GPU's entries are parsed as one
+ * concatenation, with decode_all's rule that the first such error ends the walk): an entry that fails there fails the call — with that
+ * error, or with the one its bytes yield once the next entry's follow them (a truncated entry runs into its neighbour) — and nothing stays staged. What the DEVICE finds (table descriptions, bitstreams, sequence execution) is per entry:
+ * zgpu_pool_frame gives the status of the entry's first failing frame and the size of all its frames, zgpu_pool_read their bytes. */
 int zgpu_pool_stage(zgpu_pool*, const uint8_t* const* frames, const size_t* lens, uint32_t n);
 int zgpu_pool_run(zgpu_pool*, float* gpu_ms /* [num_gpus] kernel pipeline ms per GPU */, float* wall_ms);
 /* per-kernel times of GPU g's last pass (ms, the order of zgpu_batch_timings), summed over its resident jobs, and what they hold */

@@ -233,3 +233,31 @@ def test_offset_error_in_front_of_a_sequence_the_post_pass_rejects():
     assert e.value.status == ost
     s.close()
     ctx.close()
+
+
+def test_pool_entries_that_are_runs_of_frames():
+    """zgpu_pool_stage takes entries that are one frame or a run of frames (skippable ones in between): zgpu_pool_frame / zgpu_pool_read speak
+    for the whole entry — until tools/dev/soak_pool.py they looked at its first frame only"""
+    sys.path.insert(0, os.path.join(ROOT, "zstd-rs_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import oracle
+    import zgpu
+    from golden_io import read_pack
+    pack = read_pack("decodecorpus.pack")
+    names = sorted(k for k in pack if k.endswith(".zst"))[:12]
+    skip = bytes([0x5A, 0x2A, 0x4D, 0x18, 5, 0, 0, 0]) + b"12345"
+    bad = bytearray(pack[names[3]])
+    bad[len(bad) // 2] ^= 0x10
+    entries = [pack[names[0]], pack[names[1]] + skip + pack[names[2]], skip, pack[names[4]] + bytes(bad) + pack[names[5]],
+               pack[names[6]] + pack[names[7]] + pack[names[8]]]
+    pool = zgpu.Pool()
+    pool.stage(entries)
+    pool.run()
+    for i, z in enumerate(entries):
+        ost, oout = oracle.FrameDecoder().decode_all(z, 1 << 25)
+        gpu, size, st = pool.frame(i)
+        assert st == ost, (i, st, ost)
+        if ost == 0:
+            assert size == len(oout) and pool.read(i, size) == oout, i
+    pool.close()

@@ -338,9 +338,17 @@ int zgpu_pool_frame(zgpu_pool* p, uint32_t i, int* gpu, uint64_t* out_size, uint
   if (gpu) *gpu = p->eng[s.gpu]->device();
   if (p->frame_count[i] == 0) { if (out_size) *out_size = 0; if (status) *status = 0; return s.batch ? ZGPU_OK : ZGPU_E_BAD_ARG; }   // skippable frames only
   if (!s.batch || p->frame_slot[i] >= s.batch->frame_out.size()) return ZGPU_E_BAD_ARG;
-  const ZgFrameOut& fo = s.batch->frame_out[p->frame_slot[i]];
-  if (out_size) *out_size = fo.out_size;
-  if (status) *status = fo.status;
+  // an entry is one frame or a run of frames (skippable ones hold no slot): their bytes lie back to back in the job's output, the
+  // first frame that failed is the entry's verdict (until late in round 6 only the entry's FIRST frame was looked at: tools/dev/soak_pool.py)
+  uint64_t size = 0;
+  uint32_t st = 0;
+  for (uint32_t k = 0; k < p->frame_count[i] && p->frame_slot[i] + k < s.batch->frame_out.size(); k++) {
+    const ZgFrameOut& fo = s.batch->frame_out[p->frame_slot[i] + k];
+    if (fo.status) { st = fo.status; break; }
+    size += fo.out_size;
+  }
+  if (out_size) *out_size = size;
+  if (status) *status = st;
   return ZGPU_OK;
 }
 int zgpu_pool_read(zgpu_pool* p, uint32_t i, uint8_t* dst, size_t cap, size_t* written) {
@@ -349,11 +357,15 @@ int zgpu_pool_read(zgpu_pool* p, uint32_t i, uint8_t* dst, size_t cap, size_t* w
   if (p->frame_count[i] == 0) { if (written) *written = 0; return s.batch ? ZGPU_OK : ZGPU_E_BAD_ARG; }
   if (!s.batch || p->frame_slot[i] >= s.batch->frame_out.size()) return ZGPU_E_BAD_ARG;
   DeviceGuard guard;
-  const ZgFrameOut& fo = s.batch->frame_out[p->frame_slot[i]];
-  if (fo.status) return (int)fo.status;
-  if (fo.out_size > cap) return ZGPU_E_TARGET_TOO_SMALL;
-  int st = s.batch->read_output(fo.out_base, dst, fo.out_size);
-  if (!st && written) *written = (size_t)fo.out_size;
+  uint64_t size = 0;
+  for (uint32_t k = 0; k < p->frame_count[i] && p->frame_slot[i] + k < s.batch->frame_out.size(); k++) {
+    const ZgFrameOut& fo = s.batch->frame_out[p->frame_slot[i] + k];
+    if (fo.status) return (int)fo.status;                       // (decode_all of the entry: the first failing frame's error)
+    size += fo.out_size;
+  }
+  if (size > cap) return ZGPU_E_TARGET_TOO_SMALL;
+  int st = s.batch->read_output(s.batch->frame_out[p->frame_slot[i]].out_base, dst, size);
+  if (!st && written) *written = (size_t)size;
   return st;
 }
 
