@@ -287,12 +287,15 @@ extern "C" {
 
 static int streaming_build2(zgpu_ctx* c, zgpu_streaming* s, const zgpu_stream_opts* opts, zgpu_streaming** out);
 static int streaming_build(zgpu_ctx* c, zgpu_streaming* s, const zgpu_stream_opts* opts, zgpu_streaming** out) {
-  try { return streaming_build2(c, s, opts, out); } catch (...) { return ZGPU_E_NOMEM; }
+  int st;
+  try { st = streaming_build2(c, s, opts, out); } catch (...) { st = ZGPU_E_NOMEM; }
+  if (st) zgpu_streaming_destroy(s);       // whatever of it exists (the decoder, the backend, the core)
+  return st;
 }
 static int streaming_build2(zgpu_ctx* c, zgpu_streaming* s, const zgpu_stream_opts* opts, zgpu_streaming** out) {
   // StreamingDecoder::new (streaming_decoder.rs:51-58): reads the frame header from the source
   int st = zgpu_decoder_create(c, &s->dec);
-  if (st) { delete s; return st; }
+  if (st) return st;
   uint8_t head[18];
   size_t have = s->take(head, 5);
   if (have == 5 && head[0] == 0x28 && head[1] == 0xB5 && head[2] == 0x2F && head[3] == 0xFD) {
@@ -304,7 +307,7 @@ static int streaming_build2(zgpu_ctx* c, zgpu_streaming* s, const zgpu_stream_op
   size_t used = 0;
   uint32_t sm = 0, sl = 0;
   st = zgpu_decoder_init(s->dec, head, have, &used, &sm, &sl);
-  if (st) { zgpu_decoder_destroy(s->dec); delete s; return st; }
+  if (st) return st;
   zgpu_decoder* d = s->dec;
   StreamOpts o;
   if (opts) {
@@ -317,7 +320,7 @@ static int streaming_build2(zgpu_ctx* c, zgpu_streaming* s, const zgpu_stream_op
   d->hash_on = o.hash;
   s->be = new (std::nothrow) GpuStreamBackend(d);
   s->core = s->be ? new (std::nothrow) StreamCore(s->be, o) : nullptr;
-  if (!s->core) { delete s->be; zgpu_decoder_destroy(d); delete s; return ZGPU_E_NOMEM; }
+  if (!s->core) return ZGPU_E_NOMEM;
   StreamCore* k = s->core;
   k->window = d->window_size;
   k->content_size = d->fh.has_fcs() ? d->fh.frame_content_size : 0;
