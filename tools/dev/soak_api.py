@@ -21,7 +21,7 @@ dnames = sorted(k for k in dpack if k.endswith(".zst"))
 bad = nerr = ncalls = 0
 leaves = {}
 o = g = None
-ra = 0
+rahead = 0
 oracle_default_window = 128 << 20          # DEFAULT_MAX_WINDOW_SIZE, frame_decoder.rs:25
 for it in range(n):
     use_dict = it % 5 == 4
@@ -55,8 +55,8 @@ for it in range(n):
         else:
             g.set_max_window_size(oracle_default_window)
         # the decoder's read-ahead: UptoBytes(n) behaves like UptoBytes(max(n, read_ahead)) of the reference (zgpu_decoder_set_read_ahead)
-        ra = rng.choice([0, 0, 1, 200000, 1 << 20])
-        g.set_read_ahead(ra)
+        rahead = rng.choice([0, 0, 1, 200000, 1 << 20])
+        g.set_read_ahead(rahead)
     a, b = o.init(m), g.init(m)
     trace = [("init", a, b)]
     ok = a == b
@@ -92,7 +92,7 @@ for it in range(n):
                 k = rng.choice([0, 1, 2, 3, 7]) if strat == oracle.STRAT_UPTO_BLOCKS else rng.choice([0, 1, 1000, 70000, 200000, 1 << 20])
                 # what the caller hands over: everything, or a slice that may end inside a block
                 end = len(m) if rng.random() < 0.93 else min(len(m), pos + rng.choice([0, 1, 2, 3, 5, 100, 5000, 140000]))
-                a = o.decode_blocks(m[pos:end], strat, max(k, ra) if strat == oracle.STRAT_UPTO_BYTES else k)
+                a = o.decode_blocks(m[pos:end], strat, max(k, rahead) if strat == oracle.STRAT_UPTO_BYTES else k)
                 b = g.decode_blocks(m[pos:end], strat, k)
                 trace.append(("decode_blocks", strat, k, end - pos, a, b))
                 if a[0] != b[0] or (a[0] == 0 and a != b):       # (an Err carries no byte count and no "finished" in the reference)
