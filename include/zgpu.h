@@ -226,10 +226,11 @@ int zgpu_decoder_init(zgpu_decoder*, const uint8_t* src, size_t len, size_t* con
  * carries neither a count nor "finished", and the two outputs mean nothing then). The call does not look at an earlier "finished": bytes
  * handed over behind the frame's end are read as further blocks, as by the reference. After an error the decoder answers like the
  * reference's — blocks_decoded counts the blocks in front of the failing one, bytes_read_from_source their bytes plus the failing block's
- * header when it was its body that failed (:325-341), frame_finished is set by a last block whose checksum then is not there (:347-357) —
- * with ONE difference: a block whose sequence EXECUTION fails (ZGPU_E_EXE_*) has, in the reference, already written the output of the
- * sequences in front of the failing one (and that one's literals) to the decode buffer, where collect() / read() would still find it
- * (sequence_execution.rs:6-52); here a block that fails contributes nothing. */
+ * header when it was its body that failed (:325-341), frame_finished is set by a last block whose checksum then is not there (:347-357),
+ * and a block whose sequence EXECUTION fails (ZGPU_E_EXE_*) leaves behind what it had written before it failed — the output of the
+ * sequences in front of the failing one, and that one's literals unless it was the literals that ran out (sequence_execution.rs:6-52) —
+ * where collect() / read() still find it. (The same holds for zgpu_frame_* and zgpu_streaming_*; a frame of a many-frame submit,
+ * zgpu_batch_* / zgpu_pool_*, ends with its last good block.) */
 int zgpu_decoder_decode_blocks(zgpu_decoder*, const uint8_t* src, size_t len, size_t* consumed, int strat, size_t n, int* frame_finished);
 /* force_dict (:229-243): use a registered dictionary although the frame header names none; like the reference, at any
  * time (tables, offset history and dictionary content are replaced for the blocks that follow) */

@@ -67,9 +67,31 @@ for it in range(n):
     g = zgpu.FrameDecoder(ctx)
     g.init(m)
     gst = g.decode_blocks(m[hl:])[0]
-    if gst != ost or g.blocks_decoded() != good:
-        res.append(("decode_blocks", ost, gst, good, g.blocks_decoded()))
+    if gst != ost or g.blocks_decoded() != good or g.can_collect() != o.can_collect():
+        res.append(("decode_blocks", ost, gst, good, g.blocks_decoded(), g.can_collect(), o.can_collect()))
     g.close()
+    # the thin boundary, everything in one run: after an error all that the reference's buffer holds is readable, the failing block's
+    # partial output included
+    if ost:
+        from test_gpu_thin_boundary import parse_frame_header
+        tblocks, p = [], hl
+        while p + 3 <= len(m):
+            h = int.from_bytes(m[p:p + 3], "little")
+            ty, size = (h >> 1) & 3, h >> 3
+            if ty == 3 or size > (128 << 10) or len(m) - p - 3 < (1 if ty == 1 else size):
+                break
+            tblocks.append((p + 3, 1 if ty == 1 else size, ty, h & 1, size if ty != 2 else 0))
+            p += 3 + (1 if ty == 1 else size)
+            if h & 1:
+                break
+        if len(tblocks) > good:
+            tf = zgpu.BlockFrame(ctx, o.window_size(), o.content_size(), 0)
+            tf.submit(m, tblocks)
+            tb, ts = tf.sync()
+            x = tf.read(1 << 25, True)
+            if (tb, ts) != (good, ost) or x != held:
+                res.append(("thin", (tb, ts), (good, ost), len(x), len(held)))
+            tf.close()
     s = zgpu.CStreamingDecoder(ctx, data=m)
     try:
         sout, sst = s.read(1 << 25), 0

@@ -85,11 +85,11 @@ for it in range(n):
                 trace.append(("verdict", gb, gs, a[0], o.blocks_decoded(), f.blocks_decoded()))
                 ok = False
                 break
-            # what is in front of the failing block is readable (sequence execution errors: the reference also holds the failing block's
-            # partial output, include/zgpu.h)
-            x, y = f.read(1 << 22, False), o.read(1 << 22)
-            if (y[:len(x)] != x) if 50 <= a[0] <= 53 else (x != y):
-                trace.append(("read after the error", len(x), len(y)))
+            # everything the reference's buffer holds now — the good blocks of this run and, after a sequence execution error, what the
+            # failing block wrote before it failed (zg_k_partial) — is there: read it all (finished = 1 hands out the window too)
+            x, y = f.read(1 << 24, True), o.held()
+            if x != y:
+                trace.append(("held after the error", len(x), len(y)))
                 ok = False
             break
     f.close()

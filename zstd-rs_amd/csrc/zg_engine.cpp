@@ -668,7 +668,7 @@ int Batch::size_output() {
   for (const ZgFrameOut& fo : frame_out) any_fast |= fo.fast != 0;
   if (fs) {
     const uint64_t add = frame_out[0].out_size;
-    if ((st = fs->make_room(add, keep_bytes, s))) return st;
+    if ((st = fs->make_room(add + kMaxBlockSize, keep_bytes, s))) return st;   // (+ a block: what a block that fails in sequence execution leaves behind the run, zg_k_partial)
     // this run continues the frame: its bytes go right behind what exists, and matches may reach back into it — as far as
     // the caller still holds bytes (DecodeBuffer semantics: repeat() sees only what has not been drained)
     ZgFrame& fr = bb.frames[0];
@@ -846,6 +846,42 @@ int Batch::sync() {
       if (!all_pos.empty()) p = all_pos[fr.first_block + fo.good_blocks];
       else ZG_HIP(hipMemcpy(&p, dev.pos + fr.first_block + fo.good_blocks, sizeof p, hipMemcpyDeviceToHost));
       if (p.out_base < fo.out_size) fo.out_size = p.out_base;
+    }
+  }
+  // A run of ONE frame that is decoded run by run (the FrameDecoder mirror, the thin boundary, the streaming decoder: fs) and failed in
+  // sequence execution: the reference's decode buffer also holds what the failing block wrote before it failed — the output of the
+  // sequences in front of the one that could not be executed, and that one's literals unless it was the literals that ran out
+  // (sequence_execution.rs:6-52) — and hands it out like any other byte (collect / read after the Err). zg_k_partial produces exactly
+  // that behind the good blocks' bytes. (Frames of a many-frame submit end with their last good block: include/zgpu.h.)
+  if (fs && dev.nframes == 1 && !frame_out.empty()) {
+    ZgFrameOut& fo = frame_out[0];
+    const ZgFrame& fr = bb.frames[0];
+    const uint32_t st = fo.status;
+    const bool exe = st == (uint32_t)ZG_EXE_NOT_ENOUGH_LITERALS || st == (uint32_t)ZG_EXE_ZERO_OFFSET || st == (uint32_t)ZG_EXE_OFFSET_TOO_BIG ||
+                     st == (uint32_t)ZG_EXE_DICT_TOO_SMALL;
+    if (exe && fo.fast && fo.good_blocks < fr.nblocks) {
+      const uint32_t b = fr.first_block + fo.good_blocks;
+      const ZgBlock& blk = bb.blocks[b];
+      ZgBlockSeqOut so;
+      memset(&so, 0, sizeof so);
+      if (blk.btype == ZG_BT_COMPRESSED && blk.nseq && !blk.host_status)
+        ZG_HIP(hipMemcpy(&so, dev.seq_out + b, sizeof so, hipMemcpyDeviceToHost));
+      if (so.pad && so.pad <= blk.nseq) {                       // 1 + the sequence that failed (zg_k_seqpost, or zg_k_exact where it decided)
+        const uint32_t j = so.pad - 1u;
+        const bool lits = st != (uint32_t)ZG_EXE_NOT_ENOUGH_LITERALS;   // (:14-19 come before the push; the offset checks :28-38 behind it)
+        ZgSeq rec[2];
+        memset(rec, 0, sizeof rec);
+        const uint32_t first = j ? j - 1u : 0u, cnt = j ? 2u : 1u;
+        ZG_HIP(hipMemcpy(rec, dev.seq_arena + blk.seq_base + first, cnt * sizeof(ZgSeq), hipMemcpyDeviceToHost));
+        const ZgSeq& rj = rec[j ? 1 : 0];
+        const uint32_t psize = lits ? ZG_SEQ_MDST(rj) : (j ? ZG_SEQ_MDST(rec[0]) + ZG_SEQ_ML(rec[0]) : 0u);
+        if (psize && psize <= kMaxBlockSize) {
+          zg_launch_partial(dev, eng->stream_, 0, b, j, lits);
+          ZG_HIP(hipStreamSynchronize(eng->stream_));
+          fo.out_size += psize;
+          dev.dst_cap += psize;                                 // (size_output reserved a block's worth behind the run for this)
+        }
+      }
     }
   }
   hipEvent_t* ev = sc->ev;

@@ -130,6 +130,7 @@ ZX_DEV void zg_exact_frame(const ZgBatchDev& d, const uint32_t f, const uint32_t
           ZgFrameOut* o = &d.frame_out[f];
           o->status = (uint32_t)bad & 0xFFu; o->bad_block = i; o->good_blocks = i;
           o->err_packed = (i << 8) | ((uint32_t)bad & 0xFFu);
+          d.seq_out[b].pad = (uint32_t)(bad >> 8) + 1u;             // 1 + the sequence that failed, as zg_k_seqpost leaves it for its own verdicts (Batch::sync: zg_k_partial)
         }
         return;
       }

@@ -1896,6 +1896,65 @@ __global__ void __launch_bounds__(64) zg_k_sparse(ZgBatchDev d) {
     }
   }
 }
+// ------------------------------------------------------------------------------------------------------------
+// zg_k_partial: what the reference's decode buffer holds of a block whose sequence EXECUTION failed. execute_sequences
+// (sequence_execution.rs:6-52) pushes a sequence's literals, then its match, one sequence after the other, and returns at the first one it
+// cannot execute: the output of the sequences in front of it stays in the buffer (and that sequence's literals, unless it was the
+// literals that ran out), where collect() / read() still find it after the Err. The fast path produces a block as a whole or not at
+// all; for the ONE block that failed, of a frame that is decoded run by run (FrameDecoder mirror, thin boundary, streaming decoder),
+// Batch::sync() runs this kernel: sequences [0, nexec) in order behind the bytes of the good blocks, plus the literals of sequence
+// nexec when lits_of_next is set. One wave, 64 sequences per round (zg_k_sparse's scheme: a match is copied once everything below the
+// lowest pending destination is final); an error path, at most 128 KiB.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) zg_k_partial(ZgBatchDev d, uint32_t f, uint32_t b, uint32_t nexec, uint32_t lits_of_next) {
+  const uint32_t lane = threadIdx.x;
+  const ZgFrameOut fo = d.frame_out[f];
+  const ZgBlockPos p = d.pos[b];
+  const ZgBlock* blk = &d.blocks[b];
+  uint8_t* frame_out = d.dst + fo.out_base;
+  const ZgSeq* sq = d.seq_arena + blk->seq_base;
+  const uint8_t* body = d.src + blk->src_off;
+  const bool lit_rle = blk->lit_type == ZG_LT_RLE;
+  const uint8_t* lit = blk->lit_type <= ZG_LT_RLE ? body + blk->lit_off : d.lit_arena + blk->lit_base;
+  const uint32_t total = nexec + (lits_of_next ? 1u : 0u);          // sequences whose literals go out
+  for (uint32_t s0 = 0; s0 < total; s0 += 64) {
+    const uint32_t i = s0 + lane;
+    bool pending = false;
+    uint32_t off = 0, ml = 0, mdst = 0xFFFFFFFFu;
+    uint64_t dpos = 0;
+    if (i < total) {
+      const ZgSeq q = sq[i];
+      mdst = ZG_SEQ_MDST(q);
+      uint32_t prev_end = 0;                                         // where the sequence in front of this one ended = where this one's literals start
+      if (i) { const ZgSeq pq = sq[i - 1]; prev_end = ZG_SEQ_MDST(pq) + ZG_SEQ_ML(pq); }
+      const uint32_t ll = mdst - prev_end, lp = ZG_SEQ_LIT(q);
+      uint8_t* o = frame_out + p.out_base + prev_end;
+      if (lit_rle) { const uint8_t v = lit[0]; for (uint32_t k = 0; k < ll; k++) o[k] = v; }
+      else for (uint32_t k = 0; k < ll; k++) o[k] = lit[lp + k];
+      if (i < nexec) {
+        ml = ZG_SEQ_ML(q);
+        off = zg_sym_resolve(q.of, p.hist_init);
+        dpos = p.out_base + mdst;
+        pending = ml > 0;
+      }
+    }
+    __threadfence_block();                                           // the literals are in place for the matches that copy from them
+    for (uint32_t guard = 0; guard <= 64u; guard++) {                // (every round retires the first pending match at least)
+      uint32_t hwm = pending ? mdst : 0xFFFFFFFFu;
+      for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t o2 = __shfl_xor(hwm, sh, 64); hwm = o2 < hwm ? o2 : hwm; }
+      if (hwm == 0xFFFFFFFFu) break;
+      if (pending) {
+        const int64_t src_end = (int64_t)dpos - (int64_t)off + (int64_t)ml;
+        const uint64_t need_end = ml < off ? (src_end > 0 ? (uint64_t)src_end : 0ull) : dpos;
+        if (need_end <= p.out_base + hwm) { zg_lane_match_copy(frame_out + dpos, off, ml); pending = false; }
+      }
+      __threadfence_block();
+    }
+  }
+}
+void zg_launch_partial(const ZgBatchDev& d, hipStream_t s, uint32_t frame, uint32_t block, uint32_t nexec, bool lits_of_next) {
+  hipLaunchKernelGGL(zg_k_partial, dim3(1), dim3(64), 0, s, d, frame, block, nexec, lits_of_next ? 1u : 0u);
+}
 void zg_launch_sparse(const ZgBatchDev& d, hipStream_t s) {
   if (d.nframes) hipLaunchKernelGGL(zg_k_sparse, dim3(d.nframes), dim3(64), 0, s, d);
 }

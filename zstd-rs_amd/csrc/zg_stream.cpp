@@ -120,7 +120,7 @@ class GpuStreamBackend : public StreamBackend {
     // the plaintext of the run in front may still be on its way to the host: nothing may move under it. A move is harmless when the
     // buffer is compacted in place and both what moves (the kept tail, to the front) and what this run will write behind it stay in
     // FRONT of the bytes that are being fetched — the window is reserved for three runs, so that is the usual case.
-    const uint64_t bound = (uint64_t)nb_->bb.blocks.size() * kMaxBlockSize;
+    const uint64_t bound = ((uint64_t)nb_->bb.blocks.size() + 1u) * kMaxBlockSize;   // (+ the block Batch::size_output reserves behind the run, zg_k_partial)
     if (fetching_ && fs->room_moves(bound, keep)) {
       const uint64_t k2 = keep < fs->have ? keep : fs->have;
       const bool inplace = fs->d_out.p && !fs->base && kOutFront + k2 + bound + 64 <= fs->d_out.cap;
