@@ -67,12 +67,12 @@ enum zgpu_status {
    *  - offsets >= 2^30 (offset codes 30, 31) while >= 1 GiB of the frame is held undrained (FrameDecoder::decode_blocks(All) on a
    *    frame beyond 1 GiB that nobody reads from): ZGPU_E_UNSUPPORTED. With less than 1 GiB held — always the case in decode_all
    *    and the streaming decoder — such an offset fails in the reference too, and with the same error here;
-   *  - a block that regenerates >= 2^31 bytes: ZGPU_E_UNSUPPORTED;
-   *  - decode_all on a frame WITH a dictionary that holds more than 1 MiB of raw / RLE output (not counted by total_output_counter) in
-   *    front of a match that starts in the dictionary: the reference has drained bytes inside that call (frame_decoder.rs:560-563) and
-   *    splices the dictionary's tail with the oldest byte it still holds; one submit keeps every byte in place: ZGPU_E_UNSUPPORTED
-   *    (never wrong bytes). The same frame through decode_blocks / the streaming decoder, where drains fall between submits, is decoded.
-   * (Rounds 2-4 listed a third case here: a match that starts in the dictionary and continues BEHIND bytes the caller has drained — the
+   *  - a block that regenerates >= 2^31 bytes: ZGPU_E_UNSUPPORTED.
+   * (Round 5 listed a third case: decode_all on a frame WITH a dictionary that holds more than 1 MiB of raw / RLE output in front of a
+   *  match that starts in the dictionary — the reference has drained bytes inside that call, frame_decoder.rs:560-563, and splices the
+   *  dictionary's tail with the oldest byte it still holds, which one submit that keeps every byte in place cannot serve. zgpu_decode_all
+   *  now decodes such a frame a second time on the reference's own schedule, rounds of UptoBytes(1 MiB) + read(), and returns its bytes.)
+   * (Rounds 2-4 listed another case here: a match that starts in the dictionary and continues BEHIND bytes the caller has drained — the
    *  reference splices the dictionary's tail with the oldest byte it still holds, decode_buffer.rs:159-163. Since round 5 the device
    *  window of a frame with a dictionary is laid out like the reference's buffer, [dictionary content][undrained bytes], and the match
    *  yields the reference's bytes.)

@@ -208,8 +208,9 @@ def test_dictionary_spliced_behind_drained_bytes(ctx):
 def test_dictionary_splice_behind_a_drain_inside_decode_all(ctx):
     """decode_all on a frame that names a dictionary is ONE submit (decode_all_per_frame -> decode_blocks(All) with the drain
     rule of decode_all). With fewer than 1 MiB in front nothing is drained inside it and the splice yields the oracle's bytes; with a
-    drain inside the submit the device still holds the drained bytes in place, and the engine must refuse (ZGPU_E_UNSUPPORTED, listed in
-    include/zgpu.h) rather than return bytes the reference would not."""
+    drain inside the submit the device still holds the drained bytes in place: zg_k_exact refuses that submit (never wrong bytes), and
+    since late in round 6 decode_all then decodes the frame again on the reference's own schedule — rounds of UptoBytes(1 MiB) + read(),
+    the drains between submits — and returns the reference's bytes."""
     import zgpu
     raw = read_pack("dict_tests.pack")["dictionary"]
     did = ctx.add_dict(raw)
@@ -224,7 +225,18 @@ def test_dictionary_splice_behind_a_drain_inside_decode_all(ctx):
             out, st = ctx.decode_all(z, 1 << 26), 0
         except zgpu.ZgpuError as e:
             out, st = None, e.status
-        if nraw == 3:
-            assert st == 0 and out == oout
-        else:
-            assert st == 80, st
+        assert st == 0 and out == oout, (nraw, st)
+        assert ctx.decode_all_to_vec(z) == oout
+    # two such frames and an ordinary one between them in one call; a target that is too small by one byte
+    from golden_io import read_pack as rp
+    plain = rp("decodecorpus.pack")["z000033.zst"]
+    z2 = z + plain + z
+    o = oracle.FrameDecoder()
+    o.add_dict(raw)
+    ost, oout = o.decode_all(z2, 1 << 26)
+    assert ost == 0 and ctx.decode_all(z2, 1 << 26) == oout
+    with pytest.raises(zgpu.ZgpuError) as e:
+        ctx.decode_all(z2, len(oout) - 1)
+    o = oracle.FrameDecoder()
+    o.add_dict(raw)
+    assert e.value.status == o.decode_all(z2, len(oout) - 1)[0] == 12

@@ -842,9 +842,31 @@ static int decode_all_per_frame(zgpu_ctx* c, const uint8_t* src, size_t len, uin
       continue;
     }
     if (st) break;
+    const size_t hdr = used, frame_at = p;
     p += used;
     int fin = 0;
     st = zgpu_decoder_decode_blocks(d, src + p, len - p, &used, ZGPU_STRAT_ALL, 0, &fin);
+    if (st == ZGPU_E_UNSUPPORTED) {
+      // The one thing a single submit cannot serve (zg_exact.h: a match that starts in the dictionary behind bytes the reference has
+      // drained INSIDE this call): the frame again, on the reference's own schedule — rounds of UptoBytes(1 MiB), each followed by read()
+      // (frame_decoder.rs:560-573) — so that the drains fall between submits, where the device window is laid out like the reference's
+      // buffer (FrameState::make_room). Slow (a submit per MiB) and only ever taken by frames no encoder makes.
+      st = zgpu_decoder_init(d, src + frame_at, len - frame_at, &used, &sm, &sl);
+      if (st) break;
+      d->drain_rule = ZG_DRAIN_NONE;
+      p = frame_at + hdr;
+      for (;;) {
+        st = zgpu_decoder_decode_blocks(d, src + p, len - p, &used, ZGPU_STRAT_UPTO_BYTES, (size_t)1 << 20, &fin);
+        p += used;
+        if (st) break;
+        total += zgpu_decoder_read(d, dst + total, cap - total);
+        if (zgpu_decoder_can_collect(d) != 0) { st = ZGPU_E_TARGET_TOO_SMALL; break; }
+        if (zgpu_decoder_is_finished(d)) break;
+      }
+      d->drain_rule = ZG_DRAIN_DECODE_ALL;
+      if (st) break;
+      continue;
+    }
     p += used;
     if (st) break;
     total += zgpu_decoder_read(d, dst + total, cap - total);
