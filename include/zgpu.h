@@ -282,7 +282,8 @@ void zgpu_frame_end(zgpu_frame*);
 int zgpu_blocks_submit(zgpu_frame*, const uint8_t* src, size_t src_len, const zgpu_block* blocks, size_t nblocks);
 /* wait for the submit in flight. *first_bad_block = frame-relative index (counted over all submits) of the first block that
  * failed, SIZE_MAX if none; *its_status = its DecompressBlockError leaf (the zgpu_status values above). Blocks in front of
- * it are decoded and readable, like the reference's. The return value only reports engine failures (HIP, memory). */
+ * it are decoded and readable, like the reference's — and, like there, what the failing block itself had written when its sequence
+ * execution failed (see zgpu_decoder_decode_blocks). The return value only reports engine failures (HIP, memory). */
 int zgpu_sync(zgpu_frame*, size_t* first_bad_block, int32_t* its_status);
 /* can_collect / read (decode_buffer.rs:182-219, frame_decoder.rs:381-424): while the frame is unfinished the last window_size
  * bytes stay back. frame_finished: the caller has submitted the last block (it reads the flag itself). */
