@@ -145,6 +145,10 @@ def model(fr, reads, trailing_junk=False):
         res.append((n, bytes(fr.plain[out_pos:out_pos + n])))
         out_pos += n
         buf_len -= n
+    # bytes_read_from_source after the first Err: the failing block's header was read and counted when it was its body that failed
+    # (frame_decoder.rs:325-341) — not for the errors of read_block_header, not for a checksum that is missing
+    first = next((r[1] for r in res if r[0] == "err"), 0)
+    model.counted = pos + (3 if first and first not in (E_HDR, E_RESERVED, E_CS) else 0) if first != E_CS else src_avail
     return res, pos
 
 
@@ -196,6 +200,8 @@ def check(fr, reads, **kw):
     if kw.get("hash_on", True) and not any(w[0] == "err" for w in want):
         assert cs == (xxhash.xxh64(handed).intdigest() & 0xFFFFFFFF)
     assert stats["src_taken"] <= fr.frame_end, (stats, fr.frame_end)          # nothing behind the frame's end is taken from the source
+    if kw.get("read_ahead") == 1 and any(w[0] == "err" for w in want) and [w for w in want if w[0] == "err"][0][1] != E_CS:
+        assert stats["bytes_read"] == model.counted, (stats["bytes_read"], model.counted, want[-1])   # block by block: the reference's counter, also after an Err
     return want, stats
 
 

@@ -45,6 +45,13 @@ for it in range(n):
             print("DISAGREE", it, name, kw, "dict" if use_dict else "", "read", k, "cap", pat[k] if k < len(pat) else None,
                   "got", got[k][:1] if k < len(got) else None, (got[k][1] if k < len(got) and isinstance(got[k][1], int) else ""),
                   "want", want[k][:1] if k < len(want) else None, (want[k][1] if k < len(want) and isinstance(want[k][1], int) else ""), flush=True)
+        if s and ok and kw.get("read_ahead") == 1 and o is not None:
+            # block by block, on the reference's schedule: the counters are the reference's too, also after an Err
+            a = (o.blocks_decoded(), o.bytes_read_from_source(), o.is_finished())
+            b = (s.blocks_decoded(), s.bytes_read_from_source(), s.is_finished())
+            if a != b:
+                bad += 1
+                print("DISAGREE", it, name, "counters", a, b, want[-1][:2] if want and want[-1][0] == "err" else "", flush=True)
         if s:
             s.close()
 print("inputs", n, "with errors", nerr, "disagreements", bad, "leaves", dict(sorted(leaves.items())))

@@ -416,6 +416,12 @@ class StreamCore {
       last_seen_ = true;
     }
   }
+  // the block that failed: its header was read and counted before its body failed (frame_decoder.rs:325-341) — every error but the
+  // three of read_block_header and a checksum that is not there
+  void count_failed_header(int st) {
+    if (st != ZG_FAILED_READ_BLOCK_HEADER && st != ZG_RESERVED_BLOCK && st != ZG_BLOCK_SIZE_TOO_LARGE && st != ZG_FAILED_READ_CHECKSUM)
+      src_bytes_.fetch_add(3, std::memory_order_relaxed);
+  }
   void publish_fin() { if (fin_pending_) { fin_pending_ = false; fin_.store(true, std::memory_order_release); } }
   bool last_seen_ = false;          // the last block has been decoded (the frame yields no more bytes)
   bool fin_pending_ = false;
@@ -446,9 +452,9 @@ class StreamCore {
       if ((e = fetch_to_buf(r.out_size))) return e;
       const size_t good_len = r.good_blocks == st.nblocks ? st.len : stream_prefix_len(st.p, st.len, r.good_blocks);
       account(r, good_len, r.good_blocks);
-      if (r.status) return r.status;
+      if (r.status) { count_failed_header(r.status); return r.status; }
     }
-    if (st.stop) return st.stop;
+    if (st.stop) { count_failed_header(st.stop); return st.stop; }
     if (st.nblocks == 0) return ZG_FAILED_READ_BLOCK_HEADER;                 // (only behind an earlier error: the frame's blocks are used up and it is not finished)
     return ZG_OK;
   }
