@@ -194,7 +194,12 @@ static void k_seq(EmuBatch& e) {
       if (lg[k] > 9) { ok = false; continue; }
       tp[k] = e.fse.data() + (size_t)sl[k] * ZG_FSE_SLOT_U32 + offs[k];
     }
-    if (!ok) { set_status(e, b, ZG_FSE_UNINIT); continue; }
+    if (!ok) {   // (the padding of the bitstream is looked at before the states are initialised: zg_k_seq)
+      const uint32_t bo = e.aux[b].seq_bits_off;
+      const bool nopad = bo <= blk.src_len && (blk.src_len == bo || e.src[blk.src_off + blk.src_len - 1u] == 0);
+      set_status(e, b, nopad ? ZG_SEQ_EXTRA_PADDING : ZG_FSE_UNINIT);
+      continue;
+    }
     uint32_t bits_off = e.aux[b].seq_bits_off;
     if (bits_off > blk.src_len) { set_status(e, b, ZG_INTERNAL); continue; }
     const uint8_t* bs = e.src + blk.src_off + bits_off;

@@ -261,3 +261,46 @@ def test_pool_entries_that_are_runs_of_frames():
         if ost == 0:
             assert size == len(oout) and pool.read(i, size) == oout, i
     pool.close()
+
+
+def test_padding_is_looked_at_before_the_states_are_initialised():
+    """a mutated corpus block (tests/golden/regress, tools/dev/soak.py seed 204): a Repeat mode without a table to repeat AND a sequence
+    bitstream whose last byte is 0. The reference checks the padding (sequence_section_decoder.rs:29-40) before it initialises the FSE states
+    (fse_decoder.rs:33-35): ExtraPadding, not TableIsUninitialized"""
+    sys.path.insert(0, os.path.join(ROOT, "zstd-rs_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    import zgpu
+    z = open(os.path.join(ROOT, "tests", "golden", "regress", "padding_before_uninitialized_table.zst"), "rb").read()
+    assert oracle.FrameDecoder().decode_all(z, 1 << 22)[0] == 44
+    ctx = zgpu.Context(0)
+    with pytest.raises(zgpu.ZgpuError) as e:
+        ctx.decode_all(z, 1 << 22)
+    assert e.value.status == 44
+    ctx.close()
+
+
+def test_partial_output_of_a_block_on_the_in_order_path():
+    """a mutated frame (tests/golden/regress, tools/dev/soak_seqbits.py seed 204) one of whose blocks regenerates more than 128 KiB — the frame
+    leaves the flatten path for zg_k_lz — and whose third block fails in sequence execution: what that block wrote before it failed is in
+    the buffer like in the reference's (zg_k_partial rebuilds the positions from the records' exact fields, the position fields wrap there)"""
+    sys.path.insert(0, os.path.join(ROOT, "zstd-rs_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    import zgpu
+    from test_gpu_thin_boundary import parse_frame_header, walk_blocks
+    z = open(os.path.join(ROOT, "tests", "golden", "regress", "seqbits_240.zst"), "rb").read()
+    o = oracle.FrameDecoder()
+    st, hl, _, _ = o.init(z)
+    assert st == 0 and o.decode_blocks(z[hl:])[0] == 53 and o.blocks_decoded() == 2
+    held = o.held()
+    assert len(held) == 2326
+    ctx = zgpu.Context(0)
+    hl2, window, fcs, did, _ = parse_frame_header(z)
+    blocks, _ = walk_blocks(z, hl2)
+    f = zgpu.BlockFrame(ctx, window, fcs, did)
+    f.submit(z, blocks)
+    assert f.sync() == (2, 53)
+    assert f.read(1 << 22, True) == held
+    f.close()
+    ctx.close()

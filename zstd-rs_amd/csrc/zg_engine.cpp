@@ -859,7 +859,7 @@ int Batch::sync() {
     const uint32_t st = fo.status;
     const bool exe = st == (uint32_t)ZG_EXE_NOT_ENOUGH_LITERALS || st == (uint32_t)ZG_EXE_ZERO_OFFSET || st == (uint32_t)ZG_EXE_OFFSET_TOO_BIG ||
                      st == (uint32_t)ZG_EXE_DICT_TOO_SMALL;
-    if (exe && fo.fast && fo.good_blocks < fr.nblocks) {
+    if (exe && fo.good_blocks < fr.nblocks) {
       const uint32_t b = fr.first_block + fo.good_blocks;
       const ZgBlock& blk = bb.blocks[b];
       ZgBlockSeqOut so;
@@ -869,17 +869,18 @@ int Batch::sync() {
       if (so.pad && so.pad <= blk.nseq) {                       // 1 + the sequence that failed (zg_k_seqpost, or zg_k_exact where it decided)
         const uint32_t j = so.pad - 1u;
         const bool lits = st != (uint32_t)ZG_EXE_NOT_ENOUGH_LITERALS;   // (:14-19 come before the push; the offset checks :28-38 behind it)
-        ZgSeq rec[2];
-        memset(rec, 0, sizeof rec);
-        const uint32_t first = j ? j - 1u : 0u, cnt = j ? 2u : 1u;
-        ZG_HIP(hipMemcpy(rec, dev.seq_arena + blk.seq_base + first, cnt * sizeof(ZgSeq), hipMemcpyDeviceToHost));
-        const ZgSeq& rj = rec[j ? 1 : 0];
-        const uint32_t psize = lits ? ZG_SEQ_MDST(rj) : (j ? ZG_SEQ_MDST(rec[0]) + ZG_SEQ_ML(rec[0]) : 0u);
-        if (psize && psize <= kMaxBlockSize) {
-          zg_launch_partial(dev, eng->stream_, 0, b, j, lits);
-          ZG_HIP(hipStreamSynchronize(eng->stream_));
+        // room behind the good blocks: the block of slack size_output reserved — and, when the scan still counted the failing block (an
+        // error found while executing: the in-order path, the flatten), that block's own place
+        const uint64_t used = kOutFront + fs->base + fs->have + fo.out_size;
+        const uint64_t room = fs->d_out.cap > used + 64 ? fs->d_out.cap - used - 64 : 0;
+        const uint32_t limit = room > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)room;
+        zg_launch_partial(dev, eng->stream_, 0, b, j, lits, limit);
+        ZG_HIP(hipStreamSynchronize(eng->stream_));
+        uint32_t psize = 0;
+        ZG_HIP(hipMemcpy(&psize, dev.totals + 5, 4, hipMemcpyDeviceToHost));
+        if (psize != 0xFFFFFFFFu) {                             // (else: more than there is room for — a block beyond 128 KiB rejected by zg_k_seqpost: left out)
           fo.out_size += psize;
-          dev.dst_cap += psize;                                 // (size_output reserved a block's worth behind the run for this)
+          dev.dst_cap += psize;
         }
       }
     }

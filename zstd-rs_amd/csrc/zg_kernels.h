@@ -34,6 +34,6 @@ void zg_launch_sparse(const ZgBatchDev& d, hipStream_t s);   // the matches of f
 bool zg_launch_sweep(const ZgBatchDev& d, hipStream_t s, const ZgSweepStep* steps, uint32_t nsteps, hipStream_t s2, hipEvent_t* evs, uint32_t nev,
                      uint32_t unit_bytes, uint32_t window_max, uint32_t window_min, const ZgSweepTuning& tn);   // s2 / evs: the side stream of the split sweep (nev == 0: one stream, step by step); returns whether it split
 void zg_launch_lz(const ZgBatchDev& d, hipStream_t s);
-void zg_launch_partial(const ZgBatchDev& d, hipStream_t s, uint32_t frame, uint32_t block, uint32_t nexec, bool lits_of_next);   // what the reference's buffer holds of a block whose sequence execution failed (Batch::sync, runs of one frame)
+void zg_launch_partial(const ZgBatchDev& d, hipStream_t s, uint32_t frame, uint32_t block, uint32_t nexec, bool lits_of_next, uint32_t limit);   // what the reference's buffer holds of a block whose sequence execution failed (Batch::sync, runs of one frame)
 void zg_launch_exact(const ZgBatchDev& d, hipStream_t s, uint32_t drain_rule);   // zg_exact.h: the reference's DecodeBuffer bookkeeping, exactly (rare path, Batch::sync)
 void zg_launch_calib(const void* src, void* dst, uint64_t bytes, hipStream_t s);

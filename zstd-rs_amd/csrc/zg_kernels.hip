@@ -778,8 +778,12 @@ __global__ void __launch_bounds__(128) zg_k_seq(ZgBatchDev d) {
     b = d.seq_blocks[base + g];
     const ZgBlock blk = d.blocks[b];
     if (!s_ok[g]) {
-      // FSEDecoder::init_state on a table that was never set (fse_decoder.rs:33-35), or an upstream failure
-      if (owner && !mover) zg_set_status(d.status, b, ZG_FSE_UNINIT);
+      // FSEDecoder::init_state on a table that was never set (fse_decoder.rs:33-35), or an upstream failure (whose status stands: the first
+      // one set is kept). The reference looks at the bitstream's padding BEFORE it initialises the states (sequence_section_decoder.rs:29-40
+      // in front of :52-54 / :130-132): a block with both defects answers ExtraPadding (tools/dev/soak.py seed 204)
+      const uint32_t bo = d.aux[b].seq_bits_off;
+      const bool nopad = bo <= blk.src_len && (blk.src_len == bo || d.src[blk.src_off + blk.src_len - 1u] == 0);
+      if (owner && !mover) zg_set_status(d.status, b, nopad ? ZG_SEQ_EXTRA_PADDING : ZG_FSE_UNINIT);
       act = false;
     } else {
       const uint32_t bits_off = d.aux[b].seq_bits_off;
@@ -1906,7 +1910,7 @@ __global__ void __launch_bounds__(64) zg_k_sparse(ZgBatchDev d) {
 // nexec when lits_of_next is set. One wave, 64 sequences per round (zg_k_sparse's scheme: a match is copied once everything below the
 // lowest pending destination is final); an error path, at most 128 KiB.
 // ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) zg_k_partial(ZgBatchDev d, uint32_t f, uint32_t b, uint32_t nexec, uint32_t lits_of_next) {
+__global__ void __launch_bounds__(64) zg_k_partial(ZgBatchDev d, uint32_t f, uint32_t b, uint32_t nexec, uint32_t lits_of_next, uint32_t limit) {
   const uint32_t lane = threadIdx.x;
   const ZgFrameOut fo = d.frame_out[f];
   const ZgBlockPos p = d.pos[b];
@@ -1917,43 +1921,59 @@ __global__ void __launch_bounds__(64) zg_k_partial(ZgBatchDev d, uint32_t f, uin
   const bool lit_rle = blk->lit_type == ZG_LT_RLE;
   const uint8_t* lit = blk->lit_type <= ZG_LT_RLE ? body + blk->lit_off : d.lit_arena + blk->lit_base;
   const uint32_t total = nexec + (lits_of_next ? 1u : 0u);          // sequences whose literals go out
-  for (uint32_t s0 = 0; s0 < total; s0 += 64) {
-    const uint32_t i = s0 + lane;
-    bool pending = false;
-    uint32_t off = 0, ml = 0, mdst = 0xFFFFFFFFu;
-    uint64_t dpos = 0;
-    if (i < total) {
-      const ZgSeq q = sq[i];
-      mdst = ZG_SEQ_MDST(q);
-      uint32_t prev_end = 0;                                         // where the sequence in front of this one ended = where this one's literals start
-      if (i) { const ZgSeq pq = sq[i - 1]; prev_end = ZG_SEQ_MDST(pq) + ZG_SEQ_ML(pq); }
-      const uint32_t ll = mdst - prev_end, lp = ZG_SEQ_LIT(q);
-      uint8_t* o = frame_out + p.out_base + prev_end;
-      if (lit_rle) { const uint8_t v = lit[0]; for (uint32_t k = 0; k < ll; k++) o[k] = v; }
-      else for (uint32_t k = 0; k < ll; k++) o[k] = lit[lp + k];
-      if (i < nexec) {
-        ml = ZG_SEQ_ML(q);
-        off = zg_sym_resolve(q.of, p.hist_init);
+  // Positions are rebuilt from the exact fields of the records, as in zg_k_lz (a block beyond 128 KiB wraps the position fields): the
+  // literal run of sequence i is what lies between the end of sequence i - 1 and its match, (mdst_i - mdst_(i-1) - ml_(i-1)) mod 2^17.
+  // pass 0 only measures (the host has reserved `limit` bytes behind the run: more than that is not written at all), pass 1 executes.
+  for (int pass = 0; pass < 2; pass++) {
+    uint32_t carry = 0;                                              // block-relative end of the sequences in front of the batch
+    for (uint32_t s0 = 0; s0 < total; s0 += 64) {
+      const uint32_t i = s0 + lane;
+      bool pending = false;
+      uint32_t off = 0, ml = 0, ll = 0, lp = 0;
+      if (i < total) {
+        const ZgSeq q = sq[i];
+        uint32_t prev_end = 0;
+        if (i) { const ZgSeq pq = sq[i - 1]; prev_end = ZG_SEQ_MDST(pq) + ZG_SEQ_ML(pq); }
+        ll = (ZG_SEQ_MDST(q) - prev_end) & 0x1FFFFu;
+        lp = ZG_SEQ_LIT(q);
+        if (i < nexec) { ml = ZG_SEQ_ML(q); off = zg_sym_resolve(q.of, p.hist_init); }
+      }
+      uint32_t io = ll + ml;                                         // inclusive scan over the batch
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(io, o, 64); if ((int)lane >= o) io += v; }
+      const uint32_t start = carry + io - (ll + ml);                 // where this sequence's literals start
+      const uint32_t mdst = start + ll;                              // ... and its match
+      carry += __shfl(io, 63, 64);
+      if (pass == 0) continue;
+      uint64_t dpos = 0;
+      if (i < total) {
+        uint8_t* o = frame_out + p.out_base + start;
+        if (lit_rle) { const uint8_t v = lit[0]; for (uint32_t k = 0; k < ll; k++) o[k] = v; }
+        else for (uint32_t k = 0; k < ll; k++) o[k] = lit[lp + k];
         dpos = p.out_base + mdst;
-        pending = ml > 0;
+        pending = i < nexec && ml > 0;
+      }
+      __threadfence_block();                                         // the literals are in place for the matches that copy from them
+      for (uint32_t guard = 0; guard <= 64u; guard++) {              // (every round retires the first pending match at least)
+        uint32_t hwm = pending ? mdst : 0xFFFFFFFFu;
+        for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t o2 = __shfl_xor(hwm, sh, 64); hwm = o2 < hwm ? o2 : hwm; }
+        if (hwm == 0xFFFFFFFFu) break;
+        if (pending) {
+          const int64_t src_end = (int64_t)dpos - (int64_t)off + (int64_t)ml;
+          const uint64_t need_end = ml < off ? (src_end > 0 ? (uint64_t)src_end : 0ull) : dpos;
+          if (need_end <= p.out_base + hwm) { zg_lane_match_copy(frame_out + dpos, off, ml); pending = false; }
+        }
+        __threadfence_block();
       }
     }
-    __threadfence_block();                                           // the literals are in place for the matches that copy from them
-    for (uint32_t guard = 0; guard <= 64u; guard++) {                // (every round retires the first pending match at least)
-      uint32_t hwm = pending ? mdst : 0xFFFFFFFFu;
-      for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t o2 = __shfl_xor(hwm, sh, 64); hwm = o2 < hwm ? o2 : hwm; }
-      if (hwm == 0xFFFFFFFFu) break;
-      if (pending) {
-        const int64_t src_end = (int64_t)dpos - (int64_t)off + (int64_t)ml;
-        const uint64_t need_end = ml < off ? (src_end > 0 ? (uint64_t)src_end : 0ull) : dpos;
-        if (need_end <= p.out_base + hwm) { zg_lane_match_copy(frame_out + dpos, off, ml); pending = false; }
-      }
-      __threadfence_block();
+    if (pass == 0) {
+      if (lane == 0) d.totals[5] = carry <= limit ? carry : 0xFFFFFFFFu;   // what the block leaves behind; 0xFFFFFFFF: more than was reserved, nothing written
+      if (carry > limit) return;
     }
   }
 }
-void zg_launch_partial(const ZgBatchDev& d, hipStream_t s, uint32_t frame, uint32_t block, uint32_t nexec, bool lits_of_next) {
-  hipLaunchKernelGGL(zg_k_partial, dim3(1), dim3(64), 0, s, d, frame, block, nexec, lits_of_next ? 1u : 0u);
+void zg_launch_partial(const ZgBatchDev& d, hipStream_t s, uint32_t frame, uint32_t block, uint32_t nexec, bool lits_of_next, uint32_t limit) {
+  hipLaunchKernelGGL(zg_k_partial, dim3(1), dim3(64), 0, s, d, frame, block, nexec, lits_of_next ? 1u : 0u, limit);
 }
 void zg_launch_sparse(const ZgBatchDev& d, hipStream_t s) {
   if (d.nframes) hipLaunchKernelGGL(zg_k_sparse, dim3(d.nframes), dim3(64), 0, s, d);
