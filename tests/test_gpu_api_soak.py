@@ -304,3 +304,13 @@ def test_partial_output_of_a_block_on_the_in_order_path():
     assert f.read(1 << 22, True) == held
     f.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("tool,args", [("soak_thin.py", ["500", "13"]), ("soak_batch.py", ["300", "14"]), ("soak_seqbits.py", ["300", "15"]),
+                                       ("soak_headers.py", ["300", "16"]), ("soak_stream.py", ["400", "17"])])
+def test_fixed_seed_runs_of_the_other_soaks(tool, args):
+    """the thin boundary in random runs, many frames per submit, bit flips inside sequence bitstreams (six surfaces, everything held after an
+    Err), header edits (seven surfaces), the io::Read surface in every mode: short runs with fixed seeds (tools/dev/final_check.sh runs them long)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dev", tool)] + args, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "disagreements 0" in r.stdout
